@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference; never on the GPU box).  The
+reference's Python is imported read-only; ``torchaudio`` and ``pretty_midi`` (absent from this
+image, imported at module top by etude/data/extractor.py:22-23) are replaced by empty stub
+modules -- none of the functions exercised here touch them.  Weights are the seeded synthetic
+checkpoints of ``etude_amd.synth`` (numpy PCG64), loaded into the reference's own nn.Modules with
+``strict=True`` so the key names/shapes are checked against the reference as a side effect.
+
+Outputs are DATA only (inputs + expected outputs), never reference source:
+  hft_tiny.npz        tiny-config model: input, per-layer taps hashes, 8 outputs
+  hft_full.npz        default-config model, ONE window: onset/offset/mpe B + velocity argmax + a few logit rows
+  transcript_tiny.npz reference ``_transcript`` on 40 frames at the tiny config (ragged: 3 windows)
+  mpe2note.json       crafted + random frame arrays -> reference ``_mpe2note`` / ``_note2json`` lists
+  decoder_tiny.npz    tiny GPT-NeoX config: logits for a prompt, greedy ids for a few bars
+  decoder_full.npz    default config (512/8/8/2048, V=154): logits for a 64-token prompt,
+                      greedy ids from the reference ``generate`` for several bars x attribute tuples
+Usage:  python tests/golden/make_golden.py [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, "/root/reference")
+os.environ.setdefault("LOG_LEVEL", "ERROR")
+# transformers probes for torchaudio via importlib; import the HF-backed decoder BEFORE stubbing.
+import etude.models.etude_decoder  # noqa: E402,F401
+for _m in ("torchaudio", "pretty_midi"):
+    sys.modules.setdefault(_m, types.ModuleType(_m))
+
+from etude_amd import synth  # noqa: E402
+
+TINY_EXT = dict(n_margin=4, n_frame=16, n_bin=32, cnn_channel=4, cnn_kernel=5, hid_dim=32, pf_dim=64,
+                n_heads=4, n_layers_enc=3, n_layers_dec=3, n_note=12, n_velocity=8)
+TINY_DEC = dict(vocab_size=154, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128,
+                max_position_embeddings=128, attribute_emb_dim=16)
+TINY_DEC_KW = dict(gain=2.0, p_eos=0.15)
+
+
+def _t(sd):
+    return {k: torch.from_numpy(v) for k, v in sd.items()}
+
+
+def ref_extractor(dims, seed):
+    from etude.config.schema import ExtractorConfig
+    from etude.data.extractor import AMTAPC_Extractor, _Spec2MIDI
+    from etude.models.amt_apc import Decoder_SPEC2MIDI, Encoder_SPEC2MIDI
+    d = synth.extractor_dims(**dims)
+    enc = Encoder_SPEC2MIDI(d["n_margin"], d["n_frame"], d["n_bin"], d["cnn_channel"], d["cnn_kernel"], d["hid_dim"],
+                            d["n_layers_enc"], d["n_heads"], d["pf_dim"], 0.1, "cpu")
+    dec = Decoder_SPEC2MIDI(d["n_frame"], d["n_bin"], d["n_note"], d["n_velocity"], d["hid_dim"], d["n_layers_dec"],
+                            d["n_heads"], d["pf_dim"], 0.1, "cpu")
+    model = _Spec2MIDI(enc, dec, sv_dim=0)
+    sd = synth.extractor_state_dict(seed, dims)
+    model.load_state_dict(_t(sd), strict=True)
+    model.eval()
+    cfg = ExtractorConfig()
+    cfg.input.margin_b = cfg.input.margin_f = d["n_margin"]
+    cfg.input.num_frame = d["n_frame"]
+    cfg.feature.n_bins = cfg.feature.mel_bins = d["n_bin"]
+    cfg.midi.num_note = d["n_note"]
+    cfg.midi.num_velocity = d["n_velocity"]
+    ex = AMTAPC_Extractor.__new__(AMTAPC_Extractor)
+    ex.device = torch.device("cpu")
+    ex.config = cfg
+    ex.model = model
+    return ex, d
+
+
+def gen_hft_tiny():
+    ex, d = ref_extractor(TINY_EXT, seed=11)
+    x = synth.window_features(3, 2, d["n_bin"], d["n_frame"] + 2 * d["n_margin"])
+    with torch.no_grad():
+        r = ex.model(torch.from_numpy(x))
+    np.savez_compressed(HERE / "hft_tiny.npz", x=x,
+                        onset_A=r[0].numpy(), offset_A=r[1].numpy(), mpe_A=r[2].numpy(), velocity_A=r[3].numpy(),
+                        attention=r[4].numpy(),
+                        onset_B=r[5].numpy(), offset_B=r[6].numpy(), mpe_B=r[7].numpy(), velocity_B=r[8].numpy())
+
+
+def gen_hft_full():
+    ex, d = ref_extractor({}, seed=7)
+    x = synth.window_features(5, 1)
+    with torch.no_grad():
+        r = ex.model(torch.from_numpy(x))
+    np.savez_compressed(HERE / "hft_full.npz",
+                        onset_A=r[0][0].numpy().astype(np.float16), mpe_A=r[2][0].numpy().astype(np.float16),
+                        onset_B=r[5][0].numpy(), offset_B=r[6][0].numpy(), mpe_B=r[7][0].numpy(),
+                        velocity_B_argmax=r[8][0].argmax(2).numpy().astype(np.int8),
+                        velocity_B_rows=r[8][0, ::64].numpy(),       # logits of every 64th frame [8,88,128]
+                        velocity_B_top2gap=(lambda t: (t[..., 0] - t[..., 1]))(torch.topk(r[8][0], 2, dim=-1).values).numpy().astype(np.float16))
+
+
+def gen_transcript_tiny():
+    ex, d = ref_extractor(TINY_EXT, seed=11)
+    rng = np.random.default_rng(21)
+    feat = np.clip(rng.normal(-8, 2, (40, d["n_bin"])), -18, 5).astype(np.float32)   # 40 frames -> 3 windows of 16, ragged
+    out = ex._transcript(feat)
+    np.savez_compressed(HERE / "transcript_tiny.npz", feature=feat, **{f"out{i}": o for i, o in enumerate(out)})
+
+
+def gen_mpe2note():
+    ex, _ = ref_extractor(TINY_EXT, seed=11)
+    ex.config.midi.num_note = 4
+    cases = []
+    rng = np.random.default_rng(5)
+
+    def run(name, on, off, mpe, vel, thr=(0.5, 1.0, 0.5), min_dur=0.08):
+        on, off, mpe = (np.asarray(a, np.float32) for a in (on, off, mpe))
+        vel = np.asarray(vel, np.int8)
+        notes = ex._mpe2note(on, off, mpe, vel, thred_onset=thr[0], thred_offset=thr[1], thred_mpe=thr[2])
+        tmp = HERE / "_tmp.json"
+        ex._note2json(notes, str(tmp), min_dur)
+        filt = json.loads(tmp.read_text())
+        tmp.unlink()
+        cases.append(dict(name=name, thr=list(thr), min_dur=min_dur, onset=on.tolist(), offset=off.tolist(),
+                          mpe=mpe.tolist(), velocity=vel.tolist(), notes=notes, json=filt))
+
+    T = 24
+    z = np.zeros((T, 4), np.float32)
+    # 1. plateau onset, saturated offsets (==1.0) with threshold 1.0, mpe dip
+    on = z.copy(); off = z.copy(); mpe = z.copy() + 0.9; vel = np.full((T, 4), 64, np.int8)
+    on[3:6, 0] = 0.8; on[10, 0] = 0.7; on[9, 0] = 0.3; on[11, 0] = 0.6
+    off[7:9, 0] = 1.0; off[15, 0] = 1.0
+    mpe[13:, 0] = 0.2
+    on[0, 1] = 0.9; on[T - 1, 1] = 0.95; on[12, 1] = 0.55; on[11, 1] = 0.5; on[13, 1] = 0.52
+    on[5, 2] = 0.6; on[6, 2] = 0.6; on[8, 2] = 0.9; vel[8, 2] = 0
+    on[4, 3] = 0.51; on[5, 3] = 0.2; on[6, 3] = 0.99; mpe[5, 3] = 0.1
+    run("crafted_plateau_edges", on, off, mpe, vel)
+    # 2. overlapping same-pitch notes (offset clipped to next onset), threshold 0.5 offsets
+    on = z.copy(); off = z.copy(); mpe = z.copy() + 0.9; vel = np.full((T, 4), 100, np.int8)
+    on[2, 0] = 0.9; on[4, 0] = 0.8; on[3, 0] = 0.1
+    off[20, 0] = 0.7; off[19, 0] = 0.6; off[21, 0] = 0.65
+    run("crafted_overlap", on, off, mpe, vel, thr=(0.5, 0.5, 0.5), min_dur=0.0)
+    # 3-5. random, with quantised values so ties/plateaus occur
+    for k in range(3):
+        Tn = 200
+        on = np.round(rng.random((Tn, 4)) ** 4, 2).astype(np.float32)
+        off = np.where(rng.random((Tn, 4)) > 0.97, 1.0, rng.random((Tn, 4)) * 0.99).astype(np.float32)
+        mpe = rng.random((Tn, 4)).astype(np.float32)
+        vel = rng.integers(0, 128, (Tn, 4)).astype(np.int8)
+        run(f"random_{k}", on, off, mpe, vel, thr=(0.5, 1.0, 0.5) if k < 2 else (0.6, 0.9, 0.3))
+    # 6. empty
+    run("all_zero", z, z, z, np.zeros((T, 4), np.int8))
+    (HERE / "mpe2note.json").write_text(json.dumps(cases))
+
+
+def ref_decoder(dims, seed, **kw):
+    from etude.models.etude_decoder import EtudeDecoder, EtudeDecoderConfig
+    d = synth.decoder_dims(**dims)
+    cfg = EtudeDecoderConfig(**{k: v for k, v in d.items()})
+    model = EtudeDecoder(cfg)
+    sd = synth.decoder_state_dict(seed, dims, **kw)
+    model.load_state_dict(_t(sd), strict=True)
+    model.eval()
+    return model, d
+
+
+class _Vocab:
+    def __init__(self):
+        from etude.data.vocab import Vocab
+        p = HERE / "_vocab_tmp.json"
+        synth.write_vocab(str(p))
+        self.v = Vocab.load(p)
+        p.unlink()
+
+
+def _gen_decoder(name, dims, seed, kw, n_bars, attr_sets, prompt_len, max_bar_token_limit):
+    model, d = ref_decoder(dims, seed, **kw)
+    vocab = _Vocab().v
+    rng = np.random.default_rng(99)
+    ids = rng.integers(4, d["vocab_size"], (1, prompt_len))
+    cls = rng.integers(1, 3, (1, prompt_len))
+    at = {k: rng.integers(0, 3, (1, prompt_len)) for k in ("polyphony", "rhythm", "sustain", "overlap")}
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids), class_ids=torch.from_numpy(cls),
+                    polyphony_bin_ids=torch.from_numpy(at["polyphony"]), rhythm_intensity_bin_ids=torch.from_numpy(at["rhythm"]),
+                    note_sustain_bin_ids=torch.from_numpy(at["sustain"]), pitch_overlap_bin_ids=torch.from_numpy(at["overlap"]),
+                    use_cache=True)
+    save = dict(prompt_ids=ids, prompt_cls=cls, prompt_polyphony=at["polyphony"], prompt_rhythm=at["rhythm"],
+                prompt_sustain=at["sustain"], prompt_overlap=at["overlap"], logits=out.logits[0].numpy())
+    bars = synth.song_bars(seed=3, n_bars=n_bars)
+    save["n_bars"] = np.int64(n_bars)
+    for j, a in enumerate(attr_sets):
+        attrs = synth.attrs(*a)
+        ev = model.generate(vocab, bars, [attrs] * n_bars, temperature=0.0, top_p=0.9, max_bar_token_limit=max_bar_token_limit)
+        gen_ids = [vocab.encode(e) if e.type_ not in vocab.special_tokens else vocab.token_to_id[e.type_] for e in ev]
+        save[f"gen_ids_{j}"] = np.asarray(gen_ids, np.int32)
+        save[f"gen_attrs_{j}"] = np.asarray(a, np.int64)
+        n_eos = int((np.asarray(gen_ids) == vocab.get_bar_eos_id()).sum())
+        print(f"  {name} attrs={a}: {len(gen_ids)} ids, {n_eos} Bar_EOS, {len(set(gen_ids))} distinct")
+    np.savez_compressed(HERE / f"{name}.npz", **save)
+
+
+def gen_decoder_tiny():
+    _gen_decoder("decoder_tiny", TINY_DEC, seed=2, kw=TINY_DEC_KW, n_bars=6, attr_sets=[(1, 1, 1, 2), (0, 2, 1, 2)],
+                 prompt_len=24, max_bar_token_limit=40)
+
+
+def gen_decoder_full():
+    _gen_decoder("decoder_full", {}, seed=1, kw={}, n_bars=7, attr_sets=[(1, 1, 1, 2), (0, 2, 1, 2), (2, 0, 2, 2)],
+                 prompt_len=64, max_bar_token_limit=48)
+
+
+ALL = dict(hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
+           decoder_tiny=gen_decoder_tiny, decoder_full=gen_decoder_full)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.manual_seed(0)
+    for n, f in ALL.items():
+        if a.only and a.only != n:
+            continue
+        print("generating", n)
+        f()

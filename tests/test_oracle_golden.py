@@ -1,0 +1,82 @@
+"""The oracle (CPU restatement) against the golden vectors captured from the reference."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from etude_amd import synth
+from oracle import hft, mpe2note, neox
+from tests._util import TINY_DEC, TINY_DEC_KW, TINY_EXT, hft_dims, neox_dims, split_generated, torch_sd
+
+
+def test_hft_tiny_all_outputs(golden_dir):
+    g = np.load(golden_dir / "hft_tiny.npz")
+    d = hft_dims(TINY_EXT)
+    sd = torch_sd(synth.extractor_state_dict(11, TINY_EXT))
+    r = hft.model_forward(sd, torch.from_numpy(g["x"]), d, want_attention=True)
+    names = ["onset_A", "offset_A", "mpe_A", "velocity_A", "attention", "onset_B", "offset_B", "mpe_B", "velocity_B"]
+    for n, t in zip(names, r):
+        np.testing.assert_allclose(t.numpy(), g[n], rtol=1e-5, atol=2e-6, err_msg=n)
+
+
+def test_hft_full_window(golden_dir):
+    g = np.load(golden_dir / "hft_full.npz")
+    d = hft_dims({})
+    sd = torch_sd(synth.extractor_state_dict(7, {}))
+    x = torch.from_numpy(synth.window_features(5, 1))
+    r = hft.model_forward(sd, x, d)
+    for n, i in (("onset_B", 5), ("offset_B", 6), ("mpe_B", 7)):
+        np.testing.assert_allclose(r[i][0].numpy(), g[n], rtol=1e-4, atol=2e-5, err_msg=n)
+    np.testing.assert_allclose(r[8][0, ::64].numpy(), g["velocity_B_rows"], rtol=1e-4, atol=2e-4)
+    am = r[8][0].argmax(2).numpy().astype(np.int8)
+    clear = g["velocity_B_top2gap"].astype(np.float32) > 1e-3
+    assert (am == g["velocity_B_argmax"])[clear].all()
+    assert (am == g["velocity_B_argmax"]).mean() > 0.999
+
+
+def test_transcript_tiny_ragged(golden_dir):
+    g = np.load(golden_dir / "transcript_tiny.npz")
+    d = hft_dims(TINY_EXT)
+    sd = torch_sd(synth.extractor_state_dict(11, TINY_EXT))
+    out = hft.transcript(sd, g["feature"], d)
+    assert out[0].shape == (48, 12)          # 40 frames padded to 3 windows of 16
+    for i in range(8):
+        if out[i].dtype == np.int8:
+            assert (out[i] == g[f"out{i}"]).mean() > 0.99
+        else:
+            np.testing.assert_allclose(out[i], g[f"out{i}"], rtol=1e-5, atol=2e-6)
+
+
+def test_mpe2note_cases(golden_dir):
+    cases = json.loads((golden_dir / "mpe2note.json").read_text())
+    assert len(cases) >= 6
+    for c in cases:
+        on, off, mpe = (np.asarray(c[k], np.float32) for k in ("onset", "offset", "mpe"))
+        vel = np.asarray(c["velocity"], np.int8)
+        notes = mpe2note.mpe2note(on, off, mpe, vel, *c["thr"])
+        assert notes == c["notes"], c["name"]                    # exact: pitch/velocity ints, float64 times
+        assert mpe2note.notes_for_json(notes, c["min_dur"]) == c["json"], c["name"]
+
+
+@pytest.mark.parametrize("name,dims,seed,kw", [("decoder_tiny", TINY_DEC, 2, TINY_DEC_KW), ("decoder_full", {}, 1, {})])
+def test_decoder_logits_and_greedy_ids(golden_dir, name, dims, seed, kw):
+    g = np.load(golden_dir / f"{name}.npz")
+    d = neox_dims(dims)
+    sd = torch_sd(synth.decoder_state_dict(seed, dims, **kw))
+    attrs = {"polyphony": torch.from_numpy(g["prompt_polyphony"]), "rhythm_intensity": torch.from_numpy(g["prompt_rhythm"]),
+             "note_sustain": torch.from_numpy(g["prompt_sustain"]), "pitch_overlap": torch.from_numpy(g["prompt_overlap"])}
+    logits, _ = neox.forward_logits(sd, d, torch.from_numpy(g["prompt_ids"]), torch.from_numpy(g["prompt_cls"]), attrs)
+    np.testing.assert_allclose(logits[0].numpy(), g["logits"], rtol=1e-4, atol=1e-4)
+    v = synth.vocab_json()["token_to_id"]
+    n_bars = int(g["n_bars"])
+    bars = synth.song_bars(seed=3, n_bars=n_bars)
+    limit = 40 if name == "decoder_tiny" else 48
+    j = 0
+    while f"gen_ids_{j}" in g:
+        a = synth.attrs(*[int(x) for x in g[f"gen_attrs_{j}"]])
+        out = neox.generate_ids(sd, d, v["Bar_BOS"], v["Bar_EOS"], bars, [a] * n_bars, max_bar_token_limit=limit)
+        flat = [t for b in out for t in b]
+        assert flat == g[f"gen_ids_{j}"].tolist(), (name, j)
+        j += 1
+    assert j >= 2
