@@ -1,0 +1,117 @@
+"""ctypes binding of libetude_hip.so (the C ABI declared in include/etude_hip.h).
+
+``import torch`` happens first on purpose: torch ships its own ``libamdhip64.so`` (same SONAME as
+/opt/rocm's), and loading our library afterwards makes the dynamic linker bind it to that already
+loaded HIP runtime -- one runtime per process, so ``tensor.data_ptr()`` addresses and
+``torch.cuda`` streams are valid inside the library.
+
+There is NO fallback: if the shared object is missing or a symbol is absent this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+LIB_PATH = Path(__file__).resolve().parent / "libetude_hip.so"
+
+c_int_p = C.POINTER(C.c_int)
+c_i32_p = C.POINTER(C.c_int32)
+c_i64_p = C.POINTER(C.c_int64)
+c_f32_p = C.POINTER(C.c_float)
+
+
+class ExtCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n_margin", "n_frame", "n_bin", "cnn_channel", "cnn_kernel", "hid_dim", "pf_dim",
+                                       "n_heads", "n_layers_enc", "n_layers_dec", "n_note", "n_velocity")] + \
+               [("min_value", C.c_float), ("max_windows", C.c_int), ("chunk_frames", C.c_int)]
+
+
+class DecCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads",
+                                       "intermediate_size", "max_position_embeddings", "num_classes",
+                                       "num_attribute_bins", "attribute_emb_dim")] + \
+               [("rotary_pct", C.c_float), ("rope_theta", C.c_float), ("layer_norm_eps", C.c_float),
+                ("max_streams", C.c_int), ("max_ctx", C.c_int), ("precision", C.c_int)]
+
+
+class Note(C.Structure):
+    _fields_ = [("onset", C.c_double), ("offset", C.c_double), ("pitch", C.c_int32), ("velocity", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/etude_hip.h one to one
+SIGNATURES = {
+    "etd_version": (C.c_int, []),
+    "etd_last_error": (C.c_char_p, []),
+    "etd_frontend_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
+    "etd_frontend_destroy": (None, [C.c_void_p]),
+    "etd_frontend_resampled_len": (C.c_longlong, [C.c_void_p, C.c_longlong]),
+    "etd_frontend_num_frames": (C.c_longlong, [C.c_void_p, C.c_longlong]),
+    "etd_frontend_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong,
+                                   C.POINTER(C.c_longlong), C.c_void_p]),
+    "etd_extractor_create": (C.c_int, [C.POINTER(ExtCfg), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_i64_p, C.c_int,
+                                       C.POINTER(C.c_void_p)]),
+    "etd_extractor_destroy": (None, [C.c_void_p]),
+    "etd_transcript": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong] + [C.c_void_p] * 8 + [C.c_void_p]),
+    "etd_transcript_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p]),
+    "etd_extractor_debug_vel_logits": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "etd_extractor_debug_tap": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "etd_extractor_window_flops": (C.c_double, [C.c_void_p]),
+    "etd_mpe2note": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_float,
+                               C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(Note), C.c_longlong, C.POINTER(C.c_longlong)]),
+    "etd_decoder_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_i64_p, C.c_int,
+                                     C.POINTER(C.c_void_p)]),
+    "etd_decoder_destroy": (None, [C.c_void_p]),
+    "etd_decoder_prefill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "etd_decoder_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "etd_decoder_set_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "etd_decoder_read_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_int_p, C.c_void_p]),
+    "etd_decoder_generate_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                           C.c_int, C.c_int, C.c_void_p, c_int_p, C.c_void_p]),
+    "etd_decoder_prefill_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                             C.c_void_p]),
+}
+
+_lib = None
+
+
+class EtudeHipError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the library; raises if it is missing -- there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise EtudeHipError(f"{LIB_PATH} not found: build it with `python -m etude_amd.build` "
+                                "(hipcc --offload-arch=gfx950); etude_amd has no CPU fallback")
+        l = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("ETD_PARTIAL") and not hasattr(l, name):
+                continue                   # bring-up only: a library built from a subset of the sources
+            fn = getattr(l, name)          # AttributeError if the .so does not export it: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().etd_last_error()
+        raise EtudeHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def weights_arrays(state: dict):
+    """name->float32 ndarray dict  ->  (names**, ptrs**, numels*, n, keepalive)."""
+    import numpy as np
+    names = list(state.keys())
+    arrs = [np.ascontiguousarray(np.asarray(state[k], dtype=np.float32)) for k in names]
+    c_names = (C.c_char_p * len(names))(*[k.encode() for k in names])
+    c_ptrs = (C.c_void_p * len(names))(*[a.ctypes.data for a in arrs])
+    c_num = (C.c_int64 * len(names))(*[a.size for a in arrs])
+    return c_names, c_ptrs, c_num, len(names), arrs

@@ -1,0 +1,66 @@
+"""Build libetude_hip.so (gfx950) in-tree with hipcc.  ``python -m etude_amd.build [--force]``.
+
+The shared object lands next to this file so that it travels with a repository snapshot; there is
+no JIT cache and no pip install.  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+OBJ = HERE / "csrc" / "_obj"
+LIB = HERE / "libetude_hip.so"
+SOURCES = ["ext_kernels.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "api_dec.hip", "mpe2note.cpp"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result",
+         "-I", str(HERE.parent / "include")]
+# -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (Path(c).exists() or c == "hipcc"):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    OBJ.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "etude_hip.h"]
+    newest_h = max(h.stat().st_mtime for h in headers)
+    objs = []
+    rebuilt = False
+    procs = []
+    for s in SOURCES:
+        src = CSRC / s
+        if not src.exists():
+            continue
+        o = OBJ / (s + ".o")
+        objs.append(o)
+        if force or not o.exists() or o.stat().st_mtime < max(src.stat().st_mtime, newest_h):
+            cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(o)]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            rebuilt = True
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    if rebuilt or not LIB.exists():
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", *map(str, objs), "-o", str(LIB)]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}")
+    return LIB
+
+
+if __name__ == "__main__":
+    p = build(force="--force" in sys.argv, verbose=True)
+    print("built", p)

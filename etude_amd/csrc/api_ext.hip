@@ -1,0 +1,487 @@
+// C-ABI glue for the Extract stage: weight preparation (fp32 checkpoint -> bf16 device layout,
+// conv+linear folding, QKV concatenation, constant query precompute) and the launch sequence of
+// _Spec2MIDI.forward / AMTAPC_Extractor._transcript (etude/data/extractor.py:53-56,199-253).
+#include <map>
+#include <string>
+#include <vector>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/etude_hip.h"
+#include "ext_kernels.h"
+
+thread_local std::string g_etd_err;
+extern "C" const char* etd_last_error(void) { return g_etd_err.c_str(); }
+extern "C" int etd_version(void) { return ETD_ABI_VERSION; }
+
+namespace {
+
+struct DevPool {   // everything the extractor allocates; freed in destroy
+  std::vector<void*> ptrs;
+  template <typename T> int alloc(T** p, size_t n, bool zero = false) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, n * sizeof(T) + 256));
+    if (zero) HIP_TRY(hipMemset(q, 0, n * sizeof(T) + 256));
+    ptrs.push_back(q);
+    *p = (T*)q;
+    return ETD_OK;
+  }
+  void free_all() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
+};
+
+inline uint16_t f2bf(float f) {   // round-to-nearest-even, NaN kept
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct LinW { bf16* W = nullptr; float* b = nullptr; };
+struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; };
+struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; };
+
+}  // namespace
+
+struct etd_ext {
+  etd_ext_cfg cfg;
+  DevPool pool;
+  int nf, nn, margin, wb, fc;
+  // weights
+  bf16* Wf = nullptr; float* bfold = nullptr; bf16* pos_freq_enc = nullptr;
+  EncLayerW enc[3];
+  DecLayerW dec[3];
+  bf16* q0 = nullptr;          // fc_q(pos_embedding_freq) of layer zero, [nn][256]
+  bf16* trg0 = nullptr;        // decoder.pos_embedding_freq [nn][256]
+  float* pos_time = nullptr;   // [nf][256] fp32
+  EncLayerW tim[3];
+  LinW head_time, head_freq;   // [160][256]
+  bf16* Wkv_all = nullptr; float* bkv_all = nullptr;   // the 3 cross-attention K/V projections, z-batched [3][512][256]
+  // workspaces (bf16 unless noted)
+  size_t MT = 0, MQ = 0;       // token capacities
+  bf16 *X = nullptr, *X1 = nullptr, *QK = nullptr, *VT = nullptr, *AO = nullptr, *HF = nullptr;
+  bf16 *Kc = nullptr, *VTc = nullptr;              // [3][MTe][256] each
+  bf16 *Tq = nullptr, *T1 = nullptr, *QKd = nullptr, *VTd = nullptr, *AOd = nullptr, *HFd = nullptr, *Qd = nullptr, *Tfreq = nullptr;
+  bf16* TI = nullptr;          // time-decoder input [wb*nn*nf][256]
+  size_t MTe = 0;              // encoder chunk token capacity (wb*fc*256)
+  float* dbg_vel = nullptr;
+  void* tap[16] = {nullptr};   // test hook: device destinations for intermediate activations (first chunk only)
+};
+
+namespace {
+
+struct Loader {
+  std::map<std::string, std::pair<const float*, int64_t>> t;
+  const float* get(const std::string& k, int64_t numel) {
+    auto it = t.find(k);
+    if (it == t.end()) { g_etd_err = "missing weight '" + k + "'"; return nullptr; }
+    if (it->second.second != numel) { g_etd_err = "weight '" + k + "' has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel); return nullptr; }
+    return it->second.first;
+  }
+};
+
+int up_bf16(DevPool& pool, bf16** dst, const float* src, size_t n) {
+  std::vector<uint16_t> h(n);
+  for (size_t i = 0; i < n; ++i) h[i] = f2bf(src[i]);
+  ETD_TRY(pool.alloc(dst, n));
+  HIP_TRY(hipMemcpy(*dst, h.data(), n * 2, hipMemcpyHostToDevice));
+  return ETD_OK;
+}
+int up_f32(DevPool& pool, float** dst, const float* src, size_t n) {
+  ETD_TRY(pool.alloc(dst, n));
+  HIP_TRY(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+  return ETD_OK;
+}
+int load_lin(DevPool& pool, Loader& L, const std::string& pfx, int out_f, int in_f, LinW* w) {
+  const float* W = L.get(pfx + ".weight", (int64_t)out_f * in_f);
+  const float* b = L.get(pfx + ".bias", out_f);
+  if (!W || !b) return ETD_EINVAL;
+  ETD_TRY(up_bf16(pool, &w->W, W, (size_t)out_f * in_f));
+  ETD_TRY(up_f32(pool, &w->b, b, out_f));
+  return ETD_OK;
+}
+// concatenate several [256][256] linears along the output dim
+int load_cat(DevPool& pool, Loader& L, const std::vector<std::string>& pfx, LinW* w, std::vector<float>* keepW = nullptr, std::vector<float>* keepB = nullptr) {
+  std::vector<float> W, b;
+  for (auto& p : pfx) {
+    const float* Wi = L.get(p + ".weight", 256 * 256);
+    const float* bi = L.get(p + ".bias", 256);
+    if (!Wi || !bi) return ETD_EINVAL;
+    W.insert(W.end(), Wi, Wi + 256 * 256);
+    b.insert(b.end(), bi, bi + 256);
+  }
+  ETD_TRY(up_bf16(pool, &w->W, W.data(), W.size()));
+  ETD_TRY(up_f32(pool, &w->b, b.data(), b.size()));
+  if (keepW) *keepW = W;
+  if (keepB) *keepB = b;
+  return ETD_OK;
+}
+int load_ln(DevPool& pool, Loader& L, const std::string& pfx, float** g, float** b) {
+  const float* gw = L.get(pfx + ".weight", 256);
+  const float* bw = L.get(pfx + ".bias", 256);
+  if (!gw || !bw) return ETD_EINVAL;
+  ETD_TRY(up_f32(pool, g, gw, 256));
+  ETD_TRY(up_f32(pool, b, bw, 256));
+  return ETD_OK;
+}
+int load_enc_layer(DevPool& pool, Loader& L, const std::string& p, EncLayerW* w) {
+  ETD_TRY(load_cat(pool, L, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, &w->qkv));
+  ETD_TRY(load_lin(pool, L, p + ".self_attention.fc_o", 256, 256, &w->o));
+  ETD_TRY(load_lin(pool, L, p + ".positionwise_feedforward.fc_1", 512, 256, &w->f1));
+  ETD_TRY(load_lin(pool, L, p + ".positionwise_feedforward.fc_2", 256, 512, &w->f2));
+  ETD_TRY(load_ln(pool, L, p + ".layer_norm", &w->g, &w->be));
+  return ETD_OK;
+}
+int load_heads(DevPool& pool, Loader& L, const std::string& sfx, LinW* w) {
+  std::vector<float> W(160 * 256, 0.f), b(160, 0.f);
+  const float* vw = L.get("decoder.fc_velocity_" + sfx + ".weight", 128 * 256);
+  const float* vb = L.get("decoder.fc_velocity_" + sfx + ".bias", 128);
+  if (!vw || !vb) return ETD_EINVAL;
+  memcpy(W.data(), vw, 128 * 256 * 4);
+  memcpy(b.data(), vb, 128 * 4);
+  const char* nm[3] = {"onset", "offset", "mpe"};
+  for (int i = 0; i < 3; ++i) {
+    const float* hw = L.get(std::string("decoder.fc_") + nm[i] + "_" + sfx + ".weight", 256);
+    const float* hb = L.get(std::string("decoder.fc_") + nm[i] + "_" + sfx + ".bias", 1);
+    if (!hw || !hb) return ETD_EINVAL;
+    memcpy(W.data() + (128 + i) * 256, hw, 256 * 4);
+    b[128 + i] = hb[0];
+  }
+  ETD_TRY(up_bf16(pool, &w->W, W.data(), W.size()));
+  ETD_TRY(up_f32(pool, &w->b, b.data(), b.size()));
+  return ETD_OK;
+}
+
+}  // namespace
+
+extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* names, const float* const* host_ptrs,
+                                    const int64_t* numels, int n, etd_ext** out) {
+  if (!cfg || !names || !host_ptrs || !numels || !out) ETD_FAIL(ETD_EINVAL, "extractor_create: null argument");
+  const etd_ext_cfg& c = *cfg;
+  // The kernels are specialised for the reference's default architecture (schema.py:103-112).
+  if (c.hid_dim != 256 || c.n_heads != 4 || c.pf_dim != 512 || c.n_bin != 256 || c.n_margin != 32 || c.cnn_channel != 4 ||
+      c.cnn_kernel != 5 || c.n_layers_enc != 3 || c.n_layers_dec != 3 || c.n_velocity != 128)
+    ETD_FAIL(ETD_EINVAL, "extractor_create: unsupported architecture (kernels are built for hid 256 / 4 heads / pf 512 / 256 bins / margin 32 / cnn 4x5 / 3+3 layers / 128 velocities)");
+  if (c.n_frame < 32 || c.n_frame % 32 || c.n_note < 4 || c.n_note % 4 || c.n_note > 128 || c.max_windows < 1)
+    ETD_FAIL(ETD_EINVAL, "extractor_create: need n_frame %% 32 == 0, n_note %% 4 == 0 and <= 128, max_windows >= 1");
+  etd_ext* e = new etd_ext();
+  e->cfg = c; e->nf = c.n_frame; e->nn = c.n_note; e->margin = c.n_margin; e->wb = c.max_windows;
+  e->fc = c.chunk_frames > 0 ? c.chunk_frames : 128;
+  if (const char* s = getenv("ETD_CHUNK_FRAMES")) e->fc = atoi(s);
+  if (e->fc > e->nf) e->fc = e->nf;
+  if (e->fc < 1) e->fc = e->nf;
+  Loader L;
+  for (int i = 0; i < n; ++i) L.t[names[i]] = {host_ptrs[i], numels[i]};
+  DevPool& P = e->pool;
+  auto fail = [&](int rc) { e->pool.free_all(); delete e; return rc; };
+
+  // ---- front end: fold Conv2d(1,4,(1,5)) and Linear(244,256) into one [256][65] map (amt_apc.py:79-99)
+  {
+    const float* cw = L.get("encoder.conv.weight", 4 * 5);
+    const float* cb = L.get("encoder.conv.bias", 4);
+    const float* tw = L.get("encoder.tok_embedding_freq.weight", 256 * 244);
+    const float* tb = L.get("encoder.tok_embedding_freq.bias", 256);
+    const float* pe = L.get("encoder.pos_embedding_freq.weight", 256 * 256);
+    if (!cw || !cb || !tw || !tb || !pe) return fail(ETD_EINVAL);
+    const float center = -8.0f;
+    std::vector<float> Wf(256 * 80, 0.f), bf(256);
+    for (int o = 0; o < 256; ++o) {
+      double fold[65] = {0};
+      double bacc = tb[o];
+      for (int ch = 0; ch < 4; ++ch)
+        for (int p = 0; p < 61; ++p) {
+          const double w = tw[o * 244 + ch * 61 + p];
+          bacc += w * cb[ch];
+          for (int k = 0; k < 5; ++k) fold[p + k] += w * cw[ch * 5 + k];
+        }
+      double wsum = 0;
+      for (int t = 0; t < 65; ++t) {
+        Wf[o * 80 + t] = (float)fold[t];
+        uint16_t q = f2bf((float)fold[t]); uint32_t u = (uint32_t)q << 16; float wq; memcpy(&wq, &u, 4);
+        wsum += wq;                                 // the kernel multiplies by the bf16-rounded weight
+      }
+      bf[o] = (float)(bacc + (double)center * wsum);  // x = (x - center) + center
+    }
+    int rc = up_bf16(P, &e->Wf, Wf.data(), Wf.size()); if (rc) return fail(rc);
+    rc = up_f32(P, &e->bfold, bf.data(), 256); if (rc) return fail(rc);
+    rc = up_bf16(P, &e->pos_freq_enc, pe, 256 * 256); if (rc) return fail(rc);
+  }
+  for (int i = 0; i < 3; ++i) { int rc = load_enc_layer(P, L, "encoder.layers_freq." + std::to_string(i), &e->enc[i]); if (rc) return fail(rc); }
+  for (int i = 0; i < 3; ++i) { int rc = load_enc_layer(P, L, "decoder.layers_time." + std::to_string(i), &e->tim[i]); if (rc) return fail(rc); }
+  // ---- frequency decoder
+  std::vector<float> kvW, kvB;
+  for (int i = 0; i < 3; ++i) {
+    const std::string p = i == 0 ? std::string("decoder.layer_zero_freq") : "decoder.layers_freq." + std::to_string(i - 1);
+    DecLayerW& w = e->dec[i];
+    int rc;
+    w.has_self = i > 0;
+    if (w.has_self) {
+      rc = load_cat(P, L, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, &w.qkv_s); if (rc) return fail(rc);
+      rc = load_lin(P, L, p + ".self_attention.fc_o", 256, 256, &w.o_s); if (rc) return fail(rc);
+    }
+    rc = load_lin(P, L, p + ".encoder_attention.fc_q", 256, 256, &w.q_c); if (rc) return fail(rc);
+    std::vector<float> W1, b1;
+    rc = load_cat(P, L, {p + ".encoder_attention.fc_k", p + ".encoder_attention.fc_v"}, &w.kv_c, &W1, &b1); if (rc) return fail(rc);
+    kvW.insert(kvW.end(), W1.begin(), W1.end()); kvB.insert(kvB.end(), b1.begin(), b1.end());
+    rc = load_lin(P, L, p + ".encoder_attention.fc_o", 256, 256, &w.o_c); if (rc) return fail(rc);
+    rc = load_lin(P, L, p + ".positionwise_feedforward.fc_1", 512, 256, &w.f1); if (rc) return fail(rc);
+    rc = load_lin(P, L, p + ".positionwise_feedforward.fc_2", 256, 512, &w.f2); if (rc) return fail(rc);
+    rc = load_ln(P, L, p + ".layer_norm", &w.g, &w.be); if (rc) return fail(rc);
+  }
+  { int rc = up_bf16(P, &e->Wkv_all, kvW.data(), kvW.size()); if (rc) return fail(rc);
+    rc = up_f32(P, &e->bkv_all, kvB.data(), kvB.size()); if (rc) return fail(rc); }
+  {
+    const int nn = e->nn;
+    const float* pe = L.get("decoder.pos_embedding_freq.weight", (int64_t)nn * 256);
+    const float* qw = L.get("decoder.layer_zero_freq.encoder_attention.fc_q.weight", 256 * 256);
+    const float* qb = L.get("decoder.layer_zero_freq.encoder_attention.fc_q.bias", 256);
+    const float* pt = L.get("decoder.pos_embedding_time.weight", (int64_t)e->nf * 256);
+    if (!pe || !qw || !qb || !pt) return fail(ETD_EINVAL);
+    // layer-zero queries are input independent: fc_q(pos_embedding_freq) (amt_apc.py:168-175,342)
+    std::vector<float> q0((size_t)nn * 256);
+    for (int r = 0; r < nn; ++r)
+      for (int o = 0; o < 256; ++o) {
+        double s = qb[o];
+        for (int k = 0; k < 256; ++k) s += (double)pe[r * 256 + k] * qw[o * 256 + k];
+        q0[(size_t)r * 256 + o] = (float)s;
+      }
+    int rc = up_bf16(P, &e->q0, q0.data(), q0.size()); if (rc) return fail(rc);
+    rc = up_bf16(P, &e->trg0, pe, (size_t)nn * 256); if (rc) return fail(rc);
+    rc = up_f32(P, &e->pos_time, pt, (size_t)e->nf * 256); if (rc) return fail(rc);
+  }
+  { int rc = load_heads(P, L, "time", &e->head_time); if (rc) return fail(rc);
+    rc = load_heads(P, L, "freq", &e->head_freq); if (rc) return fail(rc); }
+
+  // ---- workspaces
+  const size_t MTe = (size_t)e->wb * e->fc * 256;           // encoder tokens per chunk
+  const size_t MTt = (size_t)e->wb * e->nn * e->nf;         // time-decoder tokens per window batch
+  const size_t MT = MTe > MTt ? MTe : MTt;
+  const size_t MQ = (size_t)e->wb * e->fc * e->nn;          // freq-decoder query tokens per chunk
+  e->MT = MT; e->MQ = MQ; e->MTe = MTe;
+  int rc = 0;
+  rc = rc ? rc : P.alloc(&e->X, MT * 256);
+  rc = rc ? rc : P.alloc(&e->X1, MT * 256);
+  rc = rc ? rc : P.alloc(&e->QK, MT * 512);
+  rc = rc ? rc : P.alloc(&e->VT, MT * 256, true);
+  rc = rc ? rc : P.alloc(&e->AO, MT * 256);
+  rc = rc ? rc : P.alloc(&e->HF, MT * 512);
+  rc = rc ? rc : P.alloc(&e->Kc, 3 * MTe * 256);
+  rc = rc ? rc : P.alloc(&e->VTc, 3 * MTe * 256, true);
+  rc = rc ? rc : P.alloc(&e->Tq, MQ * 256);
+  rc = rc ? rc : P.alloc(&e->T1, MQ * 256);
+  rc = rc ? rc : P.alloc(&e->Tfreq, MQ * 256);
+  rc = rc ? rc : P.alloc(&e->QKd, MQ * 512);
+  rc = rc ? rc : P.alloc(&e->VTd, (size_t)e->wb * e->fc * 4 * 64 * 128, true);   // S = nn <= 128 padded to 128; pad stays 0
+  rc = rc ? rc : P.alloc(&e->AOd, MQ * 256);
+  rc = rc ? rc : P.alloc(&e->HFd, MQ * 512);
+  rc = rc ? rc : P.alloc(&e->Qd, MQ * 256);
+  rc = rc ? rc : P.alloc(&e->TI, MTt * 256);
+  if (rc) return fail(rc);
+  HIP_TRY(hipDeviceSynchronize());
+  *out = e;
+  return ETD_OK;
+}
+
+extern "C" void etd_extractor_destroy(etd_ext* e) {
+  if (!e) return;
+  e->pool.free_all();
+  delete e;
+}
+
+extern "C" int etd_extractor_debug_vel_logits(etd_ext* e, float* p) { if (!e) ETD_FAIL(ETD_EINVAL, "null"); e->dbg_vel = p; return ETD_OK; }
+
+extern "C" int etd_extractor_debug_tap(etd_ext* e, int stage, void* dst_dev) {
+  if (!e || stage < 0 || stage >= 16) ETD_FAIL(ETD_EINVAL, "debug_tap: bad stage");
+  e->tap[stage] = dst_dev;
+  return ETD_OK;
+}
+
+extern "C" double etd_extractor_window_flops(const etd_ext* e) {
+  // lin(t,i,o)=2tio; attn(N,q,k)=4*N*q*k*256 (4 heads x 64)
+  const double nf = e->nf, nb = 256, nn = e->nn, H = 256, PF = 512;
+  auto lin = [](double t, double i, double o) { return 2 * t * i * o; };
+  auto attn = [](double N, double q, double k) { return 4 * N * q * k * 256; };
+  const double te = nf * nb, tq = nf * nn;
+  double enc_layer = 4 * lin(te, H, H) + attn(nf, nb, nb) + lin(te, H, PF) + lin(te, PF, H);
+  double conv = 2 * te * 4 * 61 * 5, embed = lin(te, 244, H);
+  double d0 = lin(tq, H, H) + 2 * lin(te, H, H) + attn(nf, nn, nb) + lin(tq, H, H) + lin(tq, H, PF) + lin(tq, PF, H);
+  double dn = d0 + 4 * lin(tq, H, H) + attn(nf, nn, nn);
+  double heads = lin(tq, H, 131);
+  double time_layer = 4 * lin(tq, H, H) + attn(nn, nf, nf) + lin(tq, H, PF) + lin(tq, PF, H);
+  return conv + embed + 3 * enc_layer + d0 + 2 * dn + heads + 3 * time_layer + heads;
+}
+
+namespace {
+
+const float kScaleLog2e = 0.125f * 1.4426950408889634f;
+
+int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int n_seq, int S, hipStream_t st,
+                   bf16* Yfinal /* where the 2nd LN writes (X to run in place) */) {
+  // x = LN(x + MHA(x)); x = LN(x + FFN(x))          amt_apc.py:244-259
+  LinArgs a = {};
+  a.X = X; a.ldx = 256; a.W = w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = 768; a.K = 256;
+  a.Y = e->QK; a.ldy = 512; a.vt_block = 2; a.VT = e->VT; a.S = S; a.Spad = ((S + 63) / 64) * 64;
+  ETD_TRY(launch_linear(a, 1, st));
+  AttnArgs t = {};
+  t.Q = e->QK; t.ldq = 512; t.q_seq_stride = (long long)S * 512;
+  t.K = e->QK + 256; t.ldk = 512; t.k_seq_stride = (long long)S * 512;
+  t.VT = e->VT; t.Spad = a.Spad;
+  t.O = e->AO; t.ldo = 256; t.o_seq_stride = (long long)S * 256;
+  t.n_seq = n_seq; t.Sq = S; t.Sk = S; t.scale_log2e = kScaleLog2e;
+  ETD_TRY(launch_attn(t, st));
+  LinArgs o = {};
+  o.X = e->AO; o.ldx = 256; o.W = w.o.W; o.bias = w.o.b; o.M = M; o.N = 256; o.K = 256; o.vt_block = -1;
+  o.R = X; o.ldr = 256; o.gamma = w.g; o.beta = w.be; o.Y = X1; o.ldy = 256;
+  ETD_TRY(launch_linear_ln(o, st));
+  LinArgs f1 = {};
+  f1.X = X1; f1.ldx = 256; f1.W = w.f1.W; f1.bias = w.f1.b; f1.M = M; f1.N = 512; f1.K = 256; f1.vt_block = -1; f1.relu = 1;
+  f1.Y = e->HF; f1.ldy = 512;
+  ETD_TRY(launch_linear(f1, 1, st));
+  LinArgs f2 = {};
+  f2.X = e->HF; f2.ldx = 512; f2.W = w.f2.W; f2.bias = w.f2.b; f2.M = M; f2.N = 256; f2.K = 512; f2.vt_block = -1;
+  f2.R = X1; f2.ldr = 256; f2.gamma = w.g; f2.beta = w.be; f2.Y = Yfinal; f2.ldy = 256;
+  ETD_TRY(launch_linear_ln(f2, st));
+  return ETD_OK;
+}
+
+struct Outs { float *on, *off, *mpe; int8_t* vel; };
+
+int tap(etd_ext* e, int stage, const void* src, size_t bytes, bool first, hipStream_t st) {
+  if (first && e->tap[stage]) HIP_TRY(hipMemcpyAsync(e->tap[stage], src, bytes, hipMemcpyDeviceToDevice, st));
+  return ETD_OK;
+}
+
+// windows [w0, w0+nw) of the current call; src describes where their input lives
+int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long long out_row0, Outs B, Outs A, bool wantA, hipStream_t st) {
+  const int nf = e->nf, nn = e->nn;
+  for (int f0 = 0; f0 < nf; f0 += e->fc) {
+    const int fc = (nf - f0) < e->fc ? (nf - f0) : e->fc;
+    const int Mtok = nw * fc * 256, Mq = nw * fc * nn, nfr = nw * fc;
+    // ---- encoder (amt_apc.py:74-120)
+    EmbedArgs ea = src_tmpl;
+    ea.Wf = e->Wf; ea.bf = e->bfold; ea.pos = e->pos_freq_enc; ea.Y = e->X; ea.w0 = w0; ea.n_win = nw; ea.f0 = f0; ea.fc = fc;
+    ea.nf = nf; ea.margin = e->margin; ea.center = -8.0f; ea.pad_value = e->cfg.min_value;
+    ETD_TRY(launch_embed(ea, st));
+    const bool first = (w0 == 0 && f0 == 0);
+    ETD_TRY(tap(e, 0, e->X, (size_t)Mtok * 512, first, st));
+    for (int l = 0; l < 3; ++l) {
+      ETD_TRY(enc_like_layer(e, e->enc[l], e->X, e->X1, Mtok, nfr, 256, st, e->X));
+      ETD_TRY(tap(e, 1 + l, e->X, (size_t)Mtok * 512, first, st));
+    }
+    // ---- cross-attention K/V of the encoder output for the 3 decoder layers, one z-batched launch pair
+    {
+      LinArgs a = {};
+      a.X = e->X; a.ldx = 256; a.W = e->Wkv_all; a.bias = e->bkv_all; a.M = Mtok; a.N = 512; a.K = 256;
+      a.Y = e->Kc; a.ldy = 256; a.vt_block = 1; a.VT = e->VTc; a.S = 256; a.Spad = 256;
+      a.wz = 512 * 256; a.bz = 512; a.yz = (long long)e->MTe * 256; a.vtz = (long long)e->MTe * 256;
+      ETD_TRY(launch_linear(a, 3, st));
+    }
+    // ---- frequency decoder (amt_apc.py:168-177,261-320): queries = 88 note embeddings per frame
+    // D0 = layer input/output, D1 = after self-attention LN, D2 = after cross-attention LN
+    bf16 *D0 = e->Tq, *D1 = e->T1, *D2 = e->Tfreq;
+    for (int l = 0; l < 3; ++l) {
+      const DecLayerW& w = e->dec[l];
+      const bf16* cross_in = D0;        // residual + query source of the cross-attention block
+      int r_mod = 0;
+      if (l == 0) { cross_in = e->trg0; r_mod = nn; }
+      if (w.has_self) {
+        LinArgs a = {};
+        a.X = D0; a.ldx = 256; a.W = w.qkv_s.W; a.bias = w.qkv_s.b; a.M = Mq; a.N = 768; a.K = 256;
+        a.Y = e->QKd; a.ldy = 512; a.vt_block = 2; a.VT = e->VTd; a.S = nn; a.Spad = 128;
+        ETD_TRY(launch_linear(a, 1, st));
+        AttnArgs t = {};
+        t.Q = e->QKd; t.ldq = 512; t.q_seq_stride = (long long)nn * 512;
+        t.K = e->QKd + 256; t.ldk = 512; t.k_seq_stride = (long long)nn * 512;
+        t.VT = e->VTd; t.Spad = 128; t.O = e->AOd; t.ldo = 256; t.o_seq_stride = (long long)nn * 256;
+        t.n_seq = nfr; t.Sq = nn; t.Sk = nn; t.scale_log2e = kScaleLog2e;
+        ETD_TRY(launch_attn(t, st));
+        LinArgs o = {};
+        o.X = e->AOd; o.ldx = 256; o.W = w.o_s.W; o.bias = w.o_s.b; o.M = Mq; o.N = 256; o.K = 256; o.vt_block = -1;
+        o.R = D0; o.ldr = 256; o.gamma = w.g; o.beta = w.be; o.Y = D1; o.ldy = 256;
+        ETD_TRY(launch_linear_ln(o, st));
+        cross_in = D1;
+      }
+      AttnArgs t = {};
+      if (l == 0) {
+        t.Q = e->q0; t.ldq = 256; t.q_seq_stride = 0;       // constant queries, precomputed at load
+      } else {
+        LinArgs q = {};
+        q.X = cross_in; q.ldx = 256; q.W = w.q_c.W; q.bias = w.q_c.b; q.M = Mq; q.N = 256; q.K = 256; q.vt_block = -1;
+        q.Y = e->Qd; q.ldy = 256;
+        ETD_TRY(launch_linear(q, 1, st));
+        t.Q = e->Qd; t.ldq = 256; t.q_seq_stride = (long long)nn * 256;
+      }
+      t.K = e->Kc + (size_t)l * e->MTe * 256; t.ldk = 256; t.k_seq_stride = 256LL * 256;
+      t.VT = e->VTc + (size_t)l * e->MTe * 256; t.Spad = 256;
+      t.O = e->AOd; t.ldo = 256; t.o_seq_stride = (long long)nn * 256;
+      t.n_seq = nfr; t.Sq = nn; t.Sk = 256; t.scale_log2e = kScaleLog2e;
+      ETD_TRY(launch_attn(t, st));
+      LinArgs o = {};
+      o.X = e->AOd; o.ldx = 256; o.W = w.o_c.W; o.bias = w.o_c.b; o.M = Mq; o.N = 256; o.K = 256; o.vt_block = -1;
+      o.R = cross_in; o.ldr = 256; o.r_mod = r_mod; o.gamma = w.g; o.beta = w.be; o.Y = D2; o.ldy = 256;
+      ETD_TRY(launch_linear_ln(o, st));
+      LinArgs f1 = {};
+      f1.X = D2; f1.ldx = 256; f1.W = w.f1.W; f1.bias = w.f1.b; f1.M = Mq; f1.N = 512; f1.K = 256; f1.vt_block = -1; f1.relu = 1;
+      f1.Y = e->HFd; f1.ldy = 512;
+      ETD_TRY(launch_linear(f1, 1, st));
+      LinArgs f2 = {};
+      f2.X = e->HFd; f2.ldx = 512; f2.W = w.f2.W; f2.bias = w.f2.b; f2.M = Mq; f2.N = 256; f2.K = 512; f2.vt_block = -1;
+      f2.R = D2; f2.ldr = 256; f2.gamma = w.g; f2.beta = w.be; f2.Y = D0; f2.ldy = 256;
+      ETD_TRY(launch_linear_ln(f2, st));
+      ETD_TRY(tap(e, 4 + l, D0, (size_t)Mq * 512, first, st));
+    }
+    // freq -> time layout of this chunk, *16 + pos_embedding_time (amt_apc.py:203-205); optional A heads (:186-189)
+    ETD_TRY(launch_freq2time(D0, e->TI, e->pos_time, nw, fc, f0, nf, nn, st));
+    if (wantA) {
+      for (int wl = 0; wl < nw; ++wl) {
+        HeadsArgs h = {};
+        h.X = D0 + (size_t)wl * fc * nn * 256; h.W = e->head_freq.W; h.bias = e->head_freq.b; h.M = fc * nn; h.time_layout = 0;
+        h.nf = nf; h.nn = nn; h.out_off = out_row0 * nn + ((long long)wl * nf + f0) * nn;
+        h.onset = A.on; h.offset = A.off; h.mpe = A.mpe; h.vel = A.vel;
+        ETD_TRY(launch_heads(h, st));
+      }
+    }
+  }
+  // ---- time decoder (amt_apc.py:211-220): nw*nn sequences of nf frames
+  const int Mt = nw * nn * nf;
+  ETD_TRY(tap(e, 7, e->TI, (size_t)Mt * 512, w0 == 0, st));
+  for (int l = 0; l < 3; ++l) {
+    ETD_TRY(enc_like_layer(e, e->tim[l], e->TI, e->X1, Mt, nw * nn, nf, st, e->TI));
+    ETD_TRY(tap(e, 8 + l, e->TI, (size_t)Mt * 512, w0 == 0, st));
+  }
+  HeadsArgs h = {};
+  h.X = e->TI; h.W = e->head_time.W; h.bias = e->head_time.b; h.M = Mt; h.time_layout = 1; h.nf = nf; h.nn = nn;
+  h.out_off = out_row0 * nn;
+  h.onset = B.on; h.offset = B.off; h.mpe = B.mpe; h.vel = B.vel;
+  h.vel_logit = e->dbg_vel ? e->dbg_vel + out_row0 * nn * 128 : nullptr;
+  ETD_TRY(launch_heads(h, st));
+  return ETD_OK;
+}
+
+int run_all(etd_ext* e, EmbedArgs src, int n_windows, Outs B, Outs A, hipStream_t st) {
+  const bool wantA = A.on && A.off && A.mpe && A.vel;
+  for (int w0 = 0; w0 < n_windows; w0 += e->wb) {
+    const int nw = (n_windows - w0) < e->wb ? (n_windows - w0) : e->wb;
+    ETD_TRY(run_window_batch(e, src, w0, nw, (long long)w0 * e->nf, B, A, wantA, st));
+  }
+  return ETD_OK;
+}
+
+}  // namespace
+
+extern "C" int etd_transcript(etd_ext* e, const float* feat_dev, long long T, float* onset_B, float* offset_B, float* mpe_B,
+                              int8_t* vel_B, float* onset_A, float* offset_A, float* mpe_A, int8_t* vel_A, void* stream) {
+  if (!e || !feat_dev || T <= 0 || !onset_B || !offset_B || !mpe_B || !vel_B) ETD_FAIL(ETD_EINVAL, "transcript: bad args");
+  EmbedArgs s = {};
+  s.src = feat_dev; s.feat_mode = 1; s.T = T; s.s_t = 256; s.s_bin = 1; s.s_win = 0;
+  const int nwin = (int)((T + e->nf - 1) / e->nf);
+  return run_all(e, s, nwin, Outs{onset_B, offset_B, mpe_B, vel_B}, Outs{onset_A, offset_A, mpe_A, vel_A}, (hipStream_t)stream);
+}
+
+extern "C" int etd_transcript_windows(etd_ext* e, const float* spec_dev, int B, float* onset_B, float* offset_B, float* mpe_B,
+                                      int8_t* vel_B, float* onset_A, float* offset_A, float* mpe_A, int8_t* vel_A, void* stream) {
+  if (!e || !spec_dev || B <= 0 || !onset_B || !offset_B || !mpe_B || !vel_B) ETD_FAIL(ETD_EINVAL, "transcript_windows: bad args");
+  EmbedArgs s = {};
+  const long long nin = e->nf + 2 * e->margin;
+  s.src = spec_dev; s.feat_mode = 0; s.s_win = 256 * nin; s.s_bin = nin; s.s_t = 1;
+  return run_all(e, s, B, Outs{onset_B, offset_B, mpe_B, vel_B}, Outs{onset_A, offset_A, mpe_A, vel_A}, (hipStream_t)stream);
+}

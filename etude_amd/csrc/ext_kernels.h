@@ -1,0 +1,74 @@
+// Kernel argument structs + launchers for the hFT-Transformer (Extract stage) kernels.
+#pragma once
+#include "common.h"
+
+// ---- generic token-major linear layer:  Y = epi(X[M,K] * W[N,K]^T + bias) -----------------------
+// All activations are bf16 row-major with 256-multiple feature counts; weights keep nn.Linear's
+// [out][in] layout (K contiguous), which is exactly the MFMA operand layout for both operands.
+struct LinArgs {
+  const bf16* X; int ldx;            // [M, K]
+  const bf16* W;                     // [N, K]
+  const float* bias;                 // [N]
+  int M, N, K;                       // K % 64 == 0, N % 256 == 0
+  bf16* Y; int ldy;                  // row-major destination for n-blocks < vt_block (may be null if all go to VT)
+  int nb0;                           // (set by the launcher) first 256-feature block of this launch
+  int vt_block;                      // blockIdx.y == vt_block -> that 256-feature block is stored TRANSPOSED (V^T); -1 none
+  bf16* VT; int S, Spad;             // VT[((seq*4+head)*64+d)*Spad + pos], seq = m / S, pos = m % S
+  int relu;
+  // z-batching (several weight sets over the same X): per-blockIdx.z element offsets
+  long long wz, bz, yz, vtz;
+  // LayerNorm epilogue (N == 256): Y = LN(acc + bias + R) * gamma + beta
+  const bf16* R; int ldr; int r_mod;  // residual row = r_mod > 0 ? m % r_mod : m
+  const float* gamma; const float* beta;
+};
+int launch_linear(const LinArgs& a, int nz, hipStream_t st);
+int launch_linear_ln(const LinArgs& a, hipStream_t st);
+
+// ---- multi-head attention, head_dim 64, 4 heads, non-causal -------------------------------------
+struct AttnArgs {
+  const bf16* Q; int ldq; long long q_seq_stride;   // Q row = seq*q_seq_stride/ldq.. (elements): Q + seq*q_seq_stride + q*ldq + head*64
+  const bf16* K; int ldk; long long k_seq_stride;   // K + seq*k_seq_stride + key*ldk + head*64
+  const bf16* VT; int Spad;                          // VT + ((seq*4+head)*64 + d)*Spad + key
+  bf16* O; int ldo; long long o_seq_stride;          // O + seq*o_seq_stride + q*ldo + head*64
+  int n_seq, Sq, Sk;
+  float scale_log2e;                                 // (1/sqrt(64)) * log2(e)
+};
+int launch_attn(const AttnArgs& a, hipStream_t st);
+
+// ---- front-end embedding: unfold(65) + conv(1x5) + Linear(244,256) folded to one 65->256 map ----
+struct EmbedArgs {
+  const float* src;            // features
+  long long s_win, s_bin, s_t; // element strides of src for (window, bin, time-in-window)
+  int feat_mode;               // 1: src is [T][n_bin] features, time t of window w is frame w*nf + t - margin (pad value outside [0,T))
+  long long T;                 // valid frames (feat_mode)
+  float pad_value;             // -18.0
+  float center;                // value subtracted before bf16 rounding (folded into bias)
+  const bf16* Wf;              // [256][80] folded weights (K padded 65->80 with zeros)
+  const float* bf;             // [256] folded bias (incl. center * sum_t Wf)
+  const bf16* pos;             // [256 bins][256] bf16 pos_embedding_freq
+  bf16* Y;                     // [(w_local*fc + f_local)*256 + bin][256]
+  int w0, n_win;               // first window, number of windows in this launch
+  int f0, fc;                  // first frame within the window, frames in this chunk
+  int nf, margin;
+};
+int launch_embed(const EmbedArgs& a, hipStream_t st);
+
+// ---- output heads: 3 x Linear(256,1)+sigmoid (fp32) and Linear(256,128)+argmax -> int8 ----------
+struct HeadsArgs {
+  const bf16* X;               // [M, 256]
+  const bf16* W;               // [160][256]: rows 0..127 velocity, 128 onset, 129 offset, 130 mpe, rest 0
+  const float* bias;           // [160]
+  int M;
+  int time_layout;             // 1: m=(w*nn+note)*nf+f -> out[(w*nf+f)*nn+note];  0: out[m]
+  int nf, nn;
+  long long out_off;           // element offset added to the output index
+  float* onset; float* offset; float* mpe; int8_t* vel;
+  float* vel_logit;            // optional debug: [.. ][128] fp32 logits (null in production)
+};
+int launch_heads(const HeadsArgs& a, hipStream_t st);
+
+// freq-major [ (wl*fc+fl)*nn + note ][256] -> time-major TI[ (wl*nn+note)*nf + f0+fl ][256] = x*16 + pos_time[f0+fl]
+int launch_freq2time(const bf16* src, bf16* dst, const float* pos, int nw, int fc, int f0, int nf, int nn, hipStream_t st);
+
+// small utilities
+int launch_f32_to_bf16(const float* src, bf16* dst, long long n, hipStream_t st);

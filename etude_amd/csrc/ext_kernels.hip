@@ -1,0 +1,561 @@
+// hFT-Transformer (AMT-APC) kernels for gfx950: token-major bf16 activations, fp32 accumulate,
+// v_mfma_f32_32x32x16_bf16 everywhere.  Reference ops: etude/models/amt_apc.py (cited per kernel).
+//
+// Orientation convention ("swapped"): for Y = X W^T we issue mfma(A = W rows, B = X rows) so the
+// accumulator holds Y^T: the TOKEN sits on the lane (col = lane&31) and the FEATURES sit in the 16
+// registers (row = (i&3) + 8*(i>>2) + 4*(lane>>5)).  A token's row statistics (LayerNorm, softmax,
+// argmax) are then lane-local plus one exchange with lane^32, and 4 consecutive features pack into
+// one 8-byte row-major store.  Issuing the same two fragments the other way round gives Y with the
+// feature on the lane, which is how V is written out pre-transposed (V^T) for the attention kernel.
+#include "ext_kernels.h"
+
+#define LDK 72  // LDS row stride (elements) of a 64-wide bf16 K-chunk: 144 B, 16-B aligned, conflict-free ds_read_b128
+
+// ================================================================================================
+// k_linear: Y = X W^T + b  (+ReLU | + residual + LayerNorm)       amt_apc.py:342-344,371,386-389,250,256
+// Workgroup 256 threads = 4 waves; each wave owns 32 tokens x 256 features (8 accumulators).
+// ================================================================================================
+template <bool NORMAL_ORIENT>
+__device__ __forceinline__ void lin_chunk(const bf16* Xs, const bf16* Ws, int wave, int r, int h, f32x16 (&acc)[8]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + (wave * 32 + r) * LDK + s * 16 + h * 8);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + (t * 32 + r) * LDK + s * 16 + h * 8);
+      if (NORMAL_ORIENT) acc[t] = mfma32(xf, wf, acc[t]);   // D[token][feature]
+      else               acc[t] = mfma32(wf, xf, acc[t]);   // D[feature][token]
+    }
+  }
+}
+
+__device__ __forceinline__ void lin_gload(const bf16* X, int ldx, int M, int K, const bf16* W, int m0, int tid, int kc,
+                                          u32x4 (&xr)[4], u32x4 (&wr)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    int gm = m0 + row; gm = gm < M ? gm : M - 1;
+    xr[i] = *reinterpret_cast<const u32x4*>(X + (long long)gm * ldx + kc * 64 + ch * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    wr[i] = *reinterpret_cast<const u32x4*>(W + (long long)row * K + kc * 64 + ch * 8);
+  }
+}
+__device__ __forceinline__ void lin_lstore(bf16* Xs, bf16* Ws, int tid, const u32x4 (&xr)[4], const u32x4 (&wr)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    *reinterpret_cast<u32x4*>(Xs + row * LDK + ch * 8) = xr[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    *reinterpret_cast<u32x4*>(Ws + row * LDK + ch * 8) = wr[i];
+  }
+}
+
+// MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
+  constexpr bool LN = MODE == 2;
+  constexpr bool vt = MODE == 1;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 256) * LDK * 2 + 3 * 256 * 4];
+  bf16* Xs = reinterpret_cast<bf16*>(smem);
+  bf16* Ws = Xs + 128 * LDK;
+  float* sb = reinterpret_cast<float*>(smem + (128 + 256) * LDK * 2);   // bias | gamma | beta
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128, nb = blockIdx.y + a.nb0, n0 = nb * 256, z = blockIdx.z;
+  const bf16* W = a.W + (long long)z * a.wz + (long long)n0 * a.K;
+  const float* bias = a.bias + (long long)z * a.bz + n0;
+
+  sb[tid] = bias[tid];
+  if (LN) { sb[256 + tid] = a.gamma[tid]; sb[512 + tid] = a.beta[tid]; }
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // staging: X tile 128 rows x 8 chunks(16 B) = 4 per thread; W tile 256 rows x 8 chunks = 8 per thread
+  u32x4 xr[4], wr[8];
+  const int nk = a.K >> 6;
+  lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, 0, xr, wr);
+  for (int kc = 0; kc < nk; ++kc) {
+    lin_lstore(Xs, Ws, tid, xr, wr);
+    __syncthreads();
+    if (kc + 1 < nk) lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, kc + 1, xr, wr);   // next chunk's reads fly under this chunk's MFMAs
+    lin_chunk<vt>(Xs, Ws, wave, r, h, acc);
+    __syncthreads();
+  }
+
+  if constexpr (!LN) {
+    if constexpr (vt) {
+      // accumulator: col = feature (lane), rows = tokens.  Store V^T[(seq,head,d)][pos], 4 tokens = 8 B.
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int f = t * 32 + r;                       // feature inside this 256-block
+        const float b = sb[f];
+        const int head = f >> 6, d = f & 63;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int m = m0 + wave * 32 + 8 * q + 4 * h;
+          if (m < a.M) {
+            const int seq = m / a.S, pos = m - seq * a.S;
+            float v0 = acc[t][4 * q + 0] + b, v1 = acc[t][4 * q + 1] + b, v2 = acc[t][4 * q + 2] + b, v3 = acc[t][4 * q + 3] + b;
+            bf16* dst = a.VT + (long long)z * a.vtz + ((long long)(seq * 4 + head) * 64 + d) * a.Spad + pos;
+            *reinterpret_cast<bf16x4*>(dst) = pack4(v0, v1, v2, v3);
+          }
+        }
+      }
+    } else {
+      const int m = m0 + wave * 32 + r;
+      if (m < a.M) {
+        bf16* yrow = a.Y + (long long)z * a.yz + (long long)m * a.ldy + n0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int f = t * 32 + 8 * q + 4 * h;
+            float v0 = acc[t][4 * q + 0] + sb[f + 0], v1 = acc[t][4 * q + 1] + sb[f + 1];
+            float v2 = acc[t][4 * q + 2] + sb[f + 2], v3 = acc[t][4 * q + 3] + sb[f + 3];
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            *reinterpret_cast<bf16x4*>(yrow + f) = pack4(v0, v1, v2, v3);
+          }
+      }
+    }
+  } else {
+    // residual + LayerNorm over the 256 features of this lane's token (128 here, 128 in lane^32)
+    const int m = m0 + wave * 32 + r;
+    const int mc = m < a.M ? m : a.M - 1;
+    const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
+    const bf16* rp = a.R + (long long)rrow * a.ldr;
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = t * 32 + 8 * q + 4 * h;
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rp + f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[t][4 * q + j] + sb[f + j] + bf2f(rv[j]);
+          acc[t][4 * q + j] = v;
+          s1 += v;
+        }
+      }
+    s1 += xhalf(s1);
+    const float mean = s1 * (1.f / 256.f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float dlt = acc[t][i] - mean; s2 += dlt * dlt; }
+    s2 += xhalf(s2);
+    const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);
+    if (m < a.M) {
+      bf16* y1 = a.Y + (long long)m * a.ldy;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int f = t * 32 + 8 * q + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (acc[t][4 * q + j] - mean) * rstd * sb[256 + f + j] + sb[512 + f + j];
+          *reinterpret_cast<bf16x4*>(y1 + f) = pack4(v[0], v[1], v[2], v[3]);
+        }
+    }
+  }
+}
+
+int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
+  if (a.K % 64 || a.N % 256 || a.M <= 0) ETD_FAIL(ETD_EINVAL, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.vt_block >= 0 && (a.S % 4 || a.Spad % 4 || !a.VT)) ETD_FAIL(ETD_EINVAL, "linear: bad V^T args");
+  // row-major blocks [0, vt_block) (or all), then the V^T block as its own launch (orientation is a
+  // compile-time property of the MFMA loop)
+  const int nblk = a.N / 256;
+  const int n_plain = a.vt_block >= 0 ? a.vt_block : nblk;
+  if (a.vt_block >= 0 && a.vt_block != nblk - 1) ETD_FAIL(ETD_EINVAL, "linear: V^T block must be the last block");
+  if (n_plain > 0) {
+    LinArgs b = a; b.nb0 = 0;
+    hipLaunchKernelGGL(k_linear<0>, dim3((a.M + 127) / 128, n_plain, nz), dim3(256), 0, st, b);
+  }
+  if (a.vt_block >= 0) {
+    LinArgs b = a; b.nb0 = a.vt_block;
+    hipLaunchKernelGGL(k_linear<1>, dim3((a.M + 127) / 128, 1, nz), dim3(256), 0, st, b);
+  }
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+int launch_linear_ln(const LinArgs& a, hipStream_t st) {
+  if (a.K % 64 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta) ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
+  dim3 g((a.M + 127) / 128, 1, 1);
+  LinArgs b = a; b.nb0 = 0;
+  hipLaunchKernelGGL(k_linear<2>, g, dim3(256), 0, st, b);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
+// k_attn: softmax(Q K^T / 8) V per (sequence, head)                           amt_apc.py:349-368
+// S^T = K Q^T is accumulated with the QUERY on the lane, so the online-softmax state (m, l) and the
+// rescale of O^T are per-lane scalars; P^T feeds the PV product straight from the accumulator
+// registers (guide §3 "accumulator tile as the next MFMA's operand"), V^T comes from LDS.
+// Workgroup = 4 waves x 32 queries; KV tiles of 64 keys.
+// ================================================================================================
+#define LDV 68  // V^T tile row stride (elements): 136 B -> conflict-free ds_read_b64 across 32 d-rows
+
+__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * LDK * 2 + 64 * LDV * 2];
+  bf16* Ks = reinterpret_cast<bf16*>(smem);
+  bf16* Vs = Ks + 64 * LDK;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int seq = blockIdx.y >> 2, head = blockIdx.y & 3;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  int qi = q0 + r; const bool qvalid = qi < a.Sq; if (!qvalid) qi = a.Sq - 1;
+
+  const bf16* qp = a.Q + (long long)seq * a.q_seq_stride + (long long)qi * a.ldq + head * 64;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16 + h * 8);
+
+  const bf16* kbase = a.K + (long long)seq * a.k_seq_stride + head * 64;
+  const bf16* vbase = a.VT + ((long long)(seq * 4 + head) * 64) * a.Spad;
+
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  const int ntile = (a.Sk + 63) >> 6;
+  for (int jt = 0; jt < ntile; ++jt) {
+    const int kv0 = jt * 64;
+    // stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]: 512 16-B chunks each, 2 per thread
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      int key = kv0 + row; key = key < a.Sk ? key : a.Sk - 1;
+      const uint4 kvv = *reinterpret_cast<const uint4*>(kbase + (long long)key * a.ldk + ch * 8);
+      *reinterpret_cast<uint4*>(Ks + row * LDK + ch * 8) = kvv;
+      const uint4 vv = *reinterpret_cast<const uint4*>(vbase + (long long)row * a.Spad + kv0 + ch * 8);
+      uint2* vd = reinterpret_cast<uint2*>(Vs + row * LDV + ch * 8);
+      vd[0] = make_uint2(vv.x, vv.y);
+      vd[1] = make_uint2(vv.z, vv.w);
+    }
+    __syncthreads();
+
+    // S^T[key][query] for the two 32-key sub-tiles
+    f32x16 sT[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sT[kt][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * LDK + s * 16 + h * 8);
+        sT[kt] = mfma32(kf, qf[s], sT[kt]);
+      }
+    }
+    // scale, mask keys >= Sk, running max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int key = kv0 + kt * 32 + acc_row(i, h);
+        float v = sT[kt][i] * a.scale_log2e;
+        v = key < a.Sk ? v : -INFINITY;
+        sT[kt][i] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, xhalf(mx));
+    const float mnew = fmaxf(mrun, mx);          // finite: every tile holds >= 1 valid key
+    const float alpha = exp2f(mrun - mnew);
+    mrun = mnew;
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float p = exp2f(sT[kt][i] - mnew); sT[kt][i] = p; ps += p; }
+    lrun = lrun * alpha + ps;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+
+    // O^T[d][query] += V^T[d][key] * P^T[key][query]; k-step ks covers keys 16ks..16ks+15 in the
+    // accumulator's own (permuted) order: element j <-> key 16ks + 8(j>>2) + 4h + (j&3)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[ks >> 1][8 * (ks & 1) + j];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const bf16* vrow = Vs + (dt * 32 + r) * LDV + ks * 16 + 4 * h;
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
+        const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        o[dt] = mfma32(vf, pf, o[dt]);
+      }
+    }
+    __syncthreads();
+  }
+
+  lrun += xhalf(lrun);
+  const float inv = 1.f / lrun;
+  if (qvalid) {
+    bf16* op = a.O + (long long)seq * a.o_seq_stride + (long long)(q0 + r) * a.ldo + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int d = dt * 32 + 8 * q + 4 * h;
+        *reinterpret_cast<bf16x4*>(op + d) = pack4(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
+      }
+  }
+}
+
+int launch_attn(const AttnArgs& a, hipStream_t st) {
+  if (a.Sq <= 0 || a.Sk <= 0 || a.n_seq <= 0 || a.Spad % 64 || a.Spad < ((a.Sk + 63) / 64) * 64)
+    ETD_FAIL(ETD_EINVAL, "attn: bad shape Sq=%d Sk=%d Spad=%d", a.Sq, a.Sk, a.Spad);
+  dim3 g((a.Sq + 127) / 128, a.n_seq * 4);
+  hipLaunchKernelGGL(k_attn, g, dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
+// k_embed: unfold(2,65,1) -> Conv2d(1,4,(1,5)) -> Linear(244,256) -> *16 + pos_embedding_freq
+//                                                                             amt_apc.py:79-109
+// There is no non-linearity between the conv and the linear, so they are folded on the host into
+// one [256][65] map (K padded to 80).  Workgroup: 32 bins x 64 frames; each wave 16 frames.
+// ================================================================================================
+#define LDE 88    // folded-weight LDS row stride (elements): 176 B
+#define EFB 64    // frames per workgroup
+#define ELDX 33   // spec tile row stride (floats): [time][32 bins + 1]
+#define ELDP 260  // pos tile row stride (elements)
+
+__global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[256 * LDE * 2 + (EFB + 80) * ELDX * 4 + 32 * ELDP * 2 + 256 * 4];
+  bf16* Wsm = reinterpret_cast<bf16*>(smem);
+  float* Xsm = reinterpret_cast<float*>(smem + 256 * LDE * 2);
+  bf16* Psm = reinterpret_cast<bf16*>(smem + 256 * LDE * 2 + (EFB + 80) * ELDX * 4);
+  float* bsm = reinterpret_cast<float*>(smem + 256 * LDE * 2 + (EFB + 80) * ELDX * 4 + 32 * ELDP * 2);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int b0 = blockIdx.x * 32;
+  const int fl0 = blockIdx.y * EFB;              // first frame of this block inside the chunk
+  const int wl = blockIdx.z, w = a.w0 + wl;
+
+  // folded weights [256][80] -> LDS (10 chunks of 16 B per row)
+  for (int c = tid; c < 256 * 10; c += 256) {
+    const int row = c / 10, ch = c - row * 10;
+    *reinterpret_cast<uint4*>(Wsm + row * LDE + ch * 8) = *reinterpret_cast<const uint4*>(a.Wf + row * 80 + ch * 8);
+  }
+  bsm[tid] = a.bf[tid];
+  // pos rows for the 32 bins
+  for (int c = tid; c < 32 * 32; c += 256) {
+    const int row = c >> 5, ch = c & 31;
+    *reinterpret_cast<uint4*>(Psm + row * ELDP + ch * 8) = *reinterpret_cast<const uint4*>(a.pos + (long long)(b0 + row) * 256 + ch * 8);
+  }
+  // spec tile: times (f0+fl0) .. +EFB+80 of window w, 32 bins; centred
+  const int t_base = a.f0 + fl0;
+  for (int c = tid; c < (EFB + 80) * 32; c += 256) {
+    const int tr = c >> 5, bin = c & 31;
+    const int t = t_base + tr;                     // time index inside the window's input [0, nf + 2*margin)
+    float v = 0.f;
+    if (t < a.nf + 2 * a.margin) {
+      if (a.feat_mode) {
+        const long long g = (long long)w * a.nf + t - a.margin;
+        v = (g >= 0 && g < a.T) ? a.src[g * a.s_t + (long long)(b0 + bin) * a.s_bin] : a.pad_value;
+      } else {
+        v = a.src[(long long)w * a.s_win + (long long)(b0 + bin) * a.s_bin + (long long)t * a.s_t];
+      }
+      v -= a.center;
+    }
+    Xsm[tr * ELDX + bin] = v;
+  }
+  __syncthreads();
+
+  for (int fi = 0; fi < EFB / 4; ++fi) {
+    const int fl = wave * (EFB / 4) + fi;          // frame inside the block
+    if (fl0 + fl >= a.fc) break;                   // wave-uniform
+    f32x16 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      bf16x8 xf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) xf[j] = (bf16)Xsm[(fl + s * 16 + h * 8 + j) * ELDX + r];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wsm + (t * 32 + r) * LDE + s * 16 + h * 8);
+        acc[t] = mfma32(wf, xf, acc[t]);
+      }
+    }
+    bf16* yrow = a.Y + ((long long)(wl * a.fc + fl0 + fl) * 256 + b0 + r) * 256;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = t * 32 + 8 * q + 4 * h;
+        const bf16x4 p = *reinterpret_cast<const bf16x4*>(Psm + r * ELDP + f);
+        *reinterpret_cast<bf16x4*>(yrow + f) =
+            pack4((acc[t][4 * q + 0] + bsm[f + 0]) * 16.f + bf2f(p[0]), (acc[t][4 * q + 1] + bsm[f + 1]) * 16.f + bf2f(p[1]),
+                  (acc[t][4 * q + 2] + bsm[f + 2]) * 16.f + bf2f(p[2]), (acc[t][4 * q + 3] + bsm[f + 3]) * 16.f + bf2f(p[3]));
+      }
+  }
+}
+
+int launch_embed(const EmbedArgs& a, hipStream_t st) {
+  if (a.fc <= 0 || a.n_win <= 0 || a.margin != 32) ETD_FAIL(ETD_EINVAL, "embed: bad args");
+  dim3 g(8, (a.fc + EFB - 1) / EFB, a.n_win);
+  hipLaunchKernelGGL(k_embed, g, dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
+// k_heads: onset/offset/mpe = sigmoid(Linear(256,1)) in fp32, velocity = argmax(Linear(256,128))
+//                                           amt_apc.py:186-189,217-220 + extractor.py:242,248
+// Swapped orientation: a token's 128 velocity logits sit in two lanes (l, l^32) -> argmax is
+// lane-local + one exchange.  Ties resolve to the lowest index like torch.argmax.
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_heads(HeadsArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 160) * LDK * 2 + 160 * 4];
+  bf16* Xs = reinterpret_cast<bf16*>(smem);
+  bf16* Ws = Xs + 128 * LDK;
+  float* sb = reinterpret_cast<float*>(smem + (128 + 160) * LDK * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128;
+  if (tid < 160) sb[tid] = a.bias[tid];
+  f32x16 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  for (int kc = 0; kc < 4; ++kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
+      *reinterpret_cast<uint4*>(Xs + row * LDK + ch * 8) = *reinterpret_cast<const uint4*>(a.X + (long long)gm * 256 + kc * 64 + ch * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      *reinterpret_cast<uint4*>(Ws + row * LDK + ch * 8) = *reinterpret_cast<const uint4*>(a.W + (long long)row * 256 + kc * 64 + ch * 8);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + (wave * 32 + r) * LDK + s * 16 + h * 8);
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + (t * 32 + r) * LDK + s * 16 + h * 8);
+        acc[t] = mfma32(wf, xf, acc[t]);
+      }
+    }
+    __syncthreads();
+  }
+  const int m = m0 + wave * 32 + r;
+  // velocity argmax over this lane's 64 logits, then against the other half
+  float best = -INFINITY; int bidx = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = t * 32 + acc_row(i, h);
+      const float v = acc[t][i] + sb[n];
+      acc[t][i] = v;
+      if (v > best || (v == best && n < bidx)) { best = v; bidx = n; }
+    }
+  const float ob = xhalf(best);
+  const int oi = __shfl_xor(bidx, 32, 64);
+  if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  if (m < a.M) {
+    long long oidx;
+    if (a.time_layout) {
+      const int per_w = a.nn * a.nf;
+      const int w = m / per_w, rem = m - w * per_w, note = rem / a.nf, f = rem - note * a.nf;
+      oidx = ((long long)w * a.nf + f) * a.nn + note;
+    } else {
+      oidx = m;
+    }
+    oidx += a.out_off;
+    if (h == 0) {
+      a.vel[oidx] = (int8_t)bidx;
+      const float lo = acc[4][0] + sb[128], lf = acc[4][1] + sb[129], lm = acc[4][2] + sb[130];
+      a.onset[oidx] = 1.f / (1.f + expf(-lo));
+      a.offset[oidx] = 1.f / (1.f + expf(-lf));
+      a.mpe[oidx] = 1.f / (1.f + expf(-lm));
+    }
+    if (a.vel_logit) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a.vel_logit[oidx * 128 + t * 32 + acc_row(i, h)] = acc[t][i];
+    }
+  }
+}
+
+int launch_heads(const HeadsArgs& a, hipStream_t st) {
+  if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "heads: bad M");
+  hipLaunchKernelGGL(k_heads, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
+// freq-major decoder state -> time-major time-decoder input, *sqrt(256) + pos_embedding_time
+//                                                                             amt_apc.py:203-205
+__global__ void k_freq2time(const bf16* __restrict__ src, bf16* __restrict__ dst, const float* __restrict__ pos,
+                            int nw, int fc, int f0, int nf, int nn) {
+  const long long total = (long long)nw * fc * nn * 32;           // 16-byte chunks
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int ch = (int)(i & 31);
+    const long long row = i >> 5;                                 // (wl*fc + fl)*nn + note
+    const int note = (int)(row % nn);
+    const long long fr = row / nn;
+    const int fl = (int)(fr % fc), wl = (int)(fr / fc);
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + row * 256 + ch * 8);
+    const float* pp = pos + (long long)(f0 + fl) * 256 + ch * 8;
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)(bf2f(v[j]) * 16.f + pp[j]);
+    *reinterpret_cast<bf16x8*>(dst + (((long long)wl * nn + note) * nf + f0 + fl) * 256 + ch * 8) = o;
+  }
+}
+int launch_freq2time(const bf16* src, bf16* dst, const float* pos, int nw, int fc, int f0, int nf, int nn, hipStream_t st) {
+  const long long total = (long long)nw * fc * nn * 32;
+  long long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_freq2time, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, pos, nw, fc, f0, nf, nn);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
+__global__ void k_f32_to_bf16(const float* __restrict__ s, bf16* __restrict__ d, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) d[i] = (bf16)s[i];
+}
+int launch_f32_to_bf16(const float* src, bf16* dst, long long n, hipStream_t st) {
+  if (n <= 0) return ETD_OK;
+  long long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}

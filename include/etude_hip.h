@@ -1,0 +1,142 @@
+/* etude_hip.h -- C ABI of libetude_hip.so: the MI355X (gfx950) implementation of Etude's two compute
+ * hot paths.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (Xiugapurin/Etude) is pure Python and has no FFI; the "interface each entry point
+ * replaces" is therefore the Python call it stands in for (file:line under /root/reference):
+ *
+ *   etd_frontend_*        AMTAPC_Extractor._wav2feature               etude/data/extractor.py:178-197
+ *                         (torchaudio Resample + MelSpectrogram + log)
+ *   etd_extractor_create  _load_model + _Spec2MIDI construction        etude/data/extractor.py:78-113
+ *   etd_transcript        AMTAPC_Extractor._transcript                 etude/data/extractor.py:199-253
+ *   etd_transcript_windows  _Spec2MIDI.forward on [B,n_bin,n_frame+2m] etude/data/extractor.py:53-56,
+ *                         = Model_SPEC2MIDI.forward                    etude/models/amt_apc.py:29-49
+ *   etd_mpe2note          AMTAPC_Extractor._mpe2note + _note2json filter etude/data/extractor.py:256-418,432-443
+ *   etd_decoder_create    load_etude_decoder + EtudeDecoder.__init__   etude/utils/model_loader.py:12-60,
+ *                                                                      etude/models/etude_decoder.py:94-123
+ *   etd_decoder_prefill / etd_decoder_step / etd_decoder_read_tokens
+ *                         the body of EtudeDecoder.generate's token loop: forward (embeddings +
+ *                         GPT-NeoX + lm_head) + greedy argmax + KV cache  etude/models/etude_decoder.py:300-343,148-206
+ *   etd_decoder_generate_bar  one bar of generate(): prefill + <=limit greedy steps, stop at Bar_EOS
+ *                                                                      etude/models/etude_decoder.py:291-343
+ *
+ * Conventions: every function returns 0 on success or a negative errno-style code (ETD_E*); the
+ * message is available from etd_last_error() (thread-local).  "dev" pointers are device (HBM)
+ * addresses valid in the calling process's HIP context, "host" pointers are ordinary memory.  The
+ * caller owns every buffer it passes; the library owns only what *_create allocated and frees it in
+ * *_destroy.  `stream` is a hipStream_t (NULL = default stream).  Calls on one handle are not
+ * re-entrant; launches are asynchronous on `stream` unless stated otherwise.
+ */
+#ifndef ETUDE_HIP_H
+#define ETUDE_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ETD_ABI_VERSION 1
+#define ETD_OK 0
+#define ETD_EINVAL (-22)
+#define ETD_ENOMEM (-12)
+#define ETD_EHIP (-5)
+
+int etd_version(void);
+const char* etd_last_error(void);
+
+/* ------------------------------------------------------------------ audio front end */
+typedef struct etd_frontend etd_frontend;
+/* Tables are built by the host layer exactly as torchaudio builds them:
+ *   kernT_host [K][nw]   polyphase sinc kernel, transposed (k-major); orig/nw = sr_in/gcd, sr_out/gcd
+ *   window_host[n_fft]   periodic Hann
+ *   mel filterbank in CSR form: filter m covers power-spectrum bins [mel_start[m], +mel_len[m]) with
+ *   weights mel_w[sum(mel_len[:m]) ...].  */
+int etd_frontend_create(int sr_in, int sr_out, int orig, int nw, int K, int width, const float* kernT_host,
+                        int n_fft, int hop, const float* window_host, int n_mels, const int* mel_start,
+                        const int* mel_len, const float* mel_w_host, float log_offset, etd_frontend** out);
+void etd_frontend_destroy(etd_frontend*);
+long long etd_frontend_resampled_len(const etd_frontend*, long long n_in);
+long long etd_frontend_num_frames(const etd_frontend*, long long n_in);
+/* wav_dev: planar [channels][n_in] fp32.  resampled_dev: scratch >= resampled_len floats.
+ * feat_dev: [T][n_mels] fp32 log-mel, T = 1 + resampled_len / hop (written to *n_frames_out). */
+int etd_frontend_run(etd_frontend*, const float* wav_dev, int channels, long long n_in, float* resampled_dev,
+                     float* feat_dev, long long feat_capacity_frames, long long* n_frames_out, void* stream);
+
+/* ------------------------------------------------------------------ extractor (hFT-Transformer) */
+typedef struct etd_ext etd_ext;
+typedef struct {
+  int n_margin, n_frame, n_bin, cnn_channel, cnn_kernel, hid_dim, pf_dim, n_heads;
+  int n_layers_enc, n_layers_dec, n_note, n_velocity;
+  float min_value;        /* -18.0: padding value of _transcript */
+  int max_windows;        /* windows processed per internal batch (workspace size) */
+  int chunk_frames;       /* frames per encoder/freq-decoder chunk (0 = default) */
+} etd_ext_cfg;
+/* Weights: n named fp32 host tensors with the reference checkpoint's own keys ("encoder.*",
+ * "decoder.*"); every key the model needs must be present with the right element count. */
+int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* names, const float* const* host_ptrs,
+                         const int64_t* numels, int n, etd_ext** out);
+void etd_extractor_destroy(etd_ext*);
+/* feat_dev [T][n_bin] fp32 -> outputs over T_pad = ceil(T/n_frame)*n_frame rows of n_note:
+ * onset/offset/mpe fp32 probabilities and int8 velocity argmax of the time ("B") heads; the "A"
+ * (frequency) head outputs are produced only when all four *_A pointers are non-NULL. */
+int etd_transcript(etd_ext*, const float* feat_dev, long long T,
+                   float* onset_B, float* offset_B, float* mpe_B, int8_t* vel_B,
+                   float* onset_A, float* offset_A, float* mpe_A, int8_t* vel_A, void* stream);
+/* spec_dev [B][n_bin][n_frame + 2*n_margin] fp32 (the model's own input layout) -> [B*n_frame][n_note]. */
+int etd_transcript_windows(etd_ext*, const float* spec_dev, int B,
+                           float* onset_B, float* offset_B, float* mpe_B, int8_t* vel_B,
+                           float* onset_A, float* offset_A, float* mpe_A, int8_t* vel_A, void* stream);
+/* test hook: fp32 velocity logits of the time heads [rows][n_note][128] for the NEXT transcript call (NULL = off) */
+int etd_extractor_debug_vel_logits(etd_ext*, float* vel_logits_dev);
+/* test hook: after stage s of the FIRST chunk copy the bf16 activation buffer to dst_dev (NULL = off).
+ * 0 embed, 1-3 encoder layers, 4-6 freq-decoder layers [frames*n_note][256], 7 time input, 8-10 time layers. */
+int etd_extractor_debug_tap(etd_ext*, int stage, void* dst_dev);
+/* algorithmic FLOPs of one n_frame window (SURVEY.md 8d formula) */
+double etd_extractor_window_flops(const etd_ext*);
+
+/* ------------------------------------------------------------------ notes (host) */
+typedef struct { double onset, offset; int32_t pitch, velocity; } etd_note;
+/* onset/offset/mpe [T][n_note] fp32 host, velocity [T][n_note] int8 host -> notes sorted by (onset, pitch).
+ * Keeps the reference's numerics as it runs under numpy>=2 (see oracle/mpe2note.py).  Returns the
+ * number of notes in *n_out; fails with ETD_ENOMEM if cap is too small (n_out = needed). */
+int etd_mpe2note(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T,
+                 int n_note, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr,
+                 int note_min, etd_note* out, long long cap, long long* n_out);
+
+/* ------------------------------------------------------------------ decoder (EtudeDecoder / GPT-NeoX) */
+typedef struct etd_dec etd_dec;
+typedef struct {
+  int vocab_size, hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
+  int max_position_embeddings, num_classes, num_attribute_bins, attribute_emb_dim;
+  float rotary_pct, rope_theta, layer_norm_eps;
+  int max_streams;        /* concurrent token streams (KV slots) */
+  int max_ctx;            /* KV positions per stream */
+  int precision;          /* 0 = fp32 weights/activations (token-parity mode), 1 = bf16 weights */
+} etd_dec_cfg;
+int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
+                       const int64_t* numels, int n, etd_dec** out);
+void etd_decoder_destroy(etd_dec*);
+/* Reset stream `slot` and run the prompt through the model (KV cache filled, position = T).
+ * ids/cls: int32 host [T]; attrs: int32 host [4][T] in the order pitch_overlap, polyphony,
+ * note_sustain, rhythm_intensity (the concat order of etude_decoder.py:171-176).  The greedy next
+ * token is left in the stream's device-side "current token" cell.  */
+int etd_decoder_prefill(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T, void* stream);
+/* One greedy decode step for n_active streams (slot ids in host array): feeds each stream's current
+ * token (class TGT=2, the stream's target attrs), appends K/V, writes the argmax as the new current
+ * token and into the stream's output ring.  No host sync, no allocation: graph-capturable. */
+int etd_decoder_step(etd_dec*, const int32_t* slots, int n_active, void* stream);
+/* Set per-stream generation state: target attrs (4), eos id (streams freeze once they emit it). */
+int etd_decoder_set_stream(etd_dec*, int slot, const int32_t* attrs4, int eos_id);
+/* Copy out the tokens generated so far by `slot` (synchronises the stream). Returns count in *n. */
+int etd_decoder_read_tokens(etd_dec*, int slot, int32_t* out, int cap, int* n, void* stream);
+/* Convenience: prefill + up to `limit` greedy steps with EOS stop for one stream; tokens (incl. the
+ * first token produced by the prefill) are returned on the host.  Synchronous. */
+int etd_decoder_generate_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
+                             const int32_t* tgt_attrs4, int eos_id, int limit, int32_t* out, int* n_out, void* stream);
+/* test hook: logits [T][vocab] fp32 (device) of the last prefill on `slot` are copied to host. */
+int etd_decoder_prefill_logits(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
+                               float* logits_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
