@@ -1,0 +1,28 @@
+"""etude_amd -- MI355X-native (gfx950) implementation of Etude's Extract and Decode hot paths.
+
+Drop-in surfaces (same names/signatures as the reference):
+    etude_amd.AMTAPC_Extractor      <- etude.data.extractor.AMTAPC_Extractor
+    etude_amd.load_etude_decoder    <- etude.utils.model_loader.load_etude_decoder
+    etude_amd.EtudeDecoder.generate <- etude.models.etude_decoder.EtudeDecoder.generate
+    etude_amd.Vocab / Event         <- etude.data.vocab
+All arithmetic runs in libetude_hip.so (hand-written HIP, see csrc/); importing the heavy
+modules is lazy so that `import etude_amd` works on a box without a GPU.
+"""
+__all__ = ["AMTAPC_Extractor", "EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder", "Vocab", "Event",
+           "ExtractorConfig", "DecoderConfig"]
+
+
+def __getattr__(name):
+    if name == "AMTAPC_Extractor":
+        from .extractor import AMTAPC_Extractor
+        return AMTAPC_Extractor
+    if name in ("EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder"):
+        from . import decoder
+        return getattr(decoder, name)
+    if name in ("Vocab", "Event"):
+        from . import vocab
+        return getattr(vocab, name)
+    if name in ("ExtractorConfig", "DecoderConfig"):
+        from . import config
+        return getattr(config, name)
+    raise AttributeError(name)

@@ -65,14 +65,16 @@ SIGNATURES = {
     "etd_decoder_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_i64_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),
     "etd_decoder_destroy": (None, [C.c_void_p]),
-    "etd_decoder_prefill": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "etd_decoder_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
-    "etd_decoder_set_stream": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "etd_decoder_begin_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_void_p]),
+    "etd_decoder_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "etd_decoder_poll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "etd_decoder_read_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_int_p, C.c_void_p]),
     "etd_decoder_generate_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_int, C.c_int, C.c_void_p, c_int_p, C.c_void_p]),
     "etd_decoder_prefill_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p]),
+    "etd_decoder_step_bytes": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
 }
 
 _lib = None

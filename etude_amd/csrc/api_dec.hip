@@ -1,0 +1,393 @@
+// C-ABI glue for the Decode stage: EtudeDecoder weights -> device layout, per-stream KV cache and
+// generation state kept on the device, prefill / decode-step launch sequences.
+// Reference: etude/models/etude_decoder.py:148-206 (forward), :291-343 (token loop);
+// etude/utils/model_loader.py:12-60 (checkpoint contract).
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/etude_hip.h"
+#include "dec_kernels.h"
+
+namespace {
+
+inline uint16_t f2bf_h(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0; };
+struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down; };
+
+}  // namespace
+
+struct etd_dec {
+  etd_dec_cfg cfg;
+  std::vector<void*> allocs;
+  bool bf16w = false;
+  int H, I, V, L, nh, S, ctx, Mmax, out_cap;
+  float *word = nullptr, *cls_emb = nullptr, *attr_tab = nullptr;
+  std::vector<Layer> layers;
+  float *lnfg = nullptr, *lnfb = nullptr;
+  Lin head;
+  float *rope_cos = nullptr, *rope_sin = nullptr;
+  void *Kc = nullptr, *Vc = nullptr;             // [layer][slot][head][ctx][64]
+  long long slot_stride = 0, layer_stride = 0;   // elements
+  // workspaces
+  float *h = nullptr, *h2 = nullptr, *Q = nullptr, *AO = nullptr, *DO = nullptr, *M1 = nullptr, *logits = nullptr;
+  int *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *ids = nullptr, *slots_dev = nullptr;
+  // stream state
+  int *cur_tok = nullptr, *len = nullptr, *done = nullptr, *n_out = nullptr, *eos = nullptr, *limit = nullptr, *tgt_attrs = nullptr, *out_tok = nullptr;
+  std::vector<int> last_slots;                   // host copy of what slots_dev holds
+
+  template <typename T> int alloc(T** p, size_t n, bool zero = false) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, n * sizeof(T) + 256));
+    if (zero) HIP_TRY(hipMemset(q, 0, n * sizeof(T) + 256));
+    allocs.push_back(q);
+    *p = (T*)q;
+    return ETD_OK;
+  }
+};
+
+namespace {
+
+struct Loader {
+  std::map<std::string, std::pair<const float*, int64_t>> t;
+  const float* get(const std::string& k, int64_t numel) {
+    auto it = t.find(k);
+    if (it == t.end()) { g_etd_err = "missing weight '" + k + "'"; return nullptr; }
+    if (it->second.second != numel) { g_etd_err = "weight '" + k + "' has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel); return nullptr; }
+    return it->second.first;
+  }
+};
+
+int up_f32(etd_dec* d, float** dst, const float* src, size_t n) {
+  ETD_TRY(d->alloc(dst, n));
+  HIP_TRY(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+  return ETD_OK;
+}
+
+// weight [N][K] (+ bias [N] or null) -> device, rows padded with zeros to a multiple of 128
+int load_lin(etd_dec* d, Loader& L, const std::string& pfx, int N, int K, bool has_bias, Lin* w) {
+  const float* W = L.get(pfx + ".weight", (int64_t)N * K);
+  if (!W) return ETD_EINVAL;
+  const float* b = nullptr;
+  if (has_bias) { b = L.get(pfx + ".bias", N); if (!b) return ETD_EINVAL; }
+  const int Npad = ((N + 127) / 128) * 128;
+  w->N = N; w->Npad = Npad; w->K = K;
+  if (d->bf16w) {
+    std::vector<uint16_t> hb((size_t)Npad * K, 0);
+    for (size_t i = 0; i < (size_t)N * K; ++i) hb[i] = f2bf_h(W[i]);
+    uint16_t* p; ETD_TRY(d->alloc(&p, hb.size()));
+    HIP_TRY(hipMemcpy(p, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
+    w->W = p;
+  } else {
+    std::vector<float> hf((size_t)Npad * K, 0.f);
+    memcpy(hf.data(), W, (size_t)N * K * 4);
+    float* p; ETD_TRY(d->alloc(&p, hf.size()));
+    HIP_TRY(hipMemcpy(p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    w->W = p;
+  }
+  std::vector<float> hb2(Npad, 0.f);
+  if (b) memcpy(hb2.data(), b, (size_t)N * 4);
+  ETD_TRY(up_f32(d, &w->b, hb2.data(), Npad));
+  return ETD_OK;
+}
+
+int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst) {
+  const float* p = L.get(name, n);
+  if (!p) return ETD_EINVAL;
+  return up_f32(d, dst, p, n);
+}
+
+// one forward pass over M rows whose metadata (row_slot/row_pos/row_active) and embeddings (d->h) are
+// already on the device; leaves the final-LN'ed logits of rows [lrow0, lrow0+lrows) in d->logits
+int forward_layers(etd_dec* d, int M, int lrow0, int lrows, hipStream_t st) {
+  const DecRows rows{d->row_slot, d->row_pos, d->row_active};
+  float* hin = d->h; float* hout = d->h2;
+  const size_t esz = d->bf16w ? 2 : 4;
+  for (int l = 0; l < d->L; ++l) {
+    const Layer& w = d->layers[l];
+    DGemmArgs q = {};
+    q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
+    q.ln_g = w.ln1g; q.ln_b = w.ln1b; q.ln_eps = d->cfg.layer_norm_eps;
+    q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
+    q.Kc = (char*)d->Kc + (size_t)l * d->layer_stride * esz; q.Vc = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
+    q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
+    ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
+    DAttnArgs at = {};
+    at.Q = d->Q; at.Kc = q.Kc; at.Vc = q.Vc; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
+    at.rows = rows; at.M = M; at.O = d->AO; at.scale = 0.125f;
+    ETD_TRY(launch_dattn(at, d->bf16w, st));
+    DGemmArgs de = {};
+    de.X = d->AO; de.ldx = d->H; de.W = w.dense.W; de.bias = w.dense.b; de.M = M; de.N = d->H; de.Npad = w.dense.Npad; de.K = d->H;
+    de.Y = d->DO; de.ldy = d->H;
+    ETD_TRY(launch_dgemm(de, DEPI_BIAS, d->bf16w, st));
+    DGemmArgs up = {};
+    up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
+    up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; up.Y = d->M1; up.ldy = d->I;
+    ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
+    DGemmArgs dn = {};
+    dn.X = d->M1; dn.ldx = d->I; dn.W = w.down.W; dn.bias = w.down.b; dn.M = M; dn.N = d->H; dn.Npad = w.down.Npad; dn.K = d->I;
+    dn.add = d->DO; dn.hin = hin; dn.hout = hout;      // h = (mlp + attn) + h   (modeling_gpt_neox.py:272)
+    ETD_TRY(launch_dgemm(dn, DEPI_RESID, d->bf16w, st));
+    float* t = hin; hin = hout; hout = t;
+  }
+  DGemmArgs lm = {};
+  lm.X = hin + (size_t)lrow0 * d->H; lm.ldx = d->H; lm.W = d->head.W; lm.bias = nullptr; lm.M = lrows; lm.N = d->V; lm.Npad = d->head.Npad; lm.K = d->H;
+  lm.ln_g = d->lnfg; lm.ln_b = d->lnfb; lm.ln_eps = d->cfg.layer_norm_eps; lm.Y = d->logits + (size_t)lrow0 * d->V; lm.ldy = d->V;
+  ETD_TRY(launch_dgemm(lm, DEPI_LOGITS, d->bf16w, st));
+  if (hin != d->h) {   // keep the invariant "embeddings go to d->h" (even layer count leaves hin == d->h)
+    HIP_TRY(hipMemcpyAsync(d->h, hin, (size_t)M * d->H * 4, hipMemcpyDeviceToDevice, st));
+  }
+  return ETD_OK;
+}
+
+int check_slot(etd_dec* d, int slot) {
+  if (!d || slot < 0 || slot >= d->S) ETD_FAIL(ETD_EINVAL, "decoder: bad slot %d", slot);
+  return ETD_OK;
+}
+
+int prefill_common(etd_dec* d, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T, hipStream_t st) {
+  ETD_TRY(check_slot(d, slot));
+  if (!ids || !cls || !attrs4 || T <= 0 || T > d->ctx || T > d->Mmax) ETD_FAIL(ETD_EINVAL, "prefill: bad prompt (T=%d, max_ctx=%d)", T, d->ctx);
+  for (int i = 0; i < T; ++i) {
+    if (ids[i] < 0 || ids[i] >= d->V || cls[i] < 0 || cls[i] >= d->cfg.num_classes) ETD_FAIL(ETD_EINVAL, "prefill: token/class id out of range at %d", i);
+    for (int k = 0; k < 4; ++k) if (attrs4[k * T + i] < 0 || attrs4[k * T + i] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "prefill: attribute bin out of range at %d", i);
+  }
+  // staging layout in d->ids: [ids T][cls T][attrs 4T][row_slot T][row_pos T][row_active T]
+  std::vector<int> stage((size_t)9 * T);
+  memcpy(stage.data(), ids, (size_t)T * 4);
+  memcpy(stage.data() + T, cls, (size_t)T * 4);
+  memcpy(stage.data() + 2 * T, attrs4, (size_t)4 * T * 4);
+  for (int i = 0; i < T; ++i) { stage[6 * T + i] = slot; stage[7 * T + i] = i; stage[8 * T + i] = 1; }
+  HIP_TRY(hipMemcpyAsync(d->ids, stage.data(), stage.size() * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));   // `stage` is pageable and dies with this frame
+  HIP_TRY(hipMemcpyAsync(d->row_slot, d->ids + 6 * T, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->row_pos, d->ids + 7 * T, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->row_active, d->ids + 8 * T, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
+  DEmbedArgs e = {};
+  e.ids = d->ids; e.cls = d->ids + T; e.attrs = d->ids + 2 * T; e.M = T; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
+  e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
+  e.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
+  ETD_TRY(launch_dembed(e, st));
+  return ETD_OK;
+}
+
+}  // namespace
+
+extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
+                                  const int64_t* numels, int n, etd_dec** out) {
+  if (!cfg || !names || !host_ptrs || !numels || !out) ETD_FAIL(ETD_EINVAL, "decoder_create: null argument");
+  const etd_dec_cfg& c = *cfg;
+  if (c.hidden_size % 256 || c.num_attention_heads <= 0 || c.hidden_size / c.num_attention_heads != 64 || c.intermediate_size % 128 ||
+      (int)(64 * c.rotary_pct) != 16 || c.num_hidden_layers < 1 || c.vocab_size < 2 || c.max_streams < 1 || c.max_ctx < 16 ||
+      c.attribute_emb_dim < 1 || c.num_attribute_bins < 1)
+    ETD_FAIL(ETD_EINVAL, "decoder_create: unsupported config (need head_dim 64, rotary_ndims 16, hidden %% 256 == 0, intermediate %% 128 == 0)");
+  etd_dec* d = new etd_dec();
+  d->cfg = c; d->bf16w = c.precision == 1;
+  d->H = c.hidden_size; d->I = c.intermediate_size; d->V = c.vocab_size; d->L = c.num_hidden_layers; d->nh = c.num_attention_heads;
+  d->S = c.max_streams; d->ctx = c.max_ctx; d->out_cap = 1024;
+  d->Mmax = d->ctx > d->S ? d->ctx : d->S;
+  Loader Ld;
+  for (int i = 0; i < n; ++i) Ld.t[names[i]] = {host_ptrs[i], numels[i]};
+  auto fail = [&](int rc) { for (void* p : d->allocs) (void)hipFree(p); delete d; return rc; };
+  const int H = d->H, E = c.attribute_emb_dim, NB = c.num_attribute_bins;
+  int rc;
+  if ((rc = load_vec(d, Ld, "word_embeddings.weight", d->V * H, &d->word))) return fail(rc);
+  if ((rc = load_vec(d, Ld, "class_embeddings.weight", c.num_classes * H, &d->cls_emb))) return fail(rc);
+  {
+    // attribute_projection(cat(e0,e1,e2,e3)) = bias + sum_a W[:, aE:(a+1)E] e_a  -> per (attribute, bin) vectors
+    const char* an[4] = {"pitch_overlap_embeddings.weight", "polyphony_embeddings.weight", "note_sustain_embeddings.weight", "rhythm_intensity_embeddings.weight"};
+    const float* pw = Ld.get("attribute_projection.weight", (int64_t)H * 4 * E);
+    const float* pb = Ld.get("attribute_projection.bias", H);
+    if (!pw || !pb) return fail(ETD_EINVAL);
+    std::vector<float> tab((size_t)4 * NB * H);
+    for (int a = 0; a < 4; ++a) {
+      const float* em = Ld.get(an[a], (int64_t)NB * E);
+      if (!em) return fail(ETD_EINVAL);
+      for (int b = 0; b < NB; ++b)
+        for (int o = 0; o < H; ++o) {
+          double s = (a == 0) ? (double)pb[o] : 0.0;
+          for (int e = 0; e < E; ++e) s += (double)pw[(size_t)o * 4 * E + a * E + e] * em[b * E + e];
+          tab[((size_t)a * NB + b) * H + o] = (float)s;
+        }
+    }
+    if ((rc = up_f32(d, &d->attr_tab, tab.data(), tab.size()))) return fail(rc);
+  }
+  d->layers.resize(d->L);
+  for (int l = 0; l < d->L; ++l) {
+    const std::string p = "transformer.layers." + std::to_string(l) + ".";
+    Layer& w = d->layers[l];
+    if ((rc = load_vec(d, Ld, p + "input_layernorm.weight", H, &w.ln1g))) return fail(rc);
+    if ((rc = load_vec(d, Ld, p + "input_layernorm.bias", H, &w.ln1b))) return fail(rc);
+    if ((rc = load_vec(d, Ld, p + "post_attention_layernorm.weight", H, &w.ln2g))) return fail(rc);
+    if ((rc = load_vec(d, Ld, p + "post_attention_layernorm.bias", H, &w.ln2b))) return fail(rc);
+    if ((rc = load_lin(d, Ld, p + "attention.query_key_value", 3 * H, H, true, &w.qkv))) return fail(rc);
+    if ((rc = load_lin(d, Ld, p + "attention.dense", H, H, true, &w.dense))) return fail(rc);
+    if ((rc = load_lin(d, Ld, p + "mlp.dense_h_to_4h", d->I, H, true, &w.up))) return fail(rc);
+    if ((rc = load_lin(d, Ld, p + "mlp.dense_4h_to_h", H, d->I, true, &w.down))) return fail(rc);
+  }
+  if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.weight", H, &d->lnfg))) return fail(rc);
+  if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.bias", H, &d->lnfb))) return fail(rc);
+  if ((rc = load_lin(d, Ld, "lm_head", d->V, H, false, &d->head))) return fail(rc);
+  {
+    // RoPE tables as HF builds them in fp32: inv_freq = 1/theta^(2i/rot), angle = pos * inv_freq (modeling_gpt_neox.py:72-107)
+    std::vector<float> cs((size_t)d->ctx * 8), sn((size_t)d->ctx * 8);
+    for (int i = 0; i < 8; ++i) {
+      const float inv = 1.0f / powf(c.rope_theta, (float)(2 * i) / 16.0f);
+      for (int p = 0; p < d->ctx; ++p) { const float ang = (float)p * inv; cs[(size_t)p * 8 + i] = cosf(ang); sn[(size_t)p * 8 + i] = sinf(ang); }
+    }
+    if ((rc = up_f32(d, &d->rope_cos, cs.data(), cs.size()))) return fail(rc);
+    if ((rc = up_f32(d, &d->rope_sin, sn.data(), sn.size()))) return fail(rc);
+  }
+  d->slot_stride = (long long)d->nh * d->ctx * 64;
+  d->layer_stride = d->slot_stride * d->S;
+  const size_t kv_elems = (size_t)d->layer_stride * d->L;
+  if (d->bf16w) { uint16_t *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return fail(rc); d->Kc = k; d->Vc = v; }
+  else { float *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return fail(rc); d->Kc = k; d->Vc = v; }
+  const size_t M = d->Mmax;
+  rc = 0;
+  rc = rc ? rc : d->alloc(&d->h, M * H); rc = rc ? rc : d->alloc(&d->h2, M * H);
+  rc = rc ? rc : d->alloc(&d->Q, M * H); rc = rc ? rc : d->alloc(&d->AO, M * H); rc = rc ? rc : d->alloc(&d->DO, M * H);
+  rc = rc ? rc : d->alloc(&d->M1, M * d->I); rc = rc ? rc : d->alloc(&d->logits, M * d->V);
+  rc = rc ? rc : d->alloc(&d->row_slot, M); rc = rc ? rc : d->alloc(&d->row_pos, M); rc = rc ? rc : d->alloc(&d->row_active, M);
+  rc = rc ? rc : d->alloc(&d->ids, 9 * M); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
+  const size_t S = d->S;
+  rc = rc ? rc : d->alloc(&d->cur_tok, S, true); rc = rc ? rc : d->alloc(&d->len, S, true); rc = rc ? rc : d->alloc(&d->done, S, true);
+  rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
+  rc = rc ? rc : d->alloc(&d->tgt_attrs, 4 * S, true); rc = rc ? rc : d->alloc(&d->out_tok, S * d->out_cap, true);
+  if (rc) return fail(rc);
+  HIP_TRY(hipDeviceSynchronize());
+  *out = d;
+  return ETD_OK;
+}
+
+extern "C" void etd_decoder_destroy(etd_dec* d) {
+  if (!d) return;
+  for (void* p : d->allocs) (void)hipFree(p);
+  delete d;
+}
+
+extern "C" int etd_decoder_begin_bar(etd_dec* d, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
+                                     const int32_t* tgt_attrs4, int eos_id, int limit, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ETD_TRY(check_slot(d, slot));
+  if (!tgt_attrs4 || limit < 1) ETD_FAIL(ETD_EINVAL, "begin_bar: bad target attrs / limit");
+  if (limit > d->out_cap) ETD_FAIL(ETD_EINVAL, "begin_bar: limit %d exceeds the output ring (%d)", limit, d->out_cap);
+  for (int k = 0; k < 4; ++k) if (tgt_attrs4[k] < 0 || tgt_attrs4[k] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "begin_bar: target attribute out of range");
+  ETD_TRY(prefill_common(d, slot, ids, cls, attrs4, T, st));
+  int st8[4 + 6] = {tgt_attrs4[0], tgt_attrs4[1], tgt_attrs4[2], tgt_attrs4[3], 0 /*cur*/, 0 /*len*/, 0 /*done*/, 0 /*n_out*/, eos_id, limit};
+  HIP_TRY(hipMemcpyAsync(d->tgt_attrs + 4 * slot, st8, 16, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->cur_tok + slot, st8 + 4, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->len + slot, st8 + 5, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->done + slot, st8 + 6, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->n_out + slot, st8 + 7, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->eos + slot, st8 + 8, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d->limit + slot, st8 + 9, 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));   // st8 is a stack array
+  ETD_TRY(forward_layers(d, T, T - 1, 1, st));
+  DArgmaxArgs am = {};
+  am.logits = d->logits + (size_t)(T - 1) * d->V; am.ldl = d->V; am.V = d->V; am.M = 1;
+  am.rows = DecRows{d->row_slot + (T - 1), d->row_pos + (T - 1), d->row_active + (T - 1)};
+  am.cur_tok = d->cur_tok; am.len = d->len; am.done = d->done; am.n_out = d->n_out; am.out_tok = d->out_tok; am.out_cap = d->out_cap;
+  am.eos = d->eos; am.limit = d->limit;
+  ETD_TRY(launch_dargmax(am, st));
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, int n_steps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !slots || n_active < 1 || n_active > d->S || n_steps < 1) ETD_FAIL(ETD_EINVAL, "decoder_step: bad args");
+  for (int i = 0; i < n_active; ++i) ETD_TRY(check_slot(d, slots[i]));
+  if ((int)d->last_slots.size() != n_active || memcmp(d->last_slots.data(), slots, (size_t)n_active * 4)) {
+    d->last_slots.assign(slots, slots + n_active);
+    HIP_TRY(hipMemcpyAsync(d->slots_dev, d->last_slots.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, st));
+  }
+  for (int s = 0; s < n_steps; ++s) {
+    ETD_TRY(launch_decode_rows(d->slots_dev, n_active, d->len, d->done, d->row_slot, d->row_pos, d->row_active, st));
+    DEmbedArgs e = {};
+    e.cur_tok = d->cur_tok; e.tgt_attrs = d->tgt_attrs; e.tgt_cls = 2 /* TGT_CLASS_ID, etude/data/dataset.py:19 */;
+    e.M = n_active; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
+    e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
+    e.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
+    ETD_TRY(launch_dembed(e, st));
+    ETD_TRY(forward_layers(d, n_active, 0, n_active, st));
+    DArgmaxArgs am = {};
+    am.logits = d->logits; am.ldl = d->V; am.V = d->V; am.M = n_active;
+    am.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
+    am.cur_tok = d->cur_tok; am.len = d->len; am.done = d->done; am.n_out = d->n_out; am.out_tok = d->out_tok; am.out_cap = d->out_cap;
+    am.eos = d->eos; am.limit = d->limit;
+    ETD_TRY(launch_dargmax(am, st));
+  }
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_poll(etd_dec* d, const int32_t* slots, int n, int32_t* done_out, int32_t* n_out_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !slots || n < 1 || !done_out || !n_out_out) ETD_FAIL(ETD_EINVAL, "decoder_poll: bad args");
+  std::vector<int> dn(d->S), no(d->S);
+  HIP_TRY(hipMemcpyAsync(dn.data(), d->done, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(no.data(), d->n_out, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) { ETD_TRY(check_slot(d, slots[i])); done_out[i] = dn[slots[i]]; n_out_out[i] = no[slots[i]]; }
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_read_tokens(etd_dec* d, int slot, int32_t* out, int cap, int* n, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  ETD_TRY(check_slot(d, slot));
+  if (!out || !n) ETD_FAIL(ETD_EINVAL, "read_tokens: null");
+  int cnt = 0;
+  HIP_TRY(hipMemcpyAsync(&cnt, d->n_out + slot, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (cnt > d->out_cap) cnt = d->out_cap;
+  *n = cnt;
+  if (cnt > cap) ETD_FAIL(ETD_ENOMEM, "read_tokens: need room for %d tokens", cnt);
+  if (cnt > 0) {
+    HIP_TRY(hipMemcpyAsync(out, d->out_tok + (size_t)slot * d->out_cap, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_generate_bar(etd_dec* d, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
+                                        const int32_t* tgt_attrs4, int eos_id, int limit, int32_t* out, int* n_out, void* stream) {
+  ETD_TRY(etd_decoder_begin_bar(d, slot, ids, cls, attrs4, T, tgt_attrs4, eos_id, limit, stream));
+  int dn = 0, no = 0;
+  const int32_t sl = slot;
+  int chunk = 8;
+  while (true) {
+    ETD_TRY(etd_decoder_poll(d, &sl, 1, &dn, &no, stream));
+    if (dn) break;
+    ETD_TRY(etd_decoder_step(d, &sl, 1, chunk, stream));
+    if (chunk < 32) chunk *= 2;
+  }
+  return etd_decoder_read_tokens(d, slot, out, limit, n_out, stream);
+}
+
+extern "C" int etd_decoder_prefill_logits(etd_dec* d, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
+                                          float* logits_host, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!logits_host) ETD_FAIL(ETD_EINVAL, "prefill_logits: null");
+  ETD_TRY(prefill_common(d, slot, ids, cls, attrs4, T, st));
+  ETD_TRY(forward_layers(d, T, 0, T, st));
+  HIP_TRY(hipMemcpyAsync(logits_host, d->logits, (size_t)T * d->V * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return ETD_OK;
+}
+
+extern "C" double etd_decoder_step_bytes(const etd_dec* d, int n_streams, int ctx) {
+  // weights once + per stream K and V of `ctx` positions over all layers (+ the appended K/V row)
+  const double esz = d->bf16w ? 2.0 : 4.0;
+  double w = 0;
+  for (const Layer& l : d->layers) w += ((double)l.qkv.N * l.qkv.K + (double)l.dense.N * l.dense.K + (double)l.up.N * l.up.K + (double)l.down.N * l.down.K) * esz;
+  w += (double)d->V * d->H * esz;
+  const double kv = (double)n_streams * 2.0 * d->L * (double)(ctx + 1) * d->H * esz;
+  return w + kv;
+}

@@ -1,0 +1,63 @@
+// Kernel argument structs + launchers for the EtudeDecoder (GPT-NeoX) decode path.
+#pragma once
+#include "common.h"
+
+// per-row metadata of a forward pass over M rows (prefill: one stream, T rows; decode: one row per stream)
+struct DecRows {
+  const int* slot;     // [M] KV slot of the row
+  const int* pos;      // [M] position (= index of this token in the slot's KV cache)
+  const int* active;   // [M] 0 -> the row must not write KV / state (finished stream)
+};
+
+enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4 };
+
+struct DGemmArgs {
+  const float* X; int ldx;       // [M, K] fp32 activations
+  const void* W;                 // [Npad, K] weights (float or bf16), K contiguous
+  const float* bias;             // [Npad] or null
+  int M, N, K;                   // N = valid output features (stores guarded), Npad % 128 == 0
+  int Npad;
+  // LayerNorm prologue over K (only K == hidden): xhat = (x-mean)*rstd*g + b
+  const float* ln_g; const float* ln_b; float ln_eps;
+  float* Y; int ldy;             // BIAS / GELU / LOGITS destination
+  // RESID: hout = (acc + bias + add[m][n]) + h[m][n]
+  const float* add; const float* hin; float* hout;
+  // QKV: rope + scatter
+  DecRows rows;
+  const float* rope_cos; const float* rope_sin;   // [max_ctx][rot/2]
+  int rot_half;                  // rotary_ndims / 2 (8)
+  float* Q;                      // [M][hidden]
+  void* Kc; void* Vc;            // KV cache base of this LAYER: [slot][head][max_ctx][64]
+  long long slot_stride;         // elements between slots
+  int max_ctx, n_heads;
+};
+int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st);
+
+struct DAttnArgs {
+  const float* Q;                // [M][hidden]
+  const void* Kc; const void* Vc; long long slot_stride; int max_ctx, n_heads;
+  DecRows rows; int M;
+  float* O;                      // [M][hidden]
+  float scale;
+};
+int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
+
+struct DEmbedArgs {
+  const int* ids; const int* cls; const int* attrs;   // [M], [M], [4][M] (explicit mode)  -- or null:
+  const int* cur_tok; const int* tgt_attrs;           // decode mode: ids = cur_tok[slot], cls = tgt_cls, attrs = tgt_attrs[slot][4]
+  int tgt_cls;
+  DecRows rows; int M, H, n_bins;
+  const float* word; const float* cls_emb; const float* attr_tab;  // [V][H], [C][H], [4][n_bins][H] (+bias in tab 0)
+  float* h;
+};
+int launch_dembed(const DEmbedArgs& a, hipStream_t st);
+
+struct DArgmaxArgs {
+  const float* logits; int ldl; int V; int M;
+  DecRows rows;
+  int* cur_tok; int* len; int* done; int* n_out; int* out_tok; int out_cap; const int* eos; const int* limit;
+  int set_len_from_pos;          // prefill: len[slot] = pos + 1 of the row
+};
+int launch_dargmax(const DArgmaxArgs& a, hipStream_t st);
+
+int launch_decode_rows(const int* slots_dev, int n, const int* len, const int* done, int* row_slot, int* row_pos, int* row_active, hipStream_t st);

@@ -13,7 +13,7 @@
  *   etd_mpe2note          AMTAPC_Extractor._mpe2note + _note2json filter etude/data/extractor.py:256-418,432-443
  *   etd_decoder_create    load_etude_decoder + EtudeDecoder.__init__   etude/utils/model_loader.py:12-60,
  *                                                                      etude/models/etude_decoder.py:94-123
- *   etd_decoder_prefill / etd_decoder_step / etd_decoder_read_tokens
+ *   etd_decoder_begin_bar / etd_decoder_step / etd_decoder_poll / etd_decoder_read_tokens
  *                         the body of EtudeDecoder.generate's token loop: forward (embeddings +
  *                         GPT-NeoX + lm_head) + greedy argmax + KV cache  etude/models/etude_decoder.py:300-343,148-206
  *   etd_decoder_generate_bar  one bar of generate(): prefill + <=limit greedy steps, stop at Bar_EOS
@@ -115,26 +115,30 @@ typedef struct {
 int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                        const int64_t* numels, int n, etd_dec** out);
 void etd_decoder_destroy(etd_dec*);
-/* Reset stream `slot` and run the prompt through the model (KV cache filled, position = T).
- * ids/cls: int32 host [T]; attrs: int32 host [4][T] in the order pitch_overlap, polyphony,
- * note_sustain, rhythm_intensity (the concat order of etude_decoder.py:171-176).  The greedy next
- * token is left in the stream's device-side "current token" cell.  */
-int etd_decoder_prefill(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T, void* stream);
-/* One greedy decode step for n_active streams (slot ids in host array): feeds each stream's current
- * token (class TGT=2, the stream's target attrs), appends K/V, writes the argmax as the new current
- * token and into the stream's output ring.  No host sync, no allocation: graph-capturable. */
-int etd_decoder_step(etd_dec*, const int32_t* slots, int n_active, void* stream);
-/* Set per-stream generation state: target attrs (4), eos id (streams freeze once they emit it). */
-int etd_decoder_set_stream(etd_dec*, int slot, const int32_t* attrs4, int eos_id);
-/* Copy out the tokens generated so far by `slot` (synchronises the stream). Returns count in *n. */
+/* Start one bar on stream `slot` (etude_decoder.py:291-297 + first loop iteration): reset the slot's KV
+ * cache and generation state, run the prompt (ids/cls: int32 host [T]; attrs4: int32 host [4][T] in the
+ * concat order of etude_decoder.py:171-176 = pitch_overlap, polyphony, note_sustain, rhythm_intensity)
+ * through the model and leave the greedy first token in the slot's device-side state.  tgt_attrs4 (same
+ * order) condition the generated tokens; generation stops at eos_id or after `limit` tokens. */
+int etd_decoder_begin_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
+                          const int32_t* tgt_attrs4, int eos_id, int limit, void* stream);
+/* n_steps greedy decode steps for the n_active streams listed in `slots` (host array): each step feeds every
+ * stream's current token (class TGT=2, its target attrs), appends K/V, and writes the argmax back as the
+ * stream's current token and into its output ring -- all on the device: no host sync, no allocation.
+ * Streams that already finished (EOS / limit) idle. */
+int etd_decoder_step(etd_dec*, const int32_t* slots, int n_active, int n_steps, void* stream);
+/* done flag and number of generated tokens of each listed stream (synchronises the stream). */
+int etd_decoder_poll(etd_dec*, const int32_t* slots, int n, int32_t* done_out, int32_t* n_out_out, void* stream);
+/* Copy out the tokens generated so far by `slot` (synchronises). *n = count. */
 int etd_decoder_read_tokens(etd_dec*, int slot, int32_t* out, int cap, int* n, void* stream);
-/* Convenience: prefill + up to `limit` greedy steps with EOS stop for one stream; tokens (incl. the
- * first token produced by the prefill) are returned on the host.  Synchronous. */
+/* begin_bar + steps until done + read_tokens for one stream.  Synchronous. */
 int etd_decoder_generate_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
                              const int32_t* tgt_attrs4, int eos_id, int limit, int32_t* out, int* n_out, void* stream);
-/* test hook: logits [T][vocab] fp32 (device) of the last prefill on `slot` are copied to host. */
+/* test hook: full logits [T][vocab] fp32 of a prompt (EtudeDecoder.forward), copied to the host. */
 int etd_decoder_prefill_logits(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
                                float* logits_host, void* stream);
+/* algorithmic HBM bytes of one decode step for n_streams at context `ctx` (SURVEY.md 8d formula) */
+double etd_decoder_step_bytes(const etd_dec*, int n_streams, int ctx);
 
 #ifdef __cplusplus
 }
