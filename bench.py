@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""Benchmark of Etude's two hot paths on MI355X: audio-seconds/s transcribed + decoder tokens/s.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One STEP = BASELINE.json configs[1] on each rank: a 3-minute 44.1 kHz stereo clip already resident in HBM is
+taken through the whole Extract hot path (channel mean, resample, STFT/log-mel, hFT-Transformer over 22
+windows, D2H of the frame outputs, note picking -> the note list extract() writes), then the Decode hot path
+generates the cover for its ~92 condition bars with the default attributes (1/1/1, overlap 2), greedy.
+Ranks work on different clips (seed 1234 + rank) with no data-path collective: weak scaling.
+
+value = audio seconds taken through BOTH stages per wall second, whole job (all ranks).  The per-stage
+numbers the metric names are reported next to it (extract_audio_s_per_s, decoder_tokens_per_s), plus
+  roofline      the dominant kernel of the timed region (HIP-event timed inside the library)
+  cpu_baseline  the CPU oracle timed on this node's host cores on a bounded sample (rank 0, N=1 only)
+  extras        extractor-only (configs[2]) and 128-stream decoder (configs[3]) measurements taken OUTSIDE the
+                timed region, each with its own roofline fraction.
+Weights are seeded synthetic tensors of the reference's architecture (no checkpoints / network); the
+condition bars are the synthetic ~8-notes/bar song of SURVEY.md 8(d) config 1 because the Structuralize
+stage and the tokenizer are outside the hot path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0         # HBM3E spec
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(*a, file=sys.stderr, flush=True)
+
+
+def make_vocab():
+    from etude_amd import synth
+    from etude_amd.vocab import Vocab
+    v = Vocab()
+    v.token_to_id = synth.vocab_json()["token_to_id"]
+    v.id_to_token = [""] * len(v.token_to_id)
+    for t, i in v.token_to_id.items():
+        v.id_to_token[i] = t
+    return v
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """The CPU oracle (a restatement of the reference, pinned by golden vectors) on this node's host cores."""
+    from etude_amd import synth
+    from oracle import hft, neox
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    sd = {k: torch.from_numpy(v) for k, v in synth.extractor_state_dict(0).items()}
+    x = torch.from_numpy(synth.window_features(5, 1))
+    d = hft.HftDims()
+    t0 = time.time()
+    nwin = 0
+    while nwin < 2 and (nwin == 0 or time.time() - t0 < seconds_budget * 0.5):
+        hft.model_forward(sd, x, d)
+        nwin += 1
+    t_ext = time.time() - t0
+    tsd = {k: torch.from_numpy(v) for k, v in synth.decoder_state_dict(1, {}).items()}
+    bars = synth.song_bars(seed=1234, n_bars=3)
+    t0 = time.time()
+    out = neox.generate_ids(tsd, neox.NeoxDims(), 4, 5, bars, [synth.attrs()] * 3, max_bar_token_limit=48)
+    t_dec = time.time() - t0
+    ntok = sum(len(b) - 1 for b in out)
+    return {"value": round(nwin * 8.192 / t_ext, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
+            "sample": f"oracle hFT forward on {nwin} window(s) of 512 frames (8.192 s audio each) in {t_ext:.1f}s; "
+                      f"oracle greedy generate on 3 bars: {ntok} tokens in {t_dec:.1f}s",
+            "decoder_tokens_per_s": round(ntok / t_dec, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=180.0, help="clip length")
+    ap.add_argument("--bars", type=int, default=92)
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from etude_amd import _lib, parallel, synth
+    from etude_amd.config import ExtractorConfig
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    from etude_amd.extractor import AMTAPC_Extractor
+
+    cfg = ExtractorConfig()
+    ex = AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=int(os.environ.get("ETD_WB", "1")))
+    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+    dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=1)
+    vocab = make_vocab()
+    wav = torch.from_numpy(synth.clip_audio(seed=1234 + rank, seconds=args.seconds)).to(dev)   # resident in HBM
+    bars = synth.song_bars(seed=1234 + rank, n_bars=args.bars)
+    attrs = [synth.attrs(1, 1, 1, 2)] * len(bars)
+    inf = cfg.infer
+
+    def step():
+        t0 = time.perf_counter()
+        feat = ex._front(44100)(wav)
+        on, off, mpe, vel = ex.transcript(feat)
+        notes = ex._mpe2note(on.cpu().numpy(), off.cpu().numpy(), mpe.cpu().numpy(), vel.cpu().numpy(),
+                             inf.onset_threshold, inf.offset_threshold, inf.frame_threshold)
+        notes = [n for n in notes if not (n["offset"] - n["onset"] < inf.min_duration)]
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        st = {}
+        out = dec.generate_many([(bars, attrs)], vocab, stats=st)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        return t1 - t0, t2 - t1, st["tokens"], len(notes), out
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    t_ext = t_dec = 0.0
+    n_tok = n_notes = 0
+    for _ in range(args.steps):
+        a, b, c, d, out = step()
+        t_ext += a; t_dec += b; n_tok += c; n_notes = d
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    prof = _lib.prof_report()
+
+    tmax = torch.tensor([elapsed, t_ext, t_dec], dtype=torch.float64, device=dev)
+    tsum = torch.tensor([float(n_tok)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        # the path's only exchange: ONE final gather of the small variable-length results
+        parallel.gather_int_arrays([np.asarray([t for bar in out[0] for t in bar], np.int32)], device=dev)
+    elapsed, t_ext, t_dec = [float(x) for x in tmax.tolist()]
+    n_tok_all = float(tsum.item())
+
+    audio_s = args.seconds * args.steps * world
+    result = {
+        "metric": "audio-sec/s transcribed + decoder tokens/s, 3-min clip batch",
+        "value": round(audio_s / elapsed, 3), "unit": "audio-s/s (extract + decode of each clip)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1] per rank: one 3-min 44.1 kHz stereo clip, full extract (wav->notes) + greedy decode of "
+                               f"{args.bars} synthetic condition bars, attrs 1/1/1 overlap 2, bf16 compute / fp32 accumulate; synthetic seeded weights",
+                   "clip_seconds": args.seconds, "windows_per_clip": int(np.ceil((1 + int(np.ceil(160 * wav.shape[1] / 441)) // 256) / 512)),
+                   "bars": args.bars, "parallelism": f"clip-sharded x{world}"},
+        "extract_audio_s_per_s": round(audio_s / t_ext, 2),
+        "decoder_tokens_per_s": round(n_tok_all / t_dec, 2),
+        "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": n_notes,
+    }
+
+    # ---- roofline of the dominant kernel of the timed region (HIP events inside the library, own stream)
+    if prof:
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        name, p = dom
+        avg_ms = p["ms"] / max(1, p["launches"])
+        if p["flops"] > 0:
+            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
+            result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": p["launches"],
+                                  "avg_launch_ms": round(avg_ms, 5), "alg_flops_per_launch": p["flops"] / max(1, p["launches"])}
+        else:
+            ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+            result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches": p["launches"], "avg_launch_ms": round(avg_ms, 5)}
+        tp = ROOT / "profiles" / "traffic.json"
+        if tp.exists():
+            try:
+                result["roofline"]["traffic"] = json.loads(tp.read_text()).get(name)
+            except Exception:
+                pass
+        result["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+
+    # ---- extras outside the timed region
+    if not args.no_extras and rank == 0:
+        extras = {}
+        try:
+            xs = torch.from_numpy(synth.window_features(5, 16)).to(dev)          # configs[2]: 16 windows
+            ex.transcript_windows(xs)
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                ex.transcript_windows(xs)
+            torch.cuda.synchronize(dev)
+            dt = (time.perf_counter() - t) / (reps * 16)
+            tf = ex.window_flops / dt / 1e12
+            extras["extractor_only"] = {"workload": "BASELINE configs[2]: 16 x 512-frame windows (8.192 s each), hFT-Transformer only",
+                                        "ms_per_window": round(dt * 1e3, 3), "audio_s_per_s": round(8.192 / dt, 1),
+                                        "alg_gflop_per_window": round(ex.window_flops / 1e9, 1),
+                                        "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}}
+        except Exception as e:      # extras must never take the headline down
+            extras["extractor_only"] = {"error": repr(e)}
+        try:
+            extras["decoder_streams"] = decoder_stream_bench(dcfg, dev)
+        except Exception as e:
+            extras["decoder_streams"] = {"error": repr(e)}
+        result["extras"] = extras
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline()
+        except Exception as e:
+            result["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64):
+    """BASELINE configs[3]: 128 concurrent streams, each prefilled to ctx0 then `steps` greedy decode steps
+    (EOS suppressed so every stream runs the full length -- throughput does not depend on the token values)."""
+    import ctypes as C
+    from etude_amd import _lib, synth
+    from etude_amd.decoder import EtudeDecoder
+    dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=n_streams, max_ctx=4096)
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    st = dec._stream()
+    tg = np.asarray([2, 1, 1, 1], np.int32)
+    for s in range(n_streams):
+        ids = rng.integers(6, 154, ctx0).astype(np.int32)
+        cls = rng.integers(1, 3, ctx0).astype(np.int32)
+        a4 = rng.integers(0, 3, (4, ctx0)).astype(np.int32)
+        _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data,
+                                             -1, 1000, st), "begin_bar")
+    slots = np.arange(n_streams, dtype=np.int32)
+    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, 4, st), "step")
+    torch.cuda.synchronize(dev)
+    _lib.prof_reset(); _lib.prof_enable(True)
+    t = time.perf_counter()
+    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, steps, st), "step")
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t
+    _lib.prof_enable(False)
+    prof = _lib.prof_report()
+    ctx_mid = ctx0 + 4 + steps // 2
+    bytes_step = dec.step_bytes(n_streams, ctx_mid)
+    gbs = bytes_step * steps / dt / 1e9
+    out = {"workload": f"BASELINE configs[3]: {n_streams} streams, bf16 weights+KV, ctx {ctx0}->{ctx0 + 4 + steps}, {steps} greedy steps, EOS suppressed",
+           "tokens_per_s": round(n_streams * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
+           "alg_bytes_per_step": bytes_step,
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
+           "kernel_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+    dec.close()
+    return out
+
+
+if __name__ == "__main__":
+    main()

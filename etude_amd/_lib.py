@@ -45,6 +45,12 @@ class Note(C.Structure):
 SIGNATURES = {
     "etd_version": (C.c_int, []),
     "etd_last_error": (C.c_char_p, []),
+    "etd_prof_enable": (C.c_int, [C.c_int]),
+    "etd_prof_reset": (C.c_int, []),
+    "etd_prof_collect": (C.c_int, []),
+    "etd_prof_count": (C.c_int, []),
+    "etd_prof_entry": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "etd_frontend_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
     "etd_frontend_destroy": (None, [C.c_void_p]),
@@ -117,3 +123,24 @@ def weights_arrays(state: dict):
     c_ptrs = (C.c_void_p * len(names))(*[a.ctypes.data for a in arrs])
     c_num = (C.c_int64 * len(names))(*[a.size for a in arrs])
     return c_names, c_ptrs, c_num, len(names), arrs
+
+
+def prof_enable(on: bool) -> None:
+    lib().etd_prof_enable(1 if on else 0)
+
+
+def prof_reset() -> None:
+    lib().etd_prof_reset()
+
+
+def prof_report() -> dict:
+    """name -> dict(ms, launches, flops, bytes) accumulated since the last reset (synchronises)."""
+    l = lib()
+    l.etd_prof_collect()
+    out = {}
+    for i in range(l.etd_prof_count()):
+        name = C.create_string_buffer(64)
+        ms, n, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        check(l.etd_prof_entry(i, name, 64, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "etd_prof_entry")
+        out[name.value.decode()] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+    return out

@@ -8,6 +8,7 @@
 //   * bf16: v_mfma_f32_32x32x16_bf16 on bf16 weights and a bf16 KV cache (the HBM-bound serving mode).
 // The residual stream, LayerNorm, RoPE, softmax and the logits are fp32 in both.
 #include "dec_kernels.h"
+#include "prof.h"
 
 #define DLD32 36   // fp32 LDS row stride (floats) for a 32-wide K chunk: 144 B
 #define DLD16 72   // bf16 LDS row stride (elements) for a 64-wide K chunk: 144 B
@@ -208,6 +209,7 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
   if (a.ln_g && a.K % 256) ETD_FAIL(ETD_EINVAL, "dgemm: LayerNorm prologue needs K %% 256 == 0");
   if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "dgemm: QKV epilogue needs head_dim 64 and rotary_ndims 16");
   if (epi == DEPI_RESID && (a.N % 4)) ETD_FAIL(ETD_EINVAL, "dgemm: resid needs N %% 4 == 0");
+  ProfScope ps("k_dgemm", st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * (w_bf16 ? 2 : 4));
   dim3 g((a.M + 31) / 32, a.Npad / 128);
   if (w_bf16) dgemm_dispatch<true>(a, epi, g, st);
   else dgemm_dispatch<false>(a, epi, g, st);
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
 
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "dattn: bad M");
+  ProfScope ps("k_dattn", st, 0, 0);
   dim3 g(a.M, a.n_heads);
   if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a);

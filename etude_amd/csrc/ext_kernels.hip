@@ -8,6 +8,7 @@
 // one 8-byte row-major store.  Issuing the same two fragments the other way round gives Y with the
 // feature on the lane, which is how V is written out pre-transposed (V^T) for the attention kernel.
 #include "ext_kernels.h"
+#include "prof.h"
 
 #define LDK 72  // LDS row stride (elements) of a 64-wide bf16 K-chunk: 144 B, 16-B aligned, conflict-free ds_read_b128
 
@@ -177,6 +178,7 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   if (a.vt_block >= 0 && (a.S % 4 || a.Spad % 4 || !a.VT)) ETD_FAIL(ETD_EINVAL, "linear: bad V^T args");
   // row-major blocks [0, vt_block) (or all), then the V^T block as its own launch (orientation is a
   // compile-time property of the MFMA loop)
+  ProfScope ps("k_linear", st, 2.0 * a.M * a.N * a.K * nz, ((double)a.M * a.K + (double)a.N * a.K * nz + (double)a.M * a.N * nz) * 2);
   const int nblk = a.N / 256;
   const int n_plain = a.vt_block >= 0 ? a.vt_block : nblk;
   if (a.vt_block >= 0 && a.vt_block != nblk - 1) ETD_FAIL(ETD_EINVAL, "linear: V^T block must be the last block");
@@ -193,6 +195,7 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
 }
 int launch_linear_ln(const LinArgs& a, hipStream_t st) {
   if (a.K % 64 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta) ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
+  ProfScope ps("k_linear_ln", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * a.N) * 2);
   dim3 g((a.M + 127) / 128, 1, 1);
   LinArgs b = a; b.nb0 = 0;
   hipLaunchKernelGGL(k_linear<2>, g, dim3(256), 0, st, b);
@@ -325,6 +328,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 int launch_attn(const AttnArgs& a, hipStream_t st) {
   if (a.Sq <= 0 || a.Sk <= 0 || a.n_seq <= 0 || a.Spad % 64 || a.Spad < ((a.Sk + 63) / 64) * 64)
     ETD_FAIL(ETD_EINVAL, "attn: bad shape Sq=%d Sk=%d Spad=%d", a.Sq, a.Sk, a.Spad);
+  ProfScope ps("k_attn", st, 1024.0 * a.n_seq * a.Sq * a.Sk, ((double)a.n_seq * (2.0 * a.Sq + 2.0 * a.Sk) * 256) * 2);
   dim3 g((a.Sq + 127) / 128, a.n_seq * 4);
   hipLaunchKernelGGL(k_attn, g, dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -419,6 +423,7 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
 
 int launch_embed(const EmbedArgs& a, hipStream_t st) {
   if (a.fc <= 0 || a.n_win <= 0 || a.margin != 32) ETD_FAIL(ETD_EINVAL, "embed: bad args");
+  ProfScope ps("k_embed", st, 2.0 * a.n_win * a.fc * 256.0 * 256 * 65, (double)a.n_win * a.fc * 256 * 256 * 2);
   dim3 g(8, (a.fc + EFB - 1) / EFB, a.n_win);
   hipLaunchKernelGGL(k_embed, g, dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -511,6 +516,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadsArgs a) {
 
 int launch_heads(const HeadsArgs& a, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "heads: bad M");
+  ProfScope ps("k_heads", st, 2.0 * a.M * 256 * 131, (double)a.M * 256 * 2);
   hipLaunchKernelGGL(k_heads, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
@@ -540,6 +546,7 @@ __global__ void k_freq2time(const bf16* __restrict__ src, bf16* __restrict__ dst
 }
 int launch_freq2time(const bf16* src, bf16* dst, const float* pos, int nw, int fc, int f0, int nf, int nn, hipStream_t st) {
   const long long total = (long long)nw * fc * nn * 32;
+  ProfScope ps("k_freq2time", st, 0, (double)total * 32);
   long long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_freq2time, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, pos, nw, fc, f0, nf, nn);
   HIP_TRY(hipGetLastError());

@@ -4,6 +4,7 @@
 // All tables (resampling kernel, window, twiddles, mel filterbank in CSR form) are built by the
 // host layer exactly as torchaudio builds them and handed over through etd_frontend_create.
 #include "frontend.h"
+#include "prof.h"
 
 // ------------------------------------------------------------------------------------------------
 // Resampler: y[j*new + p] = sum_k kern[p][k] * mono[j*orig + k - width]        (zero outside [0,L))
@@ -185,6 +186,8 @@ extern "C" int etd_frontend_run(etd_frontend* f, const float* wav_dev, int chann
   const long long T = 1 + n16 / f->hop;
   if (n16 <= f->n_fft / 2) ETD_FAIL(ETD_EINVAL, "frontend_run: clip shorter than n_fft/2 after resampling (reflect pad undefined)");
   if (T > feat_capacity_frames) ETD_FAIL(ETD_EINVAL, "frontend_run: feature buffer too small (%lld > %lld)", T, feat_capacity_frames);
+  {
+  ProfScope ps("k_resample", st, 2.0 * n16 * f->K, (double)n_in * channels * 4 + (double)n16 * 4);
   if (f->sr_in == f->sr_out) {
     hipLaunchKernelGGL(k_mono, dim3(2048), dim3(256), 0, st, wav_dev, channels, n_in, resampled_dev);
   } else {
@@ -193,6 +196,8 @@ extern "C" int etd_frontend_run(etd_frontend* f, const float* wav_dev, int chann
     hipLaunchKernelGGL(k_resample, dim3((unsigned)((nblk + RB - 1) / RB)), dim3(256), span * sizeof(float), st, wav_dev, channels, n_in,
                        f->kernT, f->K, f->width, f->orig, f->nw, resampled_dev, n16);
   }
+  }
+  ProfScope ps2("k_stft_mel", st, 0, (double)n16 * 4 + (double)T * f->n_mels * 4);
   const size_t sm = (size_t)(2 * f->n_fft + f->n_fft / 2 + 1) * sizeof(float);
   hipLaunchKernelGGL(k_stft_mel, dim3((unsigned)T), dim3(256), sm, st, resampled_dev, n16, f->n_fft, f->lg, f->hop, f->window, f->tw,
                      f->mel_start, f->mel_len, f->mel_off, f->mel_w, f->n_mels, f->log_offset, feat_dev, T);

@@ -1,0 +1,76 @@
+#include "prof.h"
+
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "../../include/etude_hip.h"
+
+namespace {
+struct Entry { double ms = 0; long long n = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; hipEvent_t open = nullptr; };
+std::mutex g_mu;
+bool g_on = false;
+std::map<std::string, Entry> g_ent;
+std::vector<hipEvent_t> g_pool;
+
+hipEvent_t get_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+}  // namespace
+
+void prof_begin(const char* name, hipStream_t st) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Entry& en = g_ent[name];
+  en.open = get_event();
+  if (en.open) (void)hipEventRecord(en.open, st);
+}
+void prof_end(const char* name, hipStream_t st, double flops, double bytes) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Entry& en = g_ent[name];
+  if (!en.open) return;
+  hipEvent_t stop = get_event();
+  if (!stop) { g_pool.push_back(en.open); en.open = nullptr; return; }
+  (void)hipEventRecord(stop, st);
+  en.pending.push_back({en.open, stop});
+  en.open = nullptr;
+  en.n += 1; en.flops += flops; en.bytes += bytes;
+}
+
+extern "C" int etd_prof_enable(int on) { std::lock_guard<std::mutex> lk(g_mu); g_on = on != 0; return ETD_OK; }
+extern "C" int etd_prof_collect(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (auto& kv : g_ent) {
+    for (auto& p : kv.second.pending) {
+      float ms = 0.f;
+      if (hipEventSynchronize(p.second) == hipSuccess && hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) kv.second.ms += ms;
+      g_pool.push_back(p.first); g_pool.push_back(p.second);
+    }
+    kv.second.pending.clear();
+  }
+  return ETD_OK;
+}
+extern "C" int etd_prof_reset(void) {
+  etd_prof_collect();
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_ent.clear();
+  return ETD_OK;
+}
+extern "C" int etd_prof_count(void) { std::lock_guard<std::mutex> lk(g_mu); return (int)g_ent.size(); }
+extern "C" int etd_prof_entry(int i, char* name, int name_cap, double* total_ms, long long* launches, double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (i < 0 || i >= (int)g_ent.size() || !name || name_cap < 2) ETD_FAIL(ETD_EINVAL, "prof_entry: bad index");
+  auto it = g_ent.begin();
+  std::advance(it, i);
+  strncpy(name, it->first.c_str(), name_cap - 1); name[name_cap - 1] = 0;
+  if (total_ms) *total_ms = it->second.ms;
+  if (launches) *launches = it->second.n;
+  if (flops) *flops = it->second.flops;
+  if (bytes) *bytes = it->second.bytes;
+  return ETD_OK;
+}

@@ -43,6 +43,15 @@ extern "C" {
 int etd_version(void);
 const char* etd_last_error(void);
 
+/* ------------------------------------------------------------------ launch profiler (measurement only)
+ * When enabled, every kernel launch of the library is bracketed by HIP events on its own stream;
+ * etd_prof_collect() synchronises them and accumulates per-kernel totals. */
+int etd_prof_enable(int on);
+int etd_prof_reset(void);
+int etd_prof_collect(void);
+int etd_prof_count(void);
+int etd_prof_entry(int i, char* name, int name_cap, double* total_ms, long long* launches, double* flops, double* bytes);
+
 /* ------------------------------------------------------------------ audio front end */
 typedef struct etd_frontend etd_frontend;
 /* Tables are built by the host layer exactly as torchaudio builds them:

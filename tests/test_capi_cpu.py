@@ -1,0 +1,75 @@
+"""CPU-side checks of the C ABI: the library loads, exports everything include/etude_hip.h declares,
+and the host-only entry point (etd_mpe2note) reproduces the reference's golden notes."""
+import ctypes as C
+import json
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from etude_amd import _lib
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.lib()
+    assert lib.etd_version() == 1
+    header = (ROOT / "include" / "etude_hip.h").read_text()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(etd_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 25
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, f"declared in etude_hip.h but not exported: {missing}"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+
+
+def test_error_reporting_without_gpu():
+    lib = _lib.lib()
+    n = C.c_longlong()
+    rc = lib.etd_mpe2note(None, None, None, None, 0, 0, 0.5, 0.5, 0.5, 256, 16000, 21, None, 0, C.byref(n))
+    assert rc == -22
+    assert b"mpe2note" in lib.etd_last_error()
+
+
+def _run_mpe2note(on, off, mpe, vel, thr, note_min=21):
+    lib = _lib.lib()
+    T, nn = on.shape
+    cap = 4096
+    buf = (_lib.Note * cap)()
+    n = C.c_longlong()
+    _lib.check(lib.etd_mpe2note(on.ctypes.data, off.ctypes.data, mpe.ctypes.data, vel.ctypes.data, T, nn, thr[0], thr[1], thr[2],
+                                256, 16000, note_min, buf, cap, C.byref(n)), "etd_mpe2note")
+    return [{"pitch": int(b.pitch), "onset": float(b.onset), "offset": float(b.offset), "velocity": int(b.velocity)} for b in buf[: n.value]]
+
+
+def test_mpe2note_capi_matches_reference_golden(golden_dir):
+    cases = json.loads((golden_dir / "mpe2note.json").read_text())
+    for c in cases:
+        on, off, mpe = (np.ascontiguousarray(c[k], np.float32) for k in ("onset", "offset", "mpe"))
+        vel = np.ascontiguousarray(c["velocity"], np.int8)
+        notes = _run_mpe2note(on, off, mpe, vel, c["thr"])
+        assert notes == c["notes"], c["name"]     # exact, incl. the float32-interpolated onset/offset times
+
+
+def test_mpe2note_capi_matches_oracle_on_random_frames():
+    from oracle import mpe2note as om
+    rng = np.random.default_rng(0)
+    for k in range(4):
+        T = 300 + 17 * k
+        on = np.round(rng.random((T, 88)) ** 6, 3).astype(np.float32)
+        off = np.where(rng.random((T, 88)) > 0.98, 1.0, rng.random((T, 88)) * 0.99).astype(np.float32)
+        mpe = rng.random((T, 88)).astype(np.float32)
+        vel = rng.integers(0, 128, (T, 88)).astype(np.int8)
+        assert _run_mpe2note(on, off, mpe, vel, (0.5, 1.0, 0.5)) == om.mpe2note(on, off, mpe, vel, 0.5, 1.0, 0.5)
+
+
+def test_mpe2note_small_capacity_reports_needed():
+    lib = _lib.lib()
+    on = np.zeros((8, 4), np.float32); on[3, 1] = 0.9
+    z = np.zeros((8, 4), np.float32)
+    vel = np.full((8, 4), 5, np.int8)
+    n = C.c_longlong()
+    rc = lib.etd_mpe2note(on.ctypes.data, z.ctypes.data, z.ctypes.data, vel.ctypes.data, 8, 4, 0.5, 0.5, 0.5, 256, 16000, 21, None, 0, C.byref(n))
+    assert rc == -12 and n.value == 1

@@ -1,0 +1,130 @@
+"""HIP EtudeDecoder against the reference's golden logits / greedy token ids, through the C ABI.
+
+fp32 mode (exact-fp32 MFMA) is the parity gate: logits within 1e-4, greedy ids IDENTICAL.
+bf16 mode: logits within 5e-2; its ids are also compared (they match on these goldens) but the
+contract for bf16 is only the logit tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from etude_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _vocab():
+    from etude_amd.vocab import Vocab
+    v = Vocab()
+    v.token_to_id = synth.vocab_json()["token_to_id"]
+    v.id_to_token = [""] * len(v.token_to_id)
+    for t, i in v.token_to_id.items():
+        v.id_to_token[i] = t
+    return v
+
+
+def _decoder(precision, seed=1, max_streams=1, **kw):
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    return EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(seed, {}), "cuda",
+                        precision=precision, max_streams=max_streams, **kw)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+def test_prompt_logits_against_reference(dev, golden_dir, precision, tol):
+    g = np.load(golden_dir / "decoder_full.npz")
+    dec = _decoder(precision)
+    a4 = np.stack([g["prompt_overlap"][0], g["prompt_polyphony"][0], g["prompt_sustain"][0], g["prompt_rhythm"][0]])
+    lg = dec.prefill_logits(g["prompt_ids"][0], g["prompt_cls"][0], a4)
+    assert lg.shape == g["logits"].shape == (64, 154)
+    assert np.abs(lg - g["logits"]).max() < tol
+    if precision == "fp32":
+        assert (lg.argmax(-1) == g["logits"].argmax(-1)).all()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_greedy_generate_ids_identical_to_reference(dev, golden_dir, precision):
+    g = np.load(golden_dir / "decoder_full.npz")
+    dec = _decoder(precision)
+    v = _vocab()
+    n_bars = int(g["n_bars"])
+    bars = synth.song_bars(seed=3, n_bars=n_bars)
+    j = 0
+    while f"gen_ids_{j}" in g:
+        a = synth.attrs(*[int(x) for x in g[f"gen_attrs_{j}"]])
+        events = dec.generate(v, bars, [a] * n_bars, temperature=0.0, top_p=0.9, max_bar_token_limit=48)
+        ids = [v.encode(e) if e.type_ not in v.special_tokens else v.token_to_id[e.type_] for e in events]
+        assert ids == g[f"gen_ids_{j}"].tolist(), (precision, j)          # bit-exact integer parity
+        j += 1
+    assert j == 3
+
+
+def test_generate_many_equals_generate_and_budget_rules(dev):
+    from oracle import neox
+    from tests._util import neox_dims, torch_sd
+    v = _vocab()
+    dec1 = _decoder("fp32", max_streams=1)
+    decN = _decoder("fp32", max_streams=5)
+    jobs = []
+    for s in range(7):                                            # more jobs than streams -> slot reuse
+        bars = synth.song_bars(seed=50 + s, n_bars=3 + s % 3)
+        jobs.append((bars, [synth.attrs(s % 3, (s + 1) % 3, (s + 2) % 3, 2)] * len(bars)))
+    many = decN.generate_many(jobs, v, max_bar_token_limit=24)
+    for (bars, at), got in zip(jobs, many):
+        assert dec1.generate_ids(v, bars, at, max_bar_token_limit=24, temperature=0.0) == got
+    # oracle cross-check of one job incl. the global max_output_tokens budget (etude_decoder.py:301,352)
+    sd = torch_sd(synth.decoder_state_dict(1, {}))
+    bars, at = jobs[2]
+    for budget in (25600, 30, 7, 1):
+        want = neox.generate_ids(sd, neox_dims({}), 4, 5, bars, at, max_output_tokens=budget, max_bar_token_limit=24)
+        got = dec1.generate_ids(v, bars, at, max_output_tokens=budget, max_bar_token_limit=24, temperature=0.0)
+        assert got == want, budget
+
+
+def test_generate_error_behaviour(dev):
+    from etude_amd.vocab import Vocab
+    dec = _decoder("fp32")
+    v = _vocab()
+    bars = synth.song_bars(seed=1, n_bars=2)
+    assert dec.generate(v, bars, [synth.attrs()], temperature=0.0) == []            # length mismatch -> [] (etude_decoder.py:234-236)
+    assert dec.generate(v, [], [], temperature=0.0) == []
+    assert dec.generate(Vocab(), bars, [synth.attrs()] * 2, temperature=0.0) == []   # no Bar_BOS/EOS in vocab (:225-232)
+    with pytest.raises(TypeError):
+        dec.generate(v, bars, [{"polyphony_bin": 1}] * 2, temperature=0.0)
+    with pytest.raises(NotImplementedError):
+        dec.generate(v, bars, [synth.attrs()] * 2)                                     # default temperature 0.8: sampling branch
+
+
+def test_long_context_truncation_path(dev):
+    """Bars long enough that the 4-pair history exceeds 1024-512 tokens: the 'keep last 512' rule (etude_decoder.py:285-289)."""
+    from oracle import neox
+    from tests._util import neox_dims, torch_sd
+    v = _vocab()
+    dec = _decoder("fp32")
+    bars = synth.song_bars(seed=8, n_bars=4, notes_per_bar=60)
+    assert max(len(b) for b in bars) > 100
+    at = [synth.attrs(2, 2, 0, 2)] * 4
+    sd = torch_sd(synth.decoder_state_dict(1, {}))
+    want = neox.generate_ids(sd, neox_dims({}), 4, 5, bars, at, max_bar_token_limit=12)
+    assert dec.generate_ids(v, bars, at, max_bar_token_limit=12, temperature=0.0) == want
+
+
+def test_checkpoint_loader_contract(dev, tmp_path):
+    import json
+    from etude_amd.decoder import load_etude_decoder
+    sd = {k: torch.from_numpy(w) for k, w in synth.decoder_state_dict(1, {}).items()}
+    (tmp_path / "etude_decoder_config.json").write_text(json.dumps(synth.decoder_config_json()))
+    torch.save({"model_state_dict": {"_orig_mod." + k: t for k, t in sd.items()}, "epoch": 3}, tmp_path / "latest.pth")
+    m = load_etude_decoder(tmp_path / "etude_decoder_config.json", tmp_path / "latest.pth", "cuda")
+    v = _vocab()
+    bars = synth.song_bars(seed=3, n_bars=2)
+    assert len(m.generate(v, bars, [synth.attrs()] * 2, temperature=0.0, max_bar_token_limit=8)) > 0
+    bad = dict(sd)
+    del bad["lm_head.weight"]
+    torch.save(bad, tmp_path / "bad.pth")
+    with pytest.raises(RuntimeError, match="missing keys"):
+        load_etude_decoder(tmp_path / "etude_decoder_config.json", tmp_path / "bad.pth", "cuda")
