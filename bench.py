@@ -60,11 +60,12 @@ def cpu_baseline(seconds_budget: float = 25.0):
     """The CPU oracle (a restatement of the reference, pinned by golden vectors) on this node's host cores."""
     from etude_amd import synth
     from oracle import hft, neox
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(avail, 32)          # torch-CPU GEMMs of this size stop scaling (and regress) beyond ~32 threads
     torch.set_num_threads(cores)
     sd = {k: torch.from_numpy(v) for k, v in synth.extractor_state_dict(0).items()}
     x = torch.from_numpy(synth.window_features(5, 1))
@@ -76,15 +77,17 @@ def cpu_baseline(seconds_budget: float = 25.0):
         nwin += 1
     t_ext = time.time() - t0
     tsd = {k: torch.from_numpy(v) for k, v in synth.decoder_state_dict(1, {}).items()}
-    bars = synth.song_bars(seed=1234, n_bars=3)
+    dthreads = min(avail, 8)        # batch-1 token loop: small ops, more threads only add sync cost
+    torch.set_num_threads(dthreads)
+    bars = synth.song_bars(seed=1234, n_bars=2)
     t0 = time.time()
-    out = neox.generate_ids(tsd, neox.NeoxDims(), 4, 5, bars, [synth.attrs()] * 3, max_bar_token_limit=48)
+    out = neox.generate_ids(tsd, neox.NeoxDims(), 4, 5, bars, [synth.attrs()] * 2, max_bar_token_limit=24)
     t_dec = time.time() - t0
     ntok = sum(len(b) - 1 for b in out)
     return {"value": round(nwin * 8.192 / t_ext, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
             "sample": f"oracle hFT forward on {nwin} window(s) of 512 frames (8.192 s audio each) in {t_ext:.1f}s; "
-                      f"oracle greedy generate on 3 bars: {ntok} tokens in {t_dec:.1f}s",
-            "decoder_tokens_per_s": round(ntok / t_dec, 2)}
+                      f"oracle greedy generate on 2 bars: {ntok} tokens in {t_dec:.1f}s on {dthreads} threads",
+            "decoder_tokens_per_s": round(ntok / t_dec, 2), "decoder_cores": dthreads}
 
 
 def main():
@@ -94,6 +97,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=180.0, help="clip length")
     ap.add_argument("--bars", type=int, default=92)
+    ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS suppressed)")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -134,7 +138,7 @@ def main():
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         st = {}
-        out = dec.generate_many([(bars, attrs)], vocab, stats=st)
+        out = dec.generate_many([(bars, attrs)], vocab, stats=st, force_bar_tokens=args.bar_tokens)
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1, st["tokens"], len(notes), out
@@ -178,7 +182,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1] per rank: one 3-min 44.1 kHz stereo clip, full extract (wav->notes) + greedy decode of "
-                               f"{args.bars} synthetic condition bars, attrs 1/1/1 overlap 2, bf16 compute / fp32 accumulate; synthetic seeded weights",
+                               f"{args.bars} synthetic condition bars x {args.bar_tokens} generated tokens each (Bar_EOS suppressed: synthetic weights carry no musical EOS statistics), "
+                               "attrs 1/1/1 overlap 2, bf16 compute / fp32 accumulate; synthetic seeded weights",
                    "clip_seconds": args.seconds, "windows_per_clip": int(np.ceil((1 + int(np.ceil(160 * wav.shape[1] / 441)) // 256) / 512)),
                    "bars": args.bars, "parallelism": f"clip-sharded x{world}"},
         "extract_audio_s_per_s": round(audio_s / t_ext, 2),

@@ -186,8 +186,11 @@ class EtudeDecoder:
     # ------------------------------------------------------------------ multi-stream engine
     def generate_many(self, jobs: Sequence[Tuple[List[List[int]], List[Dict[str, int]]]], vocab, max_output_tokens: int = 25600,
                       max_bar_token_limit: int = 512, context_overlap_ratio: float = 0.5, steps_per_poll: int = 8,
-                      _validate: bool = True, stats: Optional[dict] = None) -> List[List[List[int]]]:
-        """Greedy-decode many independent jobs on up to ``max_streams`` concurrent device streams."""
+                      _validate: bool = True, stats: Optional[dict] = None, force_bar_tokens: int = 0) -> List[List[List[int]]]:
+        """Greedy-decode many independent jobs on up to ``max_streams`` concurrent device streams.
+
+        ``force_bar_tokens=n`` (benchmarks only) suppresses Bar_EOS and makes every bar exactly n tokens long, so that
+        throughput does not depend on where synthetic weights happen to emit EOS."""
         lib = _lib.lib()
         cfg = self.config
         results: List[Optional[List[List[int]]]] = [None] * len(jobs)
@@ -212,7 +215,7 @@ class EtudeDecoder:
                 if job.i >= len(job.x_bars):
                     return False
                 y_attrs = job.attrs[job.i]
-                job.limit = min(job.bar_limit, job.max_out - job.total)
+                job.limit = min(force_bar_tokens or job.bar_limit, job.max_out - job.total)
                 if job.limit <= 0:
                     # the reference's inner loop breaks before the first forward: the bar is just [Bar_BOS]
                     job.bars_out.append([bos])
@@ -226,7 +229,7 @@ class EtudeDecoder:
                 a4 = np.ascontiguousarray(np.stack([np.asarray(at[k], np.int32) for k in ABI_ATTR_KEYS]))
                 tg = np.asarray([y_attrs[k] for k in ABI_ATTR_KEYS], np.int32)
                 _lib.check(lib.etd_decoder_begin_bar(self._h, job.slot, ids.ctypes.data, cl.ctypes.data, a4.ctypes.data, T,
-                                                     tg.ctypes.data, eos, job.limit, st), "etd_decoder_begin_bar")
+                                                     tg.ctypes.data, -1 if force_bar_tokens else eos, job.limit, st), "etd_decoder_begin_bar")
                 return True
 
         def finish_bar(job: _Job):
