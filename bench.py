@@ -151,8 +151,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    _lib.prof_reset()
-    _lib.prof_enable(True)
     barrier()
     t0 = time.perf_counter()
     t_ext = t_dec = 0.0
@@ -162,8 +160,15 @@ def main():
         t_ext += a; t_dec += b; n_tok += c; n_notes = d
     barrier()
     elapsed = time.perf_counter() - t0
+    # per-kernel HIP-event timing: one extra identical step with an event pair around every launch.  It sits
+    # outside the K timed steps because event records cannot be placed inside the hipGraph replays that the
+    # production decode loop uses (with the profiler on the library launches the same kernels eagerly).
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    step()
     _lib.prof_enable(False)
     prof = _lib.prof_report()
+    prof_steps = 1
 
     tmax = torch.tensor([elapsed, t_ext, t_dec], dtype=torch.float64, device=dev)
     tsum = torch.tensor([float(n_tok)], dtype=torch.float64, device=dev)
@@ -211,7 +216,8 @@ def main():
                 result["roofline"]["traffic"] = json.loads(tp.read_text()).get(name)
             except Exception:
                 pass
-        result["kernel_ms_per_step"] = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        result["roofline"]["measured"] = "HIP events around every launch of the library during one extra identical step right after the timed region"
+        result["kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
 
     # ---- extras outside the timed region
     if not args.no_extras and rank == 0:
@@ -271,11 +277,14 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     slots = np.arange(n_streams, dtype=np.int32)
     _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, 4, st), "step")
     torch.cuda.synchronize(dev)
-    _lib.prof_reset(); _lib.prof_enable(True)
     t = time.perf_counter()
-    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, steps, st), "step")
+    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, steps, st), "step")     # hipGraph replays
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t
+    _lib.prof_reset(); _lib.prof_enable(True)
+    psteps = 8
+    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, psteps, st), "step")    # eager + events: per-kernel breakdown
+    torch.cuda.synchronize(dev)
     _lib.prof_enable(False)
     prof = _lib.prof_report()
     ctx_mid = ctx0 + 4 + steps // 2
@@ -285,7 +294,7 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
            "tokens_per_s": round(n_streams * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
            "alg_bytes_per_step": bytes_step,
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
-           "kernel_ms_per_step": {k: round(v["ms"] / steps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+           "kernel_ms_per_step": {k: round(v["ms"] / psteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
     dec.close()
     return out
 

@@ -11,6 +11,7 @@
 
 #include "../../include/etude_hip.h"
 #include "dec_kernels.h"
+#include "prof.h"
 
 namespace {
 
@@ -43,6 +44,8 @@ struct etd_dec {
   // stream state
   int *cur_tok = nullptr, *len = nullptr, *done = nullptr, *n_out = nullptr, *eos = nullptr, *limit = nullptr, *tgt_attrs = nullptr, *out_tok = nullptr;
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
+  float* qkv_raw = nullptr;                      // [3H] scratch row of the M == 1 QKV path
+  std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
 
   template <typename T> int alloc(T** p, size_t n, bool zero = false) {
     void* q = nullptr;
@@ -116,6 +119,7 @@ int forward_layers(etd_dec* d, int M, int lrow0, int lrows, hipStream_t st) {
     DGemmArgs q = {};
     q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
     q.ln_g = w.ln1g; q.ln_b = w.ln1b; q.ln_eps = d->cfg.layer_norm_eps;
+    q.Y = d->qkv_raw; q.ldy = 3 * d->H;
     q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
     q.Kc = (char*)d->Kc + (size_t)l * d->layer_stride * esz; q.Vc = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
     q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
@@ -256,6 +260,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   rc = rc ? rc : d->alloc(&d->h, M * H); rc = rc ? rc : d->alloc(&d->h2, M * H);
   rc = rc ? rc : d->alloc(&d->Q, M * H); rc = rc ? rc : d->alloc(&d->AO, M * H); rc = rc ? rc : d->alloc(&d->DO, M * H);
   rc = rc ? rc : d->alloc(&d->M1, M * d->I); rc = rc ? rc : d->alloc(&d->logits, M * d->V);
+  rc = rc ? rc : d->alloc(&d->qkv_raw, (size_t)3 * H);
   rc = rc ? rc : d->alloc(&d->row_slot, M); rc = rc ? rc : d->alloc(&d->row_pos, M); rc = rc ? rc : d->alloc(&d->row_active, M);
   rc = rc ? rc : d->alloc(&d->ids, 9 * M); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
   const size_t S = d->S;
@@ -270,6 +275,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
 
 extern "C" void etd_decoder_destroy(etd_dec* d) {
   if (!d) return;
+  for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
   for (void* p : d->allocs) (void)hipFree(p);
   delete d;
 }
@@ -309,21 +315,45 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     d->last_slots.assign(slots, slots + n_active);
     HIP_TRY(hipMemcpyAsync(d->slots_dev, d->last_slots.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, st));
   }
-  for (int s = 0; s < n_steps; ++s) {
-    ETD_TRY(launch_decode_rows(d->slots_dev, n_active, d->len, d->done, d->row_slot, d->row_pos, d->row_active, st));
+  auto one_step = [&](hipStream_t s_) -> int {
+    ETD_TRY(launch_decode_rows(d->slots_dev, n_active, d->len, d->done, d->row_slot, d->row_pos, d->row_active, s_));
     DEmbedArgs e = {};
     e.cur_tok = d->cur_tok; e.tgt_attrs = d->tgt_attrs; e.tgt_cls = 2 /* TGT_CLASS_ID, etude/data/dataset.py:19 */;
     e.M = n_active; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
     e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
     e.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
-    ETD_TRY(launch_dembed(e, st));
-    ETD_TRY(forward_layers(d, n_active, 0, n_active, st));
+    ETD_TRY(launch_dembed(e, s_));
+    ETD_TRY(forward_layers(d, n_active, 0, n_active, s_));
     DArgmaxArgs am = {};
     am.logits = d->logits; am.ldl = d->V; am.V = d->V; am.M = n_active;
     am.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
     am.cur_tok = d->cur_tok; am.len = d->len; am.done = d->done; am.n_out = d->n_out; am.out_tok = d->out_tok; am.out_cap = d->out_cap;
     am.eos = d->eos; am.limit = d->limit;
-    ETD_TRY(launch_dargmax(am, st));
+    ETD_TRY(launch_dargmax(am, s_));
+    return ETD_OK;
+  };
+  // The step is ~50 short dependent kernels: replay it as a hipGraph (captured once per n_active; every
+  // kernel argument is a fixed workspace/state pointer, the slot list lives in device memory).  Capture needs
+  // a non-default stream and must not contain the profiler's event records.
+  const bool use_graph = st != nullptr && !prof_enabled() && !getenv("ETD_NO_GRAPH");
+  if (use_graph) {
+    auto it = d->graphs.find(n_active);
+    if (it == d->graphs.end()) {
+      hipGraph_t g = nullptr;
+      HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int rc = one_step(st);
+      const hipError_t ce = hipStreamEndCapture(st, &g);
+      if (rc != ETD_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+      if (ce != hipSuccess || !g) ETD_FAIL(ETD_EHIP, "decoder_step: stream capture failed: %s", hipGetErrorString(ce));
+      hipGraphExec_t ge = nullptr;
+      const hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (ie != hipSuccess) ETD_FAIL(ETD_EHIP, "decoder_step: graph instantiate failed: %s", hipGetErrorString(ie));
+      it = d->graphs.emplace(n_active, ge).first;
+    }
+    for (int s = 0; s < n_steps; ++s) HIP_TRY(hipGraphLaunch(it->second, st));
+  } else {
+    for (int s = 0; s < n_steps; ++s) ETD_TRY(one_step(st));
   }
   return ETD_OK;
 }

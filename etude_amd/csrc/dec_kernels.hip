@@ -15,6 +15,77 @@
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
+// ---- shared epilogue: lane = token m, registers = features nb + acc_row(i, h)
+template <bool WBF16, int EPI>
+__device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16& acc, int m, int nb, int h) {
+  // ---- epilogue: lane = token m, registers = features nb + acc_row(i, h)
+  if constexpr (EPI == DEPI_QKV) {
+    // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207)
+    const int head = nb / 192, j0 = nb - head * 192, part = j0 >> 6, dbase = j0 & 63;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = acc[i] + a.bias[nb + acc_row(i, h)];
+    const int pos = a.rows.pos[m];
+    if (part < 2 && dbase == 0) {
+      // partial RoPE on dims [0, 2*rot_half): pair (d, d + rot_half); with rot_half == 8 both sit in
+      // this lane: d = (i&3) + 4h  (i < 4)  and d + 8 = register i + 4
+      const float* cs = a.rope_cos + (long long)pos * a.rot_half;
+      const float* sn = a.rope_sin + (long long)pos * a.rot_half;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = i + 4 * h;
+        const float c = cs[d], s = sn[d];
+        const float x1 = v[i], x2 = v[i + 4];
+        v[i] = x1 * c - x2 * s;        // q*cos + rotate_half(q)*sin, first half:  x1*cos - x2*sin
+        v[i + 4] = x2 * c + x1 * s;    // second half: x2*cos + x1*sin
+      }
+    }
+    if (part == 0) {
+      float* qp = a.Q + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q + 4 * h) = o; }
+    } else if (a.rows.active[m] && pos < a.max_ctx) {
+      const long long off = (long long)a.rows.slot[m] * a.slot_stride + ((long long)head * a.max_ctx + pos) * 64 + dbase;
+      void* base = part == 1 ? a.Kc : a.Vc;
+      if constexpr (WBF16) {
+        bf16* kp = reinterpret_cast<bf16*>(base) + off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(kp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      } else {
+        float* kp = reinterpret_cast<float*>(base) + off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(kp + 8 * q + 4 * h) = o; }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = nb + 8 * q + 4 * h;
+      if (n >= a.N) continue;
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[4 * q + j];
+        if (EPI != DEPI_LOGITS) v[j] += a.bias[n + j];
+        if (EPI == DEPI_GELU) v[j] = gelu_erf(v[j]);
+      }
+      if constexpr (EPI == DEPI_RESID) {
+        const f32x4 ad = *reinterpret_cast<const f32x4*>(a.add + (long long)m * a.N + n);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(a.hin + (long long)m * a.N + n);
+        const f32x4 o = {(v[0] + ad[0]) + hi[0], (v[1] + ad[1]) + hi[1], (v[2] + ad[2]) + hi[2], (v[3] + ad[3]) + hi[3]};
+        *reinterpret_cast<f32x4*>(a.hout + (long long)m * a.N + n) = o;
+      } else if (n + 3 < a.N) {
+        const f32x4 o = {v[0], v[1], v[2], v[3]};
+        float* yp = a.Y + (long long)m * a.ldy + n;
+        if ((a.ldy & 3) == 0) *reinterpret_cast<f32x4*>(yp) = o;
+        else { yp[0] = v[0]; yp[1] = v[1]; yp[2] = v[2]; yp[3] = v[3]; }
+      } else {
+        for (int j = 0; j < 4 && n + j < a.N; ++j) a.Y[(long long)m * a.ldy + n + j] = v[j];
+      }
+    }
+  }
+}
+
 // ================================================================================================
 // k_dgemm: Y[M,N] = epi( LN?(X)[M,K] * W[N,K]^T + b ).  Workgroup = 4 waves = 32 tokens x 128
 // features (each wave one 32x32 accumulator, token on the lane).
@@ -122,97 +193,238 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
     }
   }
 
-  // ---- epilogue: lane = token m, registers = features nb + acc_row(i, h)
   const int m = m0 + r;
   if (m >= a.M) return;
-  const int nb = n0 + wave * 32;
-  if constexpr (EPI == DEPI_QKV) {
-    // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207)
-    const int head = nb / 192, j0 = nb - head * 192, part = j0 >> 6, dbase = j0 & 63;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = acc[i] + a.bias[nb + acc_row(i, h)];
-    const int pos = a.rows.pos[m];
-    if (part < 2 && dbase == 0) {
-      // partial RoPE on dims [0, 2*rot_half): pair (d, d + rot_half); with rot_half == 8 both sit in
-      // this lane: d = (i&3) + 4h  (i < 4)  and d + 8 = register i + 4
-      const float* cs = a.rope_cos + (long long)pos * a.rot_half;
-      const float* sn = a.rope_sin + (long long)pos * a.rot_half;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int d = i + 4 * h;
-        const float c = cs[d], s = sn[d];
-        const float x1 = v[i], x2 = v[i + 4];
-        v[i] = x1 * c - x2 * s;        // q*cos + rotate_half(q)*sin, first half:  x1*cos - x2*sin
-        v[i + 4] = x2 * c + x1 * s;    // second half: x2*cos + x1*sin
+  dgemm_epilogue<WBF16, EPI>(a, acc, m, n0 + wave * 32, h);
+}
+
+// ================================================================================================
+// k_dgemm_s ("skinny", M <= 128): 32 tokens x 32 features per workgroup, K split over the 4 waves,
+// fragments straight from global/L2 to registers (no LDS staging, no barrier in the K loop), partial
+// tiles reduced through LDS in a fixed order (bit-reproducible).  (N/32) x (M/32) workgroups keep many
+// more CUs streaming weights than the 128-feature tile does when M is a handful of decode rows.
+// ================================================================================================
+template <bool WBF16, int EPI>
+__global__ __launch_bounds__(256) void k_dgemm_s(DGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[3][16][64];
+  __shared__ float stat[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const bool ln = a.ln_g != nullptr;
+  if (ln) {
+    for (int rr = 0; rr < 8; ++rr) {
+      const int row = wave * 8 + rr;
+      int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
+      const float* xp = a.X + (long long)gm * a.ldx;
+      float s = 0.f;
+      for (int k = lane * 4; k < a.K; k += 256) { const f32x4 v = *reinterpret_cast<const f32x4*>(xp + k); s += v[0] + v[1] + v[2] + v[3]; }
+      s = wave_sum(s);
+      const float mean = s / (float)a.K;
+      float q = 0.f;
+      for (int k = lane * 4; k < a.K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + k);
+        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+        q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
       }
+      q = wave_sum(q);
+      if (lane == 0) { stat[row] = mean; stat[32 + row] = rsqrtf(q / (float)a.K + a.ln_eps); }
     }
-    if (part == 0) {
-      float* qp = a.Q + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
+    __syncthreads();
+  }
+  int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
+  const float mean = ln ? stat[r] : 0.f, rstd = ln ? stat[32 + r] : 1.f;
+  const float* xrow = a.X + (long long)gm * a.ldx;
+  const int kq = a.K >> 2, kb = wave * kq, ke = kb + kq;
+  f32x16 acc;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q + 4 * h) = o; }
-    } else if (a.rows.active[m] && pos < a.max_ctx) {
-      const long long off = (long long)a.rows.slot[m] * a.slot_stride + ((long long)head * a.max_ctx + pos) * 64 + dbase;
-      void* base = part == 1 ? a.Kc : a.Vc;
-      if constexpr (WBF16) {
-        bf16* kp = reinterpret_cast<bf16*>(base) + off;
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  if constexpr (WBF16) {
+    const bf16* wrow = reinterpret_cast<const bf16*>(a.W) + (long long)(n0 + r) * a.K;
+#pragma unroll 2
+    for (int k = kb; k < ke; k += 64) {
+      bf16x8 wf[4]; f32x4 x0[4], x1[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(kp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-      } else {
-        float* kp = reinterpret_cast<float*>(base) + off;
+      for (int s4 = 0; s4 < 4; ++s4) {
+        wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
+        x0[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8);
+        x1[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8 + 4);
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(kp + 8 * q + 4 * h) = o; }
+      for (int s4 = 0; s4 < 4; ++s4) {
+        if (ln) {
+          const int kk = k + s4 * 16 + h * 8;
+          const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + kk), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + kk + 4);
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_b + kk), b1 = *reinterpret_cast<const f32x4*>(a.ln_b + kk + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { x0[s4][j] = (x0[s4][j] - mean) * rstd * g0[j] + b0[j]; x1[s4][j] = (x1[s4][j] - mean) * rstd * g1[j] + b1[j]; }
+        }
+        const bf16x8 xf = {(bf16)x0[s4][0], (bf16)x0[s4][1], (bf16)x0[s4][2], (bf16)x0[s4][3], (bf16)x1[s4][0], (bf16)x1[s4][1], (bf16)x1[s4][2], (bf16)x1[s4][3]};
+        acc = mfma32(wf[s4], xf, acc);
       }
     }
   } else {
+    const float* wrow = reinterpret_cast<const float*>(a.W) + (long long)(n0 + r) * a.K;
+#pragma unroll 2
+    for (int k = kb; k < ke; k += 32) {
+      f32x4 wf[4], xf[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = nb + 8 * q + 4 * h;
-      if (n >= a.N) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = acc[4 * q + j];
-        if (EPI != DEPI_LOGITS) v[j] += a.bias[n + j];
-        if (EPI == DEPI_GELU) v[j] = gelu_erf(v[j]);
+      for (int jp = 0; jp < 4; ++jp) {
+        wf[jp] = *reinterpret_cast<const f32x4*>(wrow + k + jp * 8 + h * 4);
+        xf[jp] = *reinterpret_cast<const f32x4*>(xrow + k + jp * 8 + h * 4);
       }
-      if constexpr (EPI == DEPI_RESID) {
-        const f32x4 ad = *reinterpret_cast<const f32x4*>(a.add + (long long)m * a.N + n);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(a.hin + (long long)m * a.N + n);
-        const f32x4 o = {(v[0] + ad[0]) + hi[0], (v[1] + ad[1]) + hi[1], (v[2] + ad[2]) + hi[2], (v[3] + ad[3]) + hi[3]};
-        *reinterpret_cast<f32x4*>(a.hout + (long long)m * a.N + n) = o;
-      } else if (n + 3 < a.N) {
-        const f32x4 o = {v[0], v[1], v[2], v[3]};
-        float* yp = a.Y + (long long)m * a.ldy + n;
-        if ((a.ldy & 3) == 0) *reinterpret_cast<f32x4*>(yp) = o;
-        else { yp[0] = v[0]; yp[1] = v[1]; yp[2] = v[2]; yp[3] = v[3]; }
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        if (ln) {
+          const int kk = k + jp * 8 + h * 4;
+          const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g + kk), b = *reinterpret_cast<const f32x4*>(a.ln_b + kk);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xf[jp][j] = (xf[jp][j] - mean) * rstd * g[j] + b[j];
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[jp][s4], xf[jp][s4], acc, 0, 0, 0);
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
+  const int m = m0 + r;
+  if (m >= a.M) return;
+  dgemm_epilogue<WBF16, EPI>(a, acc, m, n0, h);
+}
+
+// ================================================================================================
+// k_dgemv (M == 1, the reference's batch-1 token loop): each wave owns 4 output features, the 64 lanes
+// split K in 16-byte pieces (one fully coalesced 1 KiB / 2 KiB row segment per load instruction).
+// ================================================================================================
+template <bool WBF16, int EPI>
+__global__ __launch_bounds__(256) void k_dgemv(DGemmArgs a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb = (blockIdx.x * 4 + wave) * 4;
+  const bool ln = a.ln_g != nullptr;
+  float mean = 0.f, rstd = 1.f;
+  if (ln) {
+    float s = 0.f;
+    for (int k = lane * 4; k < a.K; k += 256) { const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + k); s += v[0] + v[1] + v[2] + v[3]; }
+    s = wave_sum(s);
+    mean = s / (float)a.K;
+    float q = 0.f;
+    for (int k = lane * 4; k < a.K; k += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + k);
+      const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+      q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+    }
+    q = wave_sum(q);
+    rstd = rsqrtf(q / (float)a.K + a.ln_eps);
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane * 8; k < a.K; k += 512) {
+    f32x4 x0 = *reinterpret_cast<const f32x4*>(a.X + k), x1 = *reinterpret_cast<const f32x4*>(a.X + k + 4);
+    if (ln) {
+      const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + k), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + k + 4);
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_b + k), b1 = *reinterpret_cast<const f32x4*>(a.ln_b + k + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x0[j] = (x0[j] - mean) * rstd * g0[j] + b0[j]; x1[j] = (x1[j] - mean) * rstd * g1[j] + b1[j]; }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      float w[8];
+      if constexpr (WBF16) {
+        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.W) + (long long)(nb + f) * a.K + k);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = bf2f(wv[j]);
+        // the MFMA paths round x to bf16 as well; keep the GEMV consistent with them
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[f] = fmaf(w[j], bf2f((bf16)x0[j]), acc[f]); acc[f] = fmaf(w[4 + j], bf2f((bf16)x1[j]), acc[f]); }
       } else {
-        for (int j = 0; j < 4 && n + j < a.N; ++j) a.Y[(long long)m * a.ldy + n + j] = v[j];
+        const float* wp = reinterpret_cast<const float*>(a.W) + (long long)(nb + f) * a.K + k;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[f] = fmaf(w0[j], x0[j], acc[f]); acc[f] = fmaf(w1[j], x1[j], acc[f]); }
       }
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 4; ++f) acc[f] = wave_sum(acc[f]);
+  if (lane != 0) return;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int n = nb + f;
+    if (n >= a.N) break;
+    float v = acc[f];
+    if (EPI != DEPI_LOGITS) v += a.bias[n];
+    if (EPI == DEPI_GELU) v = gelu_erf(v);
+    if (EPI == DEPI_RESID) a.hout[n] = (v + a.add[n]) + a.hin[n];
+    else a.Y[n] = v;
+  }
+}
+
+// raw fused-QKV row(s) [M][3H] -> RoPE'd Q [M][H], K/V cache rows (used after the GEMV path)
+template <typename KVT>
+__global__ void k_rope_scatter(DGemmArgs a, const float* __restrict__ raw) {
+  const int m = blockIdx.x;
+  const int pos = a.rows.pos[m], slot = a.rows.slot[m];
+  const bool act = a.rows.active[m] && pos < a.max_ctx;
+  const int H3 = a.n_heads * 192;
+  for (int n = threadIdx.x; n < H3; n += blockDim.x) {
+    const int head = n / 192, j = n - head * 192, part = j >> 6, d = j & 63;
+    float v = raw[(long long)m * H3 + n];
+    if (part < 2 && d < 2 * a.rot_half) {
+      const int dd = d < a.rot_half ? d : d - a.rot_half;
+      const float c = a.rope_cos[(long long)pos * a.rot_half + dd], s = a.rope_sin[(long long)pos * a.rot_half + dd];
+      const float other = raw[(long long)m * H3 + (d < a.rot_half ? n + a.rot_half : n - a.rot_half)];
+      v = d < a.rot_half ? v * c - other * s : v * c + other * s;
+    }
+    if (part == 0) a.Q[(long long)m * (a.n_heads * 64) + head * 64 + d] = v;
+    else if (act) {
+      const long long off = (long long)slot * a.slot_stride + ((long long)head * a.max_ctx + pos) * 64 + d;
+      KVT* base = reinterpret_cast<KVT*>(part == 1 ? a.Kc : a.Vc);
+      base[off] = (KVT)v;
     }
   }
 }
 
 template <bool WBF16>
-static void dgemm_dispatch(const DGemmArgs& a, int epi, dim3 g, hipStream_t st) {
+static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st) {
+  // path 0: 128-feature tile (prefill), 1: skinny K-split tile (M <= 128), 2: GEMV (M == 1)
+  const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((a.M + 31) / 32, a.Npad / 32), g2(a.Npad / 16);
+#define ETD_DG(E)                                                                                   \
+  if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, E>), g0, dim3(256), 0, st, a);                  \
+  else if (path == 1) hipLaunchKernelGGL((k_dgemm_s<WBF16, E>), g1, dim3(256), 0, st, a);           \
+  else hipLaunchKernelGGL((k_dgemv<WBF16, E>), g2, dim3(256), 0, st, a);
   switch (epi) {
-    case DEPI_BIAS: hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_BIAS>), g, dim3(256), 0, st, a); break;
-    case DEPI_GELU: hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_GELU>), g, dim3(256), 0, st, a); break;
-    case DEPI_RESID: hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_RESID>), g, dim3(256), 0, st, a); break;
-    case DEPI_LOGITS: hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_LOGITS>), g, dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_QKV>), g, dim3(256), 0, st, a); break;
+    case DEPI_BIAS: ETD_DG(DEPI_BIAS) break;
+    case DEPI_GELU: ETD_DG(DEPI_GELU) break;
+    case DEPI_RESID: ETD_DG(DEPI_RESID) break;
+    case DEPI_LOGITS: ETD_DG(DEPI_LOGITS) break;
+    default:
+      if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_QKV>), g0, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_QKV>), g1, dim3(256), 0, st, a);
+      break;
   }
+#undef ETD_DG
 }
 
 int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
-  if (a.M <= 0 || a.Npad % 128 || a.K % 64 || a.N > a.Npad) ETD_FAIL(ETD_EINVAL, "dgemm: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
-  if (a.ln_g && a.K % 256) ETD_FAIL(ETD_EINVAL, "dgemm: LayerNorm prologue needs K %% 256 == 0");
+  if (a.M <= 0 || a.Npad % 128 || a.K % 256 || a.N > a.Npad) ETD_FAIL(ETD_EINVAL, "dgemm: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
   if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "dgemm: QKV epilogue needs head_dim 64 and rotary_ndims 16");
   if (epi == DEPI_RESID && (a.N % 4)) ETD_FAIL(ETD_EINVAL, "dgemm: resid needs N %% 4 == 0");
-  ProfScope ps("k_dgemm", st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * (w_bf16 ? 2 : 4));
-  dim3 g((a.M + 31) / 32, a.Npad / 128);
-  if (w_bf16) dgemm_dispatch<true>(a, epi, g, st);
-  else dgemm_dispatch<false>(a, epi, g, st);
+  const int path = a.M == 1 ? 2 : (a.M <= 128 ? 1 : 0);
+  ProfScope ps(path == 2 ? "k_dgemv" : (path == 1 ? "k_dgemm_s" : "k_dgemm"), st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * (w_bf16 ? 2 : 4));
+  if (path == 2 && epi == DEPI_QKV) {
+    // GEMV writes the raw fused row into a.Y (caller-provided scratch [3H]); RoPE + Q/K/V scatter follow
+    if (!a.Y) ETD_FAIL(ETD_EINVAL, "dgemm: M == 1 QKV path needs a scratch row in Y");
+    if (w_bf16) { dgemm_dispatch<true>(a, DEPI_BIAS, 2, st); hipLaunchKernelGGL(k_rope_scatter<bf16>, dim3(1), dim3(256), 0, st, a, a.Y); }
+    else { dgemm_dispatch<false>(a, DEPI_BIAS, 2, st); hipLaunchKernelGGL(k_rope_scatter<float>, dim3(1), dim3(256), 0, st, a, a.Y); }
+  } else if (w_bf16) dgemm_dispatch<true>(a, epi, path, st);
+  else dgemm_dispatch<false>(a, epi, path, st);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 
+bool prof_enabled();
 void prof_begin(const char* name, hipStream_t st);
 void prof_end(const char* name, hipStream_t st, double flops, double bytes);
 

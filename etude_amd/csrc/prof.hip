@@ -22,6 +22,7 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+bool prof_enabled() { return g_on; }
 void prof_begin(const char* name, hipStream_t st) {
   if (!g_on) return;
   std::lock_guard<std::mutex> lk(g_mu);

@@ -134,6 +134,8 @@ class EtudeDecoder:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().etd_decoder_create(C.byref(cfg), names, ptrs, numels, n, C.byref(h)), "etd_decoder_create")
         self._h = h
+        # decode steps are replayed as hipGraphs, which cannot be captured on the default stream
+        self._ts = torch.cuda.Stream(device=self.device)
 
     # ------------------------------------------------------------------ reference surface
     def eval(self):
@@ -143,7 +145,7 @@ class EtudeDecoder:
         return self
 
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        return C.c_void_p(self._ts.cuda_stream)
 
     def _validate(self, vocab, all_x_bars, target_attributes_per_bar):
         try:
