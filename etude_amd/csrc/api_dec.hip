@@ -46,6 +46,8 @@ struct etd_dec {
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
   float* qkv_raw = nullptr;                      // [3H] scratch row of the M == 1 QKV path
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
+  std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
+  double attn_bytes_hint = 0;
 
   template <typename T> int alloc(T** p, size_t n, bool zero = false) {
     void* q = nullptr;
@@ -126,7 +128,7 @@ int forward_layers(etd_dec* d, int M, int lrow0, int lrows, hipStream_t st) {
     ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
     DAttnArgs at = {};
     at.Q = d->Q; at.Kc = q.Kc; at.Vc = q.Vc; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
-    at.rows = rows; at.M = M; at.O = d->AO; at.scale = 0.125f;
+    at.rows = rows; at.M = M; at.O = d->AO; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
     ETD_TRY(launch_dattn(at, d->bf16w, st));
     DGemmArgs de = {};
     de.X = d->AO; de.ldx = d->H; de.W = w.dense.W; de.bias = w.dense.b; de.M = M; de.N = d->H; de.Npad = w.dense.Npad; de.K = d->H;
@@ -198,6 +200,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   d->H = c.hidden_size; d->I = c.intermediate_size; d->V = c.vocab_size; d->L = c.num_hidden_layers; d->nh = c.num_attention_heads;
   d->S = c.max_streams; d->ctx = c.max_ctx; d->out_cap = 1024;
   d->Mmax = d->ctx > d->S ? d->ctx : d->S;
+  d->host_len.assign(d->S, 0);
   Loader Ld;
   for (int i = 0; i < n; ++i) Ld.t[names[i]] = {host_ptrs[i], numels[i]};
   auto fail = [&](int rc) { for (void* p : d->allocs) (void)hipFree(p); delete d; return rc; };
@@ -297,6 +300,8 @@ extern "C" int etd_decoder_begin_bar(etd_dec* d, int slot, const int32_t* ids, c
   HIP_TRY(hipMemcpyAsync(d->eos + slot, st8 + 8, 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(d->limit + slot, st8 + 9, 4, hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));   // st8 is a stack array
+  d->host_len[slot] = T;
+  d->attn_bytes_hint = 0.5 * T * (T + 1.0) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4);
   ETD_TRY(forward_layers(d, T, T - 1, 1, st));
   DArgmaxArgs am = {};
   am.logits = d->logits + (size_t)(T - 1) * d->V; am.ldl = d->V; am.V = d->V; am.M = 1;
@@ -316,6 +321,9 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     HIP_TRY(hipMemcpyAsync(d->slots_dev, d->last_slots.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, st));
   }
   auto one_step = [&](hipStream_t s_) -> int {
+    double kvb = 0;
+    for (int i = 0; i < n_active; ++i) { int& hl = d->host_len[slots[i]]; kvb += (double)(hl + 1) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4); if (hl < d->ctx - 1) ++hl; }
+    d->attn_bytes_hint = kvb;
     ETD_TRY(launch_decode_rows(d->slots_dev, n_active, d->len, d->done, d->row_slot, d->row_pos, d->row_active, s_));
     DEmbedArgs e = {};
     e.cur_tok = d->cur_tok; e.tgt_attrs = d->tgt_attrs; e.tgt_cls = 2 /* TGT_CLASS_ID, etude/data/dataset.py:19 */;

@@ -39,6 +39,7 @@ struct DAttnArgs {
   DecRows rows; int M;
   float* O;                      // [M][hidden]
   float scale;
+  double bytes_hint;             // algorithmic K+V bytes this launch reads (host estimate, profiler only)
 };
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
 
