@@ -34,7 +34,7 @@ class DecCfg(C.Structure):
                                        "intermediate_size", "max_position_embeddings", "num_classes",
                                        "num_attribute_bins", "attribute_emb_dim")] + \
                [("rotary_pct", C.c_float), ("rope_theta", C.c_float), ("layer_norm_eps", C.c_float),
-                ("max_streams", C.c_int), ("max_ctx", C.c_int), ("precision", C.c_int)]
+                ("max_streams", C.c_int), ("max_ctx", C.c_int), ("precision", C.c_int), ("max_prefill_rows", C.c_int)]
 
 
 class Note(C.Structure):
@@ -73,6 +73,7 @@ SIGNATURES = {
     "etd_decoder_destroy": (None, [C.c_void_p]),
     "etd_decoder_begin_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_void_p]),
+    "etd_decoder_begin_bars": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p]),
     "etd_decoder_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "etd_decoder_poll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "etd_decoder_read_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_int_p, C.c_void_p]),

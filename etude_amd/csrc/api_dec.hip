@@ -11,6 +11,7 @@
 
 #include "../../include/etude_hip.h"
 #include "dec_kernels.h"
+#include "ext_kernels.h"
 #include "prof.h"
 
 namespace {
@@ -30,7 +31,7 @@ struct etd_dec {
   etd_dec_cfg cfg;
   std::vector<void*> allocs;
   bool bf16w = false;
-  int H, I, V, L, nh, S, ctx, Mmax, out_cap;
+  int H, I, V, L, nh, S, ctx, Mmax, Mcap, out_cap;
   float *word = nullptr, *cls_emb = nullptr, *attr_tab = nullptr;
   std::vector<Layer> layers;
   float *lnfg = nullptr, *lnfb = nullptr;
@@ -45,6 +46,9 @@ struct etd_dec {
   int *cur_tok = nullptr, *len = nullptr, *done = nullptr, *n_out = nullptr, *eos = nullptr, *limit = nullptr, *tgt_attrs = nullptr, *out_tok = nullptr;
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
   float* qkv_raw = nullptr;                      // [3H] scratch row of the M == 1 QKV path
+  bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
+  float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
+  std::vector<int> stage;                        // host staging of a prefill batch
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
   double attn_bytes_hint = 0;
@@ -110,48 +114,89 @@ int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst)
   return up_f32(d, dst, p, n);
 }
 
-// one forward pass over M rows whose metadata (row_slot/row_pos/row_active) and embeddings (d->h) are
-// already on the device; leaves the final-LN'ed logits of rows [lrow0, lrow0+lrows) in d->logits
-int forward_layers(etd_dec* d, int M, int lrow0, int lrows, hipStream_t st) {
-  const DecRows rows{d->row_slot, d->row_pos, d->row_active};
+// ---- one forward pass over M rows.  `rows` describes each row (slot, position, active); the embeddings are in
+// d->h.  Returns (in *hfinal) the buffer that holds the last layer's output (before the final LayerNorm).
+//
+// fp32 weights, or M == 1: fp32 activations, LayerNorm fused into the GEMM prologues (k_dgemm / k_dgemm_s / k_dgemv).
+// bf16 weights, M > 1:     k_ln_rows -> bf16 activations -> big-tile MFMA GEMM (k_linear decoder modes, M > 128, the
+//                          batched prefill) or the K-split skinny GEMM (M <= 128, the batched decode step).
+int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st) {
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
+  const bool bpipe = d->bf16w && M > 1;
+  const bool big = bpipe && M > 128;
   for (int l = 0; l < d->L; ++l) {
     const Layer& w = d->layers[l];
+    void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * esz;
+    void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
+    if (bpipe) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
+    // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
     q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
-    q.ln_g = w.ln1g; q.ln_b = w.ln1b; q.ln_eps = d->cfg.layer_norm_eps;
+    if (bpipe) q.Xb = d->X1b; else { q.ln_g = w.ln1g; q.ln_b = w.ln1b; q.ln_eps = d->cfg.layer_norm_eps; }
     q.Y = d->qkv_raw; q.ldy = 3 * d->H;
     q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
-    q.Kc = (char*)d->Kc + (size_t)l * d->layer_stride * esz; q.Vc = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
-    q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
-    ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
+    q.Kc = Kl; q.Vc = Vl; q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
+    if (big) {
+      LinArgs a = {};
+      a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
+      ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
+    } else {
+      ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
+    }
+    // ---- causal attention against the slot's KV cache
     DAttnArgs at = {};
-    at.Q = d->Q; at.Kc = q.Kc; at.Vc = q.Vc; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
-    at.rows = rows; at.M = M; at.O = d->AO; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+    at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
+    at.rows = rows; at.M = M; at.O = d->AO; at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
     ETD_TRY(launch_dattn(at, d->bf16w, st));
+    // ---- attention.dense
     DGemmArgs de = {};
     de.X = d->AO; de.ldx = d->H; de.W = w.dense.W; de.bias = w.dense.b; de.M = M; de.N = d->H; de.Npad = w.dense.Npad; de.K = d->H;
     de.Y = d->DO; de.ldy = d->H;
-    ETD_TRY(launch_dgemm(de, DEPI_BIAS, d->bf16w, st));
+    if (bpipe) de.Xb = d->AOb;
+    if (big) {
+      LinArgs a = {};
+      a.X = d->AOb; a.ldx = d->H; a.W = (const bf16*)w.dense.W; a.bias = w.dense.b; a.M = M; a.N = d->H; a.K = d->H; a.vt_block = -1; a.dec = de;
+      ETD_TRY(launch_linear_dec(a, DEPI_BIAS, st));
+    } else {
+      ETD_TRY(launch_dgemm(de, DEPI_BIAS, d->bf16w, st));
+    }
+    // ---- MLP up + GELU
     DGemmArgs up = {};
     up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
-    up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; up.Y = d->M1; up.ldy = d->I;
-    ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
+    up.Y = d->M1; up.ldy = d->I;
+    if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
+    if (big) {
+      LinArgs a = {};
+      a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.W; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
+      ETD_TRY(launch_linear_dec(a, DEPI_GELU, st));
+    } else {
+      ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
+    }
+    // ---- MLP down + parallel residual: h = (mlp + attn) + h   (modeling_gpt_neox.py:272)
     DGemmArgs dn = {};
     dn.X = d->M1; dn.ldx = d->I; dn.W = w.down.W; dn.bias = w.down.b; dn.M = M; dn.N = d->H; dn.Npad = w.down.Npad; dn.K = d->I;
-    dn.add = d->DO; dn.hin = hin; dn.hout = hout;      // h = (mlp + attn) + h   (modeling_gpt_neox.py:272)
-    ETD_TRY(launch_dgemm(dn, DEPI_RESID, d->bf16w, st));
+    dn.add = d->DO; dn.hin = hin; dn.hout = hout;
+    if (bpipe) dn.Xb = d->M1b;
+    if (big) {
+      LinArgs a = {};
+      a.X = d->M1b; a.ldx = d->I; a.W = (const bf16*)w.down.W; a.bias = w.down.b; a.M = M; a.N = d->H; a.K = d->I; a.vt_block = -1; a.dec = dn;
+      ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
+    } else {
+      ETD_TRY(launch_dgemm(dn, DEPI_RESID, d->bf16w, st));
+    }
     float* t = hin; hin = hout; hout = t;
   }
-  DGemmArgs lm = {};
-  lm.X = hin + (size_t)lrow0 * d->H; lm.ldx = d->H; lm.W = d->head.W; lm.bias = nullptr; lm.M = lrows; lm.N = d->V; lm.Npad = d->head.Npad; lm.K = d->H;
-  lm.ln_g = d->lnfg; lm.ln_b = d->lnfb; lm.ln_eps = d->cfg.layer_norm_eps; lm.Y = d->logits + (size_t)lrow0 * d->V; lm.ldy = d->V;
-  ETD_TRY(launch_dgemm(lm, DEPI_LOGITS, d->bf16w, st));
-  if (hin != d->h) {   // keep the invariant "embeddings go to d->h" (even layer count leaves hin == d->h)
-    HIP_TRY(hipMemcpyAsync(d->h, hin, (size_t)M * d->H * 4, hipMemcpyDeviceToDevice, st));
-  }
+  *hfinal = hin;
   return ETD_OK;
+}
+
+// final LayerNorm + lm_head for `n` rows of X (fp32 [n][H]) -> logits [n][V]
+int head_logits(etd_dec* d, const float* X, int n, float* logits, hipStream_t st) {
+  DGemmArgs lm = {};
+  lm.X = X; lm.ldx = d->H; lm.W = d->head.W; lm.bias = nullptr; lm.M = n; lm.N = d->V; lm.Npad = d->head.Npad; lm.K = d->H;
+  lm.ln_g = d->lnfg; lm.ln_b = d->lnfb; lm.ln_eps = d->cfg.layer_norm_eps; lm.Y = logits; lm.ldy = d->V;
+  return launch_dgemm(lm, DEPI_LOGITS, d->bf16w, st);
 }
 
 int check_slot(etd_dec* d, int slot) {
@@ -159,29 +204,66 @@ int check_slot(etd_dec* d, int slot) {
   return ETD_OK;
 }
 
-int prefill_common(etd_dec* d, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T, hipStream_t st) {
-  ETD_TRY(check_slot(d, slot));
-  if (!ids || !cls || !attrs4 || T <= 0 || T > d->ctx || T > d->Mmax) ETD_FAIL(ETD_EINVAL, "prefill: bad prompt (T=%d, max_ctx=%d)", T, d->ctx);
-  for (int i = 0; i < T; ++i) {
-    if (ids[i] < 0 || ids[i] >= d->V || cls[i] < 0 || cls[i] >= d->cfg.num_classes) ETD_FAIL(ETD_EINVAL, "prefill: token/class id out of range at %d", i);
-    for (int k = 0; k < 4; ++k) if (attrs4[k * T + i] < 0 || attrs4[k * T + i] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "prefill: attribute bin out of range at %d", i);
+__global__ void k_init_slots(const int* __restrict__ init, int n, int* tgt_attrs, int* cur_tok, int* len, int* done, int* n_out, int* eos, int* limit) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int* p = init + i * 7;
+  const int s = p[0];
+  tgt_attrs[4 * s] = p[1]; tgt_attrs[4 * s + 1] = p[2]; tgt_attrs[4 * s + 2] = p[3]; tgt_attrs[4 * s + 3] = p[4];
+  cur_tok[s] = 0; len[s] = 0; done[s] = 0; n_out[s] = 0; eos[s] = p[5]; limit[s] = p[6];
+}
+
+// Stage a batch of n prompts (concatenated) on the device, embed them, run the model.  On return *hfinal holds
+// the hidden states of all Mtot rows; the staged row metadata lives in d->ids (layout below).
+struct Staged { int Mtot; const int *ids, *cls, *attrs, *row_slot, *row_pos, *row_active, *last_idx, *last_slot, *last_pos, *last_active, *init; };
+
+int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T, const int32_t* ids, const int32_t* cls,
+                      const int32_t* attrs4, const int32_t* init7 /* [n][7] or null */, Staged* sg, float** hfinal, hipStream_t st) {
+  if (!d || n < 1 || n > d->S || !slots || !T || !ids || !cls || !attrs4) ETD_FAIL(ETD_EINVAL, "prefill: bad arguments");
+  long long Mtot = 0;
+  for (int i = 0; i < n; ++i) {
+    ETD_TRY(check_slot(d, slots[i]));
+    if (T[i] <= 0 || T[i] > d->ctx) ETD_FAIL(ETD_EINVAL, "prefill: prompt %d has T=%d (max_ctx=%d)", i, T[i], d->ctx);
+    for (int j = 0; j < i; ++j) if (slots[j] == slots[i]) ETD_FAIL(ETD_EINVAL, "prefill: slot %d listed twice", slots[i]);
+    Mtot += T[i];
   }
-  // staging layout in d->ids: [ids T][cls T][attrs 4T][row_slot T][row_pos T][row_active T]
-  std::vector<int> stage((size_t)9 * T);
-  memcpy(stage.data(), ids, (size_t)T * 4);
-  memcpy(stage.data() + T, cls, (size_t)T * 4);
-  memcpy(stage.data() + 2 * T, attrs4, (size_t)4 * T * 4);
-  for (int i = 0; i < T; ++i) { stage[6 * T + i] = slot; stage[7 * T + i] = i; stage[8 * T + i] = 1; }
-  HIP_TRY(hipMemcpyAsync(d->ids, stage.data(), stage.size() * 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));   // `stage` is pageable and dies with this frame
-  HIP_TRY(hipMemcpyAsync(d->row_slot, d->ids + 6 * T, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->row_pos, d->ids + 7 * T, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->row_active, d->ids + 8 * T, (size_t)T * 4, hipMemcpyDeviceToDevice, st));
+  if (Mtot > d->Mcap) ETD_FAIL(ETD_EINVAL, "prefill: %lld prompt rows exceed max_prefill_rows=%d", Mtot, d->Mcap);
+  const int M = (int)Mtot;
+  for (int i = 0; i < M; ++i) {
+    if (ids[i] < 0 || ids[i] >= d->V || cls[i] < 0 || cls[i] >= d->cfg.num_classes) ETD_FAIL(ETD_EINVAL, "prefill: token/class id out of range at row %d", i);
+    for (int k = 0; k < 4; ++k) if (attrs4[(size_t)k * M + i] < 0 || attrs4[(size_t)k * M + i] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "prefill: attribute bin out of range at row %d", i);
+  }
+  // staging layout: [ids M][cls M][attrs 4M][row_slot M][row_pos M][row_active M][last_idx n][last_slot n][last_pos n][last_active n][init 7n]
+  std::vector<int>& sv = d->stage;
+  sv.assign((size_t)9 * M + 11 * n, 0);
+  memcpy(sv.data(), ids, (size_t)M * 4);
+  memcpy(sv.data() + M, cls, (size_t)M * 4);
+  memcpy(sv.data() + 2 * (size_t)M, attrs4, (size_t)4 * M * 4);
+  int* rs = sv.data() + 6 * (size_t)M; int* rp = rs + M; int* ra = rp + M;
+  int* li = ra + M; int* ls = li + n; int* lp = ls + n; int* la = lp + n; int* in7 = la + n;
+  int row = 0; double kvb = 0;
+  for (int i = 0; i < n; ++i) {
+    for (int t = 0; t < T[i]; ++t, ++row) { rs[row] = slots[i]; rp[row] = t; ra[row] = 1; }
+    li[i] = row - 1; ls[i] = slots[i]; lp[i] = T[i] - 1; la[i] = 1;
+    d->host_len[slots[i]] = T[i];
+    kvb += 0.5 * T[i] * (T[i] + 1.0) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4);
+  }
+  if (init7) memcpy(in7, init7, (size_t)7 * n * 4);
+  d->attn_bytes_hint = kvb;
+  HIP_TRY(hipMemcpyAsync(d->ids, sv.data(), sv.size() * 4, hipMemcpyHostToDevice, st));   // pageable source: returns after staging
+  const int* b = d->ids;
+  *sg = Staged{M, b, b + M, b + 2 * (size_t)M, b + 6 * (size_t)M, b + 7 * (size_t)M, b + 8 * (size_t)M, b + 9 * (size_t)M, b + 9 * (size_t)M + n,
+               b + 9 * (size_t)M + 2 * n, b + 9 * (size_t)M + 3 * n, b + 9 * (size_t)M + 4 * n};
+  if (init7) {
+    hipLaunchKernelGGL(k_init_slots, dim3((n + 63) / 64), dim3(64), 0, st, sg->init, n, d->tgt_attrs, d->cur_tok, d->len, d->done, d->n_out, d->eos, d->limit);
+    HIP_TRY(hipGetLastError());
+  }
   DEmbedArgs e = {};
-  e.ids = d->ids; e.cls = d->ids + T; e.attrs = d->ids + 2 * T; e.M = T; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
+  e.ids = sg->ids; e.cls = sg->cls; e.attrs = sg->attrs; e.M = M; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
   e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
-  e.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
+  e.rows = DecRows{sg->row_slot, sg->row_pos, sg->row_active};
   ETD_TRY(launch_dembed(e, st));
+  ETD_TRY(forward_body(d, M, e.rows, hfinal, st));
   return ETD_OK;
 }
 
@@ -200,6 +282,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   d->H = c.hidden_size; d->I = c.intermediate_size; d->V = c.vocab_size; d->L = c.num_hidden_layers; d->nh = c.num_attention_heads;
   d->S = c.max_streams; d->ctx = c.max_ctx; d->out_cap = 1024;
   d->Mmax = d->ctx > d->S ? d->ctx : d->S;
+  d->Mcap = c.max_prefill_rows > d->Mmax ? c.max_prefill_rows : d->Mmax;
   d->host_len.assign(d->S, 0);
   Loader Ld;
   for (int i = 0; i < n; ++i) Ld.t[names[i]] = {host_ptrs[i], numels[i]};
@@ -258,14 +341,19 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   const size_t kv_elems = (size_t)d->layer_stride * d->L;
   if (d->bf16w) { uint16_t *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return fail(rc); d->Kc = k; d->Vc = v; }
   else { float *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return fail(rc); d->Kc = k; d->Vc = v; }
-  const size_t M = d->Mmax;
+  const size_t M = d->Mcap;
+  const size_t Mf = d->bf16w ? (size_t)(d->S > 1 ? d->S : 1) : M;     // rows that can take the fp32-activation path
   rc = 0;
   rc = rc ? rc : d->alloc(&d->h, M * H); rc = rc ? rc : d->alloc(&d->h2, M * H);
   rc = rc ? rc : d->alloc(&d->Q, M * H); rc = rc ? rc : d->alloc(&d->AO, M * H); rc = rc ? rc : d->alloc(&d->DO, M * H);
-  rc = rc ? rc : d->alloc(&d->M1, M * d->I); rc = rc ? rc : d->alloc(&d->logits, M * d->V);
-  rc = rc ? rc : d->alloc(&d->qkv_raw, (size_t)3 * H);
-  rc = rc ? rc : d->alloc(&d->row_slot, M); rc = rc ? rc : d->alloc(&d->row_pos, M); rc = rc ? rc : d->alloc(&d->row_active, M);
-  rc = rc ? rc : d->alloc(&d->ids, 9 * M); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
+  rc = rc ? rc : d->alloc(&d->M1, Mf * d->I); rc = rc ? rc : d->alloc(&d->logits, (size_t)d->Mmax * d->V);
+  rc = rc ? rc : d->alloc(&d->qkv_raw, (size_t)3 * H); rc = rc ? rc : d->alloc(&d->hlast, (size_t)d->S * H);
+  if (d->bf16w) {
+    rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
+    rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
+  }
+  rc = rc ? rc : d->alloc(&d->row_slot, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_pos, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_active, (size_t)d->Mmax);
+  rc = rc ? rc : d->alloc(&d->ids, 9 * M + 11 * (size_t)d->S); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
   const size_t S = d->S;
   rc = rc ? rc : d->alloc(&d->cur_tok, S, true); rc = rc ? rc : d->alloc(&d->len, S, true); rc = rc ? rc : d->alloc(&d->done, S, true);
   rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
@@ -283,33 +371,36 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
   delete d;
 }
 
-extern "C" int etd_decoder_begin_bar(etd_dec* d, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
-                                     const int32_t* tgt_attrs4, int eos_id, int limit, void* stream) {
+extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, const int32_t* T, const int32_t* ids, const int32_t* cls,
+                                      const int32_t* attrs4, const int32_t* tgt_attrs4, const int32_t* eos_ids, const int32_t* limits, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  ETD_TRY(check_slot(d, slot));
-  if (!tgt_attrs4 || limit < 1) ETD_FAIL(ETD_EINVAL, "begin_bar: bad target attrs / limit");
-  if (limit > d->out_cap) ETD_FAIL(ETD_EINVAL, "begin_bar: limit %d exceeds the output ring (%d)", limit, d->out_cap);
-  for (int k = 0; k < 4; ++k) if (tgt_attrs4[k] < 0 || tgt_attrs4[k] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "begin_bar: target attribute out of range");
-  ETD_TRY(prefill_common(d, slot, ids, cls, attrs4, T, st));
-  int st8[4 + 6] = {tgt_attrs4[0], tgt_attrs4[1], tgt_attrs4[2], tgt_attrs4[3], 0 /*cur*/, 0 /*len*/, 0 /*done*/, 0 /*n_out*/, eos_id, limit};
-  HIP_TRY(hipMemcpyAsync(d->tgt_attrs + 4 * slot, st8, 16, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->cur_tok + slot, st8 + 4, 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->len + slot, st8 + 5, 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->done + slot, st8 + 6, 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->n_out + slot, st8 + 7, 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->eos + slot, st8 + 8, 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(d->limit + slot, st8 + 9, 4, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipStreamSynchronize(st));   // st8 is a stack array
-  d->host_len[slot] = T;
-  d->attn_bytes_hint = 0.5 * T * (T + 1.0) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4);
-  ETD_TRY(forward_layers(d, T, T - 1, 1, st));
+  if (!d || n < 1 || !tgt_attrs4 || !eos_ids || !limits) ETD_FAIL(ETD_EINVAL, "begin_bars: bad arguments");
+  std::vector<int> init((size_t)7 * n);
+  for (int i = 0; i < n; ++i) {
+    if (limits[i] < 1 || limits[i] > d->out_cap) ETD_FAIL(ETD_EINVAL, "begin_bars: limit %d outside [1, %d]", limits[i], d->out_cap);
+    for (int k = 0; k < 4; ++k) if (tgt_attrs4[4 * i + k] < 0 || tgt_attrs4[4 * i + k] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "begin_bars: target attribute out of range");
+    init[7 * i] = slots ? slots[i] : 0;
+    for (int k = 0; k < 4; ++k) init[7 * i + 1 + k] = tgt_attrs4[4 * i + k];
+    init[7 * i + 5] = eos_ids[i]; init[7 * i + 6] = limits[i];
+  }
+  Staged sg; float* hf = nullptr;
+  ETD_TRY(stage_and_forward(d, n, slots, T, ids, cls, attrs4, init.data(), &sg, &hf, st));
+  // only each prompt's last position feeds the first generated token (etude_decoder.py:317)
+  ETD_TRY(launch_gather_rows(hf, sg.last_idx, n, d->H, d->hlast, st));
+  ETD_TRY(head_logits(d, d->hlast, n, d->logits, st));
   DArgmaxArgs am = {};
-  am.logits = d->logits + (size_t)(T - 1) * d->V; am.ldl = d->V; am.V = d->V; am.M = 1;
-  am.rows = DecRows{d->row_slot + (T - 1), d->row_pos + (T - 1), d->row_active + (T - 1)};
+  am.logits = d->logits; am.ldl = d->V; am.V = d->V; am.M = n;
+  am.rows = DecRows{sg.last_slot, sg.last_pos, sg.last_active};
   am.cur_tok = d->cur_tok; am.len = d->len; am.done = d->done; am.n_out = d->n_out; am.out_tok = d->out_tok; am.out_cap = d->out_cap;
   am.eos = d->eos; am.limit = d->limit;
   ETD_TRY(launch_dargmax(am, st));
   return ETD_OK;
+}
+
+extern "C" int etd_decoder_begin_bar(etd_dec* d, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
+                                     const int32_t* tgt_attrs4, int eos_id, int limit, void* stream) {
+  const int32_t sl = slot, tt = T, eo = eos_id, li = limit;
+  return etd_decoder_begin_bars(d, 1, &sl, &tt, ids, cls, attrs4, tgt_attrs4, &eo, &li, stream);
 }
 
 extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, int n_steps, void* stream) {
@@ -331,7 +422,9 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
     e.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
     ETD_TRY(launch_dembed(e, s_));
-    ETD_TRY(forward_layers(d, n_active, 0, n_active, s_));
+    float* hf = nullptr;
+    ETD_TRY(forward_body(d, n_active, e.rows, &hf, s_));
+    ETD_TRY(head_logits(d, hf, n_active, d->logits, s_));
     DArgmaxArgs am = {};
     am.logits = d->logits; am.ldl = d->V; am.V = d->V; am.M = n_active;
     am.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
@@ -413,8 +506,11 @@ extern "C" int etd_decoder_prefill_logits(etd_dec* d, int slot, const int32_t* i
                                           float* logits_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!logits_host) ETD_FAIL(ETD_EINVAL, "prefill_logits: null");
-  ETD_TRY(prefill_common(d, slot, ids, cls, attrs4, T, st));
-  ETD_TRY(forward_layers(d, T, 0, T, st));
+  if (T > d->Mmax) ETD_FAIL(ETD_EINVAL, "prefill_logits: T=%d exceeds %d", T, d->Mmax);
+  const int32_t sl = slot, tt = T;
+  Staged sg; float* hf = nullptr;
+  ETD_TRY(stage_and_forward(d, 1, &sl, &tt, ids, cls, attrs4, nullptr, &sg, &hf, st));
+  ETD_TRY(head_logits(d, hf, T, d->logits, st));
   HIP_TRY(hipMemcpyAsync(logits_host, d->logits, (size_t)T * d->V * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   return ETD_OK;

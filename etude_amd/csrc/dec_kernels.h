@@ -20,6 +20,8 @@ struct DGemmArgs {
   // LayerNorm prologue over K (only K == hidden): xhat = (x-mean)*rstd*g + b
   const float* ln_g; const float* ln_b; float ln_eps;
   float* Y; int ldy;             // BIAS / GELU / LOGITS destination
+  bf16* Yb;                      // if set, BIAS / GELU store bf16 here instead (row stride ldy)
+  const bf16* Xb;                // if set, the input is bf16 [M, K] (already LayerNorm'ed), row stride ldx
   // RESID: hout = (acc + bias + add[m][n]) + h[m][n]
   const float* add; const float* hin; float* hout;
   // QKV: rope + scatter
@@ -38,10 +40,17 @@ struct DAttnArgs {
   const void* Kc; const void* Vc; long long slot_stride; int max_ctx, n_heads;
   DecRows rows; int M;
   float* O;                      // [M][hidden]
+  bf16* Ob;                      // optional bf16 copy of O (input of the dense GEMM in the bf16 pipeline)
   float scale;
   double bytes_hint;             // algorithmic K+V bytes this launch reads (host estimate, profiler only)
 };
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
+
+// h fp32 [M,H] -> LayerNorm with (g1,b1) and (g2,b2) -> two bf16 matrices (the two parallel-residual branches read the same h)
+int launch_ln_rows(const float* h, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,
+                   bf16* x1, bf16* x2, hipStream_t st);
+// out[i][:] = src[idx[i]][:]  (fp32 rows of H)
+int launch_gather_rows(const float* src, const int* idx, int n, int H, float* out, hipStream_t st);
 
 struct DEmbedArgs {
   const int* ids; const int* cls; const int* attrs;   // [M], [M], [4][M] (explicit mode)  -- or null:

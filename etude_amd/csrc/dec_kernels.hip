@@ -13,78 +13,7 @@
 #define DLD32 36   // fp32 LDS row stride (floats) for a 32-wide K chunk: 144 B
 #define DLD16 72   // bf16 LDS row stride (elements) for a 64-wide K chunk: 144 B
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-
-// ---- shared epilogue: lane = token m, registers = features nb + acc_row(i, h)
-template <bool WBF16, int EPI>
-__device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16& acc, int m, int nb, int h) {
-  // ---- epilogue: lane = token m, registers = features nb + acc_row(i, h)
-  if constexpr (EPI == DEPI_QKV) {
-    // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207)
-    const int head = nb / 192, j0 = nb - head * 192, part = j0 >> 6, dbase = j0 & 63;
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = acc[i] + a.bias[nb + acc_row(i, h)];
-    const int pos = a.rows.pos[m];
-    if (part < 2 && dbase == 0) {
-      // partial RoPE on dims [0, 2*rot_half): pair (d, d + rot_half); with rot_half == 8 both sit in
-      // this lane: d = (i&3) + 4h  (i < 4)  and d + 8 = register i + 4
-      const float* cs = a.rope_cos + (long long)pos * a.rot_half;
-      const float* sn = a.rope_sin + (long long)pos * a.rot_half;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int d = i + 4 * h;
-        const float c = cs[d], s = sn[d];
-        const float x1 = v[i], x2 = v[i + 4];
-        v[i] = x1 * c - x2 * s;        // q*cos + rotate_half(q)*sin, first half:  x1*cos - x2*sin
-        v[i + 4] = x2 * c + x1 * s;    // second half: x2*cos + x1*sin
-      }
-    }
-    if (part == 0) {
-      float* qp = a.Q + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q + 4 * h) = o; }
-    } else if (a.rows.active[m] && pos < a.max_ctx) {
-      const long long off = (long long)a.rows.slot[m] * a.slot_stride + ((long long)head * a.max_ctx + pos) * 64 + dbase;
-      void* base = part == 1 ? a.Kc : a.Vc;
-      if constexpr (WBF16) {
-        bf16* kp = reinterpret_cast<bf16*>(base) + off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(kp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-      } else {
-        float* kp = reinterpret_cast<float*>(base) + off;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(kp + 8 * q + 4 * h) = o; }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = nb + 8 * q + 4 * h;
-      if (n >= a.N) continue;
-      float v[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = acc[4 * q + j];
-        if (EPI != DEPI_LOGITS) v[j] += a.bias[n + j];
-        if (EPI == DEPI_GELU) v[j] = gelu_erf(v[j]);
-      }
-      if constexpr (EPI == DEPI_RESID) {
-        const f32x4 ad = *reinterpret_cast<const f32x4*>(a.add + (long long)m * a.N + n);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(a.hin + (long long)m * a.N + n);
-        const f32x4 o = {(v[0] + ad[0]) + hi[0], (v[1] + ad[1]) + hi[1], (v[2] + ad[2]) + hi[2], (v[3] + ad[3]) + hi[3]};
-        *reinterpret_cast<f32x4*>(a.hout + (long long)m * a.N + n) = o;
-      } else if (n + 3 < a.N) {
-        const f32x4 o = {v[0], v[1], v[2], v[3]};
-        float* yp = a.Y + (long long)m * a.ldy + n;
-        if ((a.ldy & 3) == 0) *reinterpret_cast<f32x4*>(yp) = o;
-        else { yp[0] = v[0]; yp[1] = v[1]; yp[2] = v[2]; yp[3] = v[3]; }
-      } else {
-        for (int j = 0; j < 4 && n + j < a.N; ++j) a.Y[(long long)m * a.ldy + n + j] = v[j];
-      }
-    }
-  }
-}
+#include "dec_epilogue.h"
 
 // ================================================================================================
 // k_dgemm: Y[M,N] = epi( LN?(X)[M,K] * W[N,K]^T + b ).  Workgroup = 4 waves = 32 tokens x 128
@@ -240,26 +169,41 @@ __global__ __launch_bounds__(256) void k_dgemm_s(DGemmArgs a) {
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   if constexpr (WBF16) {
     const bf16* wrow = reinterpret_cast<const bf16*>(a.W) + (long long)(n0 + r) * a.K;
+    if (a.Xb) {
+      const bf16* xbrow = a.Xb + (long long)gm * a.ldx;
 #pragma unroll 2
-    for (int k = kb; k < ke; k += 64) {
-      bf16x8 wf[4]; f32x4 x0[4], x1[4];
+      for (int k = kb; k < ke; k += 64) {
+        bf16x8 wf[4], xf[4];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
-        x0[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8);
-        x1[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8 + 4);
-      }
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4) {
-        if (ln) {
-          const int kk = k + s4 * 16 + h * 8;
-          const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + kk), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + kk + 4);
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_b + kk), b1 = *reinterpret_cast<const f32x4*>(a.ln_b + kk + 4);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { x0[s4][j] = (x0[s4][j] - mean) * rstd * g0[j] + b0[j]; x1[s4][j] = (x1[s4][j] - mean) * rstd * g1[j] + b1[j]; }
+        for (int s4 = 0; s4 < 4; ++s4) {
+          wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
+          xf[s4] = *reinterpret_cast<const bf16x8*>(xbrow + k + s4 * 16 + h * 8);
         }
-        const bf16x8 xf = {(bf16)x0[s4][0], (bf16)x0[s4][1], (bf16)x0[s4][2], (bf16)x0[s4][3], (bf16)x1[s4][0], (bf16)x1[s4][1], (bf16)x1[s4][2], (bf16)x1[s4][3]};
-        acc = mfma32(wf[s4], xf, acc);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
+      }
+    } else {
+#pragma unroll 2
+      for (int k = kb; k < ke; k += 64) {
+        bf16x8 wf[4]; f32x4 x0[4], x1[4];
+  #pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
+          x0[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8);
+          x1[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8 + 4);
+        }
+  #pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          if (ln) {
+            const int kk = k + s4 * 16 + h * 8;
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + kk), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + kk + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_b + kk), b1 = *reinterpret_cast<const f32x4*>(a.ln_b + kk + 4);
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) { x0[s4][j] = (x0[s4][j] - mean) * rstd * g0[j] + b0[j]; x1[s4][j] = (x1[s4][j] - mean) * rstd * g1[j] + b1[j]; }
+          }
+          const bf16x8 xf = {(bf16)x0[s4][0], (bf16)x0[s4][1], (bf16)x0[s4][2], (bf16)x0[s4][3], (bf16)x1[s4][0], (bf16)x1[s4][1], (bf16)x1[s4][2], (bf16)x1[s4][3]};
+          acc = mfma32(wf[s4], xf, acc);
+        }
       }
     }
   } else {
@@ -519,6 +463,10 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
     const f32x4 x = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv}, y = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
     *reinterpret_cast<f32x4*>(op) = x;
     *reinterpret_cast<f32x4*>(op + 4) = y;
+    if (a.Ob) {
+      const bf16x8 ob = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+      *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * hidden + head * 64 + c * 8) = ob;
+    }
   }
 }
 
@@ -528,6 +476,63 @@ int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   dim3 g(a.M, a.n_heads);
   if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
+// LayerNorm of the residual stream for both parallel branches at once (input_layernorm and
+// post_attention_layernorm read the same h, modeling_gpt_neox.py:250-270); one wave per row, bf16 out.
+__global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ hsrc, int M, int H, const float* __restrict__ g1, const float* __restrict__ b1,
+                                                 const float* __restrict__ g2, const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xp = hsrc + (long long)row * H;
+  float s = 0.f;
+  for (int k = lane * 8; k < H; k += 512) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k), b = *reinterpret_cast<const f32x4*>(xp + k + 4);
+    s += (a[0] + a[1] + a[2] + a[3]) + (b[0] + b[1] + b[2] + b[3]);
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)H;
+  float q = 0.f;
+  for (int k = lane * 8; k < H; k += 512) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k), b = *reinterpret_cast<const f32x4*>(xp + k + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d0 = a[j] - mean, d1 = b[j] - mean; q += d0 * d0 + d1 * d1; }
+  }
+  q = wave_sum(q);
+  const float rstd = rsqrtf(q / (float)H + eps);
+  for (int k = lane * 8; k < H; k += 512) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k), b = *reinterpret_cast<const f32x4*>(xp + k + 4);
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    bf16x8 o1, o2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float n = (v[j] - mean) * rstd;
+      o1[j] = (bf16)(n * g1[k + j] + b1[k + j]);
+      if (x2) o2[j] = (bf16)(n * g2[k + j] + b2[k + j]);
+    }
+    *reinterpret_cast<bf16x8*>(x1 + (long long)row * H + k) = o1;
+    if (x2) *reinterpret_cast<bf16x8*>(x2 + (long long)row * H + k) = o2;
+  }
+}
+int launch_ln_rows(const float* hsrc, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,
+                   bf16* x1, bf16* x2, hipStream_t st) {
+  if (M <= 0 || H % 8) ETD_FAIL(ETD_EINVAL, "ln_rows: bad shape");
+  ProfScope ps("k_ln_rows", st, 0, (double)M * H * (4 + (x2 ? 4 : 2)));
+  hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, hsrc, M, H, g1, b1, g2, b2, eps, x1, x2);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+__global__ void k_gather_rows(const float* __restrict__ src, const int* __restrict__ idx, int n, int H, float* __restrict__ out) {
+  const int i = blockIdx.x;
+  const float* sp = src + (long long)idx[i] * H;
+  for (int k = threadIdx.x * 4; k < H; k += blockDim.x * 4) *reinterpret_cast<f32x4*>(out + (long long)i * H + k) = *reinterpret_cast<const f32x4*>(sp + k);
+}
+int launch_gather_rows(const float* src, const int* idx, int n, int H, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_gather_rows, dim3(n), dim3(128), 0, st, src, idx, n, H, out);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }

@@ -1,6 +1,7 @@
 // Kernel argument structs + launchers for the hFT-Transformer (Extract stage) kernels.
 #pragma once
 #include "common.h"
+#include "dec_kernels.h"
 
 // ---- generic token-major linear layer:  Y = epi(X[M,K] * W[N,K]^T + bias) -----------------------
 // All activations are bf16 row-major with 256-multiple feature counts; weights keep nn.Linear's
@@ -20,7 +21,10 @@ struct LinArgs {
   // LayerNorm epilogue (N == 256): Y = LN(acc + bias + R) * gamma + beta
   const bf16* R; int ldr; int r_mod;  // residual row = r_mod > 0 ? m % r_mod : m
   const float* gamma; const float* beta;
+  // decoder epilogues on the same 128x256 tile (X = bf16 [M,K], W = bf16 [N,K]): dec_epi = DEPI_* (dec_kernels.h)
+  DGemmArgs dec;
 };
+int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st);
 int launch_linear(const LinArgs& a, int nz, hipStream_t st);
 int launch_linear_ln(const LinArgs& a, hipStream_t st);
 

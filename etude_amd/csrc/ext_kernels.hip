@@ -9,6 +9,7 @@
 // feature on the lane, which is how V is written out pre-transposed (V^T) for the attention kernel.
 #include "ext_kernels.h"
 #include "prof.h"
+#include "dec_epilogue.h"
 
 #define LDK 72  // LDS row stride (elements) of a 64-wide bf16 K-chunk: 144 B, 16-B aligned, conflict-free ds_read_b128
 
@@ -57,11 +58,13 @@ __device__ __forceinline__ void lin_lstore(bf16* Xs, bf16* Ws, int tid, const u3
   }
 }
 
-// MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm
+// MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm;
+// MODE 10 + DEPI_x: EtudeDecoder epilogue x on the same tile (batched prefill of the Decode stage)
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   constexpr bool LN = MODE == 2;
   constexpr bool vt = MODE == 1;
+  constexpr bool DEC = MODE >= 10;
   __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 256) * LDK * 2 + 3 * 256 * 4];
   bf16* Xs = reinterpret_cast<bf16*>(smem);
   bf16* Ws = Xs + 128 * LDK;
@@ -93,7 +96,13 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
     __syncthreads();
   }
 
-  if constexpr (!LN) {
+  if constexpr (DEC) {
+    const int m = m0 + wave * 32 + r;
+    if (m < a.M) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) dgemm_epilogue<true, MODE - 10>(a.dec, acc[t], m, n0 + 32 * t, h);
+    }
+  } else if constexpr (!LN) {
     if constexpr (vt) {
       // accumulator: col = feature (lane), rows = tokens.  Store V^T[(seq,head,d)][pos], 4 tokens = 8 B.
 #pragma unroll
@@ -193,6 +202,22 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
+int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
+  if (a.K % 64 || a.N % 256 || a.M <= 0 || !a.bias) ETD_FAIL(ETD_EINVAL, "linear_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  ProfScope ps("k_linear_dec", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K) * 2);
+  dim3 g((a.M + 127) / 128, a.N / 256, 1);
+  LinArgs b = a; b.nb0 = 0;
+  switch (dec_epi) {
+    case DEPI_BIAS: hipLaunchKernelGGL(k_linear<10 + DEPI_BIAS>, g, dim3(256), 0, st, b); break;
+    case DEPI_GELU: hipLaunchKernelGGL(k_linear<10 + DEPI_GELU>, g, dim3(256), 0, st, b); break;
+    case DEPI_RESID: hipLaunchKernelGGL(k_linear<10 + DEPI_RESID>, g, dim3(256), 0, st, b); break;
+    case DEPI_QKV: hipLaunchKernelGGL(k_linear<10 + DEPI_QKV>, g, dim3(256), 0, st, b); break;
+    default: ETD_FAIL(ETD_EINVAL, "linear_dec: unsupported epilogue %d", dec_epi);
+  }
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
 int launch_linear_ln(const LinArgs& a, hipStream_t st) {
   if (a.K % 64 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta) ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
   ProfScope ps("k_linear_ln", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * a.N) * 2);

@@ -107,7 +107,8 @@ class EtudeDecoder:
     """GPU-resident EtudeDecoder.  ``state`` maps the reference's state-dict keys to fp32 arrays."""
 
     def __init__(self, config: EtudeDecoderConfig, state: Dict[str, np.ndarray], device: Union[str, torch.device] = "cuda",
-                 precision: Optional[str] = None, max_streams: int = 1, max_ctx: Optional[int] = None):
+                 precision: Optional[str] = None, max_streams: int = 1, max_ctx: Optional[int] = None,
+                 max_prefill_rows: Optional[int] = None):
         if device == "auto":
             device = "cuda"
         self.device = torch.device(device)
@@ -123,12 +124,16 @@ class EtudeDecoder:
         self.max_streams = int(max_streams)
         # the reference never exceeds ~max_position_embeddings + 1 positions per bar (etude_decoder.py:285-300)
         self.max_ctx = int(max_ctx) if max_ctx else int(config.max_position_embeddings) + 64
+        # one begin_bars call carries up to this many prompt rows (a prompt is <= max_pos/2 + 1 tokens after truncation)
+        self.max_prefill_rows = int(max_prefill_rows) if max_prefill_rows else self.max_streams * (int(config.max_position_embeddings) // 2 + 8)
+        self.max_prefill_rows = max(self.max_prefill_rows, self.max_ctx)
         cfg = _lib.DecCfg(vocab_size=config.vocab_size, hidden_size=config.hidden_size, num_hidden_layers=config.num_hidden_layers,
                           num_attention_heads=config.num_attention_heads, intermediate_size=config.intermediate_size,
                           max_position_embeddings=config.max_position_embeddings, num_classes=config.num_classes,
                           num_attribute_bins=config.num_attribute_bins, attribute_emb_dim=config.attribute_emb_dim,
                           rotary_pct=config.rotary_pct, rope_theta=config.rope_theta, layer_norm_eps=config.layer_norm_eps,
-                          max_streams=self.max_streams, max_ctx=self.max_ctx, precision=1 if precision == "bf16" else 0)
+                          max_streams=self.max_streams, max_ctx=self.max_ctx, precision=1 if precision == "bf16" else 0,
+                          max_prefill_rows=self.max_prefill_rows)
         names, ptrs, numels, n, keep = _lib.weights_arrays(state)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -211,28 +216,42 @@ class EtudeDecoder:
         st = self._stream()
         tokbuf = (C.c_int32 * 1024)()
 
-        def start_bar(ji: int, job: _Job) -> bool:
-            """Returns False when the job is finished."""
-            while True:
+        def start_bars(batch: List[_Job]) -> List[_Job]:
+            """Prefill the next bar of every job in `batch` in as few device passes as possible (all prompts of a call
+            go through the model as one batch).  Returns the jobs that are finished instead."""
+            finished, pend = [], []
+            for job in batch:
                 if job.i >= len(job.x_bars):
-                    return False
+                    finished.append(job)
+                    continue
                 y_attrs = job.attrs[job.i]
                 job.limit = min(force_bar_tokens or job.bar_limit, job.max_out - job.total)
                 if job.limit <= 0:
                     # the reference's inner loop breaks before the first forward: the bar is just [Bar_BOS]
                     job.bars_out.append([bos])
-                    return False
+                    finished.append(job)
+                    continue
                 toks, cls, at = assemble_bar_prompt(job.history, job.x_bars[job.i], y_attrs, job.keys, bos, eos,
                                                     cfg.context_num_past_xy_pairs, cfg.max_position_embeddings,
                                                     job.bar_limit, job.overlap)
-                T = len(toks)
-                ids = np.asarray(toks, np.int32)
-                cl = np.asarray(cls, np.int32)
-                a4 = np.ascontiguousarray(np.stack([np.asarray(at[k], np.int32) for k in ABI_ATTR_KEYS]))
-                tg = np.asarray([y_attrs[k] for k in ABI_ATTR_KEYS], np.int32)
-                _lib.check(lib.etd_decoder_begin_bar(self._h, job.slot, ids.ctypes.data, cl.ctypes.data, a4.ctypes.data, T,
-                                                     tg.ctypes.data, -1 if force_bar_tokens else eos, job.limit, st), "etd_decoder_begin_bar")
-                return True
+                pend.append((job, toks, cls, [at[k] for k in ABI_ATTR_KEYS], [y_attrs[k] for k in ABI_ATTR_KEYS]))
+            while pend:
+                take, rows = [], 0
+                while pend and (not take or rows + len(pend[0][1]) <= self.max_prefill_rows):
+                    rows += len(pend[0][1])
+                    take.append(pend.pop(0))
+                n = len(take)
+                slots = np.asarray([t[0].slot for t in take], np.int32)
+                T = np.asarray([len(t[1]) for t in take], np.int32)
+                ids = np.concatenate([np.asarray(t[1], np.int32) for t in take])
+                cl = np.concatenate([np.asarray(t[2], np.int32) for t in take])
+                a4 = np.ascontiguousarray(np.concatenate([np.asarray(t[3], np.int32) for t in take], axis=1))
+                tg = np.ascontiguousarray(np.asarray([t[4] for t in take], np.int32))
+                eo = np.full(n, -1 if force_bar_tokens else eos, np.int32)
+                li = np.asarray([t[0].limit for t in take], np.int32)
+                _lib.check(lib.etd_decoder_begin_bars(self._h, n, slots.ctypes.data, T.ctypes.data, ids.ctypes.data, cl.ctypes.data,
+                                                      a4.ctypes.data, tg.ctypes.data, eo.ctypes.data, li.ctypes.data, st), "etd_decoder_begin_bars")
+            return finished
 
         def finish_bar(job: _Job):
             n = C.c_int()
@@ -248,35 +267,46 @@ class EtudeDecoder:
 
         with torch.cuda.device(self.device):
             pending = todo[::-1]
+            job_index = {id(job): ji for ji, job in todo}
+
+            def retire(job: _Job):
+                results[job_index[id(job)]] = job.bars_out
+                if job.slot in active:
+                    del active[job.slot]
+                free.append(job.slot)
+
             while pending or active:
+                fresh = []
                 while pending and free:
                     ji, job = pending.pop()
                     job.slot = free.pop()
-                    if start_bar(ji, job):
-                        active[job.slot] = (ji, job)
-                    else:
-                        results[ji] = job.bars_out
-                        free.append(job.slot)
+                    active[job.slot] = (ji, job)
+                    fresh.append(job)
+                if fresh:
+                    for job in start_bars(fresh):
+                        retire(job)
                 if not active:
                     continue
                 slots = np.asarray(sorted(active.keys()), np.int32)
                 dn = np.zeros(len(slots), np.int32)
                 no = np.zeros(len(slots), np.int32)
                 _lib.check(lib.etd_decoder_poll(self._h, slots.ctypes.data, len(slots), dn.ctypes.data, no.ctypes.data, st), "etd_decoder_poll")
-                any_done = False
+                again = []
                 for s, d in zip(slots.tolist(), dn.tolist()):
                     if not d:
                         continue
-                    any_done = True
                     ji, job = active[s]
                     n_tokens += finish_bar(job)
-                    finished = job.total >= job.max_out          # etude_decoder.py:352
-                    if finished or not start_bar(ji, job):
-                        results[ji] = job.bars_out
-                        del active[s]
-                        free.append(s)
-                if any_done:
+                    if job.total >= job.max_out:                 # etude_decoder.py:352
+                        retire(job)
+                    else:
+                        again.append(job)
+                if again:
+                    for job in start_bars(again):
+                        retire(job)
                     continue                                      # re-poll / refill before stepping
+                if any(dn):
+                    continue
                 _lib.check(lib.etd_decoder_step(self._h, slots.ctypes.data, len(slots), steps_per_poll, st), "etd_decoder_step")
                 n_steps_total += steps_per_poll
         if stats is not None:

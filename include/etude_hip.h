@@ -120,6 +120,7 @@ typedef struct {
   int max_streams;        /* concurrent token streams (KV slots) */
   int max_ctx;            /* KV positions per stream */
   int precision;          /* 0 = fp32 weights/activations (token-parity mode), 1 = bf16 weights */
+  int max_prefill_rows;   /* prompt rows one etd_decoder_begin_bars call may carry (0 = max(max_ctx, max_streams)) */
 } etd_dec_cfg;
 int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                        const int64_t* numels, int n, etd_dec** out);
@@ -131,6 +132,11 @@ void etd_decoder_destroy(etd_dec*);
  * order) condition the generated tokens; generation stops at eos_id or after `limit` tokens. */
 int etd_decoder_begin_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
                           const int32_t* tgt_attrs4, int eos_id, int limit, void* stream);
+/* Batched form: n bars at once (distinct slots).  T[i] = prompt length of bar i; ids/cls hold the prompts back to
+ * back (sum(T) rows), attrs4 is [4][sum(T)]; tgt_attrs4 [n][4], eos_ids [n], limits [n].  All prompts go through the
+ * model as ONE pass (big-tile MFMA GEMMs over sum(T) rows in bf16 mode). */
+int etd_decoder_begin_bars(etd_dec*, int n, const int32_t* slots, const int32_t* T, const int32_t* ids, const int32_t* cls,
+                           const int32_t* attrs4, const int32_t* tgt_attrs4, const int32_t* eos_ids, const int32_t* limits, void* stream);
 /* n_steps greedy decode steps for the n_active streams listed in `slots` (host array): each step feeds every
  * stream's current token (class TGT=2, its target attrs), appends K/V, and writes the argmax back as the
  * stream's current token and into its output ring -- all on the device: no host sync, no allocation.
