@@ -246,7 +246,7 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
     for (int t = 0; t < T[i]; ++t, ++row) { rs[row] = slots[i]; rp[row] = t; ra[row] = 1; }
     li[i] = row - 1; ls[i] = slots[i]; lp[i] = T[i] - 1; la[i] = 1;
     d->host_len[slots[i]] = T[i];
-    kvb += 0.5 * T[i] * (T[i] + 1.0) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4);
+    kvb += (double)T[i] * d->nh * 64 * (2.0 * (d->bf16w ? 2 : 4) + 4 + 4);   // prefill: Q, K, V read once, O written once (K/V re-reads are L2 hits)
   }
   if (init7) memcpy(in7, init7, (size_t)7 * n * 4);
   d->attn_bytes_hint = kvb;

@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
 
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "dattn: bad M");
-  ProfScope ps("k_dattn", st, 0, a.bytes_hint);
+  ProfScope ps(a.M > 128 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
   dim3 g(a.M, a.n_heads);
   if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a);

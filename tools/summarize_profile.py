@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel trace + PMC passes) into per-kernel tables.
+
+usage: summarize_profile.py <dir with prof_trace/ prof_fetch/ prof_write/>
+Prints (a) per-kernel count / total / average duration from the kernel trace, (b) per-kernel HBM bytes per launch from
+FETCH_SIZE / WRITE_SIZE with the gfx950 corrections of MI355X_MICROARCH.md (FETCH_SIZE counts 64 B per 128-B request
+on wide coalesced streams -> x2; both counters are in KiB), and writes traffic.json next to it."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    m = re.search(r"(k_[a-z0-9_]+)(?:<([^>]*)>)?", name)
+    if m:
+        return m.group(1) + (f"<{m.group(2)}>" if m.group(2) else "")
+    return name[:60]
+
+
+def kernel_trace(d):
+    rows = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = short(r.get("Kernel_Name", ""))
+                dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+                rows[k][0] += 1
+                rows[k][1] += dur
+    return rows
+
+
+def pmc(d, counter):
+    rows = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") != counter:
+                    continue
+                k = short(r.get("Kernel_Name", ""))
+                rows[k][0] += 1
+                rows[k][1] += float(r["Counter_Value"])
+    return rows
+
+
+def main():
+    root = sys.argv[1]
+    kt = kernel_trace(os.path.join(root, "prof_trace"))
+    tot = sum(v[1] for v in kt.values()) or 1.0
+    print("== kernel trace (prof_trace): kernel, launches, total_ms, avg_us, share")
+    for k, (n, us) in sorted(kt.items(), key=lambda kv: -kv[1][1])[:30]:
+        print(f"{k:40s} {n:9d} {us/1e3:12.3f} {us/n:10.2f} {100*us/tot:6.2f}%")
+    fe = pmc(os.path.join(root, "prof_fetch"), "FETCH_SIZE")
+    wr = pmc(os.path.join(root, "prof_write"), "WRITE_SIZE")
+    traffic = {}
+    print("== HBM traffic per launch (PMC, separate passes): kernel, launches, fetch_MB(x2 corrected), write_MB, total_MB")
+    for k in sorted(set(fe) | set(wr), key=lambda k: -(fe.get(k, [0, 0])[1] + wr.get(k, [0, 0])[1])):
+        nf, f = fe.get(k, [0, 0.0])
+        nw, w = wr.get(k, [0, 0.0])
+        fb = 2.0 * f * 1024 / max(nf, 1)
+        wb = w * 1024 / max(nw, 1)
+        traffic[k] = {"fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "bytes_per_launch": fb + wb, "launches": max(nf, nw)}
+        print(f"{k:40s} {max(nf,nw):9d} {fb/1e6:12.3f} {wb/1e6:12.3f} {(fb+wb)/1e6:12.3f}")
+    with open(os.path.join(root, "traffic.json"), "w") as fh:
+        json.dump(traffic, fh, indent=1)
+
+
+if __name__ == "__main__":
+    main()
