@@ -77,6 +77,7 @@ SIGNATURES = {
     "etd_decoder_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "etd_decoder_poll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "etd_decoder_read_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_int_p, C.c_void_p]),
+    "etd_decoder_read_many": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "etd_decoder_generate_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_int, C.c_int, C.c_void_p, c_int_p, C.c_void_p]),
     "etd_decoder_prefill_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

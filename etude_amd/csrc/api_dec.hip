@@ -47,6 +47,7 @@ struct etd_dec {
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
   float* qkv_raw = nullptr;                      // [3H] scratch row of the M == 1 QKV path
   bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
+  bf16 *Qb = nullptr, *Kp = nullptr, *VTp = nullptr; int vt_spad = 0;     // batched-prefill scratch of the MFMA attention
   float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
   std::vector<int> stage;                        // host staging of a prefill batch
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
@@ -120,7 +121,9 @@ int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst)
 // fp32 weights, or M == 1: fp32 activations, LayerNorm fused into the GEMM prologues (k_dgemm / k_dgemm_s / k_dgemv).
 // bf16 weights, M > 1:     k_ln_rows -> bf16 activations -> big-tile MFMA GEMM (k_linear decoder modes, M > 128, the
 //                          batched prefill) or the K-split skinny GEMM (M <= 128, the batched decode step).
-int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st) {
+struct PrefillInfo { int n; const int* seq_row0; const int* seq_len; int max_len; double attn_flops; };
+
+int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr) {
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && M > 1;
@@ -137,6 +140,8 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     q.Y = d->qkv_raw; q.ldy = 3 * d->H;
     q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
     q.Kc = Kl; q.Vc = Vl; q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
+    const bool mfma_attn = big && pf != nullptr;
+    if (mfma_attn) { q.Qb = d->Qb; q.Kp = d->Kp; q.VTp = d->VTp; q.vt_spad = d->vt_spad; }
     if (big) {
       LinArgs a = {};
       a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
@@ -145,10 +150,19 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
     }
     // ---- causal attention against the slot's KV cache
-    DAttnArgs at = {};
-    at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
-    at.rows = rows; at.M = M; at.O = d->AO; at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
-    ETD_TRY(launch_dattn(at, d->bf16w, st));
+    if (mfma_attn) {
+      // ragged causal flash attention on the MFMA kernel of the Extract stage (prompts of all streams at once)
+      AttnArgs t = {};
+      t.Q = d->Qb; t.ldq = d->H; t.K = d->Kp; t.ldk = d->H; t.VT = d->VTp; t.Spad = d->vt_spad; t.O = d->AOb; t.ldo = d->H;
+      t.n_seq = pf->n; t.Sq = pf->max_len; t.Sk = pf->max_len; t.scale_log2e = 0.125f * 1.4426950408889634f;
+      t.n_heads = d->nh; t.seq_row0 = pf->seq_row0; t.seq_len = pf->seq_len; t.causal = 1; t.flops_hint = pf->attn_flops;
+      ETD_TRY(launch_attn(t, st));
+    } else {
+      DAttnArgs at = {};
+      at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
+      at.rows = rows; at.M = M; at.O = d->AO; at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+      ETD_TRY(launch_dattn(at, d->bf16w, st));
+    }
     // ---- attention.dense
     DGemmArgs de = {};
     de.X = d->AO; de.ldx = d->H; de.W = w.dense.W; de.bias = w.dense.b; de.M = M; de.N = d->H; de.Npad = w.dense.Npad; de.K = d->H;
@@ -215,7 +229,7 @@ __global__ void k_init_slots(const int* __restrict__ init, int n, int* tgt_attrs
 
 // Stage a batch of n prompts (concatenated) on the device, embed them, run the model.  On return *hfinal holds
 // the hidden states of all Mtot rows; the staged row metadata lives in d->ids (layout below).
-struct Staged { int Mtot; const int *ids, *cls, *attrs, *row_slot, *row_pos, *row_active, *last_idx, *last_slot, *last_pos, *last_active, *init; };
+struct Staged { int Mtot; const int *ids, *cls, *attrs, *row_slot, *row_pos, *row_active, *last_idx, *last_slot, *last_pos, *last_active, *init, *row_seq, *seq_row0, *seq_len; };
 
 int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T, const int32_t* ids, const int32_t* cls,
                       const int32_t* attrs4, const int32_t* init7 /* [n][7] or null */, Staged* sg, float** hfinal, hipStream_t st) {
@@ -234,16 +248,20 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
     for (int k = 0; k < 4; ++k) if (attrs4[(size_t)k * M + i] < 0 || attrs4[(size_t)k * M + i] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "prefill: attribute bin out of range at row %d", i);
   }
   // staging layout: [ids M][cls M][attrs 4M][row_slot M][row_pos M][row_active M][last_idx n][last_slot n][last_pos n][last_active n][init 7n]
+  //                 [row_seq M][seq_row0 n][seq_len n]
   std::vector<int>& sv = d->stage;
-  sv.assign((size_t)9 * M + 11 * n, 0);
+  sv.assign((size_t)10 * M + 13 * n, 0);
   memcpy(sv.data(), ids, (size_t)M * 4);
   memcpy(sv.data() + M, cls, (size_t)M * 4);
   memcpy(sv.data() + 2 * (size_t)M, attrs4, (size_t)4 * M * 4);
   int* rs = sv.data() + 6 * (size_t)M; int* rp = rs + M; int* ra = rp + M;
   int* li = ra + M; int* ls = li + n; int* lp = ls + n; int* la = lp + n; int* in7 = la + n;
-  int row = 0; double kvb = 0;
+  int* rq = in7 + 7 * n; int* sr0 = rq + M; int* sln = sr0 + n;
+  int row = 0, max_len = 0; double kvb = 0, aflops = 0;
   for (int i = 0; i < n; ++i) {
-    for (int t = 0; t < T[i]; ++t, ++row) { rs[row] = slots[i]; rp[row] = t; ra[row] = 1; }
+    sr0[i] = row; sln[i] = T[i]; if (T[i] > max_len) max_len = T[i];
+    aflops += 0.5 * 256.0 * d->nh * (double)T[i] * T[i];
+    for (int t = 0; t < T[i]; ++t, ++row) { rs[row] = slots[i]; rp[row] = t; ra[row] = 1; rq[row] = i; }
     li[i] = row - 1; ls[i] = slots[i]; lp[i] = T[i] - 1; la[i] = 1;
     d->host_len[slots[i]] = T[i];
     kvb += (double)T[i] * d->nh * 64 * (2.0 * (d->bf16w ? 2 : 4) + 4 + 4);   // prefill: Q, K, V read once, O written once (K/V re-reads are L2 hits)
@@ -253,7 +271,8 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   HIP_TRY(hipMemcpyAsync(d->ids, sv.data(), sv.size() * 4, hipMemcpyHostToDevice, st));   // pageable source: returns after staging
   const int* b = d->ids;
   *sg = Staged{M, b, b + M, b + 2 * (size_t)M, b + 6 * (size_t)M, b + 7 * (size_t)M, b + 8 * (size_t)M, b + 9 * (size_t)M, b + 9 * (size_t)M + n,
-               b + 9 * (size_t)M + 2 * n, b + 9 * (size_t)M + 3 * n, b + 9 * (size_t)M + 4 * n};
+               b + 9 * (size_t)M + 2 * n, b + 9 * (size_t)M + 3 * n, b + 9 * (size_t)M + 4 * n,
+               b + 9 * (size_t)M + 11 * n, b + 10 * (size_t)M + 11 * n, b + 10 * (size_t)M + 12 * n};
   if (init7) {
     hipLaunchKernelGGL(k_init_slots, dim3((n + 63) / 64), dim3(64), 0, st, sg->init, n, d->tgt_attrs, d->cur_tok, d->len, d->done, d->n_out, d->eos, d->limit);
     HIP_TRY(hipGetLastError());
@@ -261,9 +280,11 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   DEmbedArgs e = {};
   e.ids = sg->ids; e.cls = sg->cls; e.attrs = sg->attrs; e.M = M; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
   e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
-  e.rows = DecRows{sg->row_slot, sg->row_pos, sg->row_active};
+  e.rows = DecRows{sg->row_slot, sg->row_pos, sg->row_active, sg->row_seq};
   ETD_TRY(launch_dembed(e, st));
-  ETD_TRY(forward_body(d, M, e.rows, hfinal, st));
+  PrefillInfo pf{n, sg->seq_row0, sg->seq_len, max_len, aflops};
+  const bool can_mfma_attn = d->VTp != nullptr && max_len <= d->vt_spad && !getenv("ETD_NO_MFMA_PREFILL_ATTN");
+  ETD_TRY(forward_body(d, M, e.rows, hfinal, st, can_mfma_attn ? &pf : nullptr));
   return ETD_OK;
 }
 
@@ -351,9 +372,12 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   if (d->bf16w) {
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
+    rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
+    d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
+    rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)
   }
   rc = rc ? rc : d->alloc(&d->row_slot, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_pos, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_active, (size_t)d->Mmax);
-  rc = rc ? rc : d->alloc(&d->ids, 9 * M + 11 * (size_t)d->S); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
+  rc = rc ? rc : d->alloc(&d->ids, 10 * M + 13 * (size_t)d->S); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
   const size_t S = d->S;
   rc = rc ? rc : d->alloc(&d->cur_tok, S, true); rc = rc ? rc : d->alloc(&d->len, S, true); rc = rc ? rc : d->alloc(&d->done, S, true);
   rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
@@ -483,6 +507,24 @@ extern "C" int etd_decoder_read_tokens(etd_dec* d, int slot, int32_t* out, int c
   if (cnt > 0) {
     HIP_TRY(hipMemcpyAsync(out, d->out_tok + (size_t)slot * d->out_cap, (size_t)cnt * 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+  }
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_read_many(etd_dec* d, int n, const int32_t* slots, int32_t* out, int cap, int32_t* counts, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || n < 1 || !slots || !out || !counts || cap < 1) ETD_FAIL(ETD_EINVAL, "read_many: bad args");
+  std::vector<int> no(d->S);
+  std::vector<int> all((size_t)d->S * d->out_cap);
+  HIP_TRY(hipMemcpyAsync(no.data(), d->n_out, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(all.data(), d->out_tok, all.size() * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) {
+    ETD_TRY(check_slot(d, slots[i]));
+    int c = no[slots[i]]; if (c > d->out_cap) c = d->out_cap;
+    if (c > cap) ETD_FAIL(ETD_ENOMEM, "read_many: slot %d holds %d tokens (cap %d)", slots[i], c, cap);
+    counts[i] = c;
+    memcpy(out + (size_t)i * cap, all.data() + (size_t)slots[i] * d->out_cap, (size_t)c * 4);
   }
   return ETD_OK;
 }

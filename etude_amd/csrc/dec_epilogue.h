@@ -30,10 +30,24 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
         v[i + 4] = x2 * c + x1 * s;    // second half: x2*cos + x1*sin
       }
     }
-    if (part == 0) {
-      float* qp = a.Q + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
+    if (a.Qb) {
+      // batched prefill: bf16 row-major Q / K and pre-transposed V for the MFMA attention kernel
+      if (part < 2) {
+        bf16* dp = (part == 0 ? a.Qb : a.Kp) + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q + 4 * h) = o; }
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(dp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      } else {
+        bf16* vp = a.VTp + ((long long)(a.rows.seq[m] * a.n_heads + head) * 64 + dbase) * a.vt_spad + pos;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vp[(long long)acc_row(i, h) * a.vt_spad] = (bf16)v[i];
+      }
+    }
+    if (part == 0) {
+      if (!a.Qb) {
+        float* qp = a.Q + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q + 4 * h) = o; }
+      }
     } else if (a.rows.active[m] && pos < a.max_ctx) {
       const long long off = (long long)a.rows.slot[m] * a.slot_stride + ((long long)head * a.max_ctx + pos) * 64 + dbase;
       void* base = part == 1 ? a.Kc : a.Vc;

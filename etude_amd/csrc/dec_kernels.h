@@ -7,6 +7,7 @@ struct DecRows {
   const int* slot;     // [M] KV slot of the row
   const int* pos;      // [M] position (= index of this token in the slot's KV cache)
   const int* active;   // [M] 0 -> the row must not write KV / state (finished stream)
+  const int* seq;      // [M] index of the row's prompt inside a batched prefill (only read when the prefill scratch is set)
 };
 
 enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4 };
@@ -32,6 +33,9 @@ struct DGemmArgs {
   void* Kc; void* Vc;            // KV cache base of this LAYER: [slot][head][max_ctx][64]
   long long slot_stride;         // elements between slots
   int max_ctx, n_heads;
+  // batched-prefill scratch for the MFMA flash-attention kernel (all null outside the bf16 big-M path):
+  bf16* Qb; bf16* Kp;            // [M][hidden] bf16 row-major copies of RoPE'd Q and K
+  bf16* VTp; int vt_spad;        // V^T[(seq*n_heads+head)*64 + d][vt_spad]
 };
 int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st);
 

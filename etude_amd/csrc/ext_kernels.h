@@ -36,6 +36,10 @@ struct AttnArgs {
   bf16* O; int ldo; long long o_seq_stride;          // O + seq*o_seq_stride + q*ldo + head*64
   int n_seq, Sq, Sk;
   float scale_log2e;                                 // (1/sqrt(64)) * log2(e)
+  int n_heads;                                       // 0 -> 4 (the hFT model)
+  // ragged causal batches (EtudeDecoder prefill): sequence s covers rows [seq_row0[s], +seq_len[s]) of Q/K/O; key j visible to query i iff j <= i
+  const int* seq_row0; const int* seq_len; int causal;
+  double flops_hint;                                 // algorithmic FLOPs of this launch (profiler only; 0 = derive from Sq/Sk)
 };
 int launch_attn(const AttnArgs& a, hipStream_t st);
 

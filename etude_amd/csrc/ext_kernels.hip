@@ -242,17 +242,26 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   bf16* Ks = reinterpret_cast<bf16*>(smem);
   bf16* Vs = Ks + 64 * LDK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int seq = blockIdx.y >> 2, head = blockIdx.y & 3;
+  const int nh = a.n_heads > 0 ? a.n_heads : 4;
+  const int seq = blockIdx.y / nh, head = blockIdx.y - seq * nh;
   const int q0 = blockIdx.x * 128 + wave * 32;
-  int qi = q0 + r; const bool qvalid = qi < a.Sq; if (!qvalid) qi = a.Sq - 1;
+  int Sq = a.Sq, Sk = a.Sk;
+  long long qbase = (long long)seq * a.q_seq_stride, kbase_off = (long long)seq * a.k_seq_stride, obase = (long long)seq * a.o_seq_stride;
+  if (a.seq_len) {                                   // ragged batch: rows of this sequence
+    Sq = Sk = a.seq_len[seq];
+    const long long r0 = a.seq_row0[seq];
+    qbase = r0 * a.ldq; kbase_off = r0 * a.ldk; obase = r0 * a.ldo;
+    if (blockIdx.x * 128 >= Sq) return;              // whole workgroup beyond this (shorter) sequence
+  }
+  int qi = q0 + r; const bool qvalid = qi < Sq; if (!qvalid) qi = Sq - 1;
 
-  const bf16* qp = a.Q + (long long)seq * a.q_seq_stride + (long long)qi * a.ldq + head * 64;
+  const bf16* qp = a.Q + qbase + (long long)qi * a.ldq + head * 64;
   bf16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16 + h * 8);
 
-  const bf16* kbase = a.K + (long long)seq * a.k_seq_stride + head * 64;
-  const bf16* vbase = a.VT + ((long long)(seq * 4 + head) * 64) * a.Spad;
+  const bf16* kbase = a.K + kbase_off + head * 64;
+  const bf16* vbase = a.VT + ((long long)(seq * nh + head) * 64) * a.Spad;
 
   f32x16 o[2];
 #pragma unroll
@@ -261,14 +270,15 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
   float mrun = -INFINITY, lrun = 0.f;
 
-  const int ntile = (a.Sk + 63) >> 6;
+  int ntile = (Sk + 63) >> 6;
+  if (a.causal) { const int lim = (blockIdx.x * 128 + 127) / 64 + 1; ntile = ntile < lim ? ntile : lim; }   // tiles past the diagonal are fully masked
   for (int jt = 0; jt < ntile; ++jt) {
     const int kv0 = jt * 64;
     // stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]: 512 16-B chunks each, 2 per thread
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256, row = c >> 3, ch = c & 7;
-      int key = kv0 + row; key = key < a.Sk ? key : a.Sk - 1;
+      int key = kv0 + row; key = key < Sk ? key : Sk - 1;
       const uint4 kvv = *reinterpret_cast<const uint4*>(kbase + (long long)key * a.ldk + ch * 8);
       *reinterpret_cast<uint4*>(Ks + row * LDK + ch * 8) = kvv;
       const uint4 vv = *reinterpret_cast<const uint4*>(vbase + (long long)row * a.Spad + kv0 + ch * 8);
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
       for (int i = 0; i < 16; ++i) {
         const int key = kv0 + kt * 32 + acc_row(i, h);
         float v = sT[kt][i] * a.scale_log2e;
-        v = key < a.Sk ? v : -INFINITY;
+        v = (key < Sk && (!a.causal || key <= qi)) ? v : -INFINITY;
         sT[kt][i] = v;
         mx = fmaxf(mx, v);
       }
@@ -339,7 +349,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   lrun += xhalf(lrun);
   const float inv = 1.f / lrun;
   if (qvalid) {
-    bf16* op = a.O + (long long)seq * a.o_seq_stride + (long long)(q0 + r) * a.ldo + head * 64;
+    bf16* op = a.O + obase + (long long)(q0 + r) * a.ldo + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -353,8 +363,9 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 int launch_attn(const AttnArgs& a, hipStream_t st) {
   if (a.Sq <= 0 || a.Sk <= 0 || a.n_seq <= 0 || a.Spad % 64 || a.Spad < ((a.Sk + 63) / 64) * 64)
     ETD_FAIL(ETD_EINVAL, "attn: bad shape Sq=%d Sk=%d Spad=%d", a.Sq, a.Sk, a.Spad);
-  ProfScope ps("k_attn", st, 1024.0 * a.n_seq * a.Sq * a.Sk, ((double)a.n_seq * (2.0 * a.Sq + 2.0 * a.Sk) * 256) * 2);
-  dim3 g((a.Sq + 127) / 128, a.n_seq * 4);
+  const int nh = a.n_heads > 0 ? a.n_heads : 4;
+  ProfScope ps(a.causal ? "k_attn_causal" : "k_attn", st, a.flops_hint > 0 ? a.flops_hint : (a.causal ? 0.5 : 1.0) * 256.0 * nh * a.n_seq * a.Sq * a.Sk, ((double)a.n_seq * (2.0 * a.Sq + 2.0 * a.Sk) * 64 * nh) * 2);
+  dim3 g((a.Sq + 127) / 128, a.n_seq * nh);
   hipLaunchKernelGGL(k_attn, g, dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;

@@ -214,7 +214,6 @@ class EtudeDecoder:
         active: Dict[int, Tuple[int, _Job]] = {}      # slot -> (job index, job)
         n_steps_total = n_tokens = 0
         st = self._stream()
-        tokbuf = (C.c_int32 * 1024)()
 
         def start_bars(batch: List[_Job]) -> List[_Job]:
             """Prefill the next bar of every job in `batch` in as few device passes as possible (all prompts of a call
@@ -253,10 +252,15 @@ class EtudeDecoder:
                                                       a4.ctypes.data, tg.ctypes.data, eo.ctypes.data, li.ctypes.data, st), "etd_decoder_begin_bars")
             return finished
 
-        def finish_bar(job: _Job):
-            n = C.c_int()
-            _lib.check(lib.etd_decoder_read_tokens(self._h, job.slot, tokbuf, 1024, C.byref(n), st), "etd_decoder_read_tokens")
-            toks = list(tokbuf[: n.value])
+        def read_done(done_jobs: List[_Job]) -> List[List[int]]:
+            n = len(done_jobs)
+            sl = np.asarray([j.slot for j in done_jobs], np.int32)
+            out = np.zeros((n, 1024), np.int32)
+            cnt = np.zeros(n, np.int32)
+            _lib.check(lib.etd_decoder_read_many(self._h, n, sl.ctypes.data, out.ctypes.data, 1024, cnt.ctypes.data, st), "etd_decoder_read_many")
+            return [out[i, : cnt[i]].tolist() for i in range(n)]
+
+        def finish_bar(job: _Job, toks: List[int]):
             job.total += len(toks)
             job.history.append((job.x_bars[job.i], [bos] + toks, job.attrs[job.i]))
             if len(job.history) > cfg.context_num_past_xy_pairs:
@@ -292,11 +296,9 @@ class EtudeDecoder:
                 no = np.zeros(len(slots), np.int32)
                 _lib.check(lib.etd_decoder_poll(self._h, slots.ctypes.data, len(slots), dn.ctypes.data, no.ctypes.data, st), "etd_decoder_poll")
                 again = []
-                for s, d in zip(slots.tolist(), dn.tolist()):
-                    if not d:
-                        continue
-                    ji, job = active[s]
-                    n_tokens += finish_bar(job)
+                done_jobs = [active[s][1] for s, d in zip(slots.tolist(), dn.tolist()) if d]
+                for job, toks in zip(done_jobs, read_done(done_jobs) if done_jobs else []):
+                    n_tokens += finish_bar(job, toks)
                     if job.total >= job.max_out:                 # etude_decoder.py:352
                         retire(job)
                     else:
@@ -307,8 +309,11 @@ class EtudeDecoder:
                     continue                                      # re-poll / refill before stepping
                 if any(dn):
                     continue
-                _lib.check(lib.etd_decoder_step(self._h, slots.ctypes.data, len(slots), steps_per_poll, st), "etd_decoder_step")
-                n_steps_total += steps_per_poll
+                nstep = steps_per_poll
+                if force_bar_tokens:      # no early EOS possible: run every stream to the nearest bar end in one call
+                    nstep = max(1, min(active[s][1].limit - int(c) for s, c in zip(slots.tolist(), no.tolist())))
+                _lib.check(lib.etd_decoder_step(self._h, slots.ctypes.data, len(slots), nstep, st), "etd_decoder_step")
+                n_steps_total += nstep
         if stats is not None:
             stats["steps"] = n_steps_total
             stats["tokens"] = n_tokens

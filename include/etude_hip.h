@@ -146,6 +146,8 @@ int etd_decoder_step(etd_dec*, const int32_t* slots, int n_active, int n_steps, 
 int etd_decoder_poll(etd_dec*, const int32_t* slots, int n, int32_t* done_out, int32_t* n_out_out, void* stream);
 /* Copy out the tokens generated so far by `slot` (synchronises). *n = count. */
 int etd_decoder_read_tokens(etd_dec*, int slot, int32_t* out, int cap, int* n, void* stream);
+/* The same for n streams with ONE synchronisation: out is [n][cap], counts [n]. */
+int etd_decoder_read_many(etd_dec*, int n, const int32_t* slots, int32_t* out, int cap, int32_t* counts, void* stream);
 /* begin_bar + steps until done + read_tokens for one stream.  Synchronous. */
 int etd_decoder_generate_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
                              const int32_t* tgt_attrs4, int eos_id, int limit, int32_t* out, int* n_out, void* stream);
