@@ -133,16 +133,17 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 // tiles reduced through LDS in a fixed order (bit-reproducible).  (N/32) x (M/32) workgroups keep many
 // more CUs streaming weights than the 128-feature tile does when M is a handful of decode rows.
 // ================================================================================================
+#define DS_WAVES 8   // K is split over 8 waves: one L2 round trip covers K = 512, four (fully unrolled) K = 2048
 template <bool WBF16, int EPI>
-__global__ __launch_bounds__(256) void k_dgemm_s(DGemmArgs a) {
-  __shared__ __attribute__((aligned(16))) float red[3][16][64];
+__global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   __shared__ float stat[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const bool ln = a.ln_g != nullptr;
   if (ln) {
-    for (int rr = 0; rr < 8; ++rr) {
-      const int row = wave * 8 + rr;
+    for (int rr = 0; rr < 32 / DS_WAVES; ++rr) {
+      const int row = wave * (32 / DS_WAVES) + rr;
       int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
       const float* xp = a.X + (long long)gm * a.ldx;
       float s = 0.f;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_dgemm_s(DGemmArgs a) {
   int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
   const float mean = ln ? stat[r] : 0.f, rstd = ln ? stat[32 + r] : 1.f;
   const float* xrow = a.X + (long long)gm * a.ldx;
-  const int kq = a.K >> 2, kb = wave * kq, ke = kb + kq;
+  const int kq = a.K / DS_WAVES, kb = wave * kq, ke = kb + kq;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void k_dgemm_s(DGemmArgs a) {
     const bf16* wrow = reinterpret_cast<const bf16*>(a.W) + (long long)(n0 + r) * a.K;
     if (a.Xb) {
       const bf16* xbrow = a.Xb + (long long)gm * a.ldx;
-#pragma unroll 2
+#pragma unroll 4
       for (int k = kb; k < ke; k += 64) {
         bf16x8 wf[4], xf[4];
 #pragma unroll
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void k_dgemm_s(DGemmArgs a) {
   __syncthreads();
   if (wave != 0) return;
 #pragma unroll
-  for (int w = 0; w < 3; ++w)
+  for (int w = 0; w < DS_WAVES - 1; ++w)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
   const int m = m0 + r;
@@ -341,7 +342,7 @@ static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st
   const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((a.M + 31) / 32, a.Npad / 32), g2(a.Npad / 16);
 #define ETD_DG(E)                                                                                   \
   if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, E>), g0, dim3(256), 0, st, a);                  \
-  else if (path == 1) hipLaunchKernelGGL((k_dgemm_s<WBF16, E>), g1, dim3(256), 0, st, a);           \
+  else if (path == 1) hipLaunchKernelGGL((k_dgemm_s<WBF16, E>), g1, dim3(64 * DS_WAVES), 0, st, a);  \
   else hipLaunchKernelGGL((k_dgemv<WBF16, E>), g2, dim3(256), 0, st, a);
   switch (epi) {
     case DEPI_BIAS: ETD_DG(DEPI_BIAS) break;
@@ -350,7 +351,7 @@ static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st
     case DEPI_LOGITS: ETD_DG(DEPI_LOGITS) break;
     default:
       if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_QKV>), g0, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_QKV>), g1, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_QKV>), g1, dim3(64 * DS_WAVES), 0, st, a);
       break;
   }
 #undef ETD_DG
@@ -410,23 +411,36 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
   float mr = -INFINITY, lr = 0.f, o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
-  for (int k0 = wave * 8; k0 < ctx; k0 += 32) {
-    const int key = k0 + j;
-    const bool valid = key < ctx;
-    const int kk = valid ? key : ctx - 1;
-    float kv[8];
-    load8<KVT>(kb + (long long)kk * 64 + c * 8, kv);
-    float s = 0.f;
+  // two 8-key groups per iteration (independent chains): 4 loads in flight per lane before the first use
+  for (int k0 = wave * 8; k0 < ctx; k0 += 64) {
+    const int keyA = k0 + j, keyB = k0 + 32 + j;
+    const bool vA = keyA < ctx, vB = keyB < ctx;
+    const int ka = vA ? keyA : ctx - 1, kbb = vB ? keyB : ctx - 1;
+    float kA[8], kB[8], wA[8], wB[8];
+    load8<KVT>(kb + (long long)ka * 64 + c * 8, kA);
+    load8<KVT>(kb + (long long)kbb * 64 + c * 8, kB);
+    load8<KVT>(vb + (long long)ka * 64 + c * 8, wA);
+    load8<KVT>(vb + (long long)kbb * 64 + c * 8, wB);
+    float sA = 0.f, sB = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s = fmaf(q[e], kv[e], s);
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-    load8<KVT>(vb + (long long)kk * 64 + c * 8, kv);
-    if (valid) {
-      const float mn = fmaxf(mr, s);
-      const float al = expf(mr - mn), p = expf(s - mn);
+    for (int e = 0; e < 8; ++e) { sA = fmaf(q[e], kA[e], sA); sB = fmaf(q[e], kB[e], sB); }
+    sA += __shfl_xor(sA, 1, 64); sB += __shfl_xor(sB, 1, 64);
+    sA += __shfl_xor(sA, 2, 64); sB += __shfl_xor(sB, 2, 64);
+    sA += __shfl_xor(sA, 4, 64); sB += __shfl_xor(sB, 4, 64);
+    if (vA) {
+      const float mn = fmaxf(mr, sA);
+      const float al = expf(mr - mn), p = expf(sA - mn);
       lr = lr * al + p;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * kv[e];
+      for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wA[e];
+      mr = mn;
+    }
+    if (vB) {
+      const float mn = fmaxf(mr, sB);
+      const float al = expf(mr - mn), p = expf(sB - mn);
+      lr = lr * al + p;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wB[e];
       mr = mn;
     }
   }

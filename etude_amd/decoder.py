@@ -93,11 +93,40 @@ def assemble_bar_prompt(history, x_bar, y_attrs, user_keys, bar_bos_id, bar_eos_
     return toks, cls, at
 
 
+def assemble_bar_prompt_np(history, x_bar, y4, bar_bos_id, bar_eos_id, n_ctx_pairs, max_pos, max_bar_token_limit, context_overlap_ratio):
+    """numpy twin of ``assemble_bar_prompt`` for the batched engine: history = [(x ndarray, y ndarray, attrs4 ndarray)],
+    y4 = target attrs in C-ABI order.  Returns (tokens[T], classes[T], attrs[4][T]) as int32 arrays, Bar_BOS appended."""
+    hist = history[-n_ctx_pairs:] if n_ctx_pairs > 0 else []
+    segs, seg_cls, seg_at = [], [], []
+    empty = np.asarray([bar_bos_id, bar_eos_id], np.int32)
+    neutral = np.ones(4, np.int32)
+    for _ in range(n_ctx_pairs - len(hist)):
+        for c in (SRC_CLASS_ID, TGT_CLASS_ID):
+            segs.append(empty); seg_cls.append(c); seg_at.append(neutral)
+    for xs, ys, a4 in hist:
+        segs.append(xs); seg_cls.append(SRC_CLASS_ID); seg_at.append(a4)
+        segs.append(ys); seg_cls.append(TGT_CLASS_ID); seg_at.append(a4)
+    segs.append(x_bar); seg_cls.append(SRC_CLASS_ID); seg_at.append(y4)
+    lens = np.asarray([len(x) for x in segs], np.int64)
+    toks = np.concatenate(segs).astype(np.int32, copy=False)
+    cls = np.repeat(np.asarray(seg_cls, np.int32), lens)
+    at = np.repeat(np.stack(seg_at).astype(np.int32), lens, axis=0).T          # [4][T]
+    if toks.size > max_pos - max_bar_token_limit:
+        keep = int(max_pos * context_overlap_ratio)
+        toks, cls, at = toks[-keep:], cls[-keep:], at[:, -keep:]
+    toks = np.concatenate([toks, np.asarray([bar_bos_id], np.int32)])
+    cls = np.concatenate([cls, np.asarray([TGT_CLASS_ID], np.int32)])
+    at = np.concatenate([at, np.asarray(y4, np.int32)[:, None]], axis=1)
+    return toks, cls, np.ascontiguousarray(at)
+
+
 class _Job:
-    __slots__ = ("x_bars", "attrs", "keys", "max_out", "bar_limit", "overlap", "i", "history", "total", "bars_out", "slot", "limit")
+    __slots__ = ("x_bars", "attrs", "x_np", "a4", "keys", "max_out", "bar_limit", "overlap", "i", "history", "total", "bars_out", "slot", "limit")
 
     def __init__(self, x_bars, attrs, max_out, bar_limit, overlap):
         self.x_bars, self.attrs = x_bars, attrs
+        self.x_np = [np.asarray(b, np.int32) for b in x_bars]
+        self.a4 = [np.asarray([a[k] for k in ABI_ATTR_KEYS], np.int32) for a in attrs]
         self.keys = sorted(attrs[0].keys())
         self.max_out, self.bar_limit, self.overlap = max_out, bar_limit, overlap
         self.i, self.history, self.total, self.bars_out, self.slot, self.limit = 0, [], 0, [], -1, 0
@@ -230,10 +259,10 @@ class EtudeDecoder:
                     job.bars_out.append([bos])
                     finished.append(job)
                     continue
-                toks, cls, at = assemble_bar_prompt(job.history, job.x_bars[job.i], y_attrs, job.keys, bos, eos,
-                                                    cfg.context_num_past_xy_pairs, cfg.max_position_embeddings,
-                                                    job.bar_limit, job.overlap)
-                pend.append((job, toks, cls, [at[k] for k in ABI_ATTR_KEYS], [y_attrs[k] for k in ABI_ATTR_KEYS]))
+                toks, cls, at = assemble_bar_prompt_np(job.history, job.x_np[job.i], job.a4[job.i], bos, eos,
+                                                       cfg.context_num_past_xy_pairs, cfg.max_position_embeddings,
+                                                       job.bar_limit, job.overlap)
+                pend.append((job, toks, cls, at, job.a4[job.i]))
             while pend:
                 take, rows = [], 0
                 while pend and (not take or rows + len(pend[0][1]) <= self.max_prefill_rows):
@@ -242,10 +271,10 @@ class EtudeDecoder:
                 n = len(take)
                 slots = np.asarray([t[0].slot for t in take], np.int32)
                 T = np.asarray([len(t[1]) for t in take], np.int32)
-                ids = np.concatenate([np.asarray(t[1], np.int32) for t in take])
-                cl = np.concatenate([np.asarray(t[2], np.int32) for t in take])
-                a4 = np.ascontiguousarray(np.concatenate([np.asarray(t[3], np.int32) for t in take], axis=1))
-                tg = np.ascontiguousarray(np.asarray([t[4] for t in take], np.int32))
+                ids = np.ascontiguousarray(np.concatenate([t[1] for t in take]), np.int32)
+                cl = np.ascontiguousarray(np.concatenate([t[2] for t in take]), np.int32)
+                a4 = np.ascontiguousarray(np.concatenate([t[3] for t in take], axis=1), np.int32)
+                tg = np.ascontiguousarray(np.stack([t[4] for t in take]), np.int32)
                 eo = np.full(n, -1 if force_bar_tokens else eos, np.int32)
                 li = np.asarray([t[0].limit for t in take], np.int32)
                 _lib.check(lib.etd_decoder_begin_bars(self._h, n, slots.ctypes.data, T.ctypes.data, ids.ctypes.data, cl.ctypes.data,
@@ -262,7 +291,7 @@ class EtudeDecoder:
 
         def finish_bar(job: _Job, toks: List[int]):
             job.total += len(toks)
-            job.history.append((job.x_bars[job.i], [bos] + toks, job.attrs[job.i]))
+            job.history.append((job.x_np[job.i], np.asarray([bos] + toks, np.int32), job.a4[job.i]))
             if len(job.history) > cfg.context_num_past_xy_pairs:
                 job.history.pop(0)
             job.bars_out.append([bos] + toks)

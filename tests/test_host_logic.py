@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from etude_amd import synth
-from etude_amd.decoder import ABI_ATTR_KEYS, EtudeDecoderConfig, assemble_bar_prompt, expected_state_keys
+from etude_amd.decoder import ABI_ATTR_KEYS, EtudeDecoderConfig, assemble_bar_prompt, assemble_bar_prompt_np, expected_state_keys
 from etude_amd.extractor import read_wav, write_wav_f32
 from etude_amd.vocab import Event, Vocab
 from oracle import neox
@@ -28,6 +28,12 @@ def test_prompt_assembly_matches_oracle_incl_truncation():
         b = neox.build_bar_prompt(hist, x, y, keys, 4, 5, d, 512, 0.5)
         assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
         assert len(a[0]) <= 513
+        # the numpy twin used by the batched engine builds the same prompt
+        h_np = [(np.asarray(xs, np.int32), np.asarray(ys, np.int32), np.asarray([at[k] for k in ABI_ATTR_KEYS], np.int32)) for xs, ys, at in hist]
+        t, c, a4 = assemble_bar_prompt_np(h_np, np.asarray(x, np.int32), np.asarray([y[k] for k in ABI_ATTR_KEYS], np.int32), 4, 5, 4, 1024, 512, 0.5)
+        assert t.tolist() == a[0] and c.tolist() == a[1]
+        for j, k in enumerate(ABI_ATTR_KEYS):
+            assert a4[j].tolist() == a[2][k]
 
 
 def test_vocab_roundtrip_and_event_decoding(tmp_path):
