@@ -75,3 +75,40 @@ extern "C" int etd_prof_entry(int i, char* name, int name_cap, double* total_ms,
   if (bytes) *bytes = it->second.bytes;
   return ETD_OK;
 }
+
+// ---- measurement hook: cost of a dependent kernel boundary on this stack (eager vs hipGraph replay)
+struct BigArg { int v[120]; };
+__global__ void k_empty_small(int* p) { if (p && threadIdx.x == 1024) p[0] = 1; }
+__global__ void k_empty_big(BigArg a, int* p) { if (p && threadIdx.x == 1024) p[0] = a.v[3]; }
+extern "C" int etd_debug_boundary_cost(int n_nodes, int iters, int big_args, void* stream, double* eager_us, double* graph_us) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!st || n_nodes < 1 || iters < 1 || !eager_us || !graph_us) ETD_FAIL(ETD_EINVAL, "boundary_cost: need a non-default stream");
+  BigArg ba = {};
+  auto body = [&]() {
+    for (int i = 0; i < n_nodes; ++i) {
+      if (big_args) hipLaunchKernelGGL(k_empty_big, dim3(64), dim3(256), 0, st, ba, (int*)nullptr);
+      else hipLaunchKernelGGL(k_empty_small, dim3(64), dim3(256), 0, st, (int*)nullptr);
+    }
+  };
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  body(); HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int it = 0; it < iters; ++it) body();
+  HIP_TRY(hipEventRecord(e1, st)); HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *eager_us = 1e3 * ms / ((double)iters * n_nodes);
+  hipGraph_t g; hipGraphExec_t ge;
+  HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+  body();
+  HIP_TRY(hipStreamEndCapture(st, &g));
+  HIP_TRY(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  HIP_TRY(hipGraphLaunch(ge, st)); HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int it = 0; it < iters; ++it) HIP_TRY(hipGraphLaunch(ge, st));
+  HIP_TRY(hipEventRecord(e1, st)); HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *graph_us = 1e3 * ms / ((double)iters * n_nodes);
+  (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return ETD_OK;
+}

@@ -52,6 +52,9 @@ int etd_prof_collect(void);
 int etd_prof_count(void);
 int etd_prof_entry(int i, char* name, int name_cap, double* total_ms, long long* launches, double* flops, double* bytes);
 
+/* measurement hook: device time per dependent (empty) kernel, launched eagerly vs replayed from a hipGraph */
+int etd_debug_boundary_cost(int n_nodes, int iters, int big_args, void* stream, double* eager_us, double* graph_us);
+
 /* ------------------------------------------------------------------ audio front end */
 typedef struct etd_frontend etd_frontend;
 /* Tables are built by the host layer exactly as torchaudio builds them:

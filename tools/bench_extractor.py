@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""BASELINE configs[2]-style extractor-only run (N windows of 512 frames) -- for rocprofv3 / PMC runs."""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from etude_amd import synth  # noqa: E402
+from etude_amd.config import ExtractorConfig  # noqa: E402
+from etude_amd.extractor import AMTAPC_Extractor  # noqa: E402
+
+if __name__ == "__main__":
+    nwin = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    dev = torch.device("cuda:0")
+    ex = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(7), "cuda", max_windows=1)
+    xs = torch.from_numpy(synth.window_features(5, nwin)).to(dev)
+    ex.transcript_windows(xs)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        ex.transcript_windows(xs)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t) / (reps * nwin)
+    print(f"{dt*1e3:.3f} ms/window  {ex.window_flops/dt/1e12:.1f} TFLOP/s  {8.192/dt:.0f} audio-s/s")
