@@ -49,6 +49,7 @@ struct etd_dec {
   bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
   bf16 *Qb = nullptr, *Kp = nullptr, *VTp = nullptr; int vt_spad = 0;     // batched-prefill scratch of the MFMA attention
   float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
+  float* Pk = nullptr;                           // [4][128][H] split-K partials of the decode-step down projection
   std::vector<int> stage;                        // host staging of a prefill batch
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
@@ -132,7 +133,8 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     const Layer& w = d->layers[l];
     void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * esz;
     void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
-    if (bpipe) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
+    const bool small = bpipe && !big && d->I % (4 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
+    if (bpipe && (!small || l == 0)) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
     q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
@@ -196,6 +198,12 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       LinArgs a = {};
       a.X = d->M1b; a.ldx = d->I; a.W = (const bf16*)w.down.W; a.bias = w.down.b; a.M = M; a.N = d->H; a.K = d->I; a.vt_block = -1; a.dec = dn;
       ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
+    } else if (small) {
+      dn.k_splits = 4; dn.Y = d->Pk; dn.ldy = d->H;
+      ETD_TRY(launch_dgemm(dn, DEPI_PARTIAL, true, st));
+      const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
+      ETD_TRY(launch_resid_ln_rows(d->Pk, 4, w.down.b, d->DO, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
+                                   nx ? nx->ln2g : nullptr, nx ? nx->ln2b : nullptr, d->cfg.layer_norm_eps, nx ? d->X1b : nullptr, nx ? d->X2b : nullptr, st));
     } else {
       ETD_TRY(launch_dgemm(dn, DEPI_RESID, d->bf16w, st));
     }
@@ -372,6 +380,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   if (d->bf16w) {
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
+    rc = rc ? rc : d->alloc(&d->Pk, (size_t)4 * 128 * H);
     rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
     rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)

@@ -70,7 +70,7 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         v[j] = acc[4 * q + j];
-        if (EPI != DEPI_LOGITS) v[j] += a.bias[n + j];
+        if (EPI != DEPI_LOGITS && EPI != DEPI_PARTIAL) v[j] += a.bias[n + j];
         if (EPI == DEPI_GELU) v[j] = gelu_erf(v[j]);
       }
       if constexpr (EPI == DEPI_RESID) {

@@ -10,7 +10,7 @@ struct DecRows {
   const int* seq;      // [M] index of the row's prompt inside a batched prefill (only read when the prefill scratch is set)
 };
 
-enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4 };
+enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4, DEPI_PARTIAL = 5 };
 
 struct DGemmArgs {
   const float* X; int ldx;       // [M, K] fp32 activations
@@ -22,6 +22,8 @@ struct DGemmArgs {
   const float* ln_g; const float* ln_b; float ln_eps;
   float* Y; int ldy;             // BIAS / GELU / LOGITS destination
   bf16* Yb;                      // if set, BIAS / GELU store bf16 here instead (row stride ldy)
+  int k_splits;                  // DEPI_PARTIAL (skinny kernel only): K is split over this many workgroups (grid.z); slice z stores its
+                                 // raw fp32 partial products to Y + z*M*ldy, k_resid_ln_rows adds them up in a fixed order
   const bf16* Xb;                // if set, the input is bf16 [M, K] (already LayerNorm'ed), row stride ldx
   // RESID: hout = (acc + bias + add[m][n]) + h[m][n]
   const float* add; const float* hin; float* hout;
@@ -53,6 +55,9 @@ int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
 // h fp32 [M,H] -> LayerNorm with (g1,b1) and (g2,b2) -> two bf16 matrices (the two parallel-residual branches read the same h)
 int launch_ln_rows(const float* h, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,
                    bf16* x1, bf16* x2, hipStream_t st);
+// hout = ((sum_z P[z] + bias) + add) + hin   [M][H] fp32, then (optionally) LayerNorm of hout with (g1,b1) / (g2,b2) -> bf16 x1 / x2
+int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const float* add, const float* hin, float* hout, int M, int H,
+                         const float* g1, const float* b1, const float* g2, const float* b2, float eps, bf16* x1, bf16* x2, hipStream_t st);
 // out[i][:] = src[idx[i]][:]  (fp32 rows of H)
 int launch_gather_rows(const float* src, const int* idx, int n, int H, float* out, hipStream_t st);
 

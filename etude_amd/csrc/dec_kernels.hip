@@ -164,7 +164,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
   int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
   const float mean = ln ? stat[r] : 0.f, rstd = ln ? stat[32 + r] : 1.f;
   const float* xrow = a.X + (long long)gm * a.ldx;
-  const int kq = a.K / DS_WAVES, kb = wave * kq, ke = kb + kq;
+  const int Kz = a.K / (int)gridDim.z;                 // split-K over workgroups (DEPI_PARTIAL), then over the waves
+  const int kq = Kz / DS_WAVES, kb = (int)blockIdx.z * Kz + wave * kq, ke = kb + kq;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -242,7 +243,13 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
     for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
   const int m = m0 + r;
   if (m >= a.M) return;
-  dgemm_epilogue<WBF16, EPI>(a, acc, m, n0, h);
+  if constexpr (EPI == DEPI_PARTIAL) {
+    DGemmArgs b = a;
+    b.Y = a.Y + (long long)blockIdx.z * a.M * a.ldy;
+    dgemm_epilogue<WBF16, EPI>(b, acc, m, n0, h);
+  } else {
+    dgemm_epilogue<WBF16, EPI>(a, acc, m, n0, h);
+  }
 }
 
 // ================================================================================================
@@ -339,7 +346,7 @@ __global__ void k_rope_scatter(DGemmArgs a, const float* __restrict__ raw) {
 template <bool WBF16>
 static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st) {
   // path 0: 128-feature tile (prefill), 1: skinny K-split tile (M <= 128), 2: GEMV (M == 1)
-  const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((a.M + 31) / 32, a.Npad / 32), g2(a.Npad / 16);
+  const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((a.M + 31) / 32, a.Npad / 32, a.k_splits > 1 ? a.k_splits : 1), g2(a.Npad / 16);
 #define ETD_DG(E)                                                                                   \
   if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, E>), g0, dim3(256), 0, st, a);                  \
   else if (path == 1) hipLaunchKernelGGL((k_dgemm_s<WBF16, E>), g1, dim3(64 * DS_WAVES), 0, st, a);  \
@@ -349,6 +356,7 @@ static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st
     case DEPI_GELU: ETD_DG(DEPI_GELU) break;
     case DEPI_RESID: ETD_DG(DEPI_RESID) break;
     case DEPI_LOGITS: ETD_DG(DEPI_LOGITS) break;
+    case DEPI_PARTIAL: hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_PARTIAL>), g1, dim3(64 * DS_WAVES), 0, st, a); break;
     default:
       if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_QKV>), g0, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_QKV>), g1, dim3(64 * DS_WAVES), 0, st, a);
@@ -362,6 +370,8 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
   if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "dgemm: QKV epilogue needs head_dim 64 and rotary_ndims 16");
   if (epi == DEPI_RESID && (a.N % 4)) ETD_FAIL(ETD_EINVAL, "dgemm: resid needs N %% 4 == 0");
   const int path = a.M == 1 ? 2 : (a.M <= 128 ? 1 : 0);
+  if (epi == DEPI_PARTIAL && (path != 1 || a.k_splits < 1 || (a.K / a.k_splits) % (64 * DS_WAVES) || !a.Y)) ETD_FAIL(ETD_EINVAL, "dgemm: bad split-K request");
+  if (epi != DEPI_PARTIAL && a.k_splits > 1) ETD_FAIL(ETD_EINVAL, "dgemm: k_splits needs DEPI_PARTIAL");
   ProfScope ps(path == 2 ? "k_dgemv" : (path == 1 ? "k_dgemm_s" : "k_dgemm"), st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * (w_bf16 ? 2 : 4));
   if (path == 2 && epi == DEPI_QKV) {
     // GEMV writes the raw fused row into a.Y (caller-provided scratch [3H]); RoPE + Q/K/V scatter follow
@@ -499,43 +509,132 @@ int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
 // post_attention_layernorm read the same h, modeling_gpt_neox.py:250-270); one wave per row, bf16 out.
 __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ hsrc, int M, int H, const float* __restrict__ g1, const float* __restrict__ b1,
                                                  const float* __restrict__ g2, const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
+  // one wave per row, the row is read ONCE (8 floats per lane per 512 columns, H <= 2048) and kept in registers:
+  // a kernel this small is pure latency, so one global round trip instead of three is the whole optimisation
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xp = hsrc + (long long)row * H;
+  float v[4][8];
   float s = 0.f;
-  for (int k = lane * 8; k < H; k += 512) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k), b = *reinterpret_cast<const f32x4*>(xp + k + 4);
-    s += (a[0] + a[1] + a[2] + a[3]) + (b[0] + b[1] + b[2] + b[3]);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (k < H) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k), b = *reinterpret_cast<const f32x4*>(xp + k + 4);
+      v[it][0] = a[0]; v[it][1] = a[1]; v[it][2] = a[2]; v[it][3] = a[3]; v[it][4] = b[0]; v[it][5] = b[1]; v[it][6] = b[2]; v[it][7] = b[3];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[it][j];
+    }
   }
   s = wave_sum(s);
   const float mean = s / (float)H;
   float q = 0.f;
-  for (int k = lane * 8; k < H; k += 512) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k), b = *reinterpret_cast<const f32x4*>(xp + k + 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const float d0 = a[j] - mean, d1 = b[j] - mean; q += d0 * d0 + d1 * d1; }
-  }
+  for (int it = 0; it < 4; ++it)
+    if (lane * 8 + it * 512 < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d0 = v[it][j] - mean; q += d0 * d0; }
+    }
   q = wave_sum(q);
   const float rstd = rsqrtf(q / (float)H + eps);
-  for (int k = lane * 8; k < H; k += 512) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(xp + k), b = *reinterpret_cast<const f32x4*>(xp + k + 4);
-    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    bf16x8 o1, o2;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float n = (v[j] - mean) * rstd;
-      o1[j] = (bf16)(n * g1[k + j] + b1[k + j]);
-      if (x2) o2[j] = (bf16)(n * g2[k + j] + b2[k + j]);
+  for (int it = 0; it < 4; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (k < H) {
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(g1 + k), gb = *reinterpret_cast<const f32x4*>(g1 + k + 4);
+      const f32x4 ba = *reinterpret_cast<const f32x4*>(b1 + k), bb = *reinterpret_cast<const f32x4*>(b1 + k + 4);
+      bf16x8 o1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o1[j] = (bf16)((v[it][j] - mean) * rstd * ga[j] + ba[j]); o1[4 + j] = (bf16)((v[it][4 + j] - mean) * rstd * gb[j] + bb[j]); }
+      *reinterpret_cast<bf16x8*>(x1 + (long long)row * H + k) = o1;
+      if (x2) {
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(g2 + k), hb = *reinterpret_cast<const f32x4*>(g2 + k + 4);
+        const f32x4 ca = *reinterpret_cast<const f32x4*>(b2 + k), cb = *reinterpret_cast<const f32x4*>(b2 + k + 4);
+        bf16x8 o2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o2[j] = (bf16)((v[it][j] - mean) * rstd * ha[j] + ca[j]); o2[4 + j] = (bf16)((v[it][4 + j] - mean) * rstd * hb[j] + cb[j]); }
+        *reinterpret_cast<bf16x8*>(x2 + (long long)row * H + k) = o2;
+      }
     }
-    *reinterpret_cast<bf16x8*>(x1 + (long long)row * H + k) = o1;
-    if (x2) *reinterpret_cast<bf16x8*>(x2 + (long long)row * H + k) = o2;
   }
 }
 int launch_ln_rows(const float* hsrc, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,
                    bf16* x1, bf16* x2, hipStream_t st) {
-  if (M <= 0 || H % 8) ETD_FAIL(ETD_EINVAL, "ln_rows: bad shape");
+  if (M <= 0 || H % 8 || H > 2048) ETD_FAIL(ETD_EINVAL, "ln_rows: bad shape");
   ProfScope ps("k_ln_rows", st, 0, (double)M * H * (4 + (x2 ? 4 : 2)));
   hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, hsrc, M, H, g1, b1, g2, b2, eps, x1, x2);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// hout = ((sum_z P[z] + bias) + add) + hin, then the next layer's two LayerNorms -> bf16.  One wave per row, single pass.
+__global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__ P, int ks, const float* __restrict__ bias, const float* __restrict__ add,
+                                                       const float* __restrict__ hin, float* __restrict__ hout, int M, int H,
+                                                       const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2,
+                                                       const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const long long ro = (long long)row * H;
+  float v[4][8];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (k < H) {
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+      for (int z = 0; z < ks; ++z) {
+        const float* pp = P + (long long)z * M * H + ro + k;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(pp), b = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+      }
+      const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + k), bb = *reinterpret_cast<const f32x4*>(bias + k + 4);
+      const f32x4 da = *reinterpret_cast<const f32x4*>(add + ro + k), db = *reinterpret_cast<const f32x4*>(add + ro + k + 4);
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(hin + ro + k), hb = *reinterpret_cast<const f32x4*>(hin + ro + k + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[it][j] = ((acc[j] + ba[j]) + da[j]) + ha[j]; v[it][4 + j] = ((acc[4 + j] + bb[j]) + db[j]) + hb[j]; }
+      const f32x4 oa = {v[it][0], v[it][1], v[it][2], v[it][3]}, ob = {v[it][4], v[it][5], v[it][6], v[it][7]};
+      *reinterpret_cast<f32x4*>(hout + ro + k) = oa;
+      *reinterpret_cast<f32x4*>(hout + ro + k + 4) = ob;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[it][j];
+    }
+  }
+  if (!x1) return;
+  s = wave_sum(s);
+  const float mean = s / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < 4; ++it)
+    if (lane * 8 + it * 512 < H) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d0 = v[it][j] - mean; q += d0 * d0; }
+    }
+  q = wave_sum(q);
+  const float rstd = rsqrtf(q / (float)H + eps);
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int k = lane * 8 + it * 512;
+    if (k < H) {
+      bf16x8 o1, o2;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float n = (v[it][j] - mean) * rstd;
+        o1[j] = (bf16)(n * g1[k + j] + b1[k + j]);
+        o2[j] = (bf16)(n * g2[k + j] + b2[k + j]);
+      }
+      *reinterpret_cast<bf16x8*>(x1 + ro + k) = o1;
+      *reinterpret_cast<bf16x8*>(x2 + ro + k) = o2;
+    }
+  }
+}
+int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const float* add, const float* hin, float* hout, int M, int H,
+                         const float* g1, const float* b1, const float* g2, const float* b2, float eps, bf16* x1, bf16* x2, hipStream_t st) {
+  if (M <= 0 || H % 8 || H > 2048 || k_splits < 1) ETD_FAIL(ETD_EINVAL, "resid_ln_rows: bad shape");
+  ProfScope ps("k_resid_ln_rows", st, 0, (double)M * H * 4 * (k_splits + 3));
+  hipLaunchKernelGGL(k_resid_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
