@@ -401,6 +401,7 @@ template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&o
   for (int j = 0; j < 8; ++j) o[j] = bf2f(a[j]);
 }
 
+#define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
 template <typename KVT>
 __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
   __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
@@ -409,12 +410,16 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
   const int slot = a.rows.slot[m], pos = a.rows.pos[m];
   const int ctx = (pos < a.max_ctx ? pos : a.max_ctx - 1) + 1;
   const int hidden = a.n_heads * 64;
+  // bf16 serving mode: scores pre-scaled by log2(e) and v_exp_f32 (exp2) -- softmax is base-invariant; the fp32
+  // parity mode keeps the accurate expf like torch's softmax
+  constexpr bool FAST = sizeof(KVT) == 2;
+  const float qs = FAST ? a.scale * 1.4426950408889634f : a.scale;
   float q[8];
   {
     const float* qp = a.Q + (long long)m * hidden + head * 64 + c * 8;
     const f32x4 x = *reinterpret_cast<const f32x4*>(qp), y = *reinterpret_cast<const f32x4*>(qp + 4);
-    q[0] = x[0] * a.scale; q[1] = x[1] * a.scale; q[2] = x[2] * a.scale; q[3] = x[3] * a.scale;
-    q[4] = y[0] * a.scale; q[5] = y[1] * a.scale; q[6] = y[2] * a.scale; q[7] = y[3] * a.scale;
+    q[0] = x[0] * qs; q[1] = x[1] * qs; q[2] = x[2] * qs; q[3] = x[3] * qs;
+    q[4] = y[0] * qs; q[5] = y[1] * qs; q[6] = y[2] * qs; q[7] = y[3] * qs;
   }
   const KVT* kb = reinterpret_cast<const KVT*>(a.Kc) + (long long)slot * a.slot_stride + (long long)head * a.max_ctx * 64;
   const KVT* vb = reinterpret_cast<const KVT*>(a.Vc) + (long long)slot * a.slot_stride + (long long)head * a.max_ctx * 64;
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
     sA += __shfl_xor(sA, 4, 64); sB += __shfl_xor(sB, 4, 64);
     if (vA) {
       const float mn = fmaxf(mr, sA);
-      const float al = expf(mr - mn), p = expf(sA - mn);
+      const float al = EXPF(mr - mn), p = EXPF(sA - mn);
       lr = lr * al + p;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wA[e];
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
     }
     if (vB) {
       const float mn = fmaxf(mr, sB);
-      const float al = expf(mr - mn), p = expf(sB - mn);
+      const float al = EXPF(mr - mn), p = EXPF(sB - mn);
       lr = lr * al + p;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wB[e];
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
   for (int off = 8; off < 64; off <<= 1) {
     const float m2 = __shfl_xor(mr, off, 64), l2 = __shfl_xor(lr, off, 64);
     const float mn = fmaxf(mr, m2);
-    const float f1 = (mr == -INFINITY) ? 0.f : expf(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : expf(m2 - mn);
+    const float f1 = (mr == -INFINITY) ? 0.f : EXPF(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : EXPF(m2 - mn);
     lr = lr * f1 + l2 * f2;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float o2 = __shfl_xor(o[e], off, 64); o[e] = o[e] * f1 + o2 * f2; }
@@ -477,7 +482,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
     float L = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int w = 0; w < 4; ++w) {
       const float mw = red[w][c][0];
-      const float f = (mw == -INFINITY) ? 0.f : expf(mw - M2);
+      const float f = (mw == -INFINITY) ? 0.f : EXPF(mw - M2);
       L += red[w][c][1] * f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += red[w][c][2 + e] * f;
@@ -494,6 +499,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
   }
 }
 
+#undef EXPF
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "dattn: bad M");
   ProfScope ps(a.M > 128 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
