@@ -101,7 +101,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=180.0, help="clip length")
     ap.add_argument("--clips", type=int, default=8, help="clips per rank")
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
-    ap.add_argument("--streams", type=int, default=128, help="concurrent decoder streams")
+    ap.add_argument("--streams", type=int, default=256, help="concurrent decoder streams (capped at the number of jobs)")
     ap.add_argument("--bars", type=int, default=92)
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS suppressed)")
     ap.add_argument("--no-extras", action="store_true")
@@ -125,7 +125,7 @@ def main():
     from etude_amd.extractor import AMTAPC_Extractor
 
     cfg = ExtractorConfig()
-    ex = AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=int(os.environ.get("ETD_WB", "1")))
+    ex = AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=int(os.environ.get("ETD_WB", "4")))
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
     n_jobs = args.clips * args.attr_grid
     dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=min(args.streams, n_jobs))

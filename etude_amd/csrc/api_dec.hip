@@ -49,7 +49,7 @@ struct etd_dec {
   bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
   bf16 *Qb = nullptr, *Kp = nullptr, *VTp = nullptr; int vt_spad = 0;     // batched-prefill scratch of the MFMA attention
   float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
-  float* Pk = nullptr;                           // [4][128][H] split-K partials of the decode-step down projection
+  float* Pk = nullptr;                           // [4][512][H] split-K partials of the decode-step down projection
   std::vector<int> stage;                        // host staging of a prefill batch
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
@@ -120,15 +120,15 @@ int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst)
 // d->h.  Returns (in *hfinal) the buffer that holds the last layer's output (before the final LayerNorm).
 //
 // fp32 weights, or M == 1: fp32 activations, LayerNorm fused into the GEMM prologues (k_dgemm / k_dgemm_s / k_dgemv).
-// bf16 weights, M > 1:     k_ln_rows -> bf16 activations -> big-tile MFMA GEMM (k_linear decoder modes, M > 128, the
-//                          batched prefill) or the K-split skinny GEMM (M <= 128, the batched decode step).
+// bf16 weights, M > 1:     k_ln_rows -> bf16 activations -> big-tile MFMA GEMM (k_linear decoder modes, M > 512, the
+//                          batched prefill) or the K-split skinny GEMM (M <= 512, the batched decode step).
 struct PrefillInfo { int n; const int* seq_row0; const int* seq_len; int max_len; double attn_flops; };
 
 int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr) {
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && M > 1;
-  const bool big = bpipe && M > 128;
+  const bool big = bpipe && M > 512;            // must match DS_MAX_ROWS in dec_kernels.hip
   for (int l = 0; l < d->L; ++l) {
     const Layer& w = d->layers[l];
     void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * esz;
@@ -380,7 +380,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   if (d->bf16w) {
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
-    rc = rc ? rc : d->alloc(&d->Pk, (size_t)4 * 128 * H);
+    rc = rc ? rc : d->alloc(&d->Pk, (size_t)4 * 512 * H);
     rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
     rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)

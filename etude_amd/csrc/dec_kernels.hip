@@ -128,11 +128,12 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 }
 
 // ================================================================================================
-// k_dgemm_s ("skinny", M <= 128): 32 tokens x 32 features per workgroup, K split over the 4 waves,
+// k_dgemm_s ("skinny", M <= DS_MAX_ROWS): 32 tokens x 32 features per workgroup, K split over the 4 waves,
 // fragments straight from global/L2 to registers (no LDS staging, no barrier in the K loop), partial
 // tiles reduced through LDS in a fixed order (bit-reproducible).  (N/32) x (M/32) workgroups keep many
 // more CUs streaming weights than the 128-feature tile does when M is a handful of decode rows.
 // ================================================================================================
+#define DS_MAX_ROWS 512   // up to this many rows a GEMM runs on the weight-streaming skinny tile (decode steps of <= 512 streams)
 #define DS_WAVES 8   // K is split over 8 waves: one L2 round trip covers K = 512, four (fully unrolled) K = 2048
 template <bool WBF16, int EPI>
 __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
@@ -345,7 +346,7 @@ __global__ void k_rope_scatter(DGemmArgs a, const float* __restrict__ raw) {
 
 template <bool WBF16>
 static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st) {
-  // path 0: 128-feature tile (prefill), 1: skinny K-split tile (M <= 128), 2: GEMV (M == 1)
+  // path 0: 128-feature tile (prefill), 1: skinny K-split tile (M <= DS_MAX_ROWS), 2: GEMV (M == 1)
   const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((a.M + 31) / 32, a.Npad / 32, a.k_splits > 1 ? a.k_splits : 1), g2(a.Npad / 16);
 #define ETD_DG(E)                                                                                   \
   if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, E>), g0, dim3(256), 0, st, a);                  \
@@ -369,7 +370,7 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
   if (a.M <= 0 || a.Npad % 128 || a.K % 256 || a.N > a.Npad) ETD_FAIL(ETD_EINVAL, "dgemm: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
   if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "dgemm: QKV epilogue needs head_dim 64 and rotary_ndims 16");
   if (epi == DEPI_RESID && (a.N % 4)) ETD_FAIL(ETD_EINVAL, "dgemm: resid needs N %% 4 == 0");
-  const int path = a.M == 1 ? 2 : (a.M <= 128 ? 1 : 0);
+  const int path = a.M == 1 ? 2 : (a.M <= DS_MAX_ROWS ? 1 : 0);
   if (epi == DEPI_PARTIAL && (path != 1 || a.k_splits < 1 || (a.K / a.k_splits) % (64 * DS_WAVES) || !a.Y)) ETD_FAIL(ETD_EINVAL, "dgemm: bad split-K request");
   if (epi != DEPI_PARTIAL && a.k_splits > 1) ETD_FAIL(ETD_EINVAL, "dgemm: k_splits needs DEPI_PARTIAL");
   ProfScope ps(path == 2 ? "k_dgemv" : (path == 1 ? "k_dgemm_s" : "k_dgemm"), st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * (w_bf16 ? 2 : 4));
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
 #undef EXPF
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "dattn: bad M");
-  ProfScope ps(a.M > 128 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
+  ProfScope ps(a.M > 512 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
   dim3 g(a.M, a.n_heads);
   if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a);

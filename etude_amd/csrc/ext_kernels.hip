@@ -16,22 +16,8 @@
 
 // ================================================================================================
 // k_linear: Y = X W^T + b  (+ReLU | + residual + LayerNorm)       amt_apc.py:342-344,371,386-389,250,256
-// Workgroup 256 threads = 4 waves; each wave owns 32 tokens x 256 features (8 accumulators).
+// Workgroup 256 threads = 4 waves on a 128-token x 256-feature tile.
 // ================================================================================================
-template <bool NORMAL_ORIENT>
-__device__ __forceinline__ void lin_chunk(const bf16* Xs, const bf16* Ws, int wave, int r, int h, f32x16 (&acc)[8]) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + (wave * 32 + r) * LDK + s * 16 + h * 8);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-      const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + (t * 32 + r) * LDK + s * 16 + h * 8);
-      if (NORMAL_ORIENT) acc[t] = mfma32(xf, wf, acc[t]);   // D[token][feature]
-      else               acc[t] = mfma32(wf, xf, acc[t]);   // D[feature][token]
-    }
-  }
-}
-
 __device__ __forceinline__ void lin_gload(const bf16* X, int ldx, int M, int K, const bf16* W, int m0, int tid, int kc,
                                           u32x4 (&xr)[4], u32x4 (&wr)[8]) {
 #pragma unroll
@@ -60,137 +46,12 @@ __device__ __forceinline__ void lin_lstore(bf16* Xs, bf16* Ws, int tid, const u3
 }
 
 // MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm;
-// MODE 10 + DEPI_x: EtudeDecoder epilogue x on the same tile (batched prefill of the Decode stage)
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
-  constexpr bool LN = MODE == 2;
-  constexpr bool vt = MODE == 1;
-  constexpr bool DEC = MODE >= 10;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 256) * LDK * 2 + 3 * 256 * 4];
-  bf16* Xs = reinterpret_cast<bf16*>(smem);
-  bf16* Ws = Xs + 128 * LDK;
-  float* sb = reinterpret_cast<float*>(smem + (128 + 256) * LDK * 2);   // bias | gamma | beta
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * 128, nb = blockIdx.y + a.nb0, n0 = nb * 256, z = blockIdx.z;
-  const bf16* W = a.W + (long long)z * a.wz + (long long)n0 * a.K;
-  const float* bias = a.bias + (long long)z * a.bz + n0;
-
-  sb[tid] = bias[tid];
-  if (LN) { sb[256 + tid] = a.gamma[tid]; sb[512 + tid] = a.beta[tid]; }
-
-  f32x16 acc[8];
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-
-  // staging: X tile 128 rows x 8 chunks(16 B) = 4 per thread; W tile 256 rows x 8 chunks = 8 per thread
-  u32x4 xr[4], wr[8];
-  const int nk = a.K >> 6;
-  lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, 0, xr, wr);
-  for (int kc = 0; kc < nk; ++kc) {
-    lin_lstore(Xs, Ws, tid, xr, wr);
-    __syncthreads();
-    if (kc + 1 < nk) lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, kc + 1, xr, wr);   // next chunk's reads fly under this chunk's MFMAs
-    lin_chunk<vt>(Xs, Ws, wave, r, h, acc);
-    __syncthreads();
-  }
-
-  if constexpr (DEC) {
-    const int m = m0 + wave * 32 + r;
-    if (m < a.M) {
-#pragma unroll
-      for (int t = 0; t < 8; ++t) dgemm_epilogue<true, MODE - 10>(a.dec, acc[t], m, n0 + 32 * t, h);
-    }
-  } else if constexpr (!LN) {
-    if constexpr (vt) {
-      // accumulator: col = feature (lane), rows = tokens.  Store V^T[(seq,head,d)][pos], 4 tokens = 8 B.
-#pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const int f = t * 32 + r;                       // feature inside this 256-block
-        const float b = sb[f];
-        const int head = f >> 6, d = f & 63;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int m = m0 + wave * 32 + 8 * q + 4 * h;
-          if (m < a.M) {
-            const int seq = m / a.S, pos = m - seq * a.S;
-            float v0 = acc[t][4 * q + 0] + b, v1 = acc[t][4 * q + 1] + b, v2 = acc[t][4 * q + 2] + b, v3 = acc[t][4 * q + 3] + b;
-            bf16* dst = a.VT + (long long)z * a.vtz + ((long long)(seq * 4 + head) * 64 + d) * a.Spad + pos;
-            *reinterpret_cast<bf16x4*>(dst) = pack4(v0, v1, v2, v3);
-          }
-        }
-      }
-    } else {
-      const int m = m0 + wave * 32 + r;
-      if (m < a.M) {
-        bf16* yrow = a.Y + (long long)z * a.yz + (long long)m * a.ldy + n0;
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f = t * 32 + 8 * q + 4 * h;
-            float v0 = acc[t][4 * q + 0] + sb[f + 0], v1 = acc[t][4 * q + 1] + sb[f + 1];
-            float v2 = acc[t][4 * q + 2] + sb[f + 2], v3 = acc[t][4 * q + 3] + sb[f + 3];
-            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            *reinterpret_cast<bf16x4*>(yrow + f) = pack4(v0, v1, v2, v3);
-          }
-      }
-    }
-  } else {
-    // residual + LayerNorm over the 256 features of this lane's token (128 here, 128 in lane^32)
-    const int m = m0 + wave * 32 + r;
-    const int mc = m < a.M ? m : a.M - 1;
-    const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
-    const bf16* rp = a.R + (long long)rrow * a.ldr;
-    float s1 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = t * 32 + 8 * q + 4 * h;
-        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rp + f);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float v = acc[t][4 * q + j] + sb[f + j] + bf2f(rv[j]);
-          acc[t][4 * q + j] = v;
-          s1 += v;
-        }
-      }
-    s1 += xhalf(s1);
-    const float mean = s1 * (1.f / 256.f);
-    float s2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { const float dlt = acc[t][i] - mean; s2 += dlt * dlt; }
-    s2 += xhalf(s2);
-    const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);
-    if (m < a.M) {
-      bf16* y1 = a.Y + (long long)m * a.ldy;
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int f = t * 32 + 8 * q + 4 * h;
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (acc[t][4 * q + j] - mean) * rstd * sb[256 + f + j] + sb[512 + f + j];
-          *reinterpret_cast<bf16x4*>(y1 + f) = pack4(v[0], v[1], v[2], v[3]);
-        }
-    }
-  }
-}
-
-// ================================================================================================
-// k_linear8: the same GEMM family on a 256-token x 256-feature tile with 8 waves (2 per SIMD).
-// Wave (wm, wn) owns 64 tokens x 128 features = 2 x 4 accumulator tiles: per 16-deep k-step it reads 2 X + 4 W
-// fragments for 8 MFMAs (0.75 KB of LDS per MFMA instead of 1.125 KB) and the W tile is staged once per 256
-// tokens instead of once per 128 -- the 128-token kernel is LDS-bound (SQ_LDS_IDX_ACTIVE ~ SQ_BUSY_CYCLES).
-// ================================================================================================
+// MODE 10 + DEPI_x: EtudeDecoder epilogue x on the same tile (batched prefill of the Decode stage).
+// Each of the 4 waves owns 64 tokens x 128 features (2 x 4 accumulator tiles): per 16-deep k-step it reads
+// 2 X + 4 W fragments for 8 MFMAs (0.75 KB of LDS per MFMA; a 32 x 256 per-wave layout needs 1.125 KB and
+// measured 2 % slower).
 template <bool NORMAL_ORIENT>
-__device__ __forceinline__ void lin8_chunk(const bf16* Xs, const bf16* Ws, int wm, int wn, int r, int h, f32x16 (&acc)[2][4]) {
+__device__ __forceinline__ void lin_chunk(const bf16* Xs, const bf16* Ws, int wm, int wn, int r, int h, f32x16 (&acc)[2][4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     bf16x8 xf[2], wf[4];
@@ -209,25 +70,23 @@ __device__ __forceinline__ void lin8_chunk(const bf16* Xs, const bf16* Ws, int w
 }
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void k_linear8(LinArgs a) {
+__global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   constexpr bool LN = MODE == 2;
   constexpr bool vt = MODE == 1;
   constexpr bool DEC = MODE >= 10;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[(256 + 256) * LDK * 2 + 3 * 256 * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 256) * LDK * 2 + 3 * 256 * 4];
   bf16* Xs = reinterpret_cast<bf16*>(smem);
-  bf16* Ws = Xs + 256 * LDK;
-  float* sb = reinterpret_cast<float*>(smem + (256 + 256) * LDK * 2);   // bias | gamma | beta
-  float* lnred = reinterpret_cast<float*>(smem);                         // [2][256] after the K loop (LN mode)
+  bf16* Ws = Xs + 128 * LDK;
+  float* sb = reinterpret_cast<float*>(smem + (128 + 256) * LDK * 2);   // bias | gamma | beta
+  float* lnred = reinterpret_cast<float*>(smem);                         // [2][128] after the K loop (LN mode)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * 256, nb = blockIdx.y + a.nb0, n0 = nb * 256, z = blockIdx.z;
+  const int m0 = blockIdx.x * 128, nb = blockIdx.y + a.nb0, n0 = nb * 256, z = blockIdx.z;
   const bf16* W = a.W + (long long)z * a.wz + (long long)n0 * a.K;
   const float* bias = a.bias + (long long)z * a.bz + n0;
-  if (tid < 256) {
-    sb[tid] = bias[tid];
-    if (LN) { sb[256 + tid] = a.gamma[tid]; sb[512 + tid] = a.beta[tid]; }
-  }
+  sb[tid] = bias[tid];
+  if (LN) { sb[256 + tid] = a.gamma[tid]; sb[512 + tid] = a.beta[tid]; }
 
   f32x16 acc[2][4];
 #pragma unroll
@@ -237,29 +96,14 @@ __global__ __launch_bounds__(512, 2) void k_linear8(LinArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-  // staging: 2048 16-B chunks each for X (256 rows) and W (256 rows) per 64-deep chunk -> 4 + 4 per thread
-  u32x4 xr[4], wr[4];
+  u32x4 xr[4], wr[8];
   const int nk = a.K >> 6;
-  auto gload = [&](int kc) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 512, row = c >> 3, ch = c & 7;
-      int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
-      xr[i] = *reinterpret_cast<const u32x4*>(a.X + (long long)gm * a.ldx + kc * 64 + ch * 8);
-      wr[i] = *reinterpret_cast<const u32x4*>(W + (long long)row * a.K + kc * 64 + ch * 8);
-    }
-  };
-  gload(0);
+  lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, 0, xr, wr);
   for (int kc = 0; kc < nk; ++kc) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + i * 512, row = c >> 3, ch = c & 7;
-      *reinterpret_cast<u32x4*>(Xs + row * LDK + ch * 8) = xr[i];
-      *reinterpret_cast<u32x4*>(Ws + row * LDK + ch * 8) = wr[i];
-    }
+    lin_lstore(Xs, Ws, tid, xr, wr);
     __syncthreads();
-    if (kc + 1 < nk) gload(kc + 1);
-    lin8_chunk<vt>(Xs, Ws, wm, wn, r, h, acc);
+    if (kc + 1 < nk) lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, kc + 1, xr, wr);
+    lin_chunk<vt>(Xs, Ws, wm, wn, r, h, acc);
     __syncthreads();
   }
 
@@ -336,14 +180,14 @@ __global__ __launch_bounds__(512, 2) void k_linear8(LinArgs a) {
         }
       s += xhalf(s);
       s1[mt] = s;
-      if (h == 0) lnred[wn * 256 + wm * 64 + mt * 32 + r] = s;
+      if (h == 0) lnred[wn * 128 + wm * 64 + mt * 32 + r] = s;
     }
     __syncthreads();
     float mean[2], s2[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int tl = wm * 64 + mt * 32 + r;
-      mean[mt] = (lnred[tl] + lnred[256 + tl]) * (1.f / 256.f);
+      mean[mt] = (lnred[tl] + lnred[128 + tl]) * (1.f / 256.f);
     }
     __syncthreads();
 #pragma unroll
@@ -355,13 +199,13 @@ __global__ __launch_bounds__(512, 2) void k_linear8(LinArgs a) {
         for (int i = 0; i < 16; ++i) { const float dlt = acc[mt][nt][i] - mean[mt]; s += dlt * dlt; }
       s += xhalf(s);
       s2[mt] = s;
-      if (h == 0) lnred[wn * 256 + wm * 64 + mt * 32 + r] = s;
+      if (h == 0) lnred[wn * 128 + wm * 64 + mt * 32 + r] = s;
     }
     __syncthreads();
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int tl = wm * 64 + mt * 32 + r;
-      const float rstd = rsqrtf((lnred[tl] + lnred[256 + tl]) * (1.f / 256.f) + 1e-5f);
+      const float rstd = rsqrtf((lnred[tl] + lnred[128 + tl]) * (1.f / 256.f) + 1e-5f);
       const int m = m0 + tl;
       if (m < a.M) {
         bf16* y1 = a.Y + (long long)m * a.ldy;
@@ -381,8 +225,6 @@ __global__ __launch_bounds__(512, 2) void k_linear8(LinArgs a) {
   }
 }
 
-static bool use_lin8() { static int v = -1; if (v < 0) { const char* e = getenv("ETD_LIN8"); v = (e && e[0] == '0') ? 0 : 1; } return v == 1; }
-
 int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   if (a.K % 64 || a.N % 256 || a.M <= 0) ETD_FAIL(ETD_EINVAL, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.vt_block >= 0 && (a.S % 4 || a.Spad % 4 || !a.VT)) ETD_FAIL(ETD_EINVAL, "linear: bad V^T args");
@@ -392,16 +234,13 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   const int nblk = a.N / 256;
   const int n_plain = a.vt_block >= 0 ? a.vt_block : nblk;
   if (a.vt_block >= 0 && a.vt_block != nblk - 1) ETD_FAIL(ETD_EINVAL, "linear: V^T block must be the last block");
-  const bool l8 = use_lin8();
   if (n_plain > 0) {
     LinArgs b = a; b.nb0 = 0;
-    if (l8) hipLaunchKernelGGL(k_linear8<0>, dim3((a.M + 255) / 256, n_plain, nz), dim3(512), 0, st, b);
-    else hipLaunchKernelGGL(k_linear<0>, dim3((a.M + 127) / 128, n_plain, nz), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_linear<0>, dim3((a.M + 127) / 128, n_plain, nz), dim3(256), 0, st, b);
   }
   if (a.vt_block >= 0) {
     LinArgs b = a; b.nb0 = a.vt_block;
-    if (l8) hipLaunchKernelGGL(k_linear8<1>, dim3((a.M + 255) / 256, 1, nz), dim3(512), 0, st, b);
-    else hipLaunchKernelGGL(k_linear<1>, dim3((a.M + 127) / 128, 1, nz), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_linear<1>, dim3((a.M + 127) / 128, 1, nz), dim3(256), 0, st, b);
   }
   HIP_TRY(hipGetLastError());
   return ETD_OK;
@@ -409,25 +248,14 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
 int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
   if (a.K % 64 || a.N % 256 || a.M <= 0 || !a.bias) ETD_FAIL(ETD_EINVAL, "linear_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   ProfScope ps("k_linear_dec", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K) * 2);
+  dim3 g((a.M + 127) / 128, a.N / 256, 1);
   LinArgs b = a; b.nb0 = 0;
-  if (use_lin8()) {
-    dim3 g((a.M + 255) / 256, a.N / 256, 1);
-    switch (dec_epi) {
-      case DEPI_BIAS: hipLaunchKernelGGL(k_linear8<10 + DEPI_BIAS>, g, dim3(512), 0, st, b); break;
-      case DEPI_GELU: hipLaunchKernelGGL(k_linear8<10 + DEPI_GELU>, g, dim3(512), 0, st, b); break;
-      case DEPI_RESID: hipLaunchKernelGGL(k_linear8<10 + DEPI_RESID>, g, dim3(512), 0, st, b); break;
-      case DEPI_QKV: hipLaunchKernelGGL(k_linear8<10 + DEPI_QKV>, g, dim3(512), 0, st, b); break;
-      default: ETD_FAIL(ETD_EINVAL, "linear_dec: unsupported epilogue %d", dec_epi);
-    }
-  } else {
-    dim3 g((a.M + 127) / 128, a.N / 256, 1);
-    switch (dec_epi) {
-      case DEPI_BIAS: hipLaunchKernelGGL(k_linear<10 + DEPI_BIAS>, g, dim3(256), 0, st, b); break;
-      case DEPI_GELU: hipLaunchKernelGGL(k_linear<10 + DEPI_GELU>, g, dim3(256), 0, st, b); break;
-      case DEPI_RESID: hipLaunchKernelGGL(k_linear<10 + DEPI_RESID>, g, dim3(256), 0, st, b); break;
-      case DEPI_QKV: hipLaunchKernelGGL(k_linear<10 + DEPI_QKV>, g, dim3(256), 0, st, b); break;
-      default: ETD_FAIL(ETD_EINVAL, "linear_dec: unsupported epilogue %d", dec_epi);
-    }
+  switch (dec_epi) {
+    case DEPI_BIAS: hipLaunchKernelGGL(k_linear<10 + DEPI_BIAS>, g, dim3(256), 0, st, b); break;
+    case DEPI_GELU: hipLaunchKernelGGL(k_linear<10 + DEPI_GELU>, g, dim3(256), 0, st, b); break;
+    case DEPI_RESID: hipLaunchKernelGGL(k_linear<10 + DEPI_RESID>, g, dim3(256), 0, st, b); break;
+    case DEPI_QKV: hipLaunchKernelGGL(k_linear<10 + DEPI_QKV>, g, dim3(256), 0, st, b); break;
+    default: ETD_FAIL(ETD_EINVAL, "linear_dec: unsupported epilogue %d", dec_epi);
   }
   HIP_TRY(hipGetLastError());
   return ETD_OK;
@@ -436,9 +264,9 @@ int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
 int launch_linear_ln(const LinArgs& a, hipStream_t st) {
   if (a.K % 64 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta) ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
   ProfScope ps("k_linear_ln", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * a.N) * 2);
+  dim3 g((a.M + 127) / 128, 1, 1);
   LinArgs b = a; b.nb0 = 0;
-  if (use_lin8()) hipLaunchKernelGGL(k_linear8<2>, dim3((a.M + 255) / 256, 1, 1), dim3(512), 0, st, b);
-  else hipLaunchKernelGGL(k_linear<2>, dim3((a.M + 127) / 128, 1, 1), dim3(256), 0, st, b);
+  hipLaunchKernelGGL(k_linear<2>, g, dim3(256), 0, st, b);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }

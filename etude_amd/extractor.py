@@ -97,7 +97,7 @@ class AMTAPC_Extractor:
     """Audio -> notes (JSON/MIDI) on one MI355X.  Signature of etude/data/extractor.py:121-146."""
 
     def __init__(self, config: Optional[ExtractorConfig], model_path: Union[str, Path, Dict[str, np.ndarray]],
-                 device: Union[str, torch.device] = "auto", max_windows: int = 1, chunk_frames: int = 0):
+                 device: Union[str, torch.device] = "auto", max_windows: int = 4, chunk_frames: int = 0):
         if device == "auto":
             device = "cuda"
         self.device = torch.device(device)

@@ -14,8 +14,9 @@ from etude_amd.extractor import AMTAPC_Extractor  # noqa: E402
 if __name__ == "__main__":
     nwin = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    wb = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     dev = torch.device("cuda:0")
-    ex = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(7), "cuda", max_windows=1)
+    ex = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(7), "cuda", max_windows=wb)
     xs = torch.from_numpy(synth.window_features(5, nwin)).to(dev)
     ex.transcript_windows(xs)
     torch.cuda.synchronize()
