@@ -115,8 +115,12 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("ETD_FORCE_DIST") == "1"      # ETD_FORCE_DIST: exercise the RCCL path on one GPU
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29513")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     from etude_amd import _lib, parallel, synth
@@ -152,11 +156,8 @@ def main():
         t0 = time.perf_counter()
         n_notes = 0
         for wav in wavs:
-            feat = ex._front(44100)(wav)
-            on, off, mpe, vel = ex.transcript(feat)
-            notes = ex._mpe2note(on.cpu().numpy(), off.cpu().numpy(), mpe.cpu().numpy(), vel.cpu().numpy(),
-                                 inf.onset_threshold, inf.offset_threshold, inf.frame_threshold)
-            n_notes += sum(1 for n in notes if not (n["offset"] - n["onset"] < inf.min_duration))
+            notes = ex.extract_notes(wav, 44100, inf.min_duration)      # device wav -> the note list extract() writes
+            n_notes += len(notes)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         st = {}
@@ -169,7 +170,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -180,6 +181,11 @@ def main():
     for _ in range(args.steps):
         a, b, c, d, out = step()
         t_ext += a; t_dec += b; n_tok += c; n_notes = d
+    gathered_jobs = len(out)
+    if use_dist:
+        # the path's only exchange: ONE final gather of the small variable-length results (token ids of every job)
+        g = parallel.gather_int_arrays([np.asarray([t for bar in job for t in bar], np.int32) for job in out], device=dev, force=True)
+        gathered_jobs = sum(len(x) for x in g)
     barrier()
     elapsed = time.perf_counter() - t0
     # per-kernel HIP-event timing: one extra identical step with an event pair around every launch.  It sits
@@ -194,11 +200,9 @@ def main():
 
     tmax = torch.tensor([elapsed, t_ext, t_dec], dtype=torch.float64, device=dev)
     tsum = torch.tensor([float(n_tok)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        # the path's only exchange: ONE final gather of the small variable-length results
-        parallel.gather_int_arrays([np.asarray([t for bar in out[0] for t in bar], np.int32)], device=dev)
     elapsed, t_ext, t_dec = [float(x) for x in tmax.tolist()]
     n_tok_all = float(tsum.item())
 
@@ -216,7 +220,7 @@ def main():
                    "bars": args.bars, "bar_tokens": args.bar_tokens, "parallelism": f"clip-sharded x{world}"},
         "extract_audio_s_per_s": round(audio_s / t_ext, 2),
         "decoder_tokens_per_s": round(n_tok_all / t_dec, 2),
-        "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": n_notes,
+        "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": n_notes, "jobs_gathered": gathered_jobs,
     }
 
     # ---- roofline of the dominant kernel (HIP events inside the library, on the stream the kernel runs on)
@@ -277,7 +281,7 @@ def main():
             result["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -28,6 +28,9 @@ from .config import ExtractorConfig
 from .frontend import FrontEnd
 
 
+NOTE_DTYPE = np.dtype([("onset", "<f8"), ("offset", "<f8"), ("pitch", "<i4"), ("velocity", "<i4")])   # == etd_note
+
+
 def read_wav(path: Union[str, Path]):
     """PCM/float WAV -> (float32 [C, L] in [-1, 1), sample_rate); stands in for ``torchaudio.load``
     (extractor.py:180) for the RIFF/WAVE files infer.py feeds it (origin.wav, infer.py:61-80)."""
@@ -132,8 +135,8 @@ class AMTAPC_Extractor:
     def extract(self, audio_path: str, output_json_path: str, output_midi_path: Optional[str] = None):
         """extractor.py:148-176."""
         wave, sr = read_wav(audio_path)
-        notes = self.extract_notes(wave, sr)
         min_duration = self.config.infer.min_duration
+        notes = self.extract_notes(wave, sr, min_duration)       # filtered exactly as _note2json / _note2midi would
         self._note2json(notes, output_json_path, min_duration)
         if output_midi_path:
             self._note2midi(notes, output_midi_path, min_duration)
@@ -152,31 +155,39 @@ class AMTAPC_Extractor:
         res = tuple(o.cpu().numpy() for o in out)
         return res if mode == "combination" else res[:4]
 
-    def _mpe2note(self, a_onset=None, a_offset=None, a_mpe=None, a_velocity=None, thred_onset=0.5, thred_offset=0.5,
-                  thred_mpe=0.5, mode_velocity="ignore_zero", mode_offset="shorter") -> List[dict]:
-        """extractor.py:256-418 (host C++ through the C ABI)."""
-        if mode_velocity != "ignore_zero" or mode_offset != "shorter":
-            raise _lib.EtudeHipError("only the modes the reference uses are implemented (ignore_zero / shorter)")
+    def _mpe2note_array(self, a_onset, a_offset, a_mpe, a_velocity, thred_onset=0.5, thred_offset=0.5, thred_mpe=0.5) -> np.ndarray:
+        """extractor.py:256-418 through the C ABI; returns a structured array (onset f8, offset f8, pitch i4, velocity i4)."""
         on = np.ascontiguousarray(a_onset, np.float32)
         off = np.ascontiguousarray(a_offset, np.float32)
         mp = np.ascontiguousarray(a_mpe, np.float32)
         ve = np.ascontiguousarray(a_velocity, np.int8)
         T, nn = on.shape
         lib = _lib.lib()
-        cap = max(1024, T * 4)
+        cap = max(4096, T * 8)
         f = self.config.feature
         while True:
-            buf = (_lib.Note * cap)()
+            buf = np.empty(cap, dtype=NOTE_DTYPE)
             n = C.c_longlong()
             rc = lib.etd_mpe2note(on.ctypes.data, off.ctypes.data, mp.ctypes.data, ve.ctypes.data, T, nn, thred_onset,
-                                  thred_offset, thred_mpe, f.hop_sample, f.sr, self.config.midi.note_min, buf, cap, C.byref(n))
+                                  thred_offset, thred_mpe, f.hop_sample, f.sr, self.config.midi.note_min,
+                                  C.cast(buf.ctypes.data, C.POINTER(_lib.Note)), cap, C.byref(n))
             if rc == -12 and n.value > cap:
                 cap = int(n.value)
                 continue
             _lib.check(rc, "etd_mpe2note")
-            break
-        return [{"pitch": int(b.pitch), "onset": float(b.onset), "offset": float(b.offset), "velocity": int(b.velocity)}
-                for b in buf[: n.value]]
+            return buf[: n.value]
+
+    @staticmethod
+    def _notes_from_array(arr: np.ndarray) -> List[dict]:
+        return [{"pitch": p, "onset": a, "offset": b, "velocity": v}
+                for p, a, b, v in zip(arr["pitch"].tolist(), arr["onset"].tolist(), arr["offset"].tolist(), arr["velocity"].tolist())]
+
+    def _mpe2note(self, a_onset=None, a_offset=None, a_mpe=None, a_velocity=None, thred_onset=0.5, thred_offset=0.5,
+                  thred_mpe=0.5, mode_velocity="ignore_zero", mode_offset="shorter") -> List[dict]:
+        """extractor.py:256-418 (host C++ through the C ABI)."""
+        if mode_velocity != "ignore_zero" or mode_offset != "shorter":
+            raise _lib.EtudeHipError("only the modes the reference uses are implemented (ignore_zero / shorter)")
+        return self._notes_from_array(self._mpe2note_array(a_onset, a_offset, a_mpe, a_velocity, thred_onset, thred_offset, thred_mpe))
 
     def _note2json(self, notes, path_output, min_length=0.0):
         """extractor.py:432-446."""
@@ -256,13 +267,17 @@ class AMTAPC_Extractor:
     def debug_tap(self, stage: int, buf: Optional[torch.Tensor]):
         _lib.check(_lib.lib().etd_extractor_debug_tap(self._h, stage, buf.data_ptr() if buf is not None else None), "debug_tap")
 
-    def extract_notes(self, wave: Union[np.ndarray, torch.Tensor], sr: int) -> List[dict]:
-        """wav -> note dicts (everything extract() does except the file I/O)."""
+    def extract_notes(self, wave: Union[np.ndarray, torch.Tensor], sr: int, min_duration: Optional[float] = None) -> List[dict]:
+        """wav -> note dicts (everything extract() does except the file I/O).  With ``min_duration`` the
+        ``_note2json`` filter (extractor.py:435-437) is applied before the Python objects are built."""
         feat = self.wav2feature_tensor(wave, sr)
         on, off, mpe, vel = self.transcript(feat)
         inf = self.config.infer
-        return self._mpe2note(on.cpu().numpy(), off.cpu().numpy(), mpe.cpu().numpy(), vel.cpu().numpy(),
-                              thred_onset=inf.onset_threshold, thred_offset=inf.offset_threshold, thred_mpe=inf.frame_threshold)
+        arr = self._mpe2note_array(on.cpu().numpy(), off.cpu().numpy(), mpe.cpu().numpy(), vel.cpu().numpy(),
+                                   inf.onset_threshold, inf.offset_threshold, inf.frame_threshold)
+        if min_duration is not None:
+            arr = arr[~((arr["offset"] - arr["onset"]) < min_duration)]
+        return self._notes_from_array(arr)
 
     def extract_many(self, audio_paths: Sequence[str], output_json_paths: Sequence[str]) -> None:
         for a, o in zip(audio_paths, output_json_paths):

@@ -47,11 +47,11 @@ def _unpack(buf: np.ndarray) -> List[np.ndarray]:
     return out
 
 
-def gather_int_arrays(local: Sequence[np.ndarray], device: Optional[torch.device] = None, group=None) -> List[List[np.ndarray]]:
+def gather_int_arrays(local: Sequence[np.ndarray], device: Optional[torch.device] = None, group=None, force: bool = False) -> List[List[np.ndarray]]:
     """All-gather a list of variable-length int32 arrays from every rank -> per-rank lists (same on all ranks).
 
     One all_reduce(MAX) of the packed length + one all_gather of the padded buffers."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return [[np.asarray(a, np.int32).reshape(-1) for a in local]]
     world = dist.get_world_size(group)
     if device is None:

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Where does the wall time of one extract() go? (GPU box)"""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from etude_amd import synth  # noqa: E402
+from etude_amd.config import ExtractorConfig  # noqa: E402
+from etude_amd.extractor import AMTAPC_Extractor  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = ExtractorConfig()
+ex = AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), "cuda")
+wav = torch.from_numpy(synth.clip_audio(seed=1234, seconds=180.0)).to(dev)
+inf = cfg.infer
+for it in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    feat = ex._front(44100)(wav); torch.cuda.synchronize(); t1 = time.perf_counter()
+    on, off, mpe, vel = ex.transcript(feat); torch.cuda.synchronize(); t2 = time.perf_counter()
+    a = [t.cpu().numpy() for t in (on, off, mpe, vel)]; t3 = time.perf_counter()
+    notes = ex._mpe2note(*a, inf.onset_threshold, inf.offset_threshold, inf.frame_threshold); t4 = time.perf_counter()
+    print(f"front {1e3*(t1-t0):.1f} ms | model {1e3*(t2-t1):.1f} ms | D2H {1e3*(t3-t2):.1f} ms | mpe2note {1e3*(t4-t3):.1f} ms ({len(notes)} notes)")
