@@ -4,11 +4,11 @@
 #include "common.h"
 
 bool prof_enabled();
-void prof_begin(const char* name, hipStream_t st);
-void prof_end(const char* name, hipStream_t st, double flops, double bytes);
+hipEvent_t prof_begin(hipStream_t st);                       // null when the profiler is off
+void prof_end(const char* name, hipEvent_t start, hipStream_t st, double flops, double bytes);
 
-struct ProfScope {
-  const char* name; hipStream_t st; double flops, bytes;
-  ProfScope(const char* n, hipStream_t s, double f = 0, double b = 0) : name(n), st(s), flops(f), bytes(b) { prof_begin(name, st); }
-  ~ProfScope() { prof_end(name, st, flops, bytes); }
+struct ProfScope {   // the start event lives in the scope object, so concurrent launches from several host threads do not mix
+  const char* name; hipStream_t st; double flops, bytes; hipEvent_t start;
+  ProfScope(const char* n, hipStream_t s, double f = 0, double b = 0) : name(n), st(s), flops(f), bytes(b), start(prof_begin(s)) {}
+  ~ProfScope() { if (start) prof_end(name, start, st, flops, bytes); }
 };

@@ -8,7 +8,7 @@
 #include "../../include/etude_hip.h"
 
 namespace {
-struct Entry { double ms = 0; long long n = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; hipEvent_t open = nullptr; };
+struct Entry { double ms = 0; long long n = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
 std::mutex g_mu;
 bool g_on = false;
 std::map<std::string, Entry> g_ent;
@@ -23,23 +23,23 @@ hipEvent_t get_event() {
 }  // namespace
 
 bool prof_enabled() { return g_on; }
-void prof_begin(const char* name, hipStream_t st) {
-  if (!g_on) return;
-  std::lock_guard<std::mutex> lk(g_mu);
-  Entry& en = g_ent[name];
-  en.open = get_event();
-  if (en.open) (void)hipEventRecord(en.open, st);
+hipEvent_t prof_begin(hipStream_t st) {
+  if (!g_on) return nullptr;
+  hipEvent_t e;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    e = get_event();
+  }
+  if (e) (void)hipEventRecord(e, st);
+  return e;
 }
-void prof_end(const char* name, hipStream_t st, double flops, double bytes) {
-  if (!g_on) return;
+void prof_end(const char* name, hipEvent_t start, hipStream_t st, double flops, double bytes) {
   std::lock_guard<std::mutex> lk(g_mu);
-  Entry& en = g_ent[name];
-  if (!en.open) return;
   hipEvent_t stop = get_event();
-  if (!stop) { g_pool.push_back(en.open); en.open = nullptr; return; }
+  if (!stop) { g_pool.push_back(start); return; }
   (void)hipEventRecord(stop, st);
-  en.pending.push_back({en.open, stop});
-  en.open = nullptr;
+  Entry& en = g_ent[name];
+  en.pending.push_back({start, stop});
   en.n += 1; en.flops += flops; en.bytes += bytes;
 }
 
