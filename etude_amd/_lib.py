@@ -37,6 +37,16 @@ class DecCfg(C.Structure):
                 ("max_streams", C.c_int), ("max_ctx", C.c_int), ("precision", C.c_int), ("max_prefill_rows", C.c_int)]
 
 
+class Job(C.Structure):
+    _fields_ = [("x_ids", C.c_void_p), ("x_offsets", C.c_void_p), ("n_bars", C.c_int), ("attrs4", C.c_void_p)]
+
+
+class SchedCfg(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("bar_bos_id", "bar_eos_id", "n_ctx_pairs", "max_position_embeddings", "max_output_tokens",
+                                       "max_bar_token_limit")] + [("context_overlap_ratio", C.c_float)] + \
+               [(n, C.c_int) for n in ("force_bar_tokens", "max_streams", "max_prefill_rows", "steps_per_poll")]
+
+
 class Note(C.Structure):
     _fields_ = [("onset", C.c_double), ("offset", C.c_double), ("pitch", C.c_int32), ("velocity", C.c_int32)]
 
@@ -79,6 +89,10 @@ SIGNATURES = {
     "etd_decoder_poll": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "etd_decoder_read_tokens": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, c_int_p, C.c_void_p]),
     "etd_decoder_read_many": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "etd_decoder_run_jobs": (C.c_int, [C.c_void_p, C.POINTER(SchedCfg), C.POINTER(Job), C.c_int, C.c_void_p, C.c_longlong, C.c_void_p,
+                                       C.POINTER(C.c_longlong), C.c_void_p]),
+    "etd_debug_assemble_prompt": (C.c_int, [C.POINTER(SchedCfg), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, c_int_p]),
     "etd_decoder_generate_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                            C.c_int, C.c_int, C.c_void_p, c_int_p, C.c_void_p]),
     "etd_decoder_prefill_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,

@@ -3,8 +3,8 @@
 ``load_etude_decoder(config_path, checkpoint_path, device)`` (etude/utils/model_loader.py:12-60) returns an
 ``EtudeDecoder`` whose ``generate(vocab, all_x_bars, target_attributes_per_bar, ...)`` has the
 signature, defaults, error behaviour and return value of etude/models/etude_decoder.py:209-354.
-Prompt assembly / history / truncation / token budget stay on the host in Python (they are list
-manipulation); every forward pass, the KV cache, the greedy argmax and the token feedback run on the
+Prompt assembly / history / truncation / token budget run in the library's native scheduler
+(csrc/sched_dec.cpp); every forward pass, the KV cache, the greedy argmax and the token feedback run on the
 GPU through libetude_hip.so (etd_decoder_*).
 
 ``generate_many`` runs many independent (song, attribute tuple) jobs as concurrent device streams
@@ -56,80 +56,6 @@ class EtudeDecoderConfig:
     def from_json_file(cls, path: Union[str, Path]) -> "EtudeDecoderConfig":
         with open(path, "r", encoding="utf-8") as f:
             return cls(**json.load(f))
-
-
-def assemble_bar_prompt(history, x_bar, y_attrs, user_keys, bar_bos_id, bar_eos_id, n_ctx_pairs, max_pos,
-                        max_bar_token_limit, context_overlap_ratio):
-    """Prompt of one bar as etude_decoder.py:257-296 builds it: [empty-pair padding][<=n past (X,Y) pairs][X_i][Bar_BOS]."""
-    toks: List[int] = []
-    cls: List[int] = []
-    at = {k: [] for k in user_keys}
-    hist = history[-n_ctx_pairs:] if n_ctx_pairs > 0 else []
-    for _ in range(n_ctx_pairs - len(hist)):
-        for c in (SRC_CLASS_ID, TGT_CLASS_ID):
-            toks.extend((bar_bos_id, bar_eos_id))
-            cls.extend((c, c))
-            for k in user_keys:
-                at[k].extend((1, 1))                      # neutral bin 1 for every key (etude_decoder.py:250)
-    for xs, ys, a in hist:
-        for item, c in ((xs, SRC_CLASS_ID), (ys, TGT_CLASS_ID)):
-            toks.extend(item)
-            cls.extend([c] * len(item))
-            for k in user_keys:
-                at[k].extend([a[k]] * len(item))
-    toks.extend(x_bar)
-    cls.extend([SRC_CLASS_ID] * len(x_bar))
-    for k in user_keys:
-        at[k].extend([y_attrs[k]] * len(x_bar))
-    if len(toks) > max_pos - max_bar_token_limit:
-        keep = int(max_pos * context_overlap_ratio)
-        toks, cls = toks[-keep:], cls[-keep:]
-        for k in user_keys:
-            at[k] = at[k][-keep:]
-    toks.append(bar_bos_id)
-    cls.append(TGT_CLASS_ID)
-    for k in user_keys:
-        at[k].append(y_attrs[k])
-    return toks, cls, at
-
-
-def assemble_bar_prompt_np(history, x_bar, y4, bar_bos_id, bar_eos_id, n_ctx_pairs, max_pos, max_bar_token_limit, context_overlap_ratio):
-    """numpy twin of ``assemble_bar_prompt`` for the batched engine: history = [(x ndarray, y ndarray, attrs4 ndarray)],
-    y4 = target attrs in C-ABI order.  Returns (tokens[T], classes[T], attrs[4][T]) as int32 arrays, Bar_BOS appended."""
-    hist = history[-n_ctx_pairs:] if n_ctx_pairs > 0 else []
-    segs, seg_cls, seg_at = [], [], []
-    empty = np.asarray([bar_bos_id, bar_eos_id], np.int32)
-    neutral = np.ones(4, np.int32)
-    for _ in range(n_ctx_pairs - len(hist)):
-        for c in (SRC_CLASS_ID, TGT_CLASS_ID):
-            segs.append(empty); seg_cls.append(c); seg_at.append(neutral)
-    for xs, ys, a4 in hist:
-        segs.append(xs); seg_cls.append(SRC_CLASS_ID); seg_at.append(a4)
-        segs.append(ys); seg_cls.append(TGT_CLASS_ID); seg_at.append(a4)
-    segs.append(x_bar); seg_cls.append(SRC_CLASS_ID); seg_at.append(y4)
-    lens = np.asarray([len(x) for x in segs], np.int64)
-    toks = np.concatenate(segs).astype(np.int32, copy=False)
-    cls = np.repeat(np.asarray(seg_cls, np.int32), lens)
-    at = np.repeat(np.stack(seg_at).astype(np.int32), lens, axis=0).T          # [4][T]
-    if toks.size > max_pos - max_bar_token_limit:
-        keep = int(max_pos * context_overlap_ratio)
-        toks, cls, at = toks[-keep:], cls[-keep:], at[:, -keep:]
-    toks = np.concatenate([toks, np.asarray([bar_bos_id], np.int32)])
-    cls = np.concatenate([cls, np.asarray([TGT_CLASS_ID], np.int32)])
-    at = np.concatenate([at, np.asarray(y4, np.int32)[:, None]], axis=1)
-    return toks, cls, np.ascontiguousarray(at)
-
-
-class _Job:
-    __slots__ = ("x_bars", "attrs", "x_np", "a4", "keys", "max_out", "bar_limit", "overlap", "i", "history", "total", "bars_out", "slot", "limit")
-
-    def __init__(self, x_bars, attrs, max_out, bar_limit, overlap):
-        self.x_bars, self.attrs = x_bars, attrs
-        self.x_np = [np.asarray(b, np.int32) for b in x_bars]
-        self.a4 = [np.asarray([a[k] for k in ABI_ATTR_KEYS], np.int32) for a in attrs]
-        self.keys = sorted(attrs[0].keys())
-        self.max_out, self.bar_limit, self.overlap = max_out, bar_limit, overlap
-        self.i, self.history, self.total, self.bars_out, self.slot, self.limit = 0, [], 0, [], -1, 0
 
 
 class EtudeDecoder:
@@ -225,12 +151,14 @@ class EtudeDecoder:
                       _validate: bool = True, stats: Optional[dict] = None, force_bar_tokens: int = 0) -> List[List[List[int]]]:
         """Greedy-decode many independent jobs on up to ``max_streams`` concurrent device streams.
 
+        The bar loop (prompt assembly, history, truncation, token budget, EOS stop) runs in the library's native
+        scheduler (csrc/sched_dec.cpp, ``etd_decoder_run_jobs``); this method only marshals the jobs.
         ``force_bar_tokens=n`` (benchmarks only) suppresses Bar_EOS and makes every bar exactly n tokens long, so that
         throughput does not depend on where synthetic weights happen to emit EOS."""
         lib = _lib.lib()
         cfg = self.config
         results: List[Optional[List[List[int]]]] = [None] * len(jobs)
-        todo: List[Tuple[int, _Job]] = []
+        live: List[int] = []
         bos = eos = -1
         for ji, (x_bars, attrs) in enumerate(jobs):
             v = self._validate(vocab, x_bars, attrs)
@@ -238,114 +166,49 @@ class EtudeDecoder:
                 results[ji] = []
                 continue
             bos, eos = v
-            todo.append((ji, _Job(x_bars, attrs, max_output_tokens, max_bar_token_limit, context_overlap_ratio)))
-        free = list(range(self.max_streams))[::-1]
-        active: Dict[int, Tuple[int, _Job]] = {}      # slot -> (job index, job)
-        n_steps_total = n_tokens = 0
-        st = self._stream()
-
-        def start_bars(batch: List[_Job]) -> List[_Job]:
-            """Prefill the next bar of every job in `batch` in as few device passes as possible (all prompts of a call
-            go through the model as one batch).  Returns the jobs that are finished instead."""
-            finished, pend = [], []
-            for job in batch:
-                if job.i >= len(job.x_bars):
-                    finished.append(job)
-                    continue
-                y_attrs = job.attrs[job.i]
-                job.limit = min(force_bar_tokens or job.bar_limit, job.max_out - job.total)
-                if job.limit <= 0:
-                    # the reference's inner loop breaks before the first forward: the bar is just [Bar_BOS]
-                    job.bars_out.append([bos])
-                    finished.append(job)
-                    continue
-                toks, cls, at = assemble_bar_prompt_np(job.history, job.x_np[job.i], job.a4[job.i], bos, eos,
-                                                       cfg.context_num_past_xy_pairs, cfg.max_position_embeddings,
-                                                       job.bar_limit, job.overlap)
-                pend.append((job, toks, cls, at, job.a4[job.i]))
-            while pend:
-                take, rows = [], 0
-                while pend and (not take or rows + len(pend[0][1]) <= self.max_prefill_rows):
-                    rows += len(pend[0][1])
-                    take.append(pend.pop(0))
-                n = len(take)
-                slots = np.asarray([t[0].slot for t in take], np.int32)
-                T = np.asarray([len(t[1]) for t in take], np.int32)
-                ids = np.ascontiguousarray(np.concatenate([t[1] for t in take]), np.int32)
-                cl = np.ascontiguousarray(np.concatenate([t[2] for t in take]), np.int32)
-                a4 = np.ascontiguousarray(np.concatenate([t[3] for t in take], axis=1), np.int32)
-                tg = np.ascontiguousarray(np.stack([t[4] for t in take]), np.int32)
-                eo = np.full(n, -1 if force_bar_tokens else eos, np.int32)
-                li = np.asarray([t[0].limit for t in take], np.int32)
-                _lib.check(lib.etd_decoder_begin_bars(self._h, n, slots.ctypes.data, T.ctypes.data, ids.ctypes.data, cl.ctypes.data,
-                                                      a4.ctypes.data, tg.ctypes.data, eo.ctypes.data, li.ctypes.data, st), "etd_decoder_begin_bars")
-            return finished
-
-        def read_done(done_jobs: List[_Job]) -> List[List[int]]:
-            n = len(done_jobs)
-            sl = np.asarray([j.slot for j in done_jobs], np.int32)
-            out = np.zeros((n, 1024), np.int32)
-            cnt = np.zeros(n, np.int32)
-            _lib.check(lib.etd_decoder_read_many(self._h, n, sl.ctypes.data, out.ctypes.data, 1024, cnt.ctypes.data, st), "etd_decoder_read_many")
-            return [out[i, : cnt[i]].tolist() for i in range(n)]
-
-        def finish_bar(job: _Job, toks: List[int]):
-            job.total += len(toks)
-            job.history.append((job.x_np[job.i], np.asarray([bos] + toks, np.int32), job.a4[job.i]))
-            if len(job.history) > cfg.context_num_past_xy_pairs:
-                job.history.pop(0)
-            job.bars_out.append([bos] + toks)
-            job.i += 1
-            return len(toks)
-
-        with torch.cuda.device(self.device):
-            pending = todo[::-1]
-            job_index = {id(job): ji for ji, job in todo}
-
-            def retire(job: _Job):
-                results[job_index[id(job)]] = job.bars_out
-                if job.slot in active:
-                    del active[job.slot]
-                free.append(job.slot)
-
-            while pending or active:
-                fresh = []
-                while pending and free:
-                    ji, job = pending.pop()
-                    job.slot = free.pop()
-                    active[job.slot] = (ji, job)
-                    fresh.append(job)
-                if fresh:
-                    for job in start_bars(fresh):
-                        retire(job)
-                if not active:
-                    continue
-                slots = np.asarray(sorted(active.keys()), np.int32)
-                dn = np.zeros(len(slots), np.int32)
-                no = np.zeros(len(slots), np.int32)
-                _lib.check(lib.etd_decoder_poll(self._h, slots.ctypes.data, len(slots), dn.ctypes.data, no.ctypes.data, st), "etd_decoder_poll")
-                again = []
-                done_jobs = [active[s][1] for s, d in zip(slots.tolist(), dn.tolist()) if d]
-                for job, toks in zip(done_jobs, read_done(done_jobs) if done_jobs else []):
-                    n_tokens += finish_bar(job, toks)
-                    if job.total >= job.max_out:                 # etude_decoder.py:352
-                        retire(job)
-                    else:
-                        again.append(job)
-                if again:
-                    for job in start_bars(again):
-                        retire(job)
-                    continue                                      # re-poll / refill before stepping
-                if any(dn):
-                    continue
-                nstep = steps_per_poll
-                if force_bar_tokens:      # no early EOS possible: run every stream to the nearest bar end in one call
-                    nstep = max(1, min(active[s][1].limit - int(c) for s, c in zip(slots.tolist(), no.tolist())))
-                _lib.check(lib.etd_decoder_step(self._h, slots.ctypes.data, len(slots), nstep, st), "etd_decoder_step")
-                n_steps_total += nstep
-        if stats is not None:
-            stats["steps"] = n_steps_total
-            stats["tokens"] = n_tokens
+            live.append(ji)
+        if live:
+            keep = []                                   # numpy buffers referenced by the job descriptors
+            cjobs = (_lib.Job * len(live))()
+            cap = 0
+            for k, ji in enumerate(live):
+                x_bars, attrs = jobs[ji]
+                lens = np.asarray([len(b) for b in x_bars], np.int64)
+                offs = np.zeros(len(x_bars) + 1, np.int32)
+                offs[1:] = np.cumsum(lens)
+                xi = np.ascontiguousarray(np.concatenate([np.asarray(b, np.int32) for b in x_bars]) if len(x_bars) else np.zeros(0, np.int32))
+                a4 = np.ascontiguousarray(np.asarray([[a[key] for key in ABI_ATTR_KEYS] for a in attrs], np.int32).reshape(-1, 4))
+                if xi.size and (xi.min() < 0 or xi.max() >= cfg.vocab_size):
+                    raise IndexError("token id out of range in all_x_bars")
+                keep += [offs, xi, a4]
+                cjobs[k] = _lib.Job(xi.ctypes.data, offs.ctypes.data, len(x_bars), a4.ctypes.data)
+                per_bar = (force_bar_tokens or max_bar_token_limit) + 1
+                cap += 1 + len(x_bars) + min(len(x_bars) * per_bar, max(0, max_output_tokens) + len(x_bars) + per_bar)
+            sc = _lib.SchedCfg(bar_bos_id=bos, bar_eos_id=eos, n_ctx_pairs=cfg.context_num_past_xy_pairs,
+                               max_position_embeddings=cfg.max_position_embeddings, max_output_tokens=max_output_tokens,
+                               max_bar_token_limit=max_bar_token_limit, context_overlap_ratio=context_overlap_ratio,
+                               force_bar_tokens=force_bar_tokens, max_streams=self.max_streams,
+                               max_prefill_rows=self.max_prefill_rows, steps_per_poll=steps_per_poll)
+            out = np.zeros(cap, np.int32)
+            offs_out = np.zeros(len(live) + 1, np.int64)
+            nsteps = C.c_longlong()
+            with torch.cuda.device(self.device):
+                _lib.check(lib.etd_decoder_run_jobs(self._h, C.byref(sc), cjobs, len(live), out.ctypes.data, cap, offs_out.ctypes.data,
+                                                    C.byref(nsteps), self._stream()), "etd_decoder_run_jobs")
+            n_tokens = 0
+            for k, ji in enumerate(live):
+                rec = out[offs_out[k]: offs_out[k + 1]]
+                nb = int(rec[0])
+                lens = rec[1:1 + nb].astype(np.int64)
+                flat = rec[1 + nb:]
+                ends = np.cumsum(lens)
+                results[ji] = [flat[e - l: e].tolist() for l, e in zip(lens.tolist(), ends.tolist())]
+                n_tokens += int(lens.sum()) - nb
+            if stats is not None:
+                stats["steps"] = int(nsteps.value)
+                stats["tokens"] = n_tokens
+        elif stats is not None:
+            stats["steps"] = stats["tokens"] = 0
         return results  # type: ignore[return-value]
 
     # ------------------------------------------------------------------ test / bench hooks

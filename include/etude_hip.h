@@ -151,6 +151,23 @@ int etd_decoder_poll(etd_dec*, const int32_t* slots, int n, int32_t* done_out, i
 int etd_decoder_read_tokens(etd_dec*, int slot, int32_t* out, int cap, int* n, void* stream);
 /* The same for n streams with ONE synchronisation: out is [n][cap], counts [n]. */
 int etd_decoder_read_many(etd_dec*, int n, const int32_t* slots, int32_t* out, int cap, int32_t* counts, void* stream);
+/* The whole bar loop of EtudeDecoder.generate (etude_decoder.py:246-354: prompt assembly, history window, truncation,
+ * token budget, Bar_EOS stop) for MANY independent jobs, scheduled natively as concurrent device streams.  A job is
+ * one (song, attribute tuple): x_ids = its condition bars back to back, x_offsets [n_bars+1], attrs4 [n_bars][4] in
+ * C-ABI attribute order.  Result: out[job_offsets[j] ..] = [n_bars_done, len_0 .., tokens of bar 0 ([Bar_BOS]+generated), ...]. */
+typedef struct { const int32_t* x_ids; const int32_t* x_offsets; int n_bars; const int32_t* attrs4; } etd_job;
+typedef struct {
+  int bar_bos_id, bar_eos_id, n_ctx_pairs, max_position_embeddings, max_output_tokens, max_bar_token_limit;
+  float context_overlap_ratio;
+  int force_bar_tokens;   /* >0 (benchmarks): suppress Bar_EOS, every bar is exactly this many tokens */
+  int max_streams, max_prefill_rows, steps_per_poll;
+} etd_sched_cfg;
+int etd_decoder_run_jobs(etd_dec*, const etd_sched_cfg* cfg, const etd_job* jobs, int n_jobs, int32_t* out, long long out_cap,
+                         long long* job_offsets, long long* n_steps_out, void* stream);
+/* test hook (host only): the prompt etd_decoder_run_jobs builds for a bar given n_hist past (X, Y, attrs4) pairs; attrs4_out is [4][cap] */
+int etd_debug_assemble_prompt(const etd_sched_cfg* cfg, int n_hist, const int32_t* const* hx, const int32_t* hxn, const int32_t* const* hy,
+                              const int32_t* hyn, const int32_t* hattrs4, const int32_t* x, int xn, const int32_t* y_attrs4,
+                              int32_t* ids_out, int32_t* cls_out, int32_t* attrs4_out, int cap, int* T_out);
 /* begin_bar + steps until done + read_tokens for one stream.  Synchronous. */
 int etd_decoder_generate_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
                              const int32_t* tgt_attrs4, int eos_id, int limit, int32_t* out, int* n_out, void* stream);

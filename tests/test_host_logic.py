@@ -6,17 +6,44 @@ import pytest
 import torch
 
 from etude_amd import synth
-from etude_amd.decoder import ABI_ATTR_KEYS, EtudeDecoderConfig, assemble_bar_prompt, assemble_bar_prompt_np, expected_state_keys
+from etude_amd import _lib
+from etude_amd.decoder import ABI_ATTR_KEYS, EtudeDecoderConfig, expected_state_keys
 from etude_amd.extractor import read_wav, write_wav_f32
 from etude_amd.vocab import Event, Vocab
 from oracle import neox
 
 
-def test_prompt_assembly_matches_oracle_incl_truncation():
+def _native_prompt(hist, x, y, n_ctx=4, max_pos=1024, limit=512, ratio=0.5):
+    """The native scheduler's prompt for one bar (etd_debug_assemble_prompt): hist = [(xs, ys, attrs dict)]."""
+    import ctypes as C
+    lib = _lib.lib()
+    sc = _lib.SchedCfg(bar_bos_id=4, bar_eos_id=5, n_ctx_pairs=n_ctx, max_position_embeddings=max_pos, max_output_tokens=25600,
+                       max_bar_token_limit=limit, context_overlap_ratio=ratio, force_bar_tokens=0, max_streams=1, max_prefill_rows=4096,
+                       steps_per_poll=8)
+    n = len(hist)
+    hx = [np.asarray(h[0], np.int32) for h in hist]
+    hy = [np.asarray(h[1], np.int32) for h in hist]
+    hxp = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in hx])
+    hyp = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in hy])
+    hxn = np.asarray([a.size for a in hx] or [0], np.int32)
+    hyn = np.asarray([a.size for a in hy] or [0], np.int32)
+    ha = np.ascontiguousarray(np.asarray([[h[2][k] for k in ABI_ATTR_KEYS] for h in hist] or [[0, 0, 0, 0]], np.int32))
+    xa = np.asarray(x, np.int32)
+    ya = np.asarray([y[k] for k in ABI_ATTR_KEYS], np.int32)
+    cap = 4096
+    ids, cls, at = np.zeros(cap, np.int32), np.zeros(cap, np.int32), np.zeros((4, cap), np.int32)
+    T = C.c_int()
+    _lib.check(lib.etd_debug_assemble_prompt(C.byref(sc), n, hxp, hxn.ctypes.data, hyp, hyn.ctypes.data, ha.ctypes.data, xa.ctypes.data, xa.size,
+                                             ya.ctypes.data, ids.ctypes.data, cls.ctypes.data, at.ctypes.data, cap, C.byref(T)), "assemble")
+    t = T.value
+    return ids[:t].tolist(), cls[:t].tolist(), {k: at[j, :t].tolist() for j, k in enumerate(ABI_ATTR_KEYS)}
+
+
+def test_native_prompt_assembly_matches_oracle_incl_truncation():
     rng = np.random.default_rng(0)
     d = neox.NeoxDims()
     keys = sorted(ABI_ATTR_KEYS)
-    for trial in range(30):
+    for trial in range(40):
         hist = []
         for _ in range(int(rng.integers(0, 7))):
             xs = rng.integers(4, 150, int(rng.integers(2, 200))).tolist()
@@ -24,16 +51,15 @@ def test_prompt_assembly_matches_oracle_incl_truncation():
             hist.append((xs, ys, {k: int(rng.integers(0, 3)) for k in keys}))
         x = rng.integers(4, 150, int(rng.integers(2, 120))).tolist()
         y = {k: int(rng.integers(0, 3)) for k in keys}
-        a = assemble_bar_prompt(hist, x, y, keys, 4, 5, 4, 1024, 512, 0.5)
+        a = _native_prompt(hist, x, y)
         b = neox.build_bar_prompt(hist, x, y, keys, 4, 5, d, 512, 0.5)
-        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2], trial
         assert len(a[0]) <= 513
-        # the numpy twin used by the batched engine builds the same prompt
-        h_np = [(np.asarray(xs, np.int32), np.asarray(ys, np.int32), np.asarray([at[k] for k in ABI_ATTR_KEYS], np.int32)) for xs, ys, at in hist]
-        t, c, a4 = assemble_bar_prompt_np(h_np, np.asarray(x, np.int32), np.asarray([y[k] for k in ABI_ATTR_KEYS], np.int32), 4, 5, 4, 1024, 512, 0.5)
-        assert t.tolist() == a[0] and c.tolist() == a[1]
-        for j, k in enumerate(ABI_ATTR_KEYS):
-            assert a4[j].tolist() == a[2][k]
+    # non-default knobs: 2 context pairs, tighter limits
+    d2 = neox.NeoxDims(max_position_embeddings=256, context_num_past_xy_pairs=2)
+    hist = [(list(range(6, 90)), list(range(10, 140)), {k: 2 for k in keys})] * 3
+    x, y = list(range(20, 60)), {k: 0 for k in keys}
+    assert _native_prompt(hist, x, y, n_ctx=2, max_pos=256, limit=100, ratio=0.25) == tuple(neox.build_bar_prompt(hist, x, y, keys, 4, 5, d2, 100, 0.25))
 
 
 def test_vocab_roundtrip_and_event_decoding(tmp_path):
