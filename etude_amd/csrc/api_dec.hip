@@ -52,8 +52,6 @@ struct etd_dec {
   float* Pk = nullptr;                           // [4][512][H] split-K partials of the decode-step down projection
   std::vector<int> stage;                        // host staging of a prefill batch
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
-  hipStream_t st2 = nullptr;                     // second stream: the MLP branch of a decode step runs beside the attention branch
-  std::vector<hipEvent_t> ev_fork, ev_join;      // one pair per layer
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
   double attn_bytes_hint = 0;
 
@@ -137,22 +135,6 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
     const bool small = bpipe && !big && d->I % (4 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
     if (bpipe && (!small || l == 0)) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
-    // ---- decode step (small): the parallel-residual MLP branch (up + GELU, split-K down) depends only on X2b, so it
-    // is forked onto a second stream and runs beside QKV -> attention -> dense; both join in k_resid_ln_rows.
-    const bool forked = small && d->st2 != nullptr && st != nullptr;
-    if (small) {
-      hipStream_t sm = forked ? d->st2 : st;
-      if (forked) { HIP_TRY(hipEventRecord(d->ev_fork[l], st)); HIP_TRY(hipStreamWaitEvent(d->st2, d->ev_fork[l], 0)); }
-      DGemmArgs up = {};
-      up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
-      up.ldy = d->I; up.Xb = d->X2b; up.Yb = d->M1b; up.X = hin; up.Y = d->M1;
-      ETD_TRY(launch_dgemm(up, DEPI_GELU, true, sm));
-      DGemmArgs dn = {};
-      dn.ldx = d->I; dn.W = w.down.W; dn.bias = w.down.b; dn.M = M; dn.N = d->H; dn.Npad = w.down.Npad; dn.K = d->I;
-      dn.Xb = d->M1b; dn.X = d->M1; dn.k_splits = 4; dn.Y = d->Pk; dn.ldy = d->H;
-      ETD_TRY(launch_dgemm(dn, DEPI_PARTIAL, true, sm));
-      if (forked) HIP_TRY(hipEventRecord(d->ev_join[l], d->st2));
-    }
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
     q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
@@ -195,36 +177,35 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     } else {
       ETD_TRY(launch_dgemm(de, DEPI_BIAS, d->bf16w, st));
     }
-    if (small) {
-      if (forked) HIP_TRY(hipStreamWaitEvent(st, d->ev_join[l], 0));
+    // ---- MLP up + GELU
+    DGemmArgs up = {};
+    up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
+    up.Y = d->M1; up.ldy = d->I;
+    if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
+    if (big) {
+      LinArgs a = {};
+      a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.W; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
+      ETD_TRY(launch_linear_dec(a, DEPI_GELU, st));
+    } else {
+      ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
+    }
+    // ---- MLP down + parallel residual: h = (mlp + attn) + h   (modeling_gpt_neox.py:272)
+    DGemmArgs dn = {};
+    dn.X = d->M1; dn.ldx = d->I; dn.W = w.down.W; dn.bias = w.down.b; dn.M = M; dn.N = d->H; dn.Npad = w.down.Npad; dn.K = d->I;
+    dn.add = d->DO; dn.hin = hin; dn.hout = hout;
+    if (bpipe) dn.Xb = d->M1b;
+    if (big) {
+      LinArgs a = {};
+      a.X = d->M1b; a.ldx = d->I; a.W = (const bf16*)w.down.W; a.bias = w.down.b; a.M = M; a.N = d->H; a.K = d->I; a.vt_block = -1; a.dec = dn;
+      ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
+    } else if (small) {
+      dn.k_splits = 4; dn.Y = d->Pk; dn.ldy = d->H;
+      ETD_TRY(launch_dgemm(dn, DEPI_PARTIAL, true, st));
       const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
       ETD_TRY(launch_resid_ln_rows(d->Pk, 4, w.down.b, d->DO, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
                                    nx ? nx->ln2g : nullptr, nx ? nx->ln2b : nullptr, d->cfg.layer_norm_eps, nx ? d->X1b : nullptr, nx ? d->X2b : nullptr, st));
     } else {
-      // ---- MLP up + GELU
-      DGemmArgs up = {};
-      up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
-      up.Y = d->M1; up.ldy = d->I;
-      if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
-      if (big) {
-        LinArgs a = {};
-        a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.W; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
-        ETD_TRY(launch_linear_dec(a, DEPI_GELU, st));
-      } else {
-        ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
-      }
-      // ---- MLP down + parallel residual: h = (mlp + attn) + h   (modeling_gpt_neox.py:272)
-      DGemmArgs dn = {};
-      dn.X = d->M1; dn.ldx = d->I; dn.W = w.down.W; dn.bias = w.down.b; dn.M = M; dn.N = d->H; dn.Npad = w.down.Npad; dn.K = d->I;
-      dn.add = d->DO; dn.hin = hin; dn.hout = hout;
-      if (bpipe) dn.Xb = d->M1b;
-      if (big) {
-        LinArgs a = {};
-        a.X = d->M1b; a.ldx = d->I; a.W = (const bf16*)w.down.W; a.bias = w.down.b; a.M = M; a.N = d->H; a.K = d->I; a.vt_block = -1; a.dec = dn;
-        ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
-      } else {
-        ETD_TRY(launch_dgemm(dn, DEPI_RESID, d->bf16w, st));
-      }
+      ETD_TRY(launch_dgemm(dn, DEPI_RESID, d->bf16w, st));
     }
     float* t = hin; hin = hout; hout = t;
   }
@@ -411,11 +392,6 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
   rc = rc ? rc : d->alloc(&d->tgt_attrs, 4 * S, true); rc = rc ? rc : d->alloc(&d->out_tok, S * d->out_cap, true);
   if (rc) return fail(rc);
-  if (d->bf16w && !getenv("ETD_NO_FORK")) {
-    HIP_TRY(hipStreamCreateWithFlags(&d->st2, hipStreamNonBlocking));
-    d->ev_fork.resize(d->L); d->ev_join.resize(d->L);
-    for (int l = 0; l < d->L; ++l) { HIP_TRY(hipEventCreateWithFlags(&d->ev_fork[l], hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&d->ev_join[l], hipEventDisableTiming)); }
-  }
   HIP_TRY(hipDeviceSynchronize());
   *out = d;
   return ETD_OK;
@@ -424,9 +400,6 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
 extern "C" void etd_decoder_destroy(etd_dec* d) {
   if (!d) return;
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
-  for (hipEvent_t e : d->ev_fork) (void)hipEventDestroy(e);
-  for (hipEvent_t e : d->ev_join) (void)hipEventDestroy(e);
-  if (d->st2) (void)hipStreamDestroy(d->st2);
   for (void* p : d->allocs) (void)hipFree(p);
   delete d;
 }
