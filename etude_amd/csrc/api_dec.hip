@@ -23,7 +23,8 @@ inline uint16_t f2bf_h(float f) {
 }
 
 struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0; };
-struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down; };
+struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
+               Lin cat; };   // decode step: [dense_4h_to_h | attention.dense] along K, so mlp + attn come out of ONE GEMM
 
 }  // namespace
 
@@ -49,7 +50,8 @@ struct etd_dec {
   bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
   bf16 *Qb = nullptr, *Kp = nullptr, *VTp = nullptr; int vt_spad = 0;     // batched-prefill scratch of the MFMA attention
   float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
-  float* Pk = nullptr;                           // [4][512][H] split-K partials of the decode-step down projection
+  float* Pk = nullptr;                           // [5][512][H] split-K partials of the decode-step (down | dense) projection
+  bf16* Xcat = nullptr;                          // [512][I + H] bf16: GELU(up) | attention output, the K-concatenated input of that GEMM
   std::vector<int> stage;                        // host staging of a prefill batch
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
@@ -133,7 +135,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     const Layer& w = d->layers[l];
     void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * esz;
     void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
-    const bool small = bpipe && !big && d->I % (4 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
+    const bool small = bpipe && !big && (d->I + d->H) % (5 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
     if (bpipe && (!small || l == 0)) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
@@ -163,6 +165,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       DAttnArgs at = {};
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = rows; at.M = M; at.O = d->AO; at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+      if (small) { at.Ob = d->Xcat + d->I; at.ldob = d->I + d->H; }
       ETD_TRY(launch_dattn(at, d->bf16w, st));
     }
     // ---- attention.dense
@@ -174,14 +177,14 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       LinArgs a = {};
       a.X = d->AOb; a.ldx = d->H; a.W = (const bf16*)w.dense.W; a.bias = w.dense.b; a.M = M; a.N = d->H; a.K = d->H; a.vt_block = -1; a.dec = de;
       ETD_TRY(launch_linear_dec(a, DEPI_BIAS, st));
-    } else {
+    } else if (!small) {        // decode step: attention.dense is folded into the (down | dense) GEMM below
       ETD_TRY(launch_dgemm(de, DEPI_BIAS, d->bf16w, st));
     }
     // ---- MLP up + GELU
     DGemmArgs up = {};
     up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
     up.Y = d->M1; up.ldy = d->I;
-    if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
+    if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; if (small) { up.Yb = d->Xcat; up.ldy = d->I + d->H; } } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
     if (big) {
       LinArgs a = {};
       a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.W; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
@@ -199,10 +202,11 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       a.X = d->M1b; a.ldx = d->I; a.W = (const bf16*)w.down.W; a.bias = w.down.b; a.M = M; a.N = d->H; a.K = d->I; a.vt_block = -1; a.dec = dn;
       ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
     } else if (small) {
-      dn.k_splits = 4; dn.Y = d->Pk; dn.ldy = d->H;
+      dn.Xb = d->Xcat; dn.ldx = d->I + d->H; dn.W = w.cat.W; dn.K = d->I + d->H; dn.Npad = w.cat.Npad;
+      dn.k_splits = 5; dn.Y = d->Pk; dn.ldy = d->H;
       ETD_TRY(launch_dgemm(dn, DEPI_PARTIAL, true, st));
       const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
-      ETD_TRY(launch_resid_ln_rows(d->Pk, 4, w.down.b, d->DO, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
+      ETD_TRY(launch_resid_ln_rows(d->Pk, 5, w.cat.b, nullptr, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
                                    nx ? nx->ln2g : nullptr, nx ? nx->ln2b : nullptr, d->cfg.layer_norm_eps, nx ? d->X1b : nullptr, nx ? d->X2b : nullptr, st));
     } else {
       ETD_TRY(launch_dgemm(dn, DEPI_RESID, d->bf16w, st));
@@ -351,6 +355,25 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
     if ((rc = load_lin(d, Ld, p + "attention.dense", H, H, true, &w.dense))) return fail(rc);
     if ((rc = load_lin(d, Ld, p + "mlp.dense_h_to_4h", d->I, H, true, &w.up))) return fail(rc);
     if ((rc = load_lin(d, Ld, p + "mlp.dense_4h_to_h", H, d->I, true, &w.down))) return fail(rc);
+    if (d->bf16w) {
+      // h_new - h = W2 gelu(..) + b2 + Wd attn + bd  ==  [W2 | Wd] [gelu(..) ; attn] + (b2 + bd)
+      const float* W2 = Ld.get(p + "mlp.dense_4h_to_h.weight", (int64_t)H * d->I);
+      const float* Wd = Ld.get(p + "attention.dense.weight", (int64_t)H * H);
+      const float* b2 = Ld.get(p + "mlp.dense_4h_to_h.bias", H);
+      const float* bd = Ld.get(p + "attention.dense.bias", H);
+      const int Kc = d->I + H;
+      std::vector<uint16_t> wc((size_t)H * Kc);
+      for (int o = 0; o < H; ++o) {
+        for (int k = 0; k < d->I; ++k) wc[(size_t)o * Kc + k] = f2bf_h(W2[(size_t)o * d->I + k]);
+        for (int k = 0; k < H; ++k) wc[(size_t)o * Kc + d->I + k] = f2bf_h(Wd[(size_t)o * H + k]);
+      }
+      uint16_t* pw; if ((rc = d->alloc(&pw, wc.size()))) return fail(rc);
+      HIP_TRY(hipMemcpy(pw, wc.data(), wc.size() * 2, hipMemcpyHostToDevice));
+      std::vector<float> bc(H);
+      for (int o = 0; o < H; ++o) bc[o] = b2[o] + bd[o];
+      w.cat.W = pw; w.cat.N = H; w.cat.Npad = H; w.cat.K = Kc;
+      if ((rc = up_f32(d, &w.cat.b, bc.data(), H))) return fail(rc);
+    }
   }
   if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.weight", H, &d->lnfg))) return fail(rc);
   if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.bias", H, &d->lnfb))) return fail(rc);
@@ -380,7 +403,8 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   if (d->bf16w) {
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
-    rc = rc ? rc : d->alloc(&d->Pk, (size_t)4 * 512 * H);
+    rc = rc ? rc : d->alloc(&d->Pk, (size_t)5 * 512 * H);
+    rc = rc ? rc : d->alloc(&d->Xcat, (size_t)512 * (d->I + H));
     rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
     rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)

@@ -46,7 +46,7 @@ struct DAttnArgs {
   const void* Kc; const void* Vc; long long slot_stride; int max_ctx, n_heads;
   DecRows rows; int M;
   float* O;                      // [M][hidden]
-  bf16* Ob;                      // optional bf16 copy of O (input of the dense GEMM in the bf16 pipeline)
+  bf16* Ob; int ldob;            // optional bf16 copy of O (input of the dense GEMM in the bf16 pipeline), row stride ldob (0 = hidden)
   float scale;
   double bytes_hint;             // algorithmic K+V bytes this launch reads (host estimate, profiler only)
 };

@@ -495,7 +495,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
     *reinterpret_cast<f32x4*>(op + 4) = y;
     if (a.Ob) {
       const bf16x8 ob = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
-      *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * hidden + head * 64 + c * 8) = ob;
+      *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * (a.ldob > 0 ? a.ldob : hidden) + head * 64 + c * 8) = ob;
     }
   }
 }
@@ -598,7 +598,8 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
         for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
       }
       const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + k), bb = *reinterpret_cast<const f32x4*>(bias + k + 4);
-      const f32x4 da = *reinterpret_cast<const f32x4*>(add + ro + k), db = *reinterpret_cast<const f32x4*>(add + ro + k + 4);
+      f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+      if (add) { da = *reinterpret_cast<const f32x4*>(add + ro + k); db = *reinterpret_cast<const f32x4*>(add + ro + k + 4); }
       const f32x4 ha = *reinterpret_cast<const f32x4*>(hin + ro + k), hb = *reinterpret_cast<const f32x4*>(hin + ro + k + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) { v[it][j] = ((acc[j] + ba[j]) + da[j]) + ha[j]; v[it][4 + j] = ((acc[4 + j] + bb[j]) + db[j]) + hb[j]; }
