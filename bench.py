@@ -277,10 +277,11 @@ def main():
                                         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}}
         except Exception as e:      # extras must never take the headline down
             extras["extractor_only"] = {"error": repr(e)}
-        try:
-            extras["decoder_streams"] = decoder_stream_bench(dcfg, dev)
-        except Exception as e:
-            extras["decoder_streams"] = {"error": repr(e)}
+        for key, c0 in (("decoder_streams", 512), ("decoder_streams_4k", 3500)):     # reference-faithful context / 4k stress
+            try:
+                extras[key] = decoder_stream_bench(dcfg, dev, ctx0=c0)
+            except Exception as e:
+                extras[key] = {"error": repr(e)}
         result["extras"] = extras
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

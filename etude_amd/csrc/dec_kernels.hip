@@ -391,16 +391,18 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
 // grid (M, heads); 4 waves split the key blocks; a wave-iteration covers 8 keys: lane = (key j = lane>>3,
 // 8-dim chunk c = lane&7), so K/V loads are fully coalesced 2 KB (fp32) / 1 KB (bf16) blocks.
 // ================================================================================================
-template <typename KVT> __device__ __forceinline__ void load8(const KVT* p, float (&o)[8]);
-template <> __device__ __forceinline__ void load8<float>(const float* p, float (&o)[8]) {
-  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
-  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
-}
-template <> __device__ __forceinline__ void load8<bf16>(const bf16* p, float (&o)[8]) {
-  const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) o[j] = bf2f(a[j]);
-}
+// raw 8-element K/V pieces stay in their memory format in registers (so the loads remain in flight) and are widened at use
+template <typename KVT> struct Raw8;
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+  __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
+};
+template <> struct Raw8<bf16> {
+  bf16x8 v;
+  __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ float get(int j) const { return bf2f(v[j]); }
+};
 
 #define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
 template <typename KVT>
@@ -427,19 +429,26 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
   float mr = -INFINITY, lr = 0.f, o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
-  // two 8-key groups per iteration (independent chains): 4 loads in flight per lane before the first use
-  for (int k0 = wave * 8; k0 < ctx; k0 += 64) {
-    const int keyA = k0 + j, keyB = k0 + 32 + j;
-    const bool vA = keyA < ctx, vB = keyB < ctx;
-    const int ka = vA ? keyA : ctx - 1, kbb = vB ? keyB : ctx - 1;
-    float kA[8], kB[8], wA[8], wB[8];
-    load8<KVT>(kb + (long long)ka * 64 + c * 8, kA);
-    load8<KVT>(kb + (long long)kbb * 64 + c * 8, kB);
-    load8<KVT>(vb + (long long)ka * 64 + c * 8, wA);
-    load8<KVT>(vb + (long long)kbb * 64 + c * 8, wB);
+  // Software-pipelined KV stream: a wave-iteration covers two 8-key groups (16 keys); the K/V pieces of iteration i+1
+  // are requested before iteration i is consumed, so ~8 KB per wave are always in flight.
+  Raw8<KVT> kA, kB, wA, wB, nkA, nkB, nwA, nwB;
+  auto issue = [&](int k0, Raw8<KVT>& a_, Raw8<KVT>& b_, Raw8<KVT>& c_, Raw8<KVT>& d_) {
+    int ka = k0 + j, kbb = k0 + 32 + j;
+    ka = ka < ctx ? ka : ctx - 1; kbb = kbb < ctx ? kbb : ctx - 1;
+    a_.load(kb + (long long)ka * 64 + c * 8);
+    b_.load(kb + (long long)kbb * 64 + c * 8);
+    c_.load(vb + (long long)ka * 64 + c * 8);
+    d_.load(vb + (long long)kbb * 64 + c * 8);
+  };
+  int k0 = wave * 8;
+  if (k0 < ctx) issue(k0, kA, kB, wA, wB);
+  for (; k0 < ctx; k0 += 64) {
+    const bool more = k0 + 64 < ctx;
+    if (more) issue(k0 + 64, nkA, nkB, nwA, nwB);
+    const bool vA = k0 + j < ctx, vB = k0 + 32 + j < ctx;
     float sA = 0.f, sB = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sA = fmaf(q[e], kA[e], sA); sB = fmaf(q[e], kB[e], sB); }
+    for (int e = 0; e < 8; ++e) { sA = fmaf(q[e], kA.get(e), sA); sB = fmaf(q[e], kB.get(e), sB); }
     sA += __shfl_xor(sA, 1, 64); sB += __shfl_xor(sB, 1, 64);
     sA += __shfl_xor(sA, 2, 64); sB += __shfl_xor(sB, 2, 64);
     sA += __shfl_xor(sA, 4, 64); sB += __shfl_xor(sB, 4, 64);
@@ -448,7 +457,7 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
       const float al = EXPF(mr - mn), p = EXPF(sA - mn);
       lr = lr * al + p;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wA[e];
+      for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wA.get(e);
       mr = mn;
     }
     if (vB) {
@@ -456,9 +465,10 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
       const float al = EXPF(mr - mn), p = EXPF(sB - mn);
       lr = lr * al + p;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wB[e];
+      for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wB.get(e);
       mr = mn;
     }
+    if (more) { kA = nkA; kB = nkB; wA = nwA; wB = nwB; }
   }
   // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the 4 waves through LDS
 #pragma unroll
