@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
-ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --clips ${CLIPS:-8} --bars ${BARS:-16}"
+ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --clips ${CLIPS:-8} --bars ${BARS:-92}"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 $ROOT/bench.py $ARGS > $OUT/prof_trace.json 2> $OUT/prof_trace.err
 PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --clips 1 --attr-grid 27 --bars 4"
