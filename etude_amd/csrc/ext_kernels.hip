@@ -315,21 +315,32 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 
   int ntile = (Sk + 63) >> 6;
   if (a.causal) { const int lim = (blockIdx.x * 128 + 127) / 64 + 1; ntile = ntile < lim ? ntile : lim; }   // tiles past the diagonal are fully masked
+  // K/V tiles are prefetched one tile ahead into registers (global latency hides under the previous tile's MFMA/softmax)
+  u32x4 kreg[2], vreg[2];
+  auto tile_gload = [&](int kv0_) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+      int key = kv0_ + row; key = key < Sk ? key : Sk - 1;
+      kreg[i] = *reinterpret_cast<const u32x4*>(kbase + (long long)key * a.ldk + ch * 8);
+      vreg[i] = *reinterpret_cast<const u32x4*>(vbase + (long long)row * a.Spad + kv0_ + ch * 8);
+    }
+  };
+  tile_gload(0);
   for (int jt = 0; jt < ntile; ++jt) {
     const int kv0 = jt * 64;
     // stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]: 512 16-B chunks each, 2 per thread
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int c = tid + i * 256, row = c >> 3, ch = c & 7;
-      int key = kv0 + row; key = key < Sk ? key : Sk - 1;
-      const uint4 kvv = *reinterpret_cast<const uint4*>(kbase + (long long)key * a.ldk + ch * 8);
-      *reinterpret_cast<uint4*>(Ks + row * LDK + ch * 8) = kvv;
-      const uint4 vv = *reinterpret_cast<const uint4*>(vbase + (long long)row * a.Spad + kv0 + ch * 8);
-      uint2* vd = reinterpret_cast<uint2*>(Vs + row * LDV + ch * 8);
-      vd[0] = make_uint2(vv.x, vv.y);
-      vd[1] = make_uint2(vv.z, vv.w);
+      *reinterpret_cast<u32x4*>(Ks + row * LDK + ch * 8) = kreg[i];
+      u32x2* vd = reinterpret_cast<u32x2*>(Vs + row * LDV + ch * 8);
+      const u32x2 lo = {vreg[i][0], vreg[i][1]}, hi = {vreg[i][2], vreg[i][3]};
+      vd[0] = lo;
+      vd[1] = hi;
     }
     __syncthreads();
+    if (jt + 1 < ntile) tile_gload(kv0 + 64);
 
     // S^T[key][query] for the two 32-key sub-tiles
     f32x16 sT[2];
@@ -343,27 +354,37 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
         sT[kt] = mfma32(kf, qf[s], sT[kt]);
       }
     }
-    // scale, mask keys >= Sk, running max
+    // mask (only tiles that need it), running max of the RAW scores; the softmax scale rides in the exp2 argument:
+    // p = exp2(s*c - m*c) is one fma + one v_exp_f32 per element (this loop is VALU-bound: 256 FLOP per exp at d = 64)
+    const bool need_mask = (kv0 + 64 > Sk) || (a.causal && kv0 + 63 > q0);     // wave-uniform
     float mx = -INFINITY;
+    if (need_mask) {
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int key = kv0 + kt * 32 + acc_row(i, h);
-        float v = sT[kt][i] * a.scale_log2e;
-        v = (key < Sk && (!a.causal || key <= qi)) ? v : -INFINITY;
-        sT[kt][i] = v;
-        mx = fmaxf(mx, v);
-      }
+        for (int i = 0; i < 16; ++i) {
+          const int key = kv0 + kt * 32 + acc_row(i, h);
+          const float v = (key < Sk && (!a.causal || key <= qi)) ? sT[kt][i] : -INFINITY;
+          sT[kt][i] = v;
+          mx = fmaxf(mx, v);
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sT[kt][i]);
+    }
     mx = fmaxf(mx, xhalf(mx));
-    const float mnew = fmaxf(mrun, mx);          // finite: every tile holds >= 1 valid key
-    const float alpha = exp2f(mrun - mnew);
+    const float mnew = fmaxf(mrun, mx);          // finite: the first tile of every query holds >= 1 visible key
+    const float c = a.scale_log2e;
+    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);   // raw v_exp_f32: argument <= 0
     mrun = mnew;
+    const float mc = -mnew * c;
     float ps = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { const float p = exp2f(sT[kt][i] - mnew); sT[kt][i] = p; ps += p; }
+      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(fmaf(sT[kt][i], c, mc)); sT[kt][i] = p; ps += p; }
     lrun = lrun * alpha + ps;
 #pragma unroll
     for (int t = 0; t < 2; ++t)

@@ -26,3 +26,11 @@ if __name__ == "__main__":
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t) / (reps * nwin)
     print(f"{dt*1e3:.3f} ms/window  {ex.window_flops/dt/1e12:.1f} TFLOP/s  {8.192/dt:.0f} audio-s/s")
+    from etude_amd import _lib
+    _lib.prof_reset(); _lib.prof_enable(True)
+    ex.transcript_windows(xs)
+    torch.cuda.synchronize()
+    _lib.prof_enable(False)
+    for k, v in sorted(_lib.prof_report().items(), key=lambda kv: -kv[1]["ms"]):
+        tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
+        print(f"   {k:14s} {v['ms']/nwin:8.3f} ms/window  {v['launches']//nwin:4d} launches/window  {tf:7.1f} TFLOP/s")
