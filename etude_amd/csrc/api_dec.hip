@@ -150,6 +150,12 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       LinArgs a = {};
       a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
       ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
+    } else if (small) {
+      // decode step: QKV (+RoPE, KV append) and MLP up (+GELU -> Xcat) share one launch
+      DGemmArgs up = {};
+      up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
+      up.Y = d->M1; up.Xb = d->X2b; up.Yb = d->Xcat; up.ldy = d->I + d->H;
+      ETD_TRY(launch_dstep_qkv_up(q, up, st));
     } else {
       ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
     }
@@ -189,7 +195,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       LinArgs a = {};
       a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.W; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
       ETD_TRY(launch_linear_dec(a, DEPI_GELU, st));
-    } else {
+    } else if (!small) {        // (decode step: already issued together with QKV)
       ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
     }
     // ---- MLP down + parallel residual: h = (mlp + attn) + h   (modeling_gpt_neox.py:272)
@@ -472,8 +478,8 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     double kvb = 0;
     for (int i = 0; i < n_active; ++i) { int& hl = d->host_len[slots[i]]; kvb += (double)(hl + 1) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4); if (hl < d->ctx - 1) ++hl; }
     d->attn_bytes_hint = kvb;
-    ETD_TRY(launch_decode_rows(d->slots_dev, n_active, d->len, d->done, d->row_slot, d->row_pos, d->row_active, s_));
     DEmbedArgs e = {};
+    e.slots = d->slots_dev; e.len = d->len; e.done = d->done; e.row_slot_out = d->row_slot; e.row_pos_out = d->row_pos; e.row_active_out = d->row_active;
     e.cur_tok = d->cur_tok; e.tgt_attrs = d->tgt_attrs; e.tgt_cls = 2 /* TGT_CLASS_ID, etude/data/dataset.py:19 */;
     e.M = n_active; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
     e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;

@@ -40,6 +40,8 @@ struct DGemmArgs {
   bf16* VTp; int vt_spad;        // V^T[(seq*n_heads+head)*64 + d][vt_spad]
 };
 int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st);
+// decode step, bf16: fused-QKV(+RoPE, KV append) and MLP-up(+GELU) projections of one layer in a single launch
+int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st);
 
 struct DAttnArgs {
   const float* Q;                // [M][hidden]
@@ -66,6 +68,8 @@ struct DEmbedArgs {
   const int* cur_tok; const int* tgt_attrs;           // decode mode: ids = cur_tok[slot], cls = tgt_cls, attrs = tgt_attrs[slot][4]
   int tgt_cls;
   DecRows rows; int M, H, n_bins;
+  const int* slots; const int* len; const int* done;  // decode mode, optional: derive the rows from the slot list and WRITE them to
+  int* row_slot_out; int* row_pos_out; int* row_active_out;   //   these arrays (replaces a separate k_decode_rows launch)
   const float* word; const float* cls_emb; const float* attr_tab;  // [V][H], [C][H], [4][n_bins][H] (+bias in tab 0)
   float* h;
 };

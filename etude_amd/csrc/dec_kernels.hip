@@ -254,6 +254,63 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
 }
 
 // ================================================================================================
+// k_dstep_qkv_up: the two GEMMs of a decode step that only depend on the layer's LayerNorm rows -- the fused QKV
+// projection (X1b, +RoPE, KV append) and the MLP up projection (X2b, +GELU) -- in ONE launch: feature tiles
+// [0, split) belong to the first problem, the rest to the second.  Same 32x32 / 8-wave K-split body as k_dgemm_s
+// (bf16 inputs, K = hidden).  One dependent kernel boundary less per layer of a latency-bound chain.
+// ================================================================================================
+__global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGemmArgs up, int split) {
+  __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const bool isq = (int)blockIdx.y < split;
+  const int m0 = blockIdx.x * 32, n0 = (isq ? (int)blockIdx.y : (int)blockIdx.y - split) * 32;
+  const int M = q.M, K = q.K;
+  int gm = m0 + r; gm = gm < M ? gm : M - 1;
+  const bf16* wrow = reinterpret_cast<const bf16*>(isq ? q.W : up.W) + (long long)(n0 + r) * K;
+  const bf16* xbrow = (isq ? q.Xb : up.Xb) + (long long)gm * (isq ? q.ldx : up.ldx);
+  const int kq = K / DS_WAVES, kb = wave * kq, ke = kb + kq;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 2
+  for (int k = kb; k < ke; k += 64) {
+    bf16x8 wf[4], xf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
+      xf[s4] = *reinterpret_cast<const bf16x8*>(xbrow + k + s4 * 16 + h * 8);
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < DS_WAVES - 1; ++w)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
+  const int m = m0 + r;
+  if (m >= M) return;
+  if (isq) dgemm_epilogue<true, DEPI_QKV>(q, acc, m, n0, h);
+  else dgemm_epilogue<true, DEPI_GELU>(up, acc, m, n0, h);
+}
+
+int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st) {
+  if (q.M != up.M || q.K != up.K || q.M < 1 || q.M > DS_MAX_ROWS || !q.Xb || !up.Xb || !up.Yb || q.K % (64 * DS_WAVES) || q.Npad % 32 || up.Npad % 32 ||
+      q.rot_half != 8 || q.N % 192)
+    ETD_FAIL(ETD_EINVAL, "dstep_qkv_up: bad arguments");
+  ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
+  const int split = q.Npad / 32;
+  hipLaunchKernelGGL(k_dstep_qkv_up, dim3((q.M + 31) / 32, split + up.Npad / 32), dim3(64 * DS_WAVES), 0, st, q, up, split);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
 // k_dgemv (M == 1, the reference's batch-1 token loop): each wave owns 4 output features, the 64 lanes
 // split K in 16-byte pieces (one fully coalesced 1 KiB / 2 KiB row segment per load instruction).
 // ================================================================================================
@@ -680,7 +737,9 @@ __global__ void k_dembed(DEmbedArgs a) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) at[k] = a.attrs[k * a.M + m];
   } else {
-    const int slot = a.rows.slot[m];
+    // decode step: this kernel also materialises the row metadata the rest of the step reads (slot, position, active)
+    const int slot = a.slots ? a.slots[m] : a.rows.slot[m];
+    if (a.slots && threadIdx.x == 0) { a.row_slot_out[m] = slot; a.row_pos_out[m] = a.len[slot]; a.row_active_out[m] = a.done[slot] ? 0 : 1; }
     id = a.cur_tok[slot]; cl = a.tgt_cls;
 #pragma unroll
     for (int k = 0; k < 4; ++k) at[k] = a.tgt_attrs[slot * 4 + k];
