@@ -102,10 +102,11 @@ def main():
     ap.add_argument("--clips", type=int, default=8, help="clips per rank")
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
     ap.add_argument("--streams", type=int, default=256, help="concurrent decoder streams (capped at the number of jobs)")
-    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "2")),
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "3")),
                     help="independent decoder engines (own HIP stream + KV cache each) driven from host threads: the short dependent kernels of one engine's decode step overlap the other's")
     ap.add_argument("--bars", type=int, default=92)
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS suppressed)")
+    ap.add_argument("--serial", action="store_true", help="run the two stages back to back (all clips extracted, then all jobs decoded) instead of as a pipeline")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -162,18 +163,37 @@ def main():
             jobs.append((bars, [synth.attrs(p, r, s_, 2)] * len(bars)))
     inf = cfg.infer
 
+    # the extractor stays on torch's default stream: engines + default must fit the runtime's hardware queues (4 unless
+    # GPU_MAX_HW_QUEUES says otherwise) or streams start sharing a queue and serialise against each other
+    ext_stream = torch.cuda.Stream(device=dev) if os.environ.get("ETD_EXT_STREAM") == "1" else torch.cuda.default_stream(dev)
+    job_clip = [k // len(grid) for k in range(n_jobs)]              # job -> local clip whose stages must have finished
+
     def step():
+        """One pass over this rank's clips.  The stages form a pipeline per clip (infer.py:82-198: a song is decoded only after
+        it has been extracted); across clips they overlap -- the decode engines run in host threads and admit the jobs of clip c
+        once the extractor (main thread, own stream) has delivered clip c."""
         t0 = time.perf_counter()
+        ready = np.zeros(len(wavs), np.int32)
+        if args.serial:
+            ready[:] = 1
         n_notes = 0
-        for wav in wavs:
-            notes = ex.extract_notes(wav, 44100, inf.min_duration)      # device wav -> the note list extract() writes
-            n_notes += len(notes)
-        torch.cuda.synchronize(dev)
+        bg = None if args.serial else decode_jobs_async(decs, jobs, vocab, args.bar_tokens, (ready, job_clip))
+        try:
+            with torch.cuda.stream(ext_stream):
+                for c, wav in enumerate(wavs):
+                    notes = ex.extract_notes(wav, 44100, inf.min_duration)      # device wav -> the note list extract() writes (host)
+                    n_notes += len(notes)
+                    ready[c] = 1
+            ext_stream.synchronize()
+        finally:
+            ready[:] = 1                                                         # never leave a scheduler waiting
         t1 = time.perf_counter()
-        out, ntok = decode_jobs(decs, jobs, vocab, args.bar_tokens)
+        if bg is None:
+            bg = decode_jobs_async(decs, jobs, vocab, args.bar_tokens, (ready, job_clip))
+        out, ntok = bg()
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
-        return t1 - t0, t2 - t1, ntok, n_notes / len(wavs), out
+        return t1 - t0, (t2 - t1) if args.serial else (t2 - t0), ntok, n_notes / len(wavs), out
 
     for _ in range(args.warmup):
         step()
@@ -226,7 +246,8 @@ def main():
                                "(Bar_EOS suppressed: synthetic weights carry no musical EOS statistics), overlap bin 2, bf16 compute / fp32 accumulate; synthetic seeded weights",
                    "clips_per_gpu": args.clips, "attr_tuples_per_clip": args.attr_grid, "decode_jobs_per_gpu": n_jobs, "decoder_streams": per_eng * n_eng, "decoder_engines": n_eng,
                    "clip_seconds": args.seconds, "windows_per_clip": int(np.ceil((1 + int(np.ceil(160 * wavs[0].shape[1] / 441)) // 256) / 512)),
-                   "bars": args.bars, "bar_tokens": args.bar_tokens, "parallelism": f"clip-sharded x{world}"},
+                   "bars": args.bars, "bar_tokens": args.bar_tokens, "parallelism": f"clip-sharded x{world}",
+                   "stage_overlap": "serial" if args.serial else "pipelined per clip (jobs of clip c admitted when its extraction is done; extraction of c+1 overlaps)"},
         "extract_audio_s_per_s": round(audio_s / t_ext, 2),
         "decoder_tokens_per_s": round(n_tok_all / t_dec, 2),
         "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": n_notes, "jobs_gathered": gathered_jobs,
@@ -297,36 +318,39 @@ def main():
         dist.destroy_process_group()
 
 
-def decode_jobs(decs, jobs, vocab, bar_tokens):
-    """Greedy-decode all jobs; with several engines the job list is dealt round-robin and each engine runs its share
-    from its own host thread (ctypes releases the GIL inside the library calls)."""
-    if len(decs) == 1:
-        st = {}
-        out = decs[0].generate_many(jobs, vocab, stats=st, force_bar_tokens=bar_tokens)
-        return out, st["tokens"]
+def decode_jobs_async(decs, jobs, vocab, bar_tokens, ready):
+    """Greedy-decode all jobs: the job list is dealt round-robin over the engines and each engine runs its share from its
+    own host thread (ctypes releases the GIL inside the library calls).  `ready` = (flags, job -> flag index) gates the
+    admission of each job on its clip's upstream stages.  Returns a function that joins and yields (results, n_tokens)."""
     import threading
-    outs = [None] * len(decs)
+    n = len(decs)
+    outs = [None] * n
     stats = [dict() for _ in decs]
     errs = []
+    flags, idx = ready
 
     def run(i):
         try:
             torch.cuda.set_device(decs[i].device)
-            outs[i] = decs[i].generate_many(jobs[i::len(decs)], vocab, stats=stats[i], force_bar_tokens=bar_tokens)
-        except Exception as e:  # surfaced below
+            outs[i] = decs[i].generate_many(jobs[i::n], vocab, stats=stats[i], force_bar_tokens=bar_tokens, ready=(flags, idx[i::n]))
+        except Exception as e:  # surfaced by the join
             errs.append(e)
 
-    th = [threading.Thread(target=run, args=(i,)) for i in range(len(decs))]
+    th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
     for t in th:
         t.start()
-    for t in th:
-        t.join()
-    if errs:
-        raise errs[0]
-    out = [None] * len(jobs)
-    for i in range(len(decs)):
-        out[i::len(decs)] = outs[i]
-    return out, sum(s["tokens"] for s in stats)
+
+    def join():
+        for t in th:
+            t.join()
+        if errs:
+            raise errs[0]
+        out = [None] * len(jobs)
+        for i in range(n):
+            out[i::n] = outs[i]
+        return out, sum(s["tokens"] for s in stats)
+
+    return join
 
 
 def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64):

@@ -38,7 +38,7 @@ class DecCfg(C.Structure):
 
 
 class Job(C.Structure):
-    _fields_ = [("x_ids", C.c_void_p), ("x_offsets", C.c_void_p), ("n_bars", C.c_int), ("attrs4", C.c_void_p)]
+    _fields_ = [("x_ids", C.c_void_p), ("x_offsets", C.c_void_p), ("n_bars", C.c_int), ("attrs4", C.c_void_p), ("ready", C.c_void_p)]
 
 
 class SchedCfg(C.Structure):

@@ -429,6 +429,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
 
 extern "C" void etd_decoder_destroy(etd_dec* d) {
   if (!d) return;
+  (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
   for (void* p : d->allocs) (void)hipFree(p);
   delete d;

@@ -283,6 +283,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
 
 extern "C" void etd_extractor_destroy(etd_ext* e) {
   if (!e) return;
+  (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   e->pool.free_all();
   delete e;
 }

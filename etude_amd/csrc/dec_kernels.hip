@@ -266,6 +266,21 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGe
   const int m0 = blockIdx.x * 32, n0 = (isq ? (int)blockIdx.y : (int)blockIdx.y - split) * 32;
   const int M = q.M, K = q.K;
   int gm = m0 + r; gm = gm < M ? gm : M - 1;
+  // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207); a 32-feature tile is half of one part of one head
+  const int head = n0 / 192, j0 = n0 - head * 192, part = j0 >> 6, dbase = j0 & 63;
+  const bool rope = isq && part < 2 && dbase == 0;
+  // Wave 0 owns the epilogue.  Its row metadata and bias are requested BEFORE the weight stream and the RoPE factors
+  // (which depend on the row's position) right after it, so these dependent round trips overlap the K loop and the LDS
+  // reduction instead of following them.
+  f32x4 bq[4];
+  int pos = 0, slot = 0, act = 0;
+  f32x4 rc = {1.f, 1.f, 1.f, 1.f}, rs = {0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) {
+    if (isq) { pos = q.rows.pos[gm]; slot = q.rows.slot[gm]; act = q.rows.active[gm]; }
+    const float* bp = (isq ? q.bias : up.bias) + n0 + 4 * h;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) bq[q4] = *reinterpret_cast<const f32x4*>(bp + 8 * q4);
+  }
   const bf16* wrow = reinterpret_cast<const bf16*>(isq ? q.W : up.W) + (long long)(n0 + r) * K;
   const bf16* xbrow = (isq ? q.Xb : up.Xb) + (long long)gm * (isq ? q.ldx : up.ldx);
   const int kq = K / DS_WAVES, kb = wave * kq, ke = kb + kq;
@@ -279,6 +294,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGe
     for (int s4 = 0; s4 < 4; ++s4) {
       wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
       xf[s4] = *reinterpret_cast<const bf16x8*>(xbrow + k + s4 * 16 + h * 8);
+    }
+    if (k == kb && wave == 0 && rope) {
+      // partial RoPE factors of dims d = 4h + i (i < 4); the partner d + 8 sits in register i + 4 of the same lane
+      rc = *reinterpret_cast<const f32x4*>(q.rope_cos + (long long)pos * 8 + 4 * h);
+      rs = *reinterpret_cast<const f32x4*>(q.rope_sin + (long long)pos * 8 + 4 * h);
     }
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
@@ -295,13 +315,42 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGe
     for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
   const int m = m0 + r;
   if (m >= M) return;
-  if (isq) dgemm_epilogue<true, DEPI_QKV>(q, acc, m, n0, h);
-  else dgemm_epilogue<true, DEPI_GELU>(up, acc, m, n0, h);
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
+  if (!isq) {
+    // MLP up: erf-GELU, bf16 rows for the down projection
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int n = n0 + 8 * q4 + 4 * h;
+      if (n < up.N)
+        *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
+            pack4(gelu_erf(v[4 * q4]), gelu_erf(v[4 * q4 + 1]), gelu_erf(v[4 * q4 + 2]), gelu_erf(v[4 * q4 + 3]));
+    }
+    return;
+  }
+  if (rope) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x1 = v[i], x2 = v[i + 4];
+      v[i] = x1 * rc[i] - x2 * rs[i];        // q*cos + rotate_half(q)*sin, first half
+      v[i + 4] = x2 * rc[i] + x1 * rs[i];    // second half
+    }
+  }
+  if (part == 0) {
+    float* qp = q.Q + (long long)m * (q.n_heads * 64) + head * 64 + dbase;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) { const f32x4 o = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q4 + 4 * h) = o; }
+  } else if (act && pos < q.max_ctx) {
+    bf16* kp = reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)slot * q.slot_stride + ((long long)head * q.max_ctx + pos) * 64 + dbase;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<bf16x4*>(kp + 8 * q4 + 4 * h) = pack4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+  }
 }
 
 int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st) {
   if (q.M != up.M || q.K != up.K || q.M < 1 || q.M > DS_MAX_ROWS || !q.Xb || !up.Xb || !up.Yb || q.K % (64 * DS_WAVES) || q.Npad % 32 || up.Npad % 32 ||
-      q.rot_half != 8 || q.N % 192)
+      q.rot_half != 8 || q.N % 192 || q.Qb || !q.Q || !q.bias || !up.bias || up.N % 4)
     ETD_FAIL(ETD_EINVAL, "dstep_qkv_up: bad arguments");
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
   const int split = q.Npad / 32;

@@ -165,6 +165,7 @@ extern "C" int etd_frontend_create(int sr_in, int sr_out, int orig, int nw, int 
 
 extern "C" void etd_frontend_destroy(etd_frontend* f) {
   if (!f) return;
+  (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   (void)hipFree(f->kernT); (void)hipFree(f->window); (void)hipFree(f->tw);
   (void)hipFree(f->mel_start); (void)hipFree(f->mel_len); (void)hipFree(f->mel_off); (void)hipFree(f->mel_w);
   delete f;

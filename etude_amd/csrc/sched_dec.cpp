@@ -4,8 +4,10 @@
 // pass goes through the C ABI of this library (etd_decoder_begin_bars / _step / _poll / _read_many).
 // Keeping this loop out of Python removes ~50 us of interpreter work per (job, bar) from the serving path.
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/etude_hip.h"
@@ -65,7 +67,7 @@ extern "C" int etd_debug_assemble_prompt(const etd_sched_cfg* cfg, int n_hist, c
                                          const int32_t* y_attrs4, int32_t* ids_out, int32_t* cls_out, int32_t* attrs4_out, int cap, int* T_out) {
   if (!cfg || n_hist < 0 || !x || !y_attrs4 || !ids_out || !cls_out || !attrs4_out || !T_out) ETD_FAIL(ETD_EINVAL, "assemble_prompt: bad arguments");
   const int32_t offs[2] = {0, xn};
-  etd_job j{x, offs, 1, y_attrs4};
+  etd_job j{x, offs, 1, y_attrs4, nullptr};
   Job jb; jb.j = &j; jb.bar = 0;
   const int first = n_hist > cfg->n_ctx_pairs ? n_hist - cfg->n_ctx_pairs : 0;     // history_bar_pairs[-n:]
   for (int i = first; i < n_hist; ++i) {
@@ -92,6 +94,8 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
     J[i].j = &jobs[i];
     if (jobs[i].n_bars < 0 || (jobs[i].n_bars > 0 && (!jobs[i].x_ids || !jobs[i].x_offsets || !jobs[i].attrs4))) ETD_FAIL(ETD_EINVAL, "run_jobs: job %d malformed", i);
   }
+  // a job whose upstream stages are still running is not touched before its flag is set (acquire: the flag's writer filled the bars first)
+  auto is_ready = [&](int i) { return !jobs[i].ready || __atomic_load_n(jobs[i].ready, __ATOMIC_ACQUIRE) != 0; };
   std::vector<int> free_slots;
   for (int s = c.max_streams - 1; s >= 0; --s) free_slots.push_back(s);
   std::vector<int> active;          // job indices holding a slot
@@ -146,14 +150,17 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
 
   while (next_job < n_jobs || !active.empty()) {
     std::vector<int> fresh;
-    while (next_job < n_jobs && !free_slots.empty()) {
+    while (next_job < n_jobs && !free_slots.empty() && is_ready(next_job)) {
       Job& jb = J[next_job];
       jb.slot = free_slots.back(); free_slots.pop_back();
       active.push_back(next_job);
       fresh.push_back(next_job++);
     }
     if (!fresh.empty()) ETD_TRY(start_bars(fresh));
-    if (active.empty()) continue;
+    if (active.empty()) {
+      if (next_job < n_jobs && !is_ready(next_job)) std::this_thread::sleep_for(std::chrono::microseconds(100));   // idle until upstream delivers
+      continue;
+    }
     const int na = (int)active.size();
     std::sort(active.begin(), active.end(), [&](int a, int b) { return J[a].slot < J[b].slot; });
     slots.resize(na); dn.resize(na); no.resize(na);

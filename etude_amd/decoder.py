@@ -148,14 +148,22 @@ class EtudeDecoder:
     # ------------------------------------------------------------------ multi-stream engine
     def generate_many(self, jobs: Sequence[Tuple[List[List[int]], List[Dict[str, int]]]], vocab, max_output_tokens: int = 25600,
                       max_bar_token_limit: int = 512, context_overlap_ratio: float = 0.5, steps_per_poll: int = 8,
-                      _validate: bool = True, stats: Optional[dict] = None, force_bar_tokens: int = 0) -> List[List[List[int]]]:
+                      _validate: bool = True, stats: Optional[dict] = None, force_bar_tokens: int = 0,
+                      ready: Optional[Tuple[np.ndarray, Sequence[int]]] = None) -> List[List[List[int]]]:
         """Greedy-decode many independent jobs on up to ``max_streams`` concurrent device streams.
 
         The bar loop (prompt assembly, history, truncation, token budget, EOS stop) runs in the library's native
         scheduler (csrc/sched_dec.cpp, ``etd_decoder_run_jobs``); this method only marshals the jobs.
         ``force_bar_tokens=n`` (benchmarks only) suppresses Bar_EOS and makes every bar exactly n tokens long, so that
-        throughput does not depend on where synthetic weights happen to emit EOS."""
+        throughput does not depend on where synthetic weights happen to emit EOS.
+        ``ready=(flags, index)`` gates admission on upstream pipeline stages: ``flags`` is an int32 array another thread sets
+        non-zero (e.g. one entry per song, set when its extract..tokenize stages are done) and job i waits for
+        ``flags[index[i]]``; jobs are admitted in list order."""
         lib = _lib.lib()
+        if ready is not None:
+            flags, ridx = ready
+            if flags.dtype != np.int32 or not flags.flags["C_CONTIGUOUS"] or len(ridx) != len(jobs):
+                raise ValueError("ready: need a contiguous int32 flag array and one index per job")
         cfg = self.config
         results: List[Optional[List[List[int]]]] = [None] * len(jobs)
         live: List[int] = []
@@ -181,7 +189,12 @@ class EtudeDecoder:
                 if xi.size and (xi.min() < 0 or xi.max() >= cfg.vocab_size):
                     raise IndexError("token id out of range in all_x_bars")
                 keep += [offs, xi, a4]
-                cjobs[k] = _lib.Job(xi.ctypes.data, offs.ctypes.data, len(x_bars), a4.ctypes.data)
+                gate = None
+                if ready is not None:
+                    if not 0 <= int(ridx[ji]) < flags.size:
+                        raise IndexError("ready: flag index out of range")
+                    gate = flags.ctypes.data + 4 * int(ridx[ji])
+                cjobs[k] = _lib.Job(xi.ctypes.data, offs.ctypes.data, len(x_bars), a4.ctypes.data, gate)
                 per_bar = (force_bar_tokens or max_bar_token_limit) + 1
                 cap += 1 + len(x_bars) + min(len(x_bars) * per_bar, max(0, max_output_tokens) + len(x_bars) + per_bar)
             sc = _lib.SchedCfg(bar_bos_id=bos, bar_eos_id=eos, n_ctx_pairs=cfg.context_num_past_xy_pairs,

@@ -154,8 +154,11 @@ int etd_decoder_read_many(etd_dec*, int n, const int32_t* slots, int32_t* out, i
 /* The whole bar loop of EtudeDecoder.generate (etude_decoder.py:246-354: prompt assembly, history window, truncation,
  * token budget, Bar_EOS stop) for MANY independent jobs, scheduled natively as concurrent device streams.  A job is
  * one (song, attribute tuple): x_ids = its condition bars back to back, x_offsets [n_bars+1], attrs4 [n_bars][4] in
- * C-ABI attribute order.  Result: out[job_offsets[j] ..] = [n_bars_done, len_0 .., tokens of bar 0 ([Bar_BOS]+generated), ...]. */
-typedef struct { const int32_t* x_ids; const int32_t* x_offsets; int n_bars; const int32_t* attrs4; } etd_job;
+ * C-ABI attribute order.  Result: out[job_offsets[j] ..] = [n_bars_done, len_0 .., tokens of bar 0 ([Bar_BOS]+generated), ...].
+ * `ready` (may be null = ready now) points at a host int another thread sets non-zero once the job's condition bars are
+ * valid -- the upstream pipeline stages (infer.py:82-163: extract .. tokenize) of that song have finished; the scheduler
+ * admits jobs in list order and never reads x_ids/x_offsets/attrs4 of a job before its flag is set. */
+typedef struct { const int32_t* x_ids; const int32_t* x_offsets; int n_bars; const int32_t* attrs4; const int32_t* ready; } etd_job;
 typedef struct {
   int bar_bos_id, bar_eos_id, n_ctx_pairs, max_position_embeddings, max_output_tokens, max_bar_token_limit;
   float context_overlap_ratio;

@@ -76,6 +76,19 @@ def test_generate_many_equals_generate_and_budget_rules(dev):
     many = decN.generate_many(jobs, v, max_bar_token_limit=24)
     for (bars, at), got in zip(jobs, many):
         assert dec1.generate_ids(v, bars, at, max_bar_token_limit=24, temperature=0.0) == got
+    # jobs gated on upstream stages (delivered late, in two waves, from another thread) decode to the same ids
+    import threading, time
+    flags = np.zeros(2, np.int32)
+    idx = [0 if s < 3 else 1 for s in range(7)]
+
+    def deliver():
+        time.sleep(0.05); flags[0] = 1
+        time.sleep(0.2); flags[1] = 1
+    th = threading.Thread(target=deliver)
+    th.start()
+    gated = decN.generate_many(jobs, v, max_bar_token_limit=24, ready=(flags, idx))
+    th.join()
+    assert gated == many
     # oracle cross-check of one job incl. the global max_output_tokens budget (etude_decoder.py:301,352)
     sd = torch_sd(synth.decoder_state_dict(1, {}))
     bars, at = jobs[2]

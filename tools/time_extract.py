@@ -22,5 +22,7 @@ for it in range(3):
     feat = ex._front(44100)(wav); torch.cuda.synchronize(); t1 = time.perf_counter()
     on, off, mpe, vel = ex.transcript(feat); torch.cuda.synchronize(); t2 = time.perf_counter()
     a = [t.cpu().numpy() for t in (on, off, mpe, vel)]; t3 = time.perf_counter()
-    notes = ex._mpe2note(*a, inf.onset_threshold, inf.offset_threshold, inf.frame_threshold); t4 = time.perf_counter()
-    print(f"front {1e3*(t1-t0):.1f} ms | model {1e3*(t2-t1):.1f} ms | D2H {1e3*(t3-t2):.1f} ms | mpe2note {1e3*(t4-t3):.1f} ms ({len(notes)} notes)")
+    arr = ex._mpe2note_array(*a, inf.onset_threshold, inf.offset_threshold, inf.frame_threshold); t4 = time.perf_counter()
+    arr = arr[~((arr["offset"] - arr["onset"]) < inf.min_duration)]
+    notes = ex._notes_from_array(arr); t5 = time.perf_counter()
+    print(f"front {1e3*(t1-t0):.1f} ms | model {1e3*(t2-t1):.1f} ms | D2H {1e3*(t3-t2):.1f} ms | mpe2note C++ {1e3*(t4-t3):.1f} ms ({len(arr)} kept) | dicts {1e3*(t5-t4):.1f} ms")
