@@ -136,6 +136,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * esz;
     void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
     const bool small = bpipe && !big && (d->I + d->H) % (5 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
+    const bool catk = small || big;     // attention.dense folded into the down projection: [W2 | Wd] [gelu(..) ; attn] + (b2 + bd), one GEMM and no fp32 round trip of the dense output
     if (bpipe && (!small || l == 0)) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
@@ -163,7 +164,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     if (mfma_attn) {
       // ragged causal flash attention on the MFMA kernel of the Extract stage (prompts of all streams at once)
       AttnArgs t = {};
-      t.Q = d->Qb; t.ldq = d->H; t.K = d->Kp; t.ldk = d->H; t.VT = d->VTp; t.Spad = d->vt_spad; t.O = d->AOb; t.ldo = d->H;
+      t.Q = d->Qb; t.ldq = d->H; t.K = d->Kp; t.ldk = d->H; t.VT = d->VTp; t.Spad = d->vt_spad; t.O = d->Xcat + d->I; t.ldo = d->I + d->H;
       t.n_seq = pf->n; t.Sq = pf->max_len; t.Sk = pf->max_len; t.scale_log2e = 0.125f * 1.4426950408889634f;
       t.n_heads = d->nh; t.seq_row0 = pf->seq_row0; t.seq_len = pf->seq_len; t.causal = 1; t.flops_hint = pf->attn_flops;
       ETD_TRY(launch_attn(t, st));
@@ -171,7 +172,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       DAttnArgs at = {};
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = rows; at.M = M; at.O = d->AO; at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
-      if (small) { at.Ob = d->Xcat + d->I; at.ldob = d->I + d->H; }
+      if (catk) { at.Ob = d->Xcat + d->I; at.ldob = d->I + d->H; }
       ETD_TRY(launch_dattn(at, d->bf16w, st));
     }
     // ---- attention.dense
@@ -179,18 +180,14 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     de.X = d->AO; de.ldx = d->H; de.W = w.dense.W; de.bias = w.dense.b; de.M = M; de.N = d->H; de.Npad = w.dense.Npad; de.K = d->H;
     de.Y = d->DO; de.ldy = d->H;
     if (bpipe) de.Xb = d->AOb;
-    if (big) {
-      LinArgs a = {};
-      a.X = d->AOb; a.ldx = d->H; a.W = (const bf16*)w.dense.W; a.bias = w.dense.b; a.M = M; a.N = d->H; a.K = d->H; a.vt_block = -1; a.dec = de;
-      ETD_TRY(launch_linear_dec(a, DEPI_BIAS, st));
-    } else if (!small) {        // decode step: attention.dense is folded into the (down | dense) GEMM below
+    if (!catk) {                // (otherwise attention.dense is folded into the (down | dense) GEMM below)
       ETD_TRY(launch_dgemm(de, DEPI_BIAS, d->bf16w, st));
     }
     // ---- MLP up + GELU
     DGemmArgs up = {};
     up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
     up.Y = d->M1; up.ldy = d->I;
-    if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; if (small) { up.Yb = d->Xcat; up.ldy = d->I + d->H; } } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
+    if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; if (catk) { up.Yb = d->Xcat; up.ldy = d->I + d->H; } } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
     if (big) {
       LinArgs a = {};
       a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.W; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
@@ -204,8 +201,9 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     dn.add = d->DO; dn.hin = hin; dn.hout = hout;
     if (bpipe) dn.Xb = d->M1b;
     if (big) {
+      dn.add = nullptr;
       LinArgs a = {};
-      a.X = d->M1b; a.ldx = d->I; a.W = (const bf16*)w.down.W; a.bias = w.down.b; a.M = M; a.N = d->H; a.K = d->I; a.vt_block = -1; a.dec = dn;
+      a.X = d->Xcat; a.ldx = d->I + d->H; a.W = (const bf16*)w.cat.W; a.bias = w.cat.b; a.M = M; a.N = d->H; a.K = d->I + d->H; a.vt_block = -1; a.dec = dn;
       ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
     } else if (small) {
       dn.Xb = d->Xcat; dn.ldx = d->I + d->H; dn.W = w.cat.W; dn.K = d->I + d->H; dn.Npad = w.cat.Npad;
@@ -410,7 +408,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
     rc = rc ? rc : d->alloc(&d->Pk, (size_t)5 * 512 * H);
-    rc = rc ? rc : d->alloc(&d->Xcat, (size_t)512 * (d->I + H));
+    rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
     rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
     rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)

@@ -4,6 +4,18 @@
 #include "dec_kernels.h"
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU for the bf16 pipeline: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside bf16 rounding) -- one
+// v_rcp, one v_exp and 7 FMAs instead of libm's two-branch erff, which costs more VALU time than the K = 512 MFMA loop
+// of the up projection it follows.  The fp32 parity mode keeps erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f); p = fmaf(p, t, -0.284496736f); p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float er = fmaf(-p * t, e, 1.f);                  // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.f + copysignf(er, x));
+}
 
 // ---- shared epilogue: lane = token m, registers = features nb + acc_row(i, h)
 template <bool WBF16, int EPI>
@@ -71,7 +83,7 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
       for (int j = 0; j < 4; ++j) {
         v[j] = acc[4 * q + j];
         if (EPI != DEPI_LOGITS && EPI != DEPI_PARTIAL) v[j] += a.bias[n + j];
-        if (EPI == DEPI_GELU) v[j] = gelu_erf(v[j]);
+        if (EPI == DEPI_GELU) v[j] = WBF16 ? gelu_fast(v[j]) : gelu_erf(v[j]);
       }
       if constexpr (EPI == DEPI_RESID) {
         const f32x4 ad = *reinterpret_cast<const f32x4*>(a.add + (long long)m * a.N + n);

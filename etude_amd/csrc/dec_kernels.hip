@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGe
       const int n = n0 + 8 * q4 + 4 * h;
       if (n < up.N)
         *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
-            pack4(gelu_erf(v[4 * q4]), gelu_erf(v[4 * q4 + 1]), gelu_erf(v[4 * q4 + 2]), gelu_erf(v[4 * q4 + 3]));
+            pack4(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
     }
     return;
   }

@@ -12,10 +12,11 @@ struct LinArgs {
   const float* bias;                 // [N]
   int M, N, K;                       // K % 64 == 0, N % 256 == 0
   bf16* Y; int ldy;                  // row-major destination for n-blocks < vt_block (may be null if all go to VT)
-  int nb0;                           // (set by the launcher) first 256-feature block of this launch
+  int nb0, nby;                      // (set by the launcher) first 256-feature block of this launch, number of blocks
   int vt_block;                      // blockIdx.y == vt_block -> that 256-feature block is stored TRANSPOSED (V^T); -1 none
   bf16* VT; int S, Spad;             // VT[((seq*4+head)*64+d)*Spad + pos], seq = m / S, pos = m % S
   int relu;
+  int dbg;                           // timing ablations (ETD_LIN_DBG): 1 = skip the epilogue, 2 = skip the K loop; results are garbage
   // z-batching (several weight sets over the same X): per-blockIdx.z element offsets
   long long wz, bz, yz, vtz;
   // LayerNorm epilogue (N == 256): Y = LN(acc + bias + R) * gamma + beta

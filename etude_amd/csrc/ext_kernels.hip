@@ -10,9 +10,11 @@
 #include "ext_kernels.h"
 #include "prof.h"
 #include "dec_epilogue.h"
+#include <cstdint>
 #include <cstdlib>
 
 #define LDK 72  // LDS row stride (elements) of a 64-wide bf16 K-chunk: 144 B, 16-B aligned, conflict-free ds_read_b128
+#define EPP 136 // epilogue staging row stride (bf16 elements; 68 floats): 272 B = 17 x 16 B keeps rows 16-byte aligned, 128 features + pad
 
 // ================================================================================================
 // k_linear: Y = X W^T + b  (+ReLU | + residual + LayerNorm)       amt_apc.py:342-344,371,386-389,250,256
@@ -78,11 +80,17 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   bf16* Xs = reinterpret_cast<bf16*>(smem);
   bf16* Ws = Xs + 128 * LDK;
   float* sb = reinterpret_cast<float*>(smem + (128 + 256) * LDK * 2);   // bias | gamma | beta
-  float* lnred = reinterpret_cast<float*>(smem);                         // [2][128] after the K loop (LN mode)
+  float* lnred = reinterpret_cast<float*>(smem + 4 * 32 * EPP * 2);      // [2][128] after the K loop (LN mode), behind the epilogue staging tiles
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * 128, nb = blockIdx.y + a.nb0, n0 = nb * 256, z = blockIdx.z;
+  // Workgroup -> tile: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2).  The `nby`
+  // feature blocks of one 128-token tile read the same X rows, so they take CONSECUTIVE slots of ONE XCD (id = 8*slot +
+  // xcd, slot = tile_in_xcd * nby + block): the tile is fetched from HBM once and re-read from that XCD's L2.
+  const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+  const int mtile = (slot / a.nby) * 8 + xcd;
+  if (mtile * 128 >= a.M) return;
+  const int m0 = mtile * 128, nb = slot % a.nby + a.nb0, n0 = nb * 256, z = blockIdx.z;
   const bf16* W = a.W + (long long)z * a.wz + (long long)n0 * a.K;
   const float* bias = a.bias + (long long)z * a.bz + n0;
   sb[tid] = bias[tid];
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
   u32x4 xr[4], wr[8];
-  const int nk = a.K >> 6;
+  const int nk = (a.dbg & 2) ? 0 : a.K >> 6;
   lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, 0, xr, wr);
   for (int kc = 0; kc < nk; ++kc) {
     lin_lstore(Xs, Ws, tid, xr, wr);
@@ -107,13 +115,157 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
     __syncthreads();
   }
 
+  if ((a.dbg & 1) && acc[0][0][0] != 1.2345e30f && acc[1][3][15] != 1.2345e30f) return;
+
+  // ---- epilogue.  The accumulator has the TOKEN on the lane, so a direct store touches 64 different rows with 8 bytes
+  // each; the memory pipeline then handles one row segment at a time and the store phase costs as much as the K loop
+  // (measured at K = 256: 53 % of the kernel).  Instead every wave transposes its 32-token x 128-feature half tile through
+  // a private LDS region (the K-loop buffers are free now) and reads / writes global memory in full row segments, 16 bytes
+  // per lane: 4 rows x 256 B per instruction.
+  bf16* stg = reinterpret_cast<bf16*>(smem) + wave * (32 * EPP);
+  float* stf = reinterpret_cast<float*>(smem) + wave * (32 * (EPP / 2));
+  const int er = lane >> 4, ec = lane & 15;          // row-contiguous view: row = 4*it + er, 16-byte chunk ec
+  const int mw = m0 + wm * 64, nw = n0 + wn * 128;   // first token / feature of this wave's tile
+
   if constexpr (DEC) {
+    constexpr int EPI = MODE - 10;
+    const DGemmArgs& g = a.dec;
+    if constexpr (EPI == DEPI_GELU) {
+      // MLP up: bias + erf-GELU, bf16 rows for the down projection          modeling_gpt_neox.py:239-245
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = m0 + wm * 64 + mt * 32 + r;
-      if (m < a.M) {
+      for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) dgemm_epilogue<true, MODE - 10>(a.dec, acc[mt][nt], m, n0 + wn * 128 + nt * 32, h);
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int fl = nt * 32 + 8 * q + 4 * h, f = wn * 128 + fl;
+            *reinterpret_cast<bf16x4*>(stg + r * EPP + fl) =
+                pack4(gelu_fast(acc[mt][nt][4 * q] + sb[f]), gelu_fast(acc[mt][nt][4 * q + 1] + sb[f + 1]),
+                      gelu_fast(acc[mt][nt][4 * q + 2] + sb[f + 2]), gelu_fast(acc[mt][nt][4 * q + 3] + sb[f + 3]));
+          }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 4 + er, m = mw + mt * 32 + row;
+          if (m < a.M) *reinterpret_cast<u32x4*>(g.Yb + (long long)m * g.ldy + nw + ec * 8) = *reinterpret_cast<const u32x4*>(stg + row * EPP + ec * 8);
+        }
+        __syncthreads();
+      }
+    } else if constexpr (EPI == DEPI_RESID) {
+      // parallel residual: hout = ((acc + bias) [+ add]) + hin, all fp32      modeling_gpt_neox.py:272
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ntp = 0; ntp < 2; ++ntp) {
+#pragma unroll
+          for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int nt = ntp * 2 + nn, fl = nn * 32 + 8 * q + 4 * h, f = wn * 128 + ntp * 64 + fl;
+              const f32x4 o = {acc[mt][nt][4 * q] + sb[f], acc[mt][nt][4 * q + 1] + sb[f + 1], acc[mt][nt][4 * q + 2] + sb[f + 2], acc[mt][nt][4 * q + 3] + sb[f + 3]};
+              *reinterpret_cast<f32x4*>(stf + r * (EPP / 2) + fl) = o;
+            }
+          __syncthreads();
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int row = it * 4 + er, m = mw + mt * 32 + row;
+            if (m < a.M) {
+              const long long off = (long long)m * g.N + nw + ntp * 64 + ec * 4;
+              f32x4 v = *reinterpret_cast<const f32x4*>(stf + row * (EPP / 2) + ec * 4);
+              if (g.add) { const f32x4 ad = *reinterpret_cast<const f32x4*>(g.add + off); v[0] += ad[0]; v[1] += ad[1]; v[2] += ad[2]; v[3] += ad[3]; }
+              const f32x4 hi = *reinterpret_cast<const f32x4*>(g.hin + off);
+              const f32x4 o = {v[0] + hi[0], v[1] + hi[1], v[2] + hi[2], v[3] + hi[3]};
+              *reinterpret_cast<f32x4*>(g.hout + off) = o;
+            }
+          }
+          __syncthreads();
+        }
+    } else if constexpr (EPI == DEPI_QKV) {
+      if (!g.Qb) {
+        // (no MFMA-attention scratch: the prompt is longer than the scratch rows) -- token-on-lane epilogue
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int m = mw + mt * 32 + r;
+          if (m < a.M) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) dgemm_epilogue<true, EPI>(g, acc[mt][nt], m, nw + nt * 32, h);
+          }
+        }
+      } else {
+        // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207): a 64-feature pair of accumulator tiles is one
+        // (head, part).  RoPE on the token-on-lane values, then Q / K rows and the KV-cache rows leave as 128-byte segments.
+        const int er8 = lane >> 3, ec8 = lane & 7;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const int ml = mw + mt * 32 + r, mlc = ml < a.M ? ml : a.M - 1;
+          const int pos_l = g.rows.pos[mlc];
+          int rpos[4], rslot[4], ract[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            int m = mw + mt * 32 + it * 8 + er8; m = m < a.M ? m : a.M - 1;
+            rpos[it] = g.rows.pos[m]; rslot[it] = g.rows.slot[m]; ract[it] = g.rows.active[m];
+          }
+#pragma unroll
+          for (int ntp = 0; ntp < 2; ++ntp) {
+            const int fb = nw + ntp * 64, head = fb / 192, part = (fb - head * 192) >> 6;
+            float v[2][16];
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) v[nn][i] = acc[mt][ntp * 2 + nn][i] + sb[wn * 128 + ntp * 64 + nn * 32 + acc_row(i, h)];
+            if (part < 2) {
+              // partial RoPE on dims [0, 16): pair (d, d + 8); d = (i&3) + 4h (i < 4), d + 8 = register i + 4 of the same lane
+              const f32x4 c4 = *reinterpret_cast<const f32x4*>(g.rope_cos + (long long)pos_l * 8 + 4 * h);
+              const f32x4 s4 = *reinterpret_cast<const f32x4*>(g.rope_sin + (long long)pos_l * 8 + 4 * h);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const float x1 = v[0][i], x2 = v[0][i + 4];
+                v[0][i] = x1 * c4[i] - x2 * s4[i];
+                v[0][i + 4] = x2 * c4[i] + x1 * s4[i];
+              }
+            }
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<bf16x4*>(stg + r * EPP + nn * 32 + 8 * q + 4 * h) = pack4(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
+            if (part == 2 && ml < a.M) {
+              // V^T scratch of the MFMA attention kernel: [(seq, head)][d][pos]
+              bf16* vp = g.VTp + ((long long)(g.rows.seq[ml] * g.n_heads + head) * 64) * g.vt_spad + pos_l;
+#pragma unroll
+              for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) vp[(long long)(nn * 32 + acc_row(i, h)) * g.vt_spad] = (bf16)v[nn][i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int row = it * 8 + er8, m = mw + mt * 32 + row;
+              if (m < a.M) {
+                const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * EPP + ec8 * 8);
+                const long long ro = (long long)m * (g.n_heads * 64) + head * 64 + ec8 * 8;
+                if (part == 0) *reinterpret_cast<u32x4*>(g.Qb + ro) = val;
+                else {
+                  if (part == 1) *reinterpret_cast<u32x4*>(g.Kp + ro) = val;
+                  if (ract[it] && rpos[it] < g.max_ctx) {
+                    bf16* cp = reinterpret_cast<bf16*>(part == 1 ? g.Kc : g.Vc) + (long long)rslot[it] * g.slot_stride + ((long long)head * g.max_ctx + rpos[it]) * 64 + ec8 * 8;
+                    *reinterpret_cast<u32x4*>(cp) = val;
+                  }
+                }
+              }
+            }
+            __syncthreads();
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int m = mw + mt * 32 + r;
+        if (m < a.M) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) dgemm_epilogue<true, EPI>(g, acc[mt][nt], m, nw + nt * 32, h);
+        }
       }
     }
   } else if constexpr (!LN) {
@@ -136,41 +288,49 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
           }
       }
     } else {
+      bf16* ybase = a.Y + (long long)z * a.yz + nw + ec * 8;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const int m = m0 + wm * 64 + mt * 32 + r;
-        if (m < a.M) {
-          bf16* yrow = a.Y + (long long)z * a.yz + (long long)m * a.ldy + n0;
 #pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int f = wn * 128 + nt * 32 + 8 * q + 4 * h;
-              float v0 = acc[mt][nt][4 * q + 0] + sb[f + 0], v1 = acc[mt][nt][4 * q + 1] + sb[f + 1];
-              float v2 = acc[mt][nt][4 * q + 2] + sb[f + 2], v3 = acc[mt][nt][4 * q + 3] + sb[f + 3];
-              if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-              *reinterpret_cast<bf16x4*>(yrow + f) = pack4(v0, v1, v2, v3);
-            }
+          for (int q = 0; q < 4; ++q) {
+            const int fl = nt * 32 + 8 * q + 4 * h, f = wn * 128 + fl;
+            float v0 = acc[mt][nt][4 * q + 0] + sb[f + 0], v1 = acc[mt][nt][4 * q + 1] + sb[f + 1];
+            float v2 = acc[mt][nt][4 * q + 2] + sb[f + 2], v3 = acc[mt][nt][4 * q + 3] + sb[f + 3];
+            if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            *reinterpret_cast<bf16x4*>(stg + r * EPP + fl) = pack4(v0, v1, v2, v3);
+          }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int row = it * 4 + er, m = mw + mt * 32 + row;
+          if (m < a.M) *reinterpret_cast<u32x4*>(ybase + (long long)m * a.ldy) = *reinterpret_cast<const u32x4*>(stg + row * EPP + ec * 8);
         }
+        __syncthreads();
       }
     }
   } else {
     // residual + LayerNorm: a token's 256 features live in 2 waves (wn = 0, 1) x 2 half-lanes; the halves combine
-    // with one lane exchange, the waves through LDS in a fixed order
-    float s1[2];
+    // with one lane exchange, the waves through LDS in a fixed order.  The residual rows come in through the same
+    // staging region (row-segment loads), the normalised rows leave through it.
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int m = m0 + wm * 64 + mt * 32 + r;
-      const int mc = m < a.M ? m : a.M - 1;
-      const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
-      const bf16* rp = a.R + (long long)rrow * a.ldr;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + er, m = mw + mt * 32 + row;
+        const int mc = m < a.M ? m : a.M - 1;
+        const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
+        *reinterpret_cast<u32x4*>(stg + row * EPP + ec * 8) = *reinterpret_cast<const u32x4*>(a.R + (long long)rrow * a.ldr + wn * 128 + ec * 8);
+      }
+      __syncthreads();
       float s = 0.f;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int f = wn * 128 + nt * 32 + 8 * q + 4 * h;
-          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rp + f);
+          const int fl = nt * 32 + 8 * q + 4 * h, f = wn * 128 + fl;
+          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(stg + r * EPP + fl);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float v = acc[mt][nt][4 * q + j] + sb[f + j] + bf2f(rv[j]);
@@ -179,11 +339,10 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
           }
         }
       s += xhalf(s);
-      s1[mt] = s;
       if (h == 0) lnred[wn * 128 + wm * 64 + mt * 32 + r] = s;
+      __syncthreads();
     }
-    __syncthreads();
-    float mean[2], s2[2];
+    float mean[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const int tl = wm * 64 + mt * 32 + r;
@@ -198,7 +357,6 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { const float dlt = acc[mt][nt][i] - mean[mt]; s += dlt * dlt; }
       s += xhalf(s);
-      s2[mt] = s;
       if (h == 0) lnred[wn * 128 + wm * 64 + mt * 32 + r] = s;
     }
     __syncthreads();
@@ -206,28 +364,34 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
       const int tl = wm * 64 + mt * 32 + r;
       const float rstd = rsqrtf((lnred[tl] + lnred[128 + tl]) * (1.f / 256.f) + 1e-5f);
-      const int m = m0 + tl;
-      if (m < a.M) {
-        bf16* y1 = a.Y + (long long)m * a.ldy;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+      for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f = wn * 128 + nt * 32 + 8 * q + 4 * h;
-            float v[4];
+        for (int q = 0; q < 4; ++q) {
+          const int fl = nt * 32 + 8 * q + 4 * h, f = wn * 128 + fl;
+          float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (acc[mt][nt][4 * q + j] - mean[mt]) * rstd * sb[256 + f + j] + sb[512 + f + j];
-            *reinterpret_cast<bf16x4*>(y1 + f) = pack4(v[0], v[1], v[2], v[3]);
-          }
+          for (int j = 0; j < 4; ++j) v[j] = (acc[mt][nt][4 * q + j] - mean[mt]) * rstd * sb[256 + f + j] + sb[512 + f + j];
+          *reinterpret_cast<bf16x4*>(stg + r * EPP + fl) = pack4(v[0], v[1], v[2], v[3]);
+        }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + er, m = mw + mt * 32 + row;
+        if (m < a.M) *reinterpret_cast<u32x4*>(a.Y + (long long)m * a.ldy + wn * 128 + ec * 8) = *reinterpret_cast<const u32x4*>(stg + row * EPP + ec * 8);
       }
+      __syncthreads();
     }
-    (void)s1; (void)s2;
   }
 }
 
+// token tiles padded to a multiple of 8 (one per XCD), times the feature blocks of the launch
+static unsigned lin_grid_x(int M, int nby) { return (unsigned)(((M + 127) / 128 + 7) / 8 * 8 * nby); }
+static int lin_dbg() { static const int v = getenv("ETD_LIN_DBG") ? atoi(getenv("ETD_LIN_DBG")) : 0; return v; }
 int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   if (a.K % 64 || a.N % 256 || a.M <= 0) ETD_FAIL(ETD_EINVAL, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.vt_block >= 0 && (a.S % 4 || a.Spad % 4 || !a.VT)) ETD_FAIL(ETD_EINVAL, "linear: bad V^T args");
+  if (a.Y && (a.ldy % 8 || a.yz % 8 || ((uintptr_t)a.Y & 15))) ETD_FAIL(ETD_EINVAL, "linear: Y rows must be 16-byte aligned (ldy=%d)", a.ldy);
   // row-major blocks [0, vt_block) (or all), then the V^T block as its own launch (orientation is a
   // compile-time property of the MFMA loop)
   ProfScope ps("k_linear", st, 2.0 * a.M * a.N * a.K * nz, ((double)a.M * a.K + (double)a.N * a.K * nz + (double)a.M * a.N * nz) * 2);
@@ -235,21 +399,24 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   const int n_plain = a.vt_block >= 0 ? a.vt_block : nblk;
   if (a.vt_block >= 0 && a.vt_block != nblk - 1) ETD_FAIL(ETD_EINVAL, "linear: V^T block must be the last block");
   if (n_plain > 0) {
-    LinArgs b = a; b.nb0 = 0;
-    hipLaunchKernelGGL(k_linear<0>, dim3((a.M + 127) / 128, n_plain, nz), dim3(256), 0, st, b);
+    LinArgs b = a; b.nb0 = 0; b.dbg = lin_dbg(); b.nby = n_plain;
+    hipLaunchKernelGGL(k_linear<0>, dim3(lin_grid_x(a.M, n_plain), 1, nz), dim3(256), 0, st, b);
   }
   if (a.vt_block >= 0) {
-    LinArgs b = a; b.nb0 = a.vt_block;
-    hipLaunchKernelGGL(k_linear<1>, dim3((a.M + 127) / 128, 1, nz), dim3(256), 0, st, b);
+    LinArgs b = a; b.nb0 = a.vt_block; b.dbg = lin_dbg(); b.nby = 1;
+    hipLaunchKernelGGL(k_linear<1>, dim3(lin_grid_x(a.M, 1), 1, nz), dim3(256), 0, st, b);
   }
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
 int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
   if (a.K % 64 || a.N % 256 || a.M <= 0 || !a.bias) ETD_FAIL(ETD_EINVAL, "linear_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (dec_epi == DEPI_GELU && (!a.dec.Yb || a.dec.ldy % 8 || ((uintptr_t)a.dec.Yb & 15))) ETD_FAIL(ETD_EINVAL, "linear_dec: GELU needs 16-byte aligned bf16 rows");
+  if (dec_epi == DEPI_RESID && (!a.dec.hin || !a.dec.hout || a.dec.N % 4)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad residual arguments");
+  if (dec_epi == DEPI_QKV && a.dec.Qb && (!a.dec.Kp || !a.dec.VTp || a.dec.rot_half != 8 || a.N % 192 || !a.dec.rows.seq)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad QKV arguments");
   ProfScope ps("k_linear_dec", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K) * 2);
-  dim3 g((a.M + 127) / 128, a.N / 256, 1);
-  LinArgs b = a; b.nb0 = 0;
+  dim3 g(lin_grid_x(a.M, a.N / 256), 1, 1);
+  LinArgs b = a; b.nb0 = 0; b.dbg = lin_dbg(); b.nby = a.N / 256;
   switch (dec_epi) {
     case DEPI_BIAS: hipLaunchKernelGGL(k_linear<10 + DEPI_BIAS>, g, dim3(256), 0, st, b); break;
     case DEPI_GELU: hipLaunchKernelGGL(k_linear<10 + DEPI_GELU>, g, dim3(256), 0, st, b); break;
@@ -262,10 +429,11 @@ int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
 }
 
 int launch_linear_ln(const LinArgs& a, hipStream_t st) {
-  if (a.K % 64 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta) ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
+  if (a.K % 64 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta || a.ldr % 8 || a.ldy % 8 || (((uintptr_t)a.R | (uintptr_t)a.Y) & 15))
+    ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
   ProfScope ps("k_linear_ln", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * a.N) * 2);
-  dim3 g((a.M + 127) / 128, 1, 1);
-  LinArgs b = a; b.nb0 = 0;
+  dim3 g(lin_grid_x(a.M, 1), 1, 1);
+  LinArgs b = a; b.nb0 = 0; b.dbg = lin_dbg(); b.nby = 1;
   hipLaunchKernelGGL(k_linear<2>, g, dim3(256), 0, st, b);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
