@@ -126,7 +126,7 @@ int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst)
 //                          batched prefill) or the K-split skinny GEMM (M <= 512, the batched decode step).
 struct PrefillInfo { int n; const int* seq_row0; const int* seq_len; int max_len; double attn_flops; };
 
-int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr) {
+int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false) {
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && M > 1;
@@ -137,7 +137,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
     const bool small = bpipe && !big && (d->I + d->H) % (5 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
     const bool catk = small || big;     // attention.dense folded into the down projection: [W2 | Wd] [gelu(..) ; attn] + (b2 + bd), one GEMM and no fp32 round trip of the dense output
-    if (bpipe && (!small || l == 0)) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
+    if (bpipe && (!small || (l == 0 && !ln0_done))) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
     q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
@@ -206,6 +206,9 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       a.X = d->Xcat; a.ldx = d->I + d->H; a.W = (const bf16*)w.cat.W; a.bias = w.cat.b; a.M = M; a.N = d->H; a.K = d->I + d->H; a.vt_block = -1; a.dec = dn;
       ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
     } else if (small) {
+      // (down | dense) projection with K split over workgroups, then ONE row kernel: partial sums + bias + residual and the
+      // next layer's two LayerNorms.  (Folding that row kernel into the GEMM's last-arriving workgroup was measured: the
+      // serial read of 5 slabs x 32 rows costs 3x the kernel boundary it saves.)
       dn.Xb = d->Xcat; dn.ldx = d->I + d->H; dn.W = w.cat.W; dn.K = d->I + d->H; dn.Npad = w.cat.Npad;
       dn.k_splits = 5; dn.Y = d->Pk; dn.ldy = d->H;
       ETD_TRY(launch_dgemm(dn, DEPI_PARTIAL, true, st));
@@ -473,28 +476,57 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     d->last_slots.assign(slots, slots + n_active);
     HIP_TRY(hipMemcpyAsync(d->slots_dev, d->last_slots.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, st));
   }
-  auto one_step = [&](hipStream_t s_) -> int {
-    double kvb = 0;
-    for (int i = 0; i < n_active; ++i) { int& hl = d->host_len[slots[i]]; kvb += (double)(hl + 1) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4); if (hl < d->ctx - 1) ++hl; }
-    d->attn_bytes_hint = kvb;
+  // bf16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
+  // (QKV|up, attention, down|dense, residual + LayerNorm) and one head launch that also prepares the next step's rows
+  const int vpad = (d->V + 31) / 32 * 32;
+  const bool fused = d->bf16w && n_active > 1 && n_active <= 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
+                     vpad <= d->head.Npad && !getenv("ETD_NO_FUSED_STEP");
+  auto embed = [&](hipStream_t s_) -> int {
     DEmbedArgs e = {};
     e.slots = d->slots_dev; e.len = d->len; e.done = d->done; e.row_slot_out = d->row_slot; e.row_pos_out = d->row_pos; e.row_active_out = d->row_active;
     e.cur_tok = d->cur_tok; e.tgt_attrs = d->tgt_attrs; e.tgt_cls = 2 /* TGT_CLASS_ID, etude/data/dataset.py:19 */;
     e.M = n_active; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
     e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
     e.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
-    ETD_TRY(launch_dembed(e, s_));
+    return launch_dembed(e, s_);
+  };
+  auto one_step = [&](hipStream_t s_) -> int {
+    double kvb = 0;
+    for (int i = 0; i < n_active; ++i) { int& hl = d->host_len[slots[i]]; kvb += (double)(hl + 1) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4); if (hl < d->ctx - 1) ++hl; }
+    d->attn_bytes_hint = kvb;
+    const DecRows rows{d->row_slot, d->row_pos, d->row_active};
+    if (!fused) ETD_TRY(embed(s_));
     float* hf = nullptr;
-    ETD_TRY(forward_body(d, n_active, e.rows, &hf, s_));
+    ETD_TRY(forward_body(d, n_active, rows, &hf, s_, nullptr, fused));
+    if (fused) {
+      const Layer& w0 = d->layers[0];
+      DHeadArgs hd = {};
+      hd.hfin = hf; hd.M = n_active; hd.H = d->H; hd.V = d->V; hd.Vpad = vpad;
+      hd.lnf_g = d->lnfg; hd.lnf_b = d->lnfb; hd.eps = d->cfg.layer_norm_eps; hd.Whead = (const bf16*)d->head.W;
+      hd.row_slot = d->row_slot; hd.row_pos = d->row_pos; hd.row_active = d->row_active;
+      hd.cur_tok = d->cur_tok; hd.len = d->len; hd.done = d->done; hd.n_out = d->n_out; hd.out_tok = d->out_tok; hd.out_cap = d->out_cap;
+      hd.eos = d->eos; hd.limit = d->limit; hd.tgt_attrs = d->tgt_attrs; hd.tgt_cls = 2; hd.n_bins = d->cfg.num_attribute_bins;
+      hd.word = d->word; hd.cls_emb = d->cls_emb; hd.attr_tab = d->attr_tab;
+      hd.g1 = w0.ln1g; hd.b1 = w0.ln1b; hd.g2 = w0.ln2g; hd.b2 = w0.ln2b;
+      hd.h = d->h; hd.x1 = d->X1b; hd.x2 = d->X2b;
+      ETD_TRY(launch_dstep_head(hd, s_));
+      return ETD_OK;
+    }
     ETD_TRY(head_logits(d, hf, n_active, d->logits, s_));
     DArgmaxArgs am = {};
     am.logits = d->logits; am.ldl = d->V; am.V = d->V; am.M = n_active;
-    am.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
+    am.rows = rows;
     am.cur_tok = d->cur_tok; am.len = d->len; am.done = d->done; am.n_out = d->n_out; am.out_tok = d->out_tok; am.out_cap = d->out_cap;
     am.eos = d->eos; am.limit = d->limit;
     ETD_TRY(launch_dargmax(am, s_));
     return ETD_OK;
   };
+  if (fused) {
+    // rows, embeddings and first-layer LayerNorms of the FIRST step of this call (every later step gets them from the head kernel)
+    ETD_TRY(embed(st));
+    const Layer& w0 = d->layers[0];
+    ETD_TRY(launch_ln_rows(d->h, n_active, d->H, w0.ln1g, w0.ln1b, w0.ln2g, w0.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
+  }
   // The step is ~50 short dependent kernels: replay it as a hipGraph (captured once per n_active; every
   // kernel argument is a fixed workspace/state pointer, the slot list lives in device memory).  Capture needs
   // a non-default stream and must not contain the profiler's event records.

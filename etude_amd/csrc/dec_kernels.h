@@ -43,6 +43,21 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st);
 // decode step, bf16: fused-QKV(+RoPE, KV append) and MLP-up(+GELU) projections of one layer in a single launch
 int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st);
 
+// decode step, bf16: final LayerNorm + lm_head + greedy argmax + stream state update, then the NEXT step's token embedding,
+// row metadata and first-layer LayerNorms -- the tail of step t and the head of step t+1 in one launch
+struct DHeadArgs {
+  const float* hfin; int M, H, V, Vpad;       // last layer's residual stream [M][H]
+  const float* lnf_g; const float* lnf_b; float eps;
+  const bf16* Whead;                           // [Vpad][H]
+  int* row_slot; int* row_pos; int* row_active;   // in: this step's rows; out: next step's
+  int* cur_tok; int* len; int* done; int* n_out; int* out_tok; int out_cap; const int* eos; const int* limit;
+  const int* tgt_attrs; int tgt_cls; int n_bins;
+  const float* word; const float* cls_emb; const float* attr_tab;
+  const float* g1; const float* b1; const float* g2; const float* b2;   // layer 0 LayerNorms
+  float* h; bf16* x1; bf16* x2;                // next step's embeddings [M][H] and their LayerNorms
+};
+int launch_dstep_head(const DHeadArgs& a, hipStream_t st);
+
 struct DAttnArgs {
   const float* Q;                // [M][hidden]
   const void* Kc; const void* Vc; long long slot_stride; int max_ctx, n_heads;

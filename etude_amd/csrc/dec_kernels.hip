@@ -360,6 +360,156 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
 }
 
 // ================================================================================================
+// k_dstep_head: tail of decode step t and head of step t+1 in one launch, one workgroup per 32 rows:
+//   final LayerNorm -> lm_head logits (MFMA, K split in the same eight 64-wide slices and added in the same order as
+//   k_dgemm_s, so the logits are bit-identical to the unfused path) -> greedy argmax (lowest index on ties) -> stream
+//   state update (etude_decoder.py:333-343) -> embedding of the new token (:166-179), row metadata and the first layer's
+//   two LayerNorms for the next step.
+// ================================================================================================
+#define DH_LDX 520   // LayerNorm'ed rows in LDS: 512 + 8 bf16 (1040 B rows: conflict-free 16-byte fragment reads)
+#define DH_LDL 257   // logits rows in LDS (floats): up to 256 vocabulary entries + 1
+__global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16 Xs[32 * DH_LDX];
+  __shared__ float Ls[32 * DH_LDL];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 32, H = a.H;     // H == 512 (checked by the launcher)
+  // ---- final LayerNorm of 4 rows per wave (summation order of k_dgemm_s's LayerNorm prologue)
+  for (int j = 0; j < 4; ++j) {
+    const int rl = wave * 4 + j;
+    int gm = m0 + rl; gm = gm < a.M ? gm : a.M - 1;
+    const float* xp = a.hfin + (long long)gm * H;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + lane * 4), v1 = *reinterpret_cast<const f32x4*>(xp + lane * 4 + 256);
+    float s = 0.f;
+    s += v0[0] + v0[1] + v0[2] + v0[3];
+    s += v1[0] + v1[1] + v1[2] + v1[3];
+    s = wave_sum(s);
+    const float mean = s / (float)H;
+    float q = 0.f;
+    { const float d0 = v0[0] - mean, d1 = v0[1] - mean, d2 = v0[2] - mean, d3 = v0[3] - mean; q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3; }
+    { const float d0 = v1[0] - mean, d1 = v1[1] - mean, d2 = v1[2] - mean, d3 = v1[3] - mean; q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3; }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)H + a.eps);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int k = lane * 4 + half * 256;
+      const f32x4 x = half ? v1 : v0;
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.lnf_g + k), b = *reinterpret_cast<const f32x4*>(a.lnf_b + k);
+      *reinterpret_cast<bf16x4*>(Xs + rl * DH_LDX + k) =
+          pack4((x[0] - mean) * rstd * g[0] + b[0], (x[1] - mean) * rstd * g[1] + b[1], (x[2] - mean) * rstd * g[2] + b[2], (x[3] - mean) * rstd * g[3] + b[3]);
+    }
+  }
+  __syncthreads();
+  // ---- logits: wave w < Vpad/32 owns features [32w, 32w+32)
+  if (wave * 32 < a.Vpad) {
+    const bf16* wrow = a.Whead + (long long)(wave * 32 + r) * H;
+    const bf16* xrow = Xs + r * DH_LDX;
+    f32x16 tot;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const int k = sl * 64 + s4 * 16 + h * 8;
+        acc = mfma32(*reinterpret_cast<const bf16x8*>(wrow + k), *reinterpret_cast<const bf16x8*>(xrow + k), acc);
+      }
+      if (sl == 0) tot = acc;
+      else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot[i] += acc[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int f = wave * 32 + acc_row(i, h);
+      if (f < a.V) Ls[r * DH_LDL + f] = tot[i];
+    }
+  }
+  __syncthreads();
+  // ---- per row: argmax, state update, next embedding + LayerNorms (4 rows per wave)
+  for (int j = 0; j < 4; ++j) {
+    const int rl = wave * 4 + j, m = m0 + rl;
+    if (m >= a.M) break;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = lane; v < a.V; v += 64) {
+      const float x = Ls[rl * DH_LDL + v];
+      if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    const int slot = a.row_slot[m];
+    int tok = a.cur_tok[slot], ln = a.len[slot], dn = a.done[slot];
+    if (a.row_active[m] && !dn) {
+      const int n = a.n_out[slot];
+      tok = bi; ln = a.row_pos[m] + 1;
+      const int fin = (bi == a.eos[slot] || n + 1 >= a.limit[slot]) ? 1 : 0;
+      if (lane == 0) {
+        if (n < a.out_cap) a.out_tok[(long long)slot * a.out_cap + n] = bi;
+        a.n_out[slot] = n + 1;
+        a.cur_tok[slot] = bi;
+        a.len[slot] = ln;
+        if (fin) a.done[slot] = 1;
+      }
+      dn = fin;
+    }
+    // next step's row: position = new length, active = not done; embedding of the token it will feed
+    if (lane == 0) { a.row_pos[m] = ln; a.row_active[m] = dn ? 0 : 1; }
+    int at[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) at[k] = a.tgt_attrs[slot * 4 + k];
+    const int k = lane * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int i = k + e;
+      float p = a.attr_tab[(0 * a.n_bins + at[0]) * H + i];
+      p += a.attr_tab[(1 * a.n_bins + at[1]) * H + i];
+      p += a.attr_tab[(2 * a.n_bins + at[2]) * H + i];
+      p += a.attr_tab[(3 * a.n_bins + at[3]) * H + i];
+      v[e] = (a.word[(long long)tok * H + i] + a.cls_emb[a.tgt_cls * H + i]) + p;
+    }
+    const long long ro = (long long)m * H;
+    { const f32x4 oa = {v[0], v[1], v[2], v[3]}, ob = {v[4], v[5], v[6], v[7]};
+      *reinterpret_cast<f32x4*>(a.h + ro + k) = oa; *reinterpret_cast<f32x4*>(a.h + ro + k + 4) = ob; }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    s = wave_sum(s);
+    const float mean = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d0 = v[e] - mean; q += d0 * d0; }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)H + a.eps);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(a.g1 + k), gb = *reinterpret_cast<const f32x4*>(a.g1 + k + 4);
+    const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b1 + k), bb = *reinterpret_cast<const f32x4*>(a.b1 + k + 4);
+    const f32x4 ha = *reinterpret_cast<const f32x4*>(a.g2 + k), hb = *reinterpret_cast<const f32x4*>(a.g2 + k + 4);
+    const f32x4 ca = *reinterpret_cast<const f32x4*>(a.b2 + k), cb = *reinterpret_cast<const f32x4*>(a.b2 + k + 4);
+    bf16x8 o1, o2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o1[e] = (bf16)((v[e] - mean) * rstd * ga[e] + ba[e]); o1[4 + e] = (bf16)((v[4 + e] - mean) * rstd * gb[e] + bb[e]);
+      o2[e] = (bf16)((v[e] - mean) * rstd * ha[e] + ca[e]); o2[4 + e] = (bf16)((v[4 + e] - mean) * rstd * hb[e] + cb[e]);
+    }
+    *reinterpret_cast<bf16x8*>(a.x1 + ro + k) = o1;
+    *reinterpret_cast<bf16x8*>(a.x2 + ro + k) = o2;
+  }
+}
+
+int launch_dstep_head(const DHeadArgs& a, hipStream_t st) {
+  if (a.M < 1 || a.H != 512 || a.V < 1 || a.V > a.Vpad || a.Vpad % 32 || a.Vpad > 256 || !a.hfin || !a.Whead || !a.h || !a.x1 || !a.x2)
+    ETD_FAIL(ETD_EINVAL, "dstep_head: bad arguments (needs hidden 512, vocabulary <= 256)");
+  ProfScope ps("k_dstep_head", st, 2.0 * a.M * a.V * a.H, (double)a.Vpad * a.H * 2);
+  hipLaunchKernelGGL(k_dstep_head, dim3((a.M + 31) / 32), dim3(512), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
 // k_dgemv (M == 1, the reference's batch-1 token loop): each wave owns 4 output features, the 64 lanes
 // split K in 16-byte pieces (one fully coalesced 1 KiB / 2 KiB row segment per load instruction).
 // ================================================================================================

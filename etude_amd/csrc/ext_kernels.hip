@@ -12,6 +12,8 @@
 #include "dec_epilogue.h"
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 
 #define LDK 72  // LDS row stride (elements) of a 64-wide bf16 K-chunk: 144 B, 16-B aligned, conflict-free ds_read_b128
 #define EPP 136 // epilogue staging row stride (bf16 elements; 68 floats): 272 B = 17 x 16 B keeps rows 16-byte aligned, 128 features + pad
@@ -20,19 +22,20 @@
 // k_linear: Y = X W^T + b  (+ReLU | + residual + LayerNorm)       amt_apc.py:342-344,371,386-389,250,256
 // Workgroup 256 threads = 4 waves on a 128-token x 256-feature tile.
 // ================================================================================================
-__device__ __forceinline__ void lin_gload(const bf16* X, int ldx, int M, int K, const bf16* W, int m0, int tid, int kc,
-                                          u32x4 (&xr)[4], u32x4 (&wr)[8]) {
+// Global -> register staging through buffer descriptors: a wave-uniform base (the workgroup's first X row / the weight
+// block) in SGPRs, one 32-bit byte offset per lane and the K-chunk as scalar offset -- 12 address VGPRs instead of ~50 for
+// flat 64-bit pointers (which is what lets the second X register set fit), and rows past M read as zeros (bounds check).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t lin_rsrc(const void* p, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes), 0x00020000);
+}
+__device__ __forceinline__ void lin_gload_x(rsrc_t xs, const int (&xo)[4], int kc, u32x4 (&xr)[4]) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
-    int gm = m0 + row; gm = gm < M ? gm : M - 1;
-    xr[i] = *reinterpret_cast<const u32x4*>(X + (long long)gm * ldx + kc * 64 + ch * 8);
-  }
+  for (int i = 0; i < 4; ++i) xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, xo[i], kc * 128, 0));
+}
+__device__ __forceinline__ void lin_gload_w(rsrc_t ws, const int (&wo)[8], int kc, u32x4 (&wr)[8]) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
-    wr[i] = *reinterpret_cast<const u32x4*>(W + (long long)row * K + kc * 64 + ch * 8);
-  }
+  for (int i = 0; i < 8; ++i) wr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, wo[i], kc * 128, 0));
 }
 __device__ __forceinline__ void lin_lstore(bf16* Xs, bf16* Ws, int tid, const u32x4 (&xr)[4], const u32x4 (&wr)[8]) {
 #pragma unroll
@@ -104,16 +107,43 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
-  u32x4 xr[4], wr[8];
-  const int nk = (a.dbg & 2) ? 0 : a.K >> 6;
-  lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, 0, xr, wr);
-  for (int kc = 0; kc < nk; ++kc) {
-    lin_lstore(Xs, Ws, tid, xr, wr);
+  // K loop, 64-deep chunks through one LDS buffer.  The activation rows come from HBM / the Infinity Cache with ~2-3 us of
+  // latency under load while a chunk's 32 MFMAs per wave take 0.4 us, so X is requested TWO chunks ahead (two register
+  // sets, alternating); the weight chunk (L2-resident) one ahead, and before the X request of the same step so that the
+  // in-order vmcnt wait for it leaves the younger X loads in flight.
+#define LIN_STAMP(i) do { if (a.tbuf && tid == 0) a.tbuf[(long long)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+  LIN_STAMP(0);
+  u32x4 xa[4], xb[4], wr[8];
+  const int nk = (a.dbg & 2) ? 0 : a.K >> 6;       // even: K % 128 == 0 is checked by the launchers
+  const rsrc_t xs = lin_rsrc(a.X + (long long)m0 * a.ldx, ((long long)(a.M - m0) * a.ldx) * 2);
+  const rsrc_t ws = lin_rsrc(W, (long long)256 * a.K * 2);
+  int xo[4], wo[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int c = tid + i * 256; xo[i] = ((c >> 3) * a.ldx + (c & 7) * 8) * 2; }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { const int c = tid + i * 256; wo[i] = ((c >> 3) * a.K + (c & 7) * 8) * 2; }
+  lin_gload_x(xs, xo, 0, xa);
+  lin_gload_w(ws, wo, 0, wr);
+  lin_gload_x(xs, xo, nk > 1 ? 1 : 0, xb);
+  for (int kc = 0; kc < nk; kc += 2) {
+    lin_lstore(Xs, Ws, tid, xa, wr);
     __syncthreads();
-    if (kc + 1 < nk) lin_gload(a.X, a.ldx, a.M, a.K, W, m0, tid, kc + 1, xr, wr);
+    if (kc == 0) LIN_STAMP(1);
+    lin_gload_w(ws, wo, kc + 1, wr);                                        // kc + 1 < nk always (nk even)
+    if (kc + 2 < nk) lin_gload_x(xs, xo, kc + 2, xa);
     lin_chunk<vt>(Xs, Ws, wm, wn, r, h, acc);
     __syncthreads();
+    if (kc == 0) LIN_STAMP(2);
+    lin_lstore(Xs, Ws, tid, xb, wr);
+    __syncthreads();
+    if (kc == 0) LIN_STAMP(3);
+    if (kc + 2 < nk) lin_gload_w(ws, wo, kc + 2, wr);
+    if (kc + 3 < nk) lin_gload_x(xs, xo, kc + 3, xb);
+    lin_chunk<vt>(Xs, Ws, wm, wn, r, h, acc);
+    __syncthreads();
+    if (kc == 0) LIN_STAMP(4);
   }
+  LIN_STAMP(5);
 
   if ((a.dbg & 1) && acc[0][0][0] != 1.2345e30f && acc[1][3][15] != 1.2345e30f) return;
 
@@ -308,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
           if (m < a.M) *reinterpret_cast<u32x4*>(ybase + (long long)m * a.ldy) = *reinterpret_cast<const u32x4*>(stg + row * EPP + ec * 8);
         }
         __syncthreads();
+        LIN_STAMP(6 + mt);
       }
     }
   } else {
@@ -389,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 static unsigned lin_grid_x(int M, int nby) { return (unsigned)(((M + 127) / 128 + 7) / 8 * 8 * nby); }
 static int lin_dbg() { static const int v = getenv("ETD_LIN_DBG") ? atoi(getenv("ETD_LIN_DBG")) : 0; return v; }
 int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
-  if (a.K % 64 || a.N % 256 || a.M <= 0) ETD_FAIL(ETD_EINVAL, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.K % 128 || a.N % 256 || a.M <= 0) ETD_FAIL(ETD_EINVAL, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.vt_block >= 0 && (a.S % 4 || a.Spad % 4 || !a.VT)) ETD_FAIL(ETD_EINVAL, "linear: bad V^T args");
   if (a.Y && (a.ldy % 8 || a.yz % 8 || ((uintptr_t)a.Y & 15))) ETD_FAIL(ETD_EINVAL, "linear: Y rows must be 16-byte aligned (ldy=%d)", a.ldy);
   // row-major blocks [0, vt_block) (or all), then the V^T block as its own launch (orientation is a
@@ -400,7 +431,33 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   if (a.vt_block >= 0 && a.vt_block != nblk - 1) ETD_FAIL(ETD_EINVAL, "linear: V^T block must be the last block");
   if (n_plain > 0) {
     LinArgs b = a; b.nb0 = 0; b.dbg = lin_dbg(); b.nby = n_plain;
-    hipLaunchKernelGGL(k_linear<0>, dim3(lin_grid_x(a.M, n_plain), 1, nz), dim3(256), 0, st, b);
+    static int stamp_left = getenv("ETD_LIN_STAMP") ? atoi(getenv("ETD_LIN_STAMP")) : 0;
+    const unsigned gx = lin_grid_x(a.M, n_plain);
+    if (stamp_left > 0 && nz == 1) {
+      --stamp_left;
+      long long* tb = nullptr;
+      (void)hipMalloc(&tb, (size_t)gx * 16 * 8);
+      (void)hipMemsetAsync(tb, 0, (size_t)gx * 16 * 8, st);
+      b.tbuf = tb;
+      hipLaunchKernelGGL(k_linear<0>, dim3(gx, 1, nz), dim3(256), 0, st, b);
+      (void)hipStreamSynchronize(st);
+      std::vector<long long> hb((size_t)gx * 16);
+      (void)hipMemcpy(hb.data(), tb, hb.size() * 8, hipMemcpyDeviceToHost);
+      (void)hipFree(tb);
+      double d[8] = {0}; long long n = 0, tmin = -1, tmax = 0;
+      for (unsigned g = 0; g < gx; ++g) {
+        const long long* t = &hb[(size_t)g * 16];
+        if (!t[0] || !t[7]) continue;
+        ++n;
+        for (int i = 0; i < 7; ++i) d[i] += (double)(t[i + 1] - t[i]);
+        if (tmin < 0 || t[0] < tmin) tmin = t[0];
+        if (t[7] > tmax) tmax = t[7];
+      }
+      fprintf(stderr, "[lin stamp] M=%d N=%d K=%d relu=%d wgs=%lld span=%lld clk | load0+lstore %.0f | chunk0 %.0f | lstore1 %.0f | chunk1 %.0f | rest of K loop %.0f | epi0 %.0f | epi1 %.0f\n",
+              a.M, a.N, a.K, a.relu, n, tmax - tmin, d[0] / n, d[1] / n, d[2] / n, d[3] / n, d[4] / n, d[5] / n, d[6] / n);
+      return ETD_OK;
+    }
+    hipLaunchKernelGGL(k_linear<0>, dim3(gx, 1, nz), dim3(256), 0, st, b);
   }
   if (a.vt_block >= 0) {
     LinArgs b = a; b.nb0 = a.vt_block; b.dbg = lin_dbg(); b.nby = 1;
@@ -410,7 +467,7 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   return ETD_OK;
 }
 int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
-  if (a.K % 64 || a.N % 256 || a.M <= 0 || !a.bias) ETD_FAIL(ETD_EINVAL, "linear_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+  if (a.K % 128 || a.N % 256 || a.M <= 0 || !a.bias) ETD_FAIL(ETD_EINVAL, "linear_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (dec_epi == DEPI_GELU && (!a.dec.Yb || a.dec.ldy % 8 || ((uintptr_t)a.dec.Yb & 15))) ETD_FAIL(ETD_EINVAL, "linear_dec: GELU needs 16-byte aligned bf16 rows");
   if (dec_epi == DEPI_RESID && (!a.dec.hin || !a.dec.hout || a.dec.N % 4)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad residual arguments");
   if (dec_epi == DEPI_QKV && a.dec.Qb && (!a.dec.Kp || !a.dec.VTp || a.dec.rot_half != 8 || a.N % 192 || !a.dec.rows.seq)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad QKV arguments");
@@ -429,7 +486,7 @@ int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
 }
 
 int launch_linear_ln(const LinArgs& a, hipStream_t st) {
-  if (a.K % 64 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta || a.ldr % 8 || a.ldy % 8 || (((uintptr_t)a.R | (uintptr_t)a.Y) & 15))
+  if (a.K % 128 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta || a.ldr % 8 || a.ldy % 8 || (((uintptr_t)a.R | (uintptr_t)a.Y) & 15))
     ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
   ProfScope ps("k_linear_ln", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * a.N) * 2);
   dim3 g(lin_grid_x(a.M, 1), 1, 1);

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""How well do independent decoder engines overlap?  E engines x S streams, decode steps only (hipGraph replays), ctx ~340."""
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from etude_amd import _lib, synth  # noqa: E402
+from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig  # noqa: E402
+
+if __name__ == "__main__":
+    S = int(sys.argv[1]) if len(sys.argv) > 1 else 72
+    ctx0 = int(sys.argv[2]) if len(sys.argv) > 2 else 320
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 96
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(0)
+    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    tg = np.asarray([2, 1, 1, 1], np.int32)
+    decs = []
+    for e in range(4):
+        dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=1024)
+        st = dec._stream()
+        for s in range(S):
+            ids = rng.integers(6, 154, ctx0).astype(np.int32)
+            cls = rng.integers(1, 3, ctx0).astype(np.int32)
+            a4 = rng.integers(0, 3, (4, ctx0)).astype(np.int32)
+            _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, 1000, st), "begin_bar")
+        decs.append(dec)
+    slots = np.arange(S, dtype=np.int32)
+    for dec in decs:
+        _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, S, 4, dec._stream()), "step")
+    torch.cuda.synchronize(dev)
+
+    def run(dec):
+        torch.cuda.set_device(0)
+        _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, S, steps, dec._stream()), "step")
+        torch.cuda.current_stream().synchronize()
+
+    for E in (1, 2, 3, 4, 1):
+        th = [threading.Thread(target=run, args=(decs[i],)) for i in range(E)]
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t
+        print(f"E={E}: {1e3 * dt / steps:.4f} ms per step-round, {E * S * steps / dt / 1e3:.1f} k tok/s aggregate, {E * steps / dt / 1e3:.3f} engine-steps/ms")
