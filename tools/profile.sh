@@ -9,7 +9,7 @@ mkdir -p $OUT
 ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --clips ${CLIPS:-8} --bars ${BARS:-92}"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 $ROOT/bench.py $ARGS > $OUT/prof_trace.json 2> $OUT/prof_trace.err
-PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --clips 1 --attr-grid 27 --bars 4"
+PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --clips ${CLIPS:-8} --attr-grid 27 --bars ${PMC_BARS:-24}"   # same rows per engine and (after 4 bars) the same contexts as the full run
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -- python3 $ROOT/bench.py $PARGS > $OUT/prof_fetch.json 2> $OUT/prof_fetch.err
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -- python3 $ROOT/bench.py $PARGS > $OUT/prof_write.json 2> $OUT/prof_write.err
 cd $ROOT
