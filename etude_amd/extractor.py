@@ -126,6 +126,7 @@ class AMTAPC_Extractor:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().etd_extractor_create(C.byref(cfg), names, ptrs, numels, n, C.byref(h)), "etd_extractor_create")
         self._h = h
+        self._m2n = None          # device mpe2note handle, created on first use
         self._fronts: Dict[int, FrontEnd] = {}
         self.n_note = c.midi.num_note
         self.n_frame = c.input.num_frame
@@ -175,6 +176,35 @@ class AMTAPC_Extractor:
                 cap = int(n.value)
                 continue
             _lib.check(rc, "etd_mpe2note")
+            return buf[: n.value]
+
+    def mpe2note_device(self, onset: torch.Tensor, offset: torch.Tensor, mpe: torch.Tensor, velocity: torch.Tensor,
+                        thred_onset=0.5, thred_offset=0.5, thred_mpe=0.5) -> np.ndarray:
+        """extractor.py:256-418 on the device arrays `transcript` returned (fp32 [T, n_note] x3, int8 [T, n_note]); only the
+        notes cross PCIe.  Same structured array, bit for bit, as `_mpe2note_array` on the host copies."""
+        lib = _lib.lib()
+        for t, dt in ((onset, torch.float32), (offset, torch.float32), (mpe, torch.float32), (velocity, torch.int8)):
+            if not t.is_cuda or t.dtype != dt or not t.is_contiguous() or t.shape != onset.shape:
+                raise ValueError("mpe2note_device: need contiguous device tensors [T, n_note] (fp32, fp32, fp32, int8)")
+        T, nn = onset.shape
+        if self._m2n is None:
+            h = C.c_void_p()
+            _lib.check(lib.etd_mpe2note_dev_create(nn, C.byref(h)), "etd_mpe2note_dev_create")
+            self._m2n = h
+        f = self.config.feature
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        cap = max(4096, T * 2)
+        while True:
+            buf = np.empty(cap, dtype=NOTE_DTYPE)
+            n = C.c_longlong()
+            with torch.cuda.device(self.device):
+                rc = lib.etd_mpe2note_dev(self._m2n, onset.data_ptr(), offset.data_ptr(), mpe.data_ptr(), velocity.data_ptr(), T,
+                                          thred_onset, thred_offset, thred_mpe, f.hop_sample, f.sr, self.config.midi.note_min,
+                                          C.cast(buf.ctypes.data, C.POINTER(_lib.Note)), cap, C.byref(n), st)
+            if rc == -12 and n.value > cap:
+                cap = int(n.value)
+                continue
+            _lib.check(rc, "etd_mpe2note_dev")
             return buf[: n.value]
 
     @staticmethod
@@ -273,8 +303,7 @@ class AMTAPC_Extractor:
         feat = self.wav2feature_tensor(wave, sr)
         on, off, mpe, vel = self.transcript(feat)
         inf = self.config.infer
-        arr = self._mpe2note_array(on.cpu().numpy(), off.cpu().numpy(), mpe.cpu().numpy(), vel.cpu().numpy(),
-                                   inf.onset_threshold, inf.offset_threshold, inf.frame_threshold)
+        arr = self.mpe2note_device(on, off, mpe, vel, inf.onset_threshold, inf.offset_threshold, inf.frame_threshold)
         if min_duration is not None:
             arr = arr[~((arr["offset"] - arr["onset"]) < min_duration)]
         return self._notes_from_array(arr)
@@ -287,6 +316,9 @@ class AMTAPC_Extractor:
         for f in self._fronts.values():
             f.close()
         self._fronts = {}
+        if getattr(self, "_m2n", None):
+            _lib.lib().etd_mpe2note_dev_destroy(self._m2n)
+            self._m2n = None
         if getattr(self, "_h", None):
             _lib.lib().etd_extractor_destroy(self._h)
             self._h = None

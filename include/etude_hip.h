@@ -10,7 +10,7 @@
  *   etd_transcript        AMTAPC_Extractor._transcript                 etude/data/extractor.py:199-253
  *   etd_transcript_windows  _Spec2MIDI.forward on [B,n_bin,n_frame+2m] etude/data/extractor.py:53-56,
  *                         = Model_SPEC2MIDI.forward                    etude/models/amt_apc.py:29-49
- *   etd_mpe2note          AMTAPC_Extractor._mpe2note + _note2json filter etude/data/extractor.py:256-418,432-443
+ *   etd_mpe2note, etd_mpe2note_dev  AMTAPC_Extractor._mpe2note (host / device)  etude/data/extractor.py:256-418
  *   etd_decoder_create    load_etude_decoder + EtudeDecoder.__init__   etude/utils/model_loader.py:12-60,
  *                                                                      etude/models/etude_decoder.py:94-123
  *   etd_decoder_begin_bar / etd_decoder_step / etd_decoder_poll / etd_decoder_read_tokens
@@ -113,6 +113,15 @@ typedef struct { double onset, offset; int32_t pitch, velocity; } etd_note;
 int etd_mpe2note(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T,
                  int n_note, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr,
                  int note_min, etd_note* out, long long cap, long long* n_out);
+/* The same conversion on the DEVICE: the four frame-wise arrays stay in HBM ([T][n_note], as
+ * etd_transcript wrote them), only the notes come back, already in the reference's order.  Bit-identical to etd_mpe2note.
+ * The handle owns scratch that grows to the largest T seen; calls on one handle are not re-entrant. */
+typedef struct etd_m2n etd_m2n;
+int etd_mpe2note_dev_create(int n_note, etd_m2n** out);
+void etd_mpe2note_dev_destroy(etd_m2n*);
+int etd_mpe2note_dev(etd_m2n*, const float* onset_dev, const float* offset_dev, const float* mpe_dev, const int8_t* vel_dev,
+                     long long T, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr, int note_min,
+                     etd_note* out_host, long long cap, long long* n_out, void* stream);
 
 /* ------------------------------------------------------------------ decoder (EtudeDecoder / GPT-NeoX) */
 typedef struct etd_dec etd_dec;

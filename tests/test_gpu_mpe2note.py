@@ -1,0 +1,106 @@
+"""Device `_mpe2note` through the C ABI: bit-identical to the reference's golden notes, to the host
+C++ path and to the oracle, including plateaus, ties, array edges, zero velocity, overlaps and long saturated runs."""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from etude_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev_notes(h, on, off, mpe, vel, thr, note_min=21):
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (on.astype(np.float32), off.astype(np.float32), mpe.astype(np.float32), vel.astype(np.int8))]
+    T = on.shape[0]
+    cap = max(16, T * on.shape[1])
+    buf = (_lib.Note * cap)()
+    n = C.c_longlong()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.etd_mpe2note_dev(h, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), T, thr[0], thr[1], thr[2],
+                                    256, 16000, note_min, buf, cap, C.byref(n), st), "etd_mpe2note_dev")
+    return [{"pitch": buf[i].pitch, "onset": buf[i].onset, "offset": buf[i].offset, "velocity": buf[i].velocity} for i in range(n.value)]
+
+
+def _host_notes(on, off, mpe, vel, thr, note_min=21):
+    lib = _lib.lib()
+    on, off, mpe = (np.ascontiguousarray(a, np.float32) for a in (on, off, mpe))
+    vel = np.ascontiguousarray(vel, np.int8)
+    T, nn = on.shape
+    cap = max(16, T * nn)
+    buf = (_lib.Note * cap)()
+    n = C.c_longlong()
+    _lib.check(lib.etd_mpe2note(on.ctypes.data, off.ctypes.data, mpe.ctypes.data, vel.ctypes.data, T, nn, thr[0], thr[1], thr[2],
+                                256, 16000, note_min, buf, cap, C.byref(n)), "etd_mpe2note")
+    return [{"pitch": buf[i].pitch, "onset": buf[i].onset, "offset": buf[i].offset, "velocity": buf[i].velocity} for i in range(n.value)]
+
+
+@pytest.fixture(scope="module")
+def handle():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    torch.cuda.set_device(0)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().etd_mpe2note_dev_create(88, C.byref(h)), "create")
+    yield h
+    _lib.lib().etd_mpe2note_dev_destroy(h)
+
+
+def _pad88(a, fill=0):
+    out = np.full((a.shape[0], 88), fill, a.dtype)
+    out[:, : a.shape[1]] = a
+    return out
+
+
+def test_device_mpe2note_matches_reference_golden(handle, golden_dir):
+    cases = json.loads((golden_dir / "mpe2note.json").read_text())
+    for c in cases:
+        on, off, mpe = (np.asarray(c[k], np.float32) for k in ("onset", "offset", "mpe"))
+        vel = np.asarray(c["velocity"], np.int8)
+        if on.shape[1] > 88:
+            continue
+        got = _dev_notes(handle, _pad88(on), _pad88(off), _pad88(mpe), _pad88(vel), c["thr"])
+        assert got == c["notes"], c.get("name")
+
+
+@pytest.mark.parametrize("T,levels,seed", [(1, 4, 0), (2, 3, 1), (3, 2, 2), (257, 5, 3), (2000, 3, 4), (11264, 64, 5), (11264, 2, 6), (4097, 1000, 7)])
+def test_device_mpe2note_equals_host_on_random_frames(handle, T, levels, seed):
+    """quantised values force plateaus and ties (levels = 2: long saturated runs); T = 1, 2, 3 hit the array-edge rules"""
+    rng = np.random.default_rng(seed)
+    q = lambda: (rng.integers(0, levels + 1, (T, 88)) / levels).astype(np.float32)      # noqa: E731
+    on, off, mpe = q(), q(), q()
+    if levels > 8:            # smooth bumps: realistic isolated peaks with sub-frame interpolation
+        k = np.hanning(9).astype(np.float32)
+        on = np.apply_along_axis(lambda c: np.convolve(c, k, "same"), 0, (rng.random((T, 88)) > 0.98).astype(np.float32)).astype(np.float32) if T > 9 else on
+    vel = rng.integers(0, 4, (T, 88)).astype(np.int8) * rng.integers(0, 40, (T, 88)).astype(np.int8)
+    thr = (0.5, 1.0, 0.5) if seed % 2 else (0.5, 0.5, 0.5)
+    assert _dev_notes(handle, on, off, mpe, vel, thr) == _host_notes(on, off, mpe, vel, thr)
+
+
+def test_device_mpe2note_matches_oracle(handle):
+    from oracle import mpe2note as om
+    rng = np.random.default_rng(11)
+    T = 700
+    on = (rng.integers(0, 5, (T, 88)) / 4).astype(np.float32)
+    off = (rng.integers(0, 5, (T, 88)) / 4).astype(np.float32)
+    mpe = rng.random((T, 88)).astype(np.float32)
+    vel = rng.integers(0, 100, (T, 88)).astype(np.int8)
+    assert _dev_notes(handle, on, off, mpe, vel, (0.5, 1.0, 0.5)) == om.mpe2note(on, off, mpe, vel, 0.5, 1.0, 0.5)
+
+
+def test_device_mpe2note_empty_and_capacity(handle):
+    lib = _lib.lib()
+    z = torch.zeros((8, 88), device="cuda:0")
+    v = torch.zeros((8, 88), dtype=torch.int8, device="cuda:0")
+    n = C.c_longlong(-1)
+    _lib.check(lib.etd_mpe2note_dev(handle, z.data_ptr(), z.data_ptr(), z.data_ptr(), v.data_ptr(), 0, 0.5, 0.5, 0.5, 256, 16000, 21, None, 0,
+                                    C.byref(n), None), "T=0")
+    assert n.value == 0
+    on = torch.zeros((8, 88), device="cuda:0"); on[3, 5] = 1.0
+    vel = torch.full((8, 88), 7, dtype=torch.int8, device="cuda:0")
+    rc = lib.etd_mpe2note_dev(handle, on.data_ptr(), z.data_ptr(), z.data_ptr(), vel.data_ptr(), 8, 0.5, 0.5, 0.5, 256, 16000, 21, None, 0,
+                              C.byref(n), None)
+    assert rc == -12 and n.value == 1            # ETD_ENOMEM reports the room needed

@@ -26,3 +26,10 @@ for it in range(3):
     arr = arr[~((arr["offset"] - arr["onset"]) < inf.min_duration)]
     notes = ex._notes_from_array(arr); t5 = time.perf_counter()
     print(f"front {1e3*(t1-t0):.1f} ms | model {1e3*(t2-t1):.1f} ms | D2H {1e3*(t3-t2):.1f} ms | mpe2note C++ {1e3*(t4-t3):.1f} ms ({len(arr)} kept) | dicts {1e3*(t5-t4):.1f} ms")
+    t6 = time.perf_counter()
+    arr2 = ex.mpe2note_device(on, off, mpe, vel, inf.onset_threshold, inf.offset_threshold, inf.frame_threshold); t7 = time.perf_counter()
+    arr2 = arr2[~((arr2["offset"] - arr2["onset"]) < inf.min_duration)]
+    assert np.array_equal(arr, arr2)
+    t8 = time.perf_counter()
+    n3 = ex.extract_notes(wav, 44100, inf.min_duration); t9 = time.perf_counter()
+    print(f"   device mpe2note {1e3*(t7-t6):.2f} ms (identical notes) | extract_notes end to end {1e3*(t9-t8):.1f} ms")
