@@ -5,11 +5,12 @@ Drop-in surfaces (same names/signatures as the reference):
     etude_amd.load_etude_decoder    <- etude.utils.model_loader.load_etude_decoder
     etude_amd.EtudeDecoder.generate <- etude.models.etude_decoder.EtudeDecoder.generate
     etude_amd.Vocab / Event         <- etude.data.vocab
+    etude_amd.HFT_Transformer       <- etude.models.hft_transformer.HFT_Transformer (prepare.py's transcriber)
 All arithmetic runs in libetude_hip.so (hand-written HIP, see csrc/); importing the heavy
 modules is lazy so that `import etude_amd` works on a box without a GPU.
 """
 __all__ = ["AMTAPC_Extractor", "EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder", "Vocab", "Event",
-           "ExtractorConfig", "DecoderConfig"]
+           "ExtractorConfig", "DecoderConfig", "HFT_Transformer", "HFTConfig"]
 
 
 def __getattr__(name):
@@ -22,7 +23,10 @@ def __getattr__(name):
     if name in ("Vocab", "Event"):
         from . import vocab
         return getattr(vocab, name)
-    if name in ("ExtractorConfig", "DecoderConfig"):
+    if name == "HFT_Transformer":
+        from .hft_transformer import HFT_Transformer
+        return HFT_Transformer
+    if name in ("ExtractorConfig", "DecoderConfig", "HFTConfig"):
         from . import config
         return getattr(config, name)
     raise AttributeError(name)

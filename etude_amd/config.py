@@ -70,6 +70,45 @@ class ExtractorConfig:             # schema.py:123-131
 
 
 @dataclass
+class HFTFeatureConfig:            # schema.py:161-172
+    sr: int = 16000
+    hop_sample: int = 256
+    mel_bins: int = 256
+    n_bins: int = 256
+    fft_bins: int = 2048
+    window_length: int = 2048
+    log_offset: float = 1e-8
+    window: str = "hann"
+    pad_mode: str = "constant"     # IS passed to MelSpectrogram here (hft_transformer.py:130)
+
+
+@dataclass
+class HFTInputConfig:              # schema.py:175-181
+    margin_b: int = 32
+    margin_f: int = 32
+    num_frame: int = 128
+    min_value: float = -80.0
+
+
+@dataclass
+class HFTInferConfig:              # schema.py:184-192
+    mode: str = "combination"
+    thred_mpe: float = 0.5
+    thred_onset: float = 0.75
+    thred_offset: float = 0.5
+    n_stride: int = 32
+    bpm: float = 120.0
+
+
+@dataclass
+class HFTConfig:                   # schema.py:195-201
+    feature: HFTFeatureConfig = field(default_factory=HFTFeatureConfig)
+    input: HFTInputConfig = field(default_factory=HFTInputConfig)
+    midi: ExtractorMidiConfig = field(default_factory=ExtractorMidiConfig)
+    infer: HFTInferConfig = field(default_factory=HFTInferConfig)
+
+
+@dataclass
 class DecoderConfig:               # schema.py:204-226
     hidden_size: int = 512
     num_hidden_layers: int = 8

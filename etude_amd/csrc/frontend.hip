@@ -64,19 +64,23 @@ __global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ x, l
                                                   const float* __restrict__ window, const float2* __restrict__ tw /*[n_fft/2]*/,
                                                   const int* __restrict__ mel_start, const int* __restrict__ mel_len,
                                                   const int* __restrict__ mel_off, const float* __restrict__ mel_w, int n_mels,
-                                                  float log_offset, float* __restrict__ feat, long long T) {
+                                                  float log_offset, float* __restrict__ feat, long long T, int pad_zero) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* re = sm;
   float* im = sm + n_fft;
   float* pw = sm + 2 * n_fft;                 // power spectrum [n_fft/2 + 1]
   const long long t = blockIdx.x;
   const int half = n_fft >> 1;
-  // load + window + bit-reverse scatter (reflect padding, center=True)
+  // load + window + bit-reverse scatter (center=True; pad_mode "reflect", or "constant" = zeros: hft_transformer.py:130)
   for (int i = threadIdx.x; i < n_fft; i += blockDim.x) {
     long long idx = t * hop + i - half;
-    if (idx < 0) idx = -idx;
-    if (idx >= N) idx = 2 * (N - 1) - idx;
-    const float v = x[idx] * window[i];
+    bool inside = idx >= 0 && idx < N;
+    if (!pad_zero) {
+      if (idx < 0) idx = -idx;
+      if (idx >= N) idx = 2 * (N - 1) - idx;
+      inside = true;
+    }
+    const float v = inside ? x[idx] * window[i] : 0.f;
     const int rv = (int)(__brev((unsigned)i) >> (32 - lg));
     re[rv] = v;
     im[rv] = 0.f;
@@ -111,6 +115,7 @@ struct etd_frontend {
   int sr_in, sr_out, orig, nw, K, width;
   int n_fft, lg, hop, n_mels;
   float log_offset;
+  int pad_zero = 0;          // STFT centre padding: 0 reflect (torch.stft default), 1 zeros (pad_mode="constant")
   float* kernT = nullptr;
   float* window = nullptr;
   float2* tw = nullptr;
@@ -171,6 +176,12 @@ extern "C" void etd_frontend_destroy(etd_frontend* f) {
   delete f;
 }
 
+extern "C" int etd_frontend_set_pad_mode(etd_frontend* f, int constant_zero) {
+  if (!f || (constant_zero != 0 && constant_zero != 1)) ETD_FAIL(ETD_EINVAL, "frontend_set_pad_mode: bad args");
+  f->pad_zero = constant_zero;
+  return ETD_OK;
+}
+
 extern "C" long long etd_frontend_resampled_len(const etd_frontend* f, long long n_in) {
   if (f->sr_in == f->sr_out) return n_in;
   return ((long long)f->nw * n_in + f->orig - 1) / f->orig;      // ceil(new*L/orig)
@@ -185,7 +196,7 @@ extern "C" int etd_frontend_run(etd_frontend* f, const float* wav_dev, int chann
   if (!f || !wav_dev || !resampled_dev || !feat_dev || channels <= 0 || n_in <= 0) ETD_FAIL(ETD_EINVAL, "frontend_run: bad args");
   const long long n16 = etd_frontend_resampled_len(f, n_in);
   const long long T = 1 + n16 / f->hop;
-  if (n16 <= f->n_fft / 2) ETD_FAIL(ETD_EINVAL, "frontend_run: clip shorter than n_fft/2 after resampling (reflect pad undefined)");
+  if (!f->pad_zero && n16 <= f->n_fft / 2) ETD_FAIL(ETD_EINVAL, "frontend_run: clip shorter than n_fft/2 after resampling (reflect pad undefined)");
   if (T > feat_capacity_frames) ETD_FAIL(ETD_EINVAL, "frontend_run: feature buffer too small (%lld > %lld)", T, feat_capacity_frames);
   {
   ProfScope ps("k_resample", st, 2.0 * n16 * f->K, (double)n_in * channels * 4 + (double)n16 * 4);
@@ -201,7 +212,7 @@ extern "C" int etd_frontend_run(etd_frontend* f, const float* wav_dev, int chann
   ProfScope ps2("k_stft_mel", st, 0, (double)n16 * 4 + (double)T * f->n_mels * 4);
   const size_t sm = (size_t)(2 * f->n_fft + f->n_fft / 2 + 1) * sizeof(float);
   hipLaunchKernelGGL(k_stft_mel, dim3((unsigned)T), dim3(256), sm, st, resampled_dev, n16, f->n_fft, f->lg, f->hop, f->window, f->tw,
-                     f->mel_start, f->mel_len, f->mel_off, f->mel_w, f->n_mels, f->log_offset, feat_dev, T);
+                     f->mel_start, f->mel_len, f->mel_off, f->mel_w, f->n_mels, f->log_offset, feat_dev, T, f->pad_zero);
   HIP_TRY(hipGetLastError());
   if (n_frames_out) *n_frames_out = T;
   return ETD_OK;

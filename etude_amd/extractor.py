@@ -100,7 +100,7 @@ class AMTAPC_Extractor:
     """Audio -> notes (JSON/MIDI) on one MI355X.  Signature of etude/data/extractor.py:121-146."""
 
     def __init__(self, config: Optional[ExtractorConfig], model_path: Union[str, Path, Dict[str, np.ndarray]],
-                 device: Union[str, torch.device] = "auto", max_windows: int = 4, chunk_frames: int = 0):
+                 device: Union[str, torch.device] = "auto", max_windows: int = 4, chunk_frames: int = 0, stft_pad_mode: str = "reflect"):
         if device == "auto":
             device = "cuda"
         self.device = torch.device(device)
@@ -127,6 +127,7 @@ class AMTAPC_Extractor:
             _lib.check(_lib.lib().etd_extractor_create(C.byref(cfg), names, ptrs, numels, n, C.byref(h)), "etd_extractor_create")
         self._h = h
         self._m2n = None          # device mpe2note handle, created on first use
+        self._stft_pad_mode = stft_pad_mode     # "reflect": what extractor.py:186-193 gets from torchaudio's default; "constant": hft_transformer.py:130
         self._fronts: Dict[int, FrontEnd] = {}
         self.n_note = c.midi.num_note
         self.n_frame = c.input.num_frame
@@ -246,7 +247,7 @@ class AMTAPC_Extractor:
         if sr not in self._fronts:
             f = self.config.feature
             with torch.cuda.device(self.device):
-                self._fronts[sr] = FrontEnd(sr, f.sr, f.fft_bins, f.hop_sample, f.mel_bins, f.log_offset)
+                self._fronts[sr] = FrontEnd(sr, f.sr, f.fft_bins, f.hop_sample, f.mel_bins, f.log_offset, pad_mode=self._stft_pad_mode)
         return self._fronts[sr]
 
     def wav2feature_tensor(self, wave: Union[np.ndarray, torch.Tensor], sr: int) -> torch.Tensor:

@@ -61,7 +61,7 @@ class FrontEnd:
     """wav (device, planar [C][L] fp32) -> log-mel features (device, [T][n_mels] fp32)."""
 
     def __init__(self, sr_in: int, sr_out: int = 16000, n_fft: int = 2048, hop: int = 256, n_mels: int = 256,
-                 log_offset: float = 1e-8):
+                 log_offset: float = 1e-8, pad_mode: str = "reflect"):
         self.sr_in, self.sr_out, self.hop, self.n_mels = int(sr_in), int(sr_out), hop, n_mels
         lib = _lib.lib()
         if self.sr_in != self.sr_out:
@@ -75,6 +75,9 @@ class FrontEnd:
                                            win.ctypes.data, n_mels, ms.ctypes.data, ml.ctypes.data, mw.ctypes.data,
                                            log_offset, C.byref(h)), "etd_frontend_create")
         self._h = h
+        if pad_mode not in ("reflect", "constant"):
+            raise ValueError(f"pad_mode {pad_mode!r}: only 'reflect' and 'constant' are implemented")
+        _lib.check(lib.etd_frontend_set_pad_mode(h, 1 if pad_mode == "constant" else 0), "etd_frontend_set_pad_mode")
 
     def num_frames(self, n_in: int) -> int:
         return int(_lib.lib().etd_frontend_num_frames(self._h, n_in))

@@ -66,6 +66,9 @@ int etd_frontend_create(int sr_in, int sr_out, int orig, int nw, int K, int widt
                         int n_fft, int hop, const float* window_host, int n_mels, const int* mel_start,
                         const int* mel_len, const float* mel_w_host, float log_offset, etd_frontend** out);
 void etd_frontend_destroy(etd_frontend*);
+/* STFT centre padding: 0 = reflect (AMTAPC_Extractor, torchaudio default), 1 = zeros (HFT_Transformer: pad_mode="constant",
+ * etude/models/hft_transformer.py:124-131) */
+int etd_frontend_set_pad_mode(etd_frontend*, int constant_zero);
 long long etd_frontend_resampled_len(const etd_frontend*, long long n_in);
 long long etd_frontend_num_frames(const etd_frontend*, long long n_in);
 /* wav_dev: planar [channels][n_in] fp32.  resampled_dev: scratch >= resampled_len floats.

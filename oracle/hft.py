@@ -204,3 +204,33 @@ def transcript(sd, a_feature: np.ndarray, d: HftDims, min_value: float = -18.0,
     if return_vel_logits:
         return tuple(outs), vel_logits
     return tuple(outs)
+
+
+@torch.no_grad()
+def transcript_stride(sd, a_feature: np.ndarray, d: HftDims, n_offset: int, min_value: float = -80.0):
+    """HFT_Transformer._transcript_stride, etude/models/hft_transformer.py:282-460, mode="combination": windows start every
+    n_frame/2 frames; rows [n_offset, n_offset + n_frame/2) of each window's outputs are kept.  Returns the 8 arrays in the
+    reference's order (onset/offset/mpe/velocity A, then B)."""
+    a_feature = np.array(a_feature, dtype=np.float32)
+    T = a_feature.shape[0]
+    nf, half = d.n_frame, d.n_frame // 2
+    tmp_len = T + 2 * d.n_margin + half
+    len_s = int(np.ceil(tmp_len / half) * half) - tmp_len
+    a_in = torch.from_numpy(np.concatenate([
+        np.full([d.n_margin + n_offset, d.n_bin], min_value, np.float32), a_feature,
+        np.full([len_s + d.n_margin + (half - n_offset), d.n_bin], min_value, np.float32)], axis=0))
+    mk = lambda dt: np.zeros((T + len_s, d.n_note), dt)            # noqa: E731
+    outs = [mk(np.float32), mk(np.float32), mk(np.float32), mk(np.int8), mk(np.float32), mk(np.float32), mk(np.float32), mk(np.int8)]
+    for i in range(0, T, half):
+        spec = a_in[i:i + 2 * d.n_margin + nf].T.unsqueeze(0)
+        r = model_forward(sd, spec, d)
+        sl = slice(n_offset, n_offset + half)
+        outs[0][i:i + half] = r[0][0][sl].numpy()
+        outs[1][i:i + half] = r[1][0][sl].numpy()
+        outs[2][i:i + half] = r[2][0][sl].numpy()
+        outs[3][i:i + half] = r[3][0][sl].argmax(2).numpy()
+        outs[4][i:i + half] = r[5][0][sl].numpy()
+        outs[5][i:i + half] = r[6][0][sl].numpy()
+        outs[6][i:i + half] = r[7][0][sl].numpy()
+        outs[7][i:i + half] = r[8][0][sl].argmax(2).numpy()
+    return tuple(outs)

@@ -75,11 +75,12 @@ def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sampl
 
 
 def log_mel(wave16k: torch.Tensor, sr: int = 16000, n_fft: int = 2048, win_length: int = 2048, hop: int = 256,
-            n_mels: int = 256, log_offset: float = 1e-8) -> torch.Tensor:
-    """MelSpectrogram + log, transposed to [T, n_mels]."""
+            n_mels: int = 256, log_offset: float = 1e-8, pad_mode: str = "reflect") -> torch.Tensor:
+    """MelSpectrogram + log, transposed to [T, n_mels].  pad_mode "reflect" = torchaudio's default (extractor.py:186-193);
+    "constant" = what HFT_Transformer passes (hft_transformer.py:124-131)."""
     window = torch.hann_window(win_length, periodic=True)
     spec = torch.stft(wave16k, n_fft=n_fft, hop_length=hop, win_length=win_length, window=window, center=True,
-                      pad_mode="reflect", normalized=False, onesided=True, return_complex=True)
+                      pad_mode=pad_mode, normalized=False, onesided=True, return_complex=True)
     power = spec.abs().pow(2.0)                                             # [n_freqs, T]
     fb = melscale_fbanks(n_fft // 2 + 1, 0.0, float(sr // 2), n_mels, sr)
     mel = torch.matmul(power.transpose(-1, -2), fb)                          # [T, n_mels]

@@ -214,7 +214,72 @@ def gen_decoder_full():
                  prompt_len=64, max_bar_token_limit=48)
 
 
-ALL = dict(hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
+def ref_hft_wrapper(dims, seed, n_offset):
+    """the reference's HFT_Transformer (etude/models/hft_transformer.py) around a seeded Model_SPEC2MIDI, without the pickle"""
+    from etude.config.schema import HFTConfig
+    from etude.models import amt_apc
+    from etude.models.hft_transformer import HFT_Transformer
+    d = synth.extractor_dims(**dims)
+    enc = amt_apc.Encoder_SPEC2MIDI(d["n_margin"], d["n_frame"], d["n_bin"], d["cnn_channel"], d["cnn_kernel"], d["hid_dim"],
+                                    d["n_layers_enc"], d["n_heads"], d["pf_dim"], 0.1, "cpu")
+    dec = amt_apc.Decoder_SPEC2MIDI(d["n_frame"], d["n_bin"], d["n_note"], d["n_velocity"], d["hid_dim"], d["n_layers_dec"],
+                                    d["n_heads"], d["pf_dim"], 0.1, "cpu")
+    model = amt_apc.Model_SPEC2MIDI(enc, dec)
+    sd = synth.extractor_state_dict(seed, dims)
+    ren = {k.replace("encoder.", "encoder_spec2midi.", 1).replace("decoder.", "decoder_spec2midi.", 1) if k.split(".")[0] in ("encoder", "decoder") else k: v
+           for k, v in sd.items()}
+    model.load_state_dict(_t(ren), strict=True)
+    model.eval()
+    cfg = HFTConfig()
+    cfg.input.margin_b = cfg.input.margin_f = d["n_margin"]
+    cfg.input.num_frame = d["n_frame"]
+    cfg.feature.n_bins = cfg.feature.mel_bins = d["n_bin"]
+    cfg.midi.num_note = d["n_note"]
+    cfg.midi.num_velocity = d["n_velocity"]
+    cfg.infer.n_stride = n_offset
+    tr = HFT_Transformer.__new__(HFT_Transformer)
+    tr.device = "cpu"
+    tr.config = cfg
+    tr.model = model
+    return tr, d, sd
+
+
+def gen_hft_wrapper():
+    """HFT_Transformer._transcript_stride / _transcript / _mpe2note (hft_transformer.py:140-674) at a tiny config and at the
+    default architecture with num_frame=128; plus a plain-pickled tiny model object for the checkpoint loader."""
+    import pickle
+    # tiny: n_frame 16 -> half 8, n_offset 4; 27 frames -> 4 stride windows, ragged
+    tr, d, sd = ref_hft_wrapper(TINY_EXT, seed=13, n_offset=4)
+    rng = np.random.default_rng(31)
+    feat = np.clip(rng.normal(-8, 2, (27, d["n_bin"])), -18, 5).astype(np.float32)
+    so = tr._transcript_stride(torch.from_numpy(feat), 4)
+    to = tr._transcript(torch.from_numpy(feat))
+    np.savez_compressed(HERE / "hft_wrapper_tiny.npz", feature=feat, **{f"stride{i}": o for i, o in enumerate(so)},
+                        **{f"plain{i}": o for i, o in enumerate(to)})
+    with open(HERE / "hft_tiny_model.pkl", "wb") as f:
+        pickle.dump(tr.model, f)                                   # how the hFT-Transformer project ships checkpoints (hft_transformer.py:53-54)
+    np.savez_compressed(HERE / "hft_tiny_model_state.npz", **sd)
+    # the wrapper's own _mpe2note (a second copy of the algorithm, :462-674) on its default thresholds
+    ex, _ = ref_extractor(TINY_EXT, seed=11)
+    on = np.round(rng.random((120, d["n_note"])) ** 3, 2).astype(np.float32)
+    off = np.round(rng.random((120, d["n_note"])) ** 2, 2).astype(np.float32)
+    mpe = rng.random((120, d["n_note"])).astype(np.float32)
+    vel = (rng.integers(0, 100, (120, d["n_note"])) * (rng.random((120, d["n_note"])) > 0.1)).astype(np.int8)
+    notes = tr._mpe2note(on, off, mpe, vel, thred_onset=0.75, thred_offset=0.5, thred_mpe=0.5)
+    assert notes == ex._mpe2note(on, off, mpe, vel, thred_onset=0.75, thred_offset=0.5, thred_mpe=0.5), "the two reference copies differ"
+    (HERE / "hft_wrapper_mpe2note.json").write_text(json.dumps(dict(thr=[0.75, 0.5, 0.5], onset=on.tolist(), offset=off.tolist(), mpe=mpe.tolist(),
+                                                                    velocity=vel.tolist(), notes=notes)))
+    # default architecture, num_frame 128, n_stride 32: 150 frames -> 3 stride windows
+    tr, d, _ = ref_hft_wrapper(dict(n_frame=128), seed=7, n_offset=32)
+    feat = np.clip(rng.normal(-8, 2, (150, 256)), -18, 5).astype(np.float32)
+    so = tr._transcript_stride(torch.from_numpy(feat), 32)
+    vl = None
+    np.savez_compressed(HERE / "hft_wrapper_full.npz", feature=feat,
+                        onset_A=so[0].astype(np.float16), mpe_A=so[2].astype(np.float16),
+                        onset_B=so[4], offset_B=so[5], mpe_B=so[6], velocity_B=so[7])
+
+
+ALL = dict(hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
            decoder_tiny=gen_decoder_tiny, decoder_full=gen_decoder_full)
 
 if __name__ == "__main__":
