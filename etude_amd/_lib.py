@@ -44,7 +44,8 @@ class Job(C.Structure):
 class SchedCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("bar_bos_id", "bar_eos_id", "n_ctx_pairs", "max_position_embeddings", "max_output_tokens",
                                        "max_bar_token_limit")] + [("context_overlap_ratio", C.c_float)] + \
-               [(n, C.c_int) for n in ("force_bar_tokens", "max_streams", "max_prefill_rows", "steps_per_poll")]
+               [(n, C.c_int) for n in ("force_bar_tokens", "max_streams", "max_prefill_rows", "steps_per_poll")] + \
+               [("temperature", C.c_float), ("top_p", C.c_float), ("seed", C.c_ulonglong)]
 
 
 class Note(C.Structure):
@@ -87,6 +88,8 @@ SIGNATURES = {
     "etd_decoder_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_i64_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),
     "etd_decoder_destroy": (None, [C.c_void_p]),
+    "etd_decoder_set_sampling": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),
+    "etd_decoder_set_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "etd_decoder_begin_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                         C.c_int, C.c_void_p]),
     "etd_decoder_begin_bars": (C.c_int, [C.c_void_p, C.c_int] + [C.c_void_p] * 8 + [C.c_void_p]),

@@ -50,6 +50,9 @@ struct etd_dec {
   bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
   bf16 *Qb = nullptr, *Kp = nullptr, *VTp = nullptr; int vt_spad = 0;     // batched-prefill scratch of the MFMA attention
   float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
+  DSampleCfg* samp_dev = nullptr;                // sampling parameters (device-resident: captured graphs follow set_sampling)
+  unsigned long long* rng_key = nullptr;         // [S] per-stream draw keys
+  std::vector<unsigned long long> host_key; bool keys_dirty = true; bool sampling = false;
   float* Pk = nullptr;                           // [5][512][H] split-K partials of the decode-step (down | dense) projection
   bf16* Xcat = nullptr;                          // [512][I + H] bf16: GELU(up) | attention output, the K-concatenated input of that GEMM
   std::vector<int> stage;                        // host staging of a prefill batch
@@ -324,6 +327,8 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   d->Mmax = d->ctx > d->S ? d->ctx : d->S;
   d->Mcap = c.max_prefill_rows > d->Mmax ? c.max_prefill_rows : d->Mmax;
   d->host_len.assign(d->S, 0);
+  d->host_key.resize(d->S);
+  for (int i = 0; i < d->S; ++i) d->host_key[i] = (unsigned long long)i;
   Loader Ld;
   for (int i = 0; i < n; ++i) Ld.t[names[i]] = {host_ptrs[i], numels[i]};
   auto fail = [&](int rc) { for (void* p : d->allocs) (void)hipFree(p); delete d; return rc; };
@@ -416,6 +421,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
     rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)
   }
+  rc = rc ? rc : d->alloc(&d->samp_dev, (size_t)1, true); rc = rc ? rc : d->alloc(&d->rng_key, (size_t)d->S, true);
   rc = rc ? rc : d->alloc(&d->row_slot, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_pos, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_active, (size_t)d->Mmax);
   rc = rc ? rc : d->alloc(&d->ids, 10 * M + 13 * (size_t)d->S); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
   const size_t S = d->S;
@@ -448,6 +454,10 @@ extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, c
     for (int k = 0; k < 4; ++k) init[7 * i + 1 + k] = tgt_attrs4[4 * i + k];
     init[7 * i + 5] = eos_ids[i]; init[7 * i + 6] = limits[i];
   }
+  if (d->sampling && d->keys_dirty) {
+    HIP_TRY(hipMemcpyAsync(d->rng_key, d->host_key.data(), (size_t)d->S * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    d->keys_dirty = false;
+  }
   Staged sg; float* hf = nullptr;
   ETD_TRY(stage_and_forward(d, n, slots, T, ids, cls, attrs4, init.data(), &sg, &hf, st));
   // only each prompt's last position feeds the first generated token (etude_decoder.py:317)
@@ -458,7 +468,24 @@ extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, c
   am.rows = DecRows{sg.last_slot, sg.last_pos, sg.last_active};
   am.cur_tok = d->cur_tok; am.len = d->len; am.done = d->done; am.n_out = d->n_out; am.out_tok = d->out_tok; am.out_cap = d->out_cap;
   am.eos = d->eos; am.limit = d->limit;
+  if (d->sampling) { am.samp = d->samp_dev; am.rng_key = d->rng_key; }
   ETD_TRY(launch_dargmax(am, st));
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_set_sampling(etd_dec* d, float temperature, float top_p, unsigned long long seed, void* stream) {
+  if (!d || !(temperature >= 0.f) || !(top_p == top_p)) ETD_FAIL(ETD_EINVAL, "set_sampling: bad arguments");
+  if (temperature > 0.f && d->V > 256) ETD_FAIL(ETD_EINVAL, "set_sampling: sampling supports vocabularies up to 256 entries");
+  DSampleCfg c; c.inv_temp = temperature > 0.f ? 1.0f / temperature : 0.f; c.top_p = top_p; c.seed = seed;
+  HIP_TRY(hipMemcpyAsync(d->samp_dev, &c, sizeof(c), hipMemcpyHostToDevice, (hipStream_t)stream));   // pageable source: staged before return
+  d->sampling = temperature > 0.f;
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_set_keys(etd_dec* d, int n, const int32_t* slots, const unsigned long long* keys) {
+  if (!d || n < 1 || !slots || !keys) ETD_FAIL(ETD_EINVAL, "set_keys: bad arguments");
+  for (int i = 0; i < n; ++i) { ETD_TRY(check_slot(d, slots[i])); d->host_key[slots[i]] = keys[i]; }
+  d->keys_dirty = true;
   return ETD_OK;
 }
 
@@ -509,6 +536,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
       hd.word = d->word; hd.cls_emb = d->cls_emb; hd.attr_tab = d->attr_tab;
       hd.g1 = w0.ln1g; hd.b1 = w0.ln1b; hd.g2 = w0.ln2g; hd.b2 = w0.ln2b;
       hd.h = d->h; hd.x1 = d->X1b; hd.x2 = d->X2b;
+      hd.samp = d->samp_dev; hd.rng_key = d->rng_key;             // the device-side config selects greedy / sampling
       ETD_TRY(launch_dstep_head(hd, s_));
       return ETD_OK;
     }
@@ -518,6 +546,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     am.rows = rows;
     am.cur_tok = d->cur_tok; am.len = d->len; am.done = d->done; am.n_out = d->n_out; am.out_tok = d->out_tok; am.out_cap = d->out_cap;
     am.eos = d->eos; am.limit = d->limit;
+    am.samp = d->samp_dev; am.rng_key = d->rng_key;
     ETD_TRY(launch_dargmax(am, s_));
     return ETD_OK;
   };

@@ -10,6 +10,11 @@ struct DecRows {
   const int* seq;      // [M] index of the row's prompt inside a batched prefill (only read when the prefill scratch is set)
 };
 
+// temperature / top-p sampling (etude_decoder.py:321-331).  Lives in DEVICE memory so that captured graphs follow a change;
+// inv_temp <= 0 selects greedy argmax.  A draw is a pure function of (seed, the stream's key, tokens generated so far in the
+// bar): results do not depend on which slot or engine a job lands on.
+struct DSampleCfg { float inv_temp; float top_p; unsigned long long seed; };
+
 enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4, DEPI_PARTIAL = 5 };
 
 struct DGemmArgs {
@@ -55,6 +60,7 @@ struct DHeadArgs {
   const float* word; const float* cls_emb; const float* attr_tab;
   const float* g1; const float* b1; const float* g2; const float* b2;   // layer 0 LayerNorms
   float* h; bf16* x1; bf16* x2;                // next step's embeddings [M][H] and their LayerNorms
+  const DSampleCfg* samp; const unsigned long long* rng_key;   // [slots]; samp == null -> greedy
 };
 int launch_dstep_head(const DHeadArgs& a, hipStream_t st);
 
@@ -95,6 +101,7 @@ struct DArgmaxArgs {
   DecRows rows;
   int* cur_tok; int* len; int* done; int* n_out; int* out_tok; int out_cap; const int* eos; const int* limit;
   int set_len_from_pos;          // prefill: len[slot] = pos + 1 of the row
+  const DSampleCfg* samp; const unsigned long long* rng_key;   // [slots]; samp == null -> greedy
 };
 int launch_dargmax(const DArgmaxArgs& a, hipStream_t st);
 

@@ -360,6 +360,77 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
 }
 
 // ================================================================================================
+// Token choice for one row by ONE wave: greedy argmax (lowest index on ties, like torch.argmax), or the reference's
+// sampling branch (etude_decoder.py:321-331): p = softmax(logits / T); sort descending; drop every token whose
+// predecessors already hold more than top_p of the mass (the first token always stays); renormalise; draw.
+// `lg` may be LDS or global; `sp`/`ss`/`si` are per-wave scratch of >= V entries.  V <= 256.
+// ================================================================================================
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {      // splitmix64 finaliser
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ int wave_argmax(const float* lg, int V, int lane) {
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int v = lane; v < V; v += 64) {
+    const float x = lg[v];
+    if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  return bi;
+}
+__device__ int wave_sample(const float* lg, int V, int lane, float inv_temp, float top_p, unsigned long long seed, unsigned long long key,
+                           unsigned ctr, float* sp, float* ss, int* si) {
+  // softmax(logits / T) in fp32
+  float mx = -INFINITY;
+  for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[v] * inv_temp);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  float sum = 0.f;
+  for (int v = lane; v < V; v += 64) { const float e = expf(lg[v] * inv_temp - mx); sp[v] = e; sum += e; }
+  sum = wave_sum(sum);
+  for (int v = lane; v < V; v += 64) sp[v] = sp[v] / sum;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  // rank = position in the descending order (ties: lower index first), scatter into sorted order
+  for (int v = lane; v < V; v += 64) {
+    const float p = sp[v];
+    int rank = 0;
+    for (int u = 0; u < V; ++u) { const float q = sp[u]; rank += (q > p || (q == p && u < v)) ? 1 : 0; }
+    ss[rank] = p; si[rank] = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  int tok = 0;
+  if (lane == 0) {
+    int K = V;
+    if (top_p > 0.f && top_p < 1.f) {
+      float cum = 0.f;
+      K = 1;
+      for (int k = 0; k + 1 < V; ++k) {        // token k+1 is removed iff cumsum[k] > top_p (:326-328)
+        cum += ss[k];
+        if (cum > top_p) break;
+        K = k + 2;
+      }
+    }
+    float S = 0.f;
+    for (int k = 0; k < K; ++k) S += ss[k];
+    const unsigned long long r = mix64(mix64(seed ^ mix64(key)) + (unsigned long long)ctr);
+    const float u = (float)(r >> 40) * (1.0f / 16777216.0f);                  // 24 random bits -> [0, 1)
+    const float target = u * S;
+    float acc = 0.f;
+    tok = si[K - 1];
+    for (int k = 0; k < K; ++k) { acc += ss[k]; if (target < acc) { tok = si[k]; break; } }
+  }
+  return __shfl(tok, 0, 64);
+}
+
+// ================================================================================================
 // k_dstep_head: tail of decode step t and head of step t+1 in one launch, one workgroup per 32 rows:
 //   final LayerNorm -> lm_head logits (MFMA, K split in the same eight 64-wide slices and added in the same order as
 //   k_dgemm_s, so the logits are bit-identical to the unfused path) -> greedy argmax (lowest index on ties) -> stream
@@ -371,8 +442,11 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
 __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
   __shared__ __attribute__((aligned(16))) bf16 Xs[32 * DH_LDX];
   __shared__ float Ls[32 * DH_LDL];
+  __shared__ float sps[8][256], sss[8][256];
+  __shared__ int sis[8][256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 32, H = a.H;     // H == 512 (checked by the launcher)
+  const float inv_temp = a.samp ? a.samp->inv_temp : 0.f;
   // ---- final LayerNorm of 4 rows per wave (summation order of k_dgemm_s's LayerNorm prologue)
   for (int j = 0; j < 4; ++j) {
     const int rl = wave * 4 + j;
@@ -431,17 +505,10 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
   for (int j = 0; j < 4; ++j) {
     const int rl = wave * 4 + j, m = m0 + rl;
     if (m >= a.M) break;
-    float best = -INFINITY; int bi = 0x7fffffff;
-    for (int v = lane; v < a.V; v += 64) {
-      const float x = Ls[rl * DH_LDL + v];
-      if (x > best || (x == best && v < bi)) { best = x; bi = v; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
     const int slot = a.row_slot[m];
+    int bi;
+    if (inv_temp > 0.f) bi = wave_sample(Ls + rl * DH_LDL, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, a.rng_key[slot], (unsigned)a.n_out[slot], sps[wave], sss[wave], sis[wave]);
+    else bi = wave_argmax(Ls + rl * DH_LDL, a.V, lane);
     int tok = a.cur_tok[slot], ln = a.len[slot], dn = a.done[slot];
     if (a.row_active[m] && !dn) {
       const int n = a.n_out[slot];
@@ -501,6 +568,7 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
 }
 
 int launch_dstep_head(const DHeadArgs& a, hipStream_t st) {
+  if (a.samp && !a.rng_key) ETD_FAIL(ETD_EINVAL, "dstep_head: sampling needs stream keys");
   if (a.M < 1 || a.H != 512 || a.V < 1 || a.V > a.Vpad || a.Vpad % 32 || a.Vpad > 256 || !a.hfin || !a.Whead || !a.h || !a.x1 || !a.x2)
     ETD_FAIL(ETD_EINVAL, "dstep_head: bad arguments (needs hidden 512, vocabulary <= 256)");
   ProfScope ps("k_dstep_head", st, 2.0 * a.M * a.V * a.H, (double)a.Vpad * a.H * 2);
@@ -962,19 +1030,17 @@ int launch_dembed(const DEmbedArgs& a, hipStream_t st) {
 //                                                                    etude_decoder.py:333-343
 // ================================================================================================
 __global__ void k_dargmax(DArgmaxArgs a) {
+  __shared__ float sp[256], ss[256];
+  __shared__ int si[256];
   const int m = blockIdx.x, lane = threadIdx.x;
-  float best = -INFINITY; int bi = 0x7fffffff;
-  for (int v = lane; v < a.V; v += 64) {
-    const float x = a.logits[(long long)m * a.ldl + v];
-    if (x > best || (x == best && v < bi)) { best = x; bi = v; }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-  }
+  const float* lg = a.logits + (long long)m * a.ldl;
+  const int slot_r = a.rows.slot[m];
+  const float inv_temp = a.samp ? a.samp->inv_temp : 0.f;
+  int bi;
+  if (inv_temp > 0.f) bi = wave_sample(lg, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, a.rng_key[slot_r], (unsigned)a.n_out[slot_r], sp, ss, si);
+  else bi = wave_argmax(lg, a.V, lane);
   if (lane == 0 && a.rows.active[m]) {
-    const int slot = a.rows.slot[m];
+    const int slot = slot_r;
     if (!a.done[slot]) {
       const int n = a.n_out[slot];
       if (n < a.out_cap) a.out_tok[(long long)slot * a.out_cap + n] = bi;
@@ -986,6 +1052,7 @@ __global__ void k_dargmax(DArgmaxArgs a) {
   }
 }
 int launch_dargmax(const DArgmaxArgs& a, hipStream_t st) {
+  if (a.samp && (a.V > 256 || !a.rng_key)) ETD_FAIL(ETD_EINVAL, "dargmax: sampling needs a vocabulary <= 256 and stream keys");
   hipLaunchKernelGGL(k_dargmax, dim3(a.M), dim3(64), 0, st, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;

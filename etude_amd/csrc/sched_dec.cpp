@@ -89,6 +89,8 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
   const etd_sched_cfg& c = *cfg;
   if (c.max_streams < 1 || c.n_ctx_pairs < 0 || c.max_bar_token_limit < 1 || c.max_prefill_rows < 1 || c.steps_per_poll < 1)
     ETD_FAIL(ETD_EINVAL, "run_jobs: bad scheduler config");
+  if (!(c.temperature >= 0.f)) ETD_FAIL(ETD_EINVAL, "run_jobs: temperature must be >= 0");
+  ETD_TRY(etd_decoder_set_sampling(d, c.temperature, c.top_p, c.seed, stream));
   std::vector<Job> J(n_jobs);
   for (int i = 0; i < n_jobs; ++i) {
     J[i].j = &jobs[i];
@@ -139,6 +141,12 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
         eos.push_back(c.force_bar_tokens > 0 ? -1 : c.bar_eos_id);
         lim.push_back(jb.limit);
         ++p;
+      }
+      if (c.temperature > 0.f) {           // draw key of a stream = (job, bar): the same tokens whatever slot / pass the job lands in
+        std::vector<unsigned long long> keys(slots.size());
+        size_t q = p - slots.size();
+        for (size_t i = 0; i < slots.size(); ++i, ++q) keys[i] = ((unsigned long long)(uint32_t)pend[q] << 32) | (uint32_t)J[pend[q]].bar;
+        ETD_TRY(etd_decoder_set_keys(d, (int)slots.size(), slots.data(), keys.data()));
       }
       const size_t M = ids.size();
       a4cat.resize(4 * M);

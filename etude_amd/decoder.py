@@ -126,30 +126,32 @@ class EtudeDecoder:
     @torch.no_grad()
     def generate(self, vocab, all_x_bars: List[List[int]], target_attributes_per_bar: List[Dict[str, int]],
                  max_output_tokens: int = 25600, max_bar_token_limit: int = 512, temperature: float = 0.8,
-                 top_p: float = 0.9, context_overlap_ratio: float = 0.5) -> List:
-        """etude_decoder.py:209-354.  Returns the list of Events (``vocab.decode_sequence_to_events``)."""
+                 top_p: float = 0.9, context_overlap_ratio: float = 0.5, seed: Optional[int] = None) -> List:
+        """etude_decoder.py:209-354.  Returns the list of Events (``vocab.decode_sequence_to_events``).
+        ``temperature == 0``: greedy (token ids identical to the reference).  ``temperature > 0``: the reference's
+        softmax(logits / T) + top-p filter + one draw per token (:321-331); draws come from a counter-based generator keyed by
+        ``seed`` (default: derived from ``torch.initial_seed()`` and a per-model call counter), so runs are reproducible but not
+        bit-equal to torch.multinomial's stream."""
         ids = self.generate_ids(vocab, all_x_bars, target_attributes_per_bar, max_output_tokens, max_bar_token_limit,
-                                temperature, top_p, context_overlap_ratio)
+                                temperature, top_p, context_overlap_ratio, seed)
         events = []
         for bar in ids:
             events.extend(vocab.decode_sequence_to_events(bar))
         return events
 
     def generate_ids(self, vocab, all_x_bars, target_attributes_per_bar, max_output_tokens=25600, max_bar_token_limit=512,
-                     temperature=0.8, top_p=0.9, context_overlap_ratio=0.5) -> List[List[int]]:
+                     temperature=0.8, top_p=0.9, context_overlap_ratio=0.5, seed=None) -> List[List[int]]:
         """Same loop, but returns the per-bar id lists ``[Bar_BOS] + tokens`` (what the events are decoded from)."""
-        if temperature > 0:
-            raise NotImplementedError("etude_amd decodes greedily (temperature == 0, the reference's configured default, "
-                                      "schema.py:223); the temperature/top-p sampling branch is not implemented yet")
         r = self.generate_many([(all_x_bars, target_attributes_per_bar)], vocab, max_output_tokens, max_bar_token_limit,
-                               context_overlap_ratio, _validate=True)
+                               context_overlap_ratio, _validate=True, temperature=temperature, top_p=top_p, seed=seed)
         return r[0]
 
     # ------------------------------------------------------------------ multi-stream engine
     def generate_many(self, jobs: Sequence[Tuple[List[List[int]], List[Dict[str, int]]]], vocab, max_output_tokens: int = 25600,
                       max_bar_token_limit: int = 512, context_overlap_ratio: float = 0.5, steps_per_poll: int = 8,
                       _validate: bool = True, stats: Optional[dict] = None, force_bar_tokens: int = 0,
-                      ready: Optional[Tuple[np.ndarray, Sequence[int]]] = None) -> List[List[List[int]]]:
+                      ready: Optional[Tuple[np.ndarray, Sequence[int]]] = None, temperature: float = 0.0, top_p: float = 0.9,
+                      seed: Optional[int] = None) -> List[List[List[int]]]:
         """Greedy-decode many independent jobs on up to ``max_streams`` concurrent device streams.
 
         The bar loop (prompt assembly, history, truncation, token budget, EOS stop) runs in the library's native
@@ -160,6 +162,11 @@ class EtudeDecoder:
         non-zero (e.g. one entry per song, set when its extract..tokenize stages are done) and job i waits for
         ``flags[index[i]]``; jobs are admitted in list order."""
         lib = _lib.lib()
+        if not temperature >= 0:
+            raise ValueError("temperature must be >= 0")
+        if seed is None:
+            self._draw_calls = getattr(self, "_draw_calls", 0) + 1
+            seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self._draw_calls) & 0xFFFFFFFFFFFFFFFF
         if ready is not None:
             flags, ridx = ready
             if flags.dtype != np.int32 or not flags.flags["C_CONTIGUOUS"] or len(ridx) != len(jobs):
@@ -201,7 +208,8 @@ class EtudeDecoder:
                                max_position_embeddings=cfg.max_position_embeddings, max_output_tokens=max_output_tokens,
                                max_bar_token_limit=max_bar_token_limit, context_overlap_ratio=context_overlap_ratio,
                                force_bar_tokens=force_bar_tokens, max_streams=self.max_streams,
-                               max_prefill_rows=self.max_prefill_rows, steps_per_poll=steps_per_poll)
+                               max_prefill_rows=self.max_prefill_rows, steps_per_poll=steps_per_poll,
+                               temperature=float(temperature), top_p=float(top_p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF)
             out = np.zeros(cap, np.int32)
             offs_out = np.zeros(len(live) + 1, np.int64)
             nsteps = C.c_longlong()

@@ -145,6 +145,13 @@ void etd_decoder_destroy(etd_dec*);
  * concat order of etude_decoder.py:171-176 = pitch_overlap, polyphony, note_sustain, rhythm_intensity)
  * through the model and leave the greedy first token in the slot's device-side state.  tgt_attrs4 (same
  * order) condition the generated tokens; generation stops at eos_id or after `limit` tokens. */
+/* Sampling branch of generate() (etude_decoder.py:321-331): temperature > 0 -> softmax(logits / T), top-p filter when
+ * 0 < top_p < 1, one draw per token; temperature == 0 -> greedy argmax (the default).  Draws are a pure function of (seed, the
+ * stream's key, index of the token inside its bar) -- reproducible, independent of slot / engine placement; the reference
+ * draws from torch's global generator instead, so parity is distributional (tests/test_gpu_sampling.py).  Keys default to
+ * the slot index; etd_decoder_run_jobs sets key = (job index, bar index). */
+int etd_decoder_set_sampling(etd_dec*, float temperature, float top_p, unsigned long long seed, void* stream);
+int etd_decoder_set_keys(etd_dec*, int n, const int32_t* slots, const unsigned long long* keys);
 int etd_decoder_begin_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
                           const int32_t* tgt_attrs4, int eos_id, int limit, void* stream);
 /* Batched form: n bars at once (distinct slots).  T[i] = prompt length of bar i; ids/cls hold the prompts back to
@@ -176,6 +183,8 @@ typedef struct {
   float context_overlap_ratio;
   int force_bar_tokens;   /* >0 (benchmarks): suppress Bar_EOS, every bar is exactly this many tokens */
   int max_streams, max_prefill_rows, steps_per_poll;
+  float temperature, top_p;            /* etude_decoder.py:213-214; temperature 0 = greedy */
+  unsigned long long seed;
 } etd_sched_cfg;
 int etd_decoder_run_jobs(etd_dec*, const etd_sched_cfg* cfg, const etd_job* jobs, int n_jobs, int32_t* out, long long out_cap,
                          long long* job_offsets, long long* n_steps_out, void* stream);

@@ -202,3 +202,19 @@ def generate_ids(sd, d: NeoxDims, bar_bos_id: int, bar_eos_id: int, all_x_bars, 
         if total >= max_output_tokens:
             break
     return out
+
+
+@torch.no_grad()
+def sampling_distribution(next_logits: torch.Tensor, temperature: float, top_p: float) -> torch.Tensor:
+    """The distribution `generate` draws the next token from when temperature > 0 -- etude/models/etude_decoder.py:321-330,
+    everything but the `torch.multinomial` call itself.  next_logits [1, V] fp32 -> probs [1, V]."""
+    probs = F.softmax(next_logits / temperature, dim=-1)
+    if 0 < top_p < 1.0:
+        sorted_probs, sorted_indices = torch.sort(probs, descending=True)
+        cum_probs = torch.cumsum(sorted_probs, dim=-1)
+        indices_to_remove = cum_probs > top_p
+        indices_to_remove[..., 1:] = indices_to_remove[..., :-1].clone()
+        indices_to_remove[..., 0] = 0
+        probs[0, sorted_indices[0, indices_to_remove[0]]] = 0
+        probs = probs / probs.sum()
+    return probs

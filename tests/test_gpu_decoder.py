@@ -108,8 +108,8 @@ def test_generate_error_behaviour(dev):
     assert dec.generate(Vocab(), bars, [synth.attrs()] * 2, temperature=0.0) == []   # no Bar_BOS/EOS in vocab (:225-232)
     with pytest.raises(TypeError):
         dec.generate(v, bars, [{"polyphony_bin": 1}] * 2, temperature=0.0)
-    with pytest.raises(NotImplementedError):
-        dec.generate(v, bars, [synth.attrs()] * 2)                                     # default temperature 0.8: sampling branch
+    with pytest.raises(ValueError):
+        dec.generate(v, bars, [synth.attrs()] * 2, temperature=-1.0)
 
 
 def test_long_context_truncation_path(dev):
