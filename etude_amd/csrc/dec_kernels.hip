@@ -140,7 +140,14 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   __shared__ float stat[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  // Workgroup -> tile: the row tiles that stream the SAME weight tile (feature block x K slice) take consecutive slots of
+  // ONE XCD (id = 8*slot + xcd), so the weights come from HBM / the Infinity Cache once and from that XCD's L2 afterwards
+  // (FETCH_SIZE before: 12.9 MB per QKV|up launch at 72 rows for 3.7 MB of weights).
+  const int RT = (a.M + 31) / 32, FT = a.Npad / 32, KS = a.k_splits > 1 ? a.k_splits : 1;
+  const int bid = blockIdx.x, wt = ((bid >> 3) / RT) * 8 + (bid & 7);
+  if (wt >= FT * KS) return;
+  const int bz = wt / FT;
+  const int m0 = ((bid >> 3) % RT) * 32, n0 = (wt - bz * FT) * 32;
   const bool ln = a.ln_g != nullptr;
   if (ln) {
     for (int rr = 0; rr < 32 / DS_WAVES; ++rr) {
@@ -165,8 +172,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
   int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
   const float mean = ln ? stat[r] : 0.f, rstd = ln ? stat[32 + r] : 1.f;
   const float* xrow = a.X + (long long)gm * a.ldx;
-  const int Kz = a.K / (int)gridDim.z;                 // split-K over workgroups (DEPI_PARTIAL), then over the waves
-  const int kq = Kz / DS_WAVES, kb = (int)blockIdx.z * Kz + wave * kq, ke = kb + kq;
+  const int Kz = a.K / KS;                             // split-K over workgroups (DEPI_PARTIAL), then over the waves
+  const int kq = Kz / DS_WAVES, kb = bz * Kz + wave * kq, ke = kb + kq;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -246,7 +253,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
   if (m >= a.M) return;
   if constexpr (EPI == DEPI_PARTIAL) {
     DGemmArgs b = a;
-    b.Y = a.Y + (long long)blockIdx.z * a.M * a.ldy;
+    b.Y = a.Y + (long long)bz * a.M * a.ldy;
     dgemm_epilogue<WBF16, EPI>(b, acc, m, n0, h);
   } else {
     dgemm_epilogue<WBF16, EPI>(a, acc, m, n0, h);
@@ -262,9 +269,12 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
 __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGemmArgs up, int split) {
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const bool isq = (int)blockIdx.y < split;
-  const int m0 = blockIdx.x * 32, n0 = (isq ? (int)blockIdx.y : (int)blockIdx.y - split) * 32;
   const int M = q.M, K = q.K;
+  // workgroup -> tile as in k_dgemm_s: the row tiles of one weight tile run back to back on one XCD
+  const int RT = (M + 31) / 32, bid = blockIdx.x, ft = ((bid >> 3) / RT) * 8 + (bid & 7);
+  if (ft >= split + up.Npad / 32) return;
+  const bool isq = ft < split;
+  const int m0 = ((bid >> 3) % RT) * 32, n0 = (isq ? ft : ft - split) * 32;
   int gm = m0 + r; gm = gm < M ? gm : M - 1;
   // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207); a 32-feature tile is half of one part of one head
   const int head = n0 / 192, j0 = n0 - head * 192, part = j0 >> 6, dbase = j0 & 63;
@@ -354,7 +364,8 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
     ETD_FAIL(ETD_EINVAL, "dstep_qkv_up: bad arguments");
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
   const int split = q.Npad / 32;
-  hipLaunchKernelGGL(k_dstep_qkv_up, dim3((q.M + 31) / 32, split + up.Npad / 32), dim3(64 * DS_WAVES), 0, st, q, up, split);
+  const int ftiles = split + up.Npad / 32;
+  hipLaunchKernelGGL(k_dstep_qkv_up, dim3((unsigned)(((ftiles + 7) / 8) * 8 * ((q.M + 31) / 32))), dim3(64 * DS_WAVES), 0, st, q, up, split);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
@@ -671,7 +682,8 @@ __global__ void k_rope_scatter(DGemmArgs a, const float* __restrict__ raw) {
 template <bool WBF16>
 static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st) {
   // path 0: 128-feature tile (prefill), 1: skinny K-split tile (M <= DS_MAX_ROWS), 2: GEMV (M == 1)
-  const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((a.M + 31) / 32, a.Npad / 32, a.k_splits > 1 ? a.k_splits : 1), g2(a.Npad / 16);
+  const int wtiles = (a.Npad / 32) * (a.k_splits > 1 ? a.k_splits : 1);
+  const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((unsigned)(((wtiles + 7) / 8) * 8 * ((a.M + 31) / 32))), g2(a.Npad / 16);
 #define ETD_DG(E)                                                                                   \
   if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, E>), g0, dim3(256), 0, st, a);                  \
   else if (path == 1) hipLaunchKernelGGL((k_dgemm_s<WBF16, E>), g1, dim3(64 * DS_WAVES), 0, st, a);  \
