@@ -458,6 +458,24 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 32, H = a.H;     // H == 512 (checked by the launcher)
   const float inv_temp = a.samp ? a.samp->inv_temp : 0.f;
+  // ---- requested first, used last: the stream state of this wave's four rows (row -> slot -> state: two dependent round
+  // trips that now overlap the LayerNorm and logits phases instead of following each argmax)
+  const int k8 = lane * 8;
+  int r_slot[4], r_tok[4], r_len[4], r_done[4], r_nout[4], r_eos[4], r_lim[4], r_act[4], r_pos[4], r_at[4][4];
+  unsigned long long r_key[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int m = m0 + wave * 4 + j; m = m < a.M ? m : a.M - 1;
+    r_slot[j] = a.row_slot[m]; r_act[j] = a.row_active[m]; r_pos[j] = a.row_pos[m];
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int sl = r_slot[j];
+    r_tok[j] = a.cur_tok[sl]; r_len[j] = a.len[sl]; r_done[j] = a.done[sl]; r_nout[j] = a.n_out[sl]; r_eos[j] = a.eos[sl]; r_lim[j] = a.limit[sl];
+    r_key[j] = (inv_temp > 0.f) ? a.rng_key[sl] : 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r_at[j][k] = a.tgt_attrs[sl * 4 + k];
+  }
   // ---- final LayerNorm of 4 rows per wave (summation order of k_dgemm_s's LayerNorm prologue)
   for (int j = 0; j < 4; ++j) {
     const int rl = wave * 4 + j;
@@ -512,19 +530,22 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
     }
   }
   __syncthreads();
-  // ---- per row: argmax, state update, next embedding + LayerNorms (4 rows per wave)
+  // ---- per row: token choice and state update (registers + LDS only), then ONE round trip for the four word-embedding rows
+  int n_tok[4];
+#pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int rl = wave * 4 + j, m = m0 + rl;
-    if (m >= a.M) break;
-    const int slot = a.row_slot[m];
+    n_tok[j] = r_tok[j];
+    if (m >= a.M) continue;
+    const int slot = r_slot[j];
     int bi;
-    if (inv_temp > 0.f) bi = wave_sample(Ls + rl * DH_LDL, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, a.rng_key[slot], (unsigned)a.n_out[slot], sps[wave], sss[wave], sis[wave]);
+    if (inv_temp > 0.f) bi = wave_sample(Ls + rl * DH_LDL, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, r_key[j], (unsigned)r_nout[j], sps[wave], sss[wave], sis[wave]);
     else bi = wave_argmax(Ls + rl * DH_LDL, a.V, lane);
-    int tok = a.cur_tok[slot], ln = a.len[slot], dn = a.done[slot];
-    if (a.row_active[m] && !dn) {
-      const int n = a.n_out[slot];
-      tok = bi; ln = a.row_pos[m] + 1;
-      const int fin = (bi == a.eos[slot] || n + 1 >= a.limit[slot]) ? 1 : 0;
+    int ln = r_len[j], dn = r_done[j];
+    if (r_act[j] && !dn) {
+      const int n = r_nout[j];
+      n_tok[j] = bi; ln = r_pos[j] + 1;
+      const int fin = (bi == r_eos[j] || n + 1 >= r_lim[j]) ? 1 : 0;
       if (lane == 0) {
         if (n < a.out_cap) a.out_tok[(long long)slot * a.out_cap + n] = bi;
         a.n_out[slot] = n + 1;
@@ -534,47 +555,64 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
       }
       dn = fin;
     }
-    // next step's row: position = new length, active = not done; embedding of the token it will feed
+    // next step's row: position = new length, active = not done
     if (lane == 0) { a.row_pos[m] = ln; a.row_active[m] = dn ? 0 : 1; }
-    int at[4];
+  }
+  // next embeddings, two rows at a time: all their table rows in flight together (one round trip per pair)
+  f32x4 r_c[2], pg1[2], pb1[2], pg2[2], pb2[2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) at[k] = a.tgt_attrs[slot * 4 + k];
-    const int k = lane * 8;
-    float v[8];
+  for (int hh = 0; hh < 2; ++hh) {
+    r_c[hh] = *reinterpret_cast<const f32x4*>(a.cls_emb + (long long)a.tgt_cls * H + k8 + 4 * hh);
+    pg1[hh] = *reinterpret_cast<const f32x4*>(a.g1 + k8 + 4 * hh); pb1[hh] = *reinterpret_cast<const f32x4*>(a.b1 + k8 + 4 * hh);
+    pg2[hh] = *reinterpret_cast<const f32x4*>(a.g2 + k8 + 4 * hh); pb2[hh] = *reinterpret_cast<const f32x4*>(a.b2 + k8 + 4 * hh);
+  }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int i = k + e;
-      float p = a.attr_tab[(0 * a.n_bins + at[0]) * H + i];
-      p += a.attr_tab[(1 * a.n_bins + at[1]) * H + i];
-      p += a.attr_tab[(2 * a.n_bins + at[2]) * H + i];
-      p += a.attr_tab[(3 * a.n_bins + at[3]) * H + i];
-      v[e] = (a.word[(long long)tok * H + i] + a.cls_emb[a.tgt_cls * H + i]) + p;
+  for (int pr = 0; pr < 2; ++pr) {
+    f32x4 wv[2][2], tv[2][4][2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = pr * 2 + jj;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int i = k8 + 4 * hh;
+        wv[jj][hh] = *reinterpret_cast<const f32x4*>(a.word + (long long)n_tok[j] * H + i);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tv[jj][t][hh] = *reinterpret_cast<const f32x4*>(a.attr_tab + (long long)(t * a.n_bins + r_at[j][t]) * H + i);
+      }
     }
-    const long long ro = (long long)m * H;
-    { const f32x4 oa = {v[0], v[1], v[2], v[3]}, ob = {v[4], v[5], v[6], v[7]};
-      *reinterpret_cast<f32x4*>(a.h + ro + k) = oa; *reinterpret_cast<f32x4*>(a.h + ro + k + 4) = ob; }
-    float s = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s += v[e];
-    s = wave_sum(s);
-    const float mean = s / (float)H;
-    float q = 0.f;
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = pr * 2 + jj, m = m0 + wave * 4 + j;
+      if (m >= a.M) continue;
+      float v[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { const float d0 = v[e] - mean; q += d0 * d0; }
-    q = wave_sum(q);
-    const float rstd = rsqrtf(q / (float)H + a.eps);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(a.g1 + k), gb = *reinterpret_cast<const f32x4*>(a.g1 + k + 4);
-    const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b1 + k), bb = *reinterpret_cast<const f32x4*>(a.b1 + k + 4);
-    const f32x4 ha = *reinterpret_cast<const f32x4*>(a.g2 + k), hb = *reinterpret_cast<const f32x4*>(a.g2 + k + 4);
-    const f32x4 ca = *reinterpret_cast<const f32x4*>(a.b2 + k), cb = *reinterpret_cast<const f32x4*>(a.b2 + k + 4);
-    bf16x8 o1, o2;
+      for (int e = 0; e < 8; ++e) {
+        const int hh = e >> 2, c = e & 3;
+        const float pj = ((tv[jj][0][hh][c] + tv[jj][1][hh][c]) + tv[jj][2][hh][c]) + tv[jj][3][hh][c];      // attribute projection (etude_decoder.py:171-176)
+        v[e] = (wv[jj][hh][c] + r_c[hh][c]) + pj;
+      }
+      const long long ro = (long long)m * H;
+      { const f32x4 oa = {v[0], v[1], v[2], v[3]}, ob = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(a.h + ro + k8) = oa; *reinterpret_cast<f32x4*>(a.h + ro + k8 + 4) = ob; }
+      float s1 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      o1[e] = (bf16)((v[e] - mean) * rstd * ga[e] + ba[e]); o1[4 + e] = (bf16)((v[4 + e] - mean) * rstd * gb[e] + bb[e]);
-      o2[e] = (bf16)((v[e] - mean) * rstd * ha[e] + ca[e]); o2[4 + e] = (bf16)((v[4 + e] - mean) * rstd * hb[e] + cb[e]);
+      for (int e = 0; e < 8; ++e) s1 += v[e];
+      s1 = wave_sum(s1);
+      const float mean = s1 / (float)H;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d0 = v[e] - mean; q += d0 * d0; }
+      q = wave_sum(q);
+      const float rstd = rsqrtf(q / (float)H + a.eps);
+      bf16x8 o1, o2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o1[e] = (bf16)((v[e] - mean) * rstd * pg1[e >> 2][e & 3] + pb1[e >> 2][e & 3]);
+        o2[e] = (bf16)((v[e] - mean) * rstd * pg2[e >> 2][e & 3] + pb2[e >> 2][e & 3]);
+      }
+      *reinterpret_cast<bf16x8*>(a.x1 + ro + k8) = o1;
+      *reinterpret_cast<bf16x8*>(a.x2 + ro + k8) = o2;
     }
-    *reinterpret_cast<bf16x8*>(a.x1 + ro + k) = o1;
-    *reinterpret_cast<bf16x8*>(a.x2 + ro + k) = o2;
   }
 }
 
@@ -930,6 +968,17 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
   const long long ro = (long long)row * H;
   float v[4][8];
   float s = 0.f;
+  // the first 512 columns' LayerNorm parameters are requested together with the row itself: a kernel this small is one
+  // global round trip long, a second dependent one (parameters after the statistics) would double it
+  const int k0 = lane * 8;
+  f32x4 pg1[2], pb1[2], pg2[2], pb2[2];
+  if (x1 && k0 < H) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      pg1[hh] = *reinterpret_cast<const f32x4*>(g1 + k0 + 4 * hh); pb1[hh] = *reinterpret_cast<const f32x4*>(b1 + k0 + 4 * hh);
+      pg2[hh] = *reinterpret_cast<const f32x4*>(g2 + k0 + 4 * hh); pb2[hh] = *reinterpret_cast<const f32x4*>(b2 + k0 + 4 * hh);
+    }
+  }
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int k = lane * 8 + it * 512;
@@ -976,8 +1025,10 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float n = (v[it][j] - mean) * rstd;
-        o1[j] = (bf16)(n * g1[k + j] + b1[k + j]);
-        o2[j] = (bf16)(n * g2[k + j] + b2[k + j]);
+        const float w1 = it == 0 ? pg1[j >> 2][j & 3] : g1[k + j], c1 = it == 0 ? pb1[j >> 2][j & 3] : b1[k + j];
+        const float w2 = it == 0 ? pg2[j >> 2][j & 3] : g2[k + j], c2 = it == 0 ? pb2[j >> 2][j & 3] : b2[k + j];
+        o1[j] = (bf16)(n * w1 + c1);
+        o2[j] = (bf16)(n * w2 + c2);
       }
       *reinterpret_cast<bf16x8*>(x1 + ro + k) = o1;
       *reinterpret_cast<bf16x8*>(x2 + ro + k) = o2;
