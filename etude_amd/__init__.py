@@ -6,11 +6,12 @@ Drop-in surfaces (same names/signatures as the reference):
     etude_amd.EtudeDecoder.generate <- etude.models.etude_decoder.EtudeDecoder.generate
     etude_amd.Vocab / Event         <- etude.data.vocab
     etude_amd.HFT_Transformer       <- etude.models.hft_transformer.HFT_Transformer (prepare.py's transcriber)
+    etude_amd.TinyREMITokenizer     <- etude.data.tokenizer.TinyREMITokenizer (native encode / split / decode_to_notes)
 All arithmetic runs in libetude_hip.so (hand-written HIP, see csrc/); importing the heavy
 modules is lazy so that `import etude_amd` works on a box without a GPU.
 """
 __all__ = ["AMTAPC_Extractor", "EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder", "Vocab", "Event",
-           "ExtractorConfig", "DecoderConfig", "HFT_Transformer", "HFTConfig"]
+           "ExtractorConfig", "DecoderConfig", "HFT_Transformer", "HFTConfig", "TinyREMITokenizer"]
 
 
 def __getattr__(name):
@@ -23,6 +24,9 @@ def __getattr__(name):
     if name in ("Vocab", "Event"):
         from . import vocab
         return getattr(vocab, name)
+    if name == "TinyREMITokenizer":
+        from .tokenizer import TinyREMITokenizer
+        return TinyREMITokenizer
     if name == "HFT_Transformer":
         from .hft_transformer import HFT_Transformer
         return HFT_Transformer

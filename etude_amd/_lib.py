@@ -48,6 +48,14 @@ class SchedCfg(C.Structure):
                [("temperature", C.c_float), ("top_p", C.c_float), ("seed", C.c_ulonglong)]
 
 
+class TempoRegion(C.Structure):
+    _fields_ = [("bpm", C.c_double), ("time_sig", C.c_int), ("start", C.c_double), ("downbeats", C.c_void_p), ("n_downbeats", C.c_int)]
+
+
+class TokEvent(C.Structure):
+    _fields_ = [("type", C.c_int32), ("value", C.c_int32)]
+
+
 class Note(C.Structure):
     _fields_ = [("onset", C.c_double), ("offset", C.c_double), ("pitch", C.c_int32), ("velocity", C.c_int32)]
 
@@ -85,6 +93,15 @@ SIGNATURES = {
     "etd_mpe2note_dev_destroy": (None, [C.c_void_p]),
     "etd_mpe2note_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_int, C.c_int, C.POINTER(Note), C.c_longlong, C.POINTER(C.c_longlong), C.c_void_p]),
+    "etd_tok_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "etd_tok_destroy": (None, [C.c_void_p]),
+    "etd_tok_num_measures": (C.c_int, [C.c_void_p]),
+    "etd_tok_measures": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "etd_tok_encode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_longlong, C.POINTER(C.c_longlong)]),
+    "etd_tok_split_bars": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                     C.POINTER(C.c_longlong)]),
+    "etd_tok_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
+                                 C.POINTER(C.c_longlong)]),
     "etd_decoder_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_i64_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),
     "etd_decoder_destroy": (None, [C.c_void_p]),

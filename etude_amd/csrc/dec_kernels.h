@@ -90,7 +90,7 @@ struct DEmbedArgs {
   int tgt_cls;
   DecRows rows; int M, H, n_bins;
   const int* slots; const int* len; const int* done;  // decode mode, optional: derive the rows from the slot list and WRITE them to
-  int* row_slot_out; int* row_pos_out; int* row_active_out;   //   these arrays (replaces a separate k_decode_rows launch)
+  int* row_slot_out; int* row_pos_out; int* row_active_out;   //   these arrays
   const float* word; const float* cls_emb; const float* attr_tab;  // [V][H], [C][H], [4][n_bins][H] (+bias in tab 0)
   float* h;
 };
@@ -105,4 +105,3 @@ struct DArgmaxArgs {
 };
 int launch_dargmax(const DArgmaxArgs& a, hipStream_t st);
 
-int launch_decode_rows(const int* slots_dev, int n, const int* len, const int* done, int* row_slot, int* row_pos, int* row_active, hipStream_t st);

@@ -1121,12 +1121,3 @@ int launch_dargmax(const DArgmaxArgs& a, hipStream_t st) {
   return ETD_OK;
 }
 
-__global__ void k_decode_rows(const int* slots, int n, const int* len, const int* done, int* row_slot, int* row_pos, int* row_active) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { const int s = slots[i]; row_slot[i] = s; row_pos[i] = len[s]; row_active[i] = done[s] ? 0 : 1; }
-}
-int launch_decode_rows(const int* slots_dev, int n, const int* len, const int* done, int* row_slot, int* row_pos, int* row_active, hipStream_t st) {
-  hipLaunchKernelGGL(k_decode_rows, dim3((n + 63) / 64), dim3(64), 0, st, slots_dev, n, len, done, row_slot, row_pos, row_active);
-  HIP_TRY(hipGetLastError());
-  return ETD_OK;
-}

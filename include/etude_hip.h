@@ -201,6 +201,26 @@ int etd_decoder_prefill_logits(etd_dec*, int slot, const int32_t* ids, const int
 /* algorithmic HBM bytes of one decode step for n_streams at context `ctx` (SURVEY.md 8d formula) */
 double etd_decoder_step_bytes(const etd_dec*, int n_streams, int ctx);
 
+/* ---- TinyREMITokenizer glue on either side of the decoder (host code, no GPU) ----
+ * etd_tok_create      TinyREMITokenizer.__init__ / _create_measures      etude/data/tokenizer.py:24-41,166-229
+ * etd_tok_encode      encode (+ _assign_notes, grace-note linking)        :231-252, :78-116, :265-297
+ * etd_tok_split_bars  split_sequence_into_bars                            :43-76
+ * etd_tok_decode      decode_to_notes (+ glissandos, velocities, sort)    :300-496
+ * Results are bit-identical to the reference (same double arithmetic, tie-breaking and summation orders). */
+typedef struct { double bpm; int time_sig; double start; const double* downbeats; int n_downbeats; } etd_tempo_region;
+enum { ETD_EV_BAR = 0 /* value 1 = BOS, 0 = EOS */, ETD_EV_POS = 1, ETD_EV_NOTE = 2, ETD_EV_DURATION = 3, ETD_EV_GRACE = 4, ETD_EV_OTHER = 5 };
+typedef struct { int32_t type; int32_t value; } etd_event;
+typedef struct etd_tok etd_tok;
+int etd_tok_create(const etd_tempo_region* regions, int n_regions, etd_tok** out);
+void etd_tok_destroy(etd_tok*);
+int etd_tok_num_measures(const etd_tok*);
+int etd_tok_measures(const etd_tok*, double* start, double* end, double* bpm, int32_t* time_sig);
+int etd_tok_encode(const etd_tok*, const etd_note* notes, long long n, int with_grace_note, etd_event* out, long long cap, long long* n_out);
+int etd_tok_split_bars(const int32_t* ids, long long n, int bar_bos_id, int bar_eos_id, int32_t* out_ids, long long cap_ids,
+                       long long* bar_offsets, long long cap_bars, long long* n_bars);
+int etd_tok_decode(const etd_tok*, const etd_event* events, long long n, const double* volume /* or NULL */, long long n_volume,
+                   etd_note* out, long long cap, long long* n_out);
+
 #ifdef __cplusplus
 }
 #endif

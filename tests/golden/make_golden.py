@@ -279,7 +279,88 @@ def gen_hft_wrapper():
                         onset_B=so[4], offset_B=so[5], mpe_B=so[6], velocity_B=so[7])
 
 
-ALL = dict(hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
+def gen_tokenizer():
+    """TinyREMITokenizer (etude/data/tokenizer.py): encode (with / without grace notes), split_sequence_into_bars and
+    decode_to_notes (glissandos, velocity rules with and without a volume map) on synthetic songs."""
+    import tempfile
+    from etude.data.tokenizer import TinyREMITokenizer
+    from etude.data.vocab import Event
+    rng = np.random.default_rng(77)
+    tmp = Path(tempfile.mkdtemp())
+
+    def song(seed, tempo):
+        r = np.random.default_rng(seed)
+        t_end = max(rg["downbeats"][-1] for rg in tempo if rg["downbeats"]) + 3.0
+        notes = []
+        t = tempo[0]["downbeats"][0] - 1.0
+        while t < t_end:
+            k = int(r.integers(1, 5))
+            base = int(r.integers(36, 100))
+            for c in range(k):
+                pitch = int(np.clip(base + int(r.integers(-7, 8)), 21, 108))
+                dur = float(r.choice([0.05, 0.12, 0.25, 0.5, 0.9, 1.7, 3.1]))
+                notes.append({"onset": round(float(t + (0.0 if r.random() < 0.6 else r.uniform(0, 0.03))), 6), "offset": round(float(t + dur), 6),
+                              "pitch": pitch, "velocity": int(r.integers(1, 127))})
+            if r.random() < 0.25:                       # a grace-note-like pair: neighbour pitch 20-90 ms earlier
+                notes.append({"onset": round(float(t - r.uniform(0.02, 0.09)), 6), "offset": round(float(t), 6), "pitch": notes[-1]["pitch"] + int(r.choice([-1, 1])),
+                              "velocity": 50})
+            if r.random() < 0.1:
+                notes.append(dict(notes[-1]))           # exact duplicate (same pitch, same onset)
+            t += float(r.choice([0.125, 0.25, 0.25, 0.5, 1.0]))
+        r.shuffle(notes)
+        return notes
+
+    def ev_list(events):
+        return [[e.type_, e.value] for e in events]
+
+    tempos = {
+        "one_region_4_4": [{"start": 0.5, "bpm": 120, "time_sig": 4, "downbeats": [round(0.5 + 2.0 * i, 6) for i in range(12)]}],
+        "two_regions_3_4": [{"start": 1.0, "bpm": 90.0, "time_sig": 4, "downbeats": [round(1.0 + (240 / 90) * i, 6) for i in range(5)]},
+                            {"start": 14.5, "bpm": 140.0, "time_sig": 3, "downbeats": [round(14.5 + (180 / 140) * i, 6) for i in range(9)]}],
+        "jittered": [{"start": 0.2, "bpm": 100.0, "time_sig": 4, "downbeats": np.round(np.cumsum(np.r_[0.2, rng.uniform(2.2, 2.6, 14)]), 5).tolist()},
+                     {"start": 36.5, "bpm": 80.0, "time_sig": 4, "downbeats": []},          # skipped, but it ends the region before it
+                     {"start": 37.0, "bpm": 80.0, "time_sig": 4, "downbeats": [37.0, 40.0, 43.0]}],
+    }
+    cases = []
+    for name, tempo in tempos.items():
+        tp = tmp / f"{name}_tempo.json"
+        tp.write_text(json.dumps(tempo))
+        for seed, grace in ((1, False), (2, True)):
+            notes = song(seed + len(name), tempo)
+            mp = tmp / "extract.json"
+            mp.write_text(json.dumps(notes))
+            tk = TinyREMITokenizer(str(tp))
+            measures = [[m["start"], m["end"], m["bpm"], m["time_sig"]] for m in tk.global_measures]
+            events = list(tk.encode(str(mp), with_grace_note=grace))
+            # decode what was encoded (+ a few extra Grace events in a row to trigger the glissando path)
+            dec_in = list(events)
+            if grace:
+                ins = []
+                for e in dec_in:
+                    if e.type_ == "Note" and rng.random() < 0.35:
+                        ins.append(Event(type_="Grace", value=int(rng.choice([-1, 1]))))
+                    ins.append(e)
+                dec_in = ins
+            vol = np.round(rng.random(int(20 * (measures[-1][1] + 1))) ** 2, 4).tolist()
+            vp = tmp / "volume.json"
+            vp.write_text(json.dumps(vol))
+            keep = lambda ns: [{k: n[k] for k in ("pitch", "onset", "offset", "velocity")} for n in ns]      # noqa: E731
+            d0 = keep(TinyREMITokenizer(str(tp)).decode_to_notes(list(dec_in)))
+            d1 = keep(TinyREMITokenizer(str(tp)).decode_to_notes(list(dec_in), volume_map_path=str(vp)))
+            cases.append(dict(name=f"{name}_{'grace' if grace else 'plain'}", tempo=tempo, notes=notes, with_grace=grace, measures=measures,
+                              events=ev_list(events), decode_in=ev_list(dec_in), decoded=d0, volume=vol, decoded_vol=d1))
+    # split_sequence_into_bars on raw id streams (Bar_BOS = 4, Bar_EOS = 5 as in the synthetic vocabulary)
+    tk = TinyREMITokenizer(None)
+    splits = []
+    for k in range(6):
+        ids = rng.integers(0, 12, int(rng.integers(0, 60))).tolist()
+        splits.append(dict(ids=ids, bos=4, eos=5, bars=tk.split_sequence_into_bars(list(ids), 4, 5)))
+    splits.append(dict(ids=[4, 7, 8, 4, 9, 5, 5, 6, 4, 10], bos=4, eos=5, bars=tk.split_sequence_into_bars([4, 7, 8, 4, 9, 5, 5, 6, 4, 10], 4, 5)))
+    splits.append(dict(ids=[1, 2, 3], bos=-1, eos=5, bars=tk.split_sequence_into_bars([1, 2, 3], -1, 5)))
+    (HERE / "tokenizer.json").write_text(json.dumps(dict(cases=cases, splits=splits)))
+
+
+ALL = dict(tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
            decoder_tiny=gen_decoder_tiny, decoder_full=gen_decoder_full)
 
 if __name__ == "__main__":

@@ -1,0 +1,95 @@
+"""TinyREMITokenizer glue through the C ABI against vectors captured from the reference class
+(etude/data/tokenizer.py): measures, encode with / without grace-note linking, split_sequence_into_bars, decode_to_notes with
+glissandos and both velocity rules.  Everything is compared exactly (doubles bit for bit)."""
+import json
+
+import pytest
+
+from etude_amd.vocab import Event
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return json.loads((golden_dir / "tokenizer.json").read_text())
+
+
+def _tok(tmp_path, tempo):
+    from etude_amd.tokenizer import TinyREMITokenizer
+    p = tmp_path / "tempo.json"
+    p.write_text(json.dumps(tempo))
+    return TinyREMITokenizer(str(p))
+
+
+def _ev(pairs):
+    return [Event(type_=t, value=v) for t, v in pairs]
+
+
+def test_measures_and_encode(gold, tmp_path):
+    for c in gold["cases"]:
+        tk = _tok(tmp_path, c["tempo"])
+        got_m = [[m["start"], m["end"], m["bpm"], m["time_sig"]] for m in tk.global_measures]
+        assert got_m == c["measures"], c["name"]
+        mp = tmp_path / "extract.json"
+        mp.write_text(json.dumps(c["notes"]))
+        events = tk.encode(str(mp), with_grace_note=c["with_grace"])
+        assert [[e.type_, e.value] for e in events] == c["events"], c["name"]
+        assert any(e.type_ == "Grace" for e in events) == any(t == "Grace" for t, _ in c["events"])
+
+
+def test_decode_to_notes_with_and_without_volume_map(gold, tmp_path):
+    saw_gliss = False
+    for c in gold["cases"]:
+        tk = _tok(tmp_path, c["tempo"])
+        got = tk.decode_to_notes(_ev(c["decode_in"]))
+        assert got == c["decoded"], c["name"]
+        vp = tmp_path / "volume.json"
+        vp.write_text(json.dumps(c["volume"]))
+        assert tk.decode_to_notes(_ev(c["decode_in"]), volume_map_path=str(vp)) == c["decoded_vol"], c["name"]
+        assert tk.decode_to_notes(_ev(c["decode_in"]), volume_map_path=str(tmp_path / "missing.json")) == c["decoded"]    # unreadable map -> count rule
+        saw_gliss = saw_gliss or any(abs((n["offset"] - n["onset"]) - 0.1) < 1e-12 and n["velocity"] != 65 for n in c["decoded"])
+    assert saw_gliss, "no case exercised the glissando rewrite"
+
+
+def test_split_sequence_into_bars(gold):
+    from etude_amd.tokenizer import TinyREMITokenizer
+    tk = TinyREMITokenizer(None)
+    assert tk.global_measures == [] and tk.tempo_data == []
+    for s in gold["splits"]:
+        assert tk.split_sequence_into_bars(s["ids"], s["bos"], s["eos"]) == s["bars"]
+
+
+def test_round_trip_through_the_decoder_boundary(gold, tmp_path):
+    """encode -> vocabulary ids -> bars -> events -> notes: the path infer.py:180-206 walks around the decoder"""
+    from etude_amd.vocab import Vocab
+    c = gold["cases"][0]
+    tk = _tok(tmp_path, c["tempo"])
+    events = tk.encode_notes(c["notes"])
+    v = Vocab()
+    for e in events:
+        v._add_token(str(e))
+    ids = v.encode_sequence(events)
+    bars = tk.split_sequence_into_bars(ids, v.get_bar_bos_id(), v.get_bar_eos_id())
+    assert len(bars) == len(tk.global_measures) and sum(len(b) for b in bars) == len(ids)
+    back = [e for b in bars for e in v.decode_sequence_to_events(b)]
+    assert tk.decode_to_notes(back) == c["decoded"]
+
+
+def test_array_fast_path_equals_object_path(gold, tmp_path):
+    """ids -> notes without per-token Python objects (what a batched run over (clip, attribute tuple) jobs uses)"""
+    import numpy as np
+
+    from etude_amd.vocab import Vocab
+    c = gold["cases"][3]
+    tk = _tok(tmp_path, c["tempo"])
+    events = _ev(c["decode_in"])
+    v = Vocab()
+    for e in events:
+        v._add_token(str(e))
+    ids = v.encode_sequence(events)
+    tab = tk.event_table(v)
+    arr = tk.decode_ids_to_note_array(ids + [v.get_pad_id()] * 3, tab, volume=np.asarray(c["volume"]), pad_id=v.get_pad_id())
+    got = [{"pitch": int(p), "onset": float(a), "offset": float(b), "velocity": int(w)} for p, a, b, w in zip(arr["pitch"], arr["onset"], arr["offset"], arr["velocity"])]
+    assert got == c["decoded_vol"]
+    ev = tk.encode_note_array_to_events(np.asarray([(n["onset"], n["offset"], n["pitch"], n["velocity"]) for n in c["notes"]], dtype=arr.dtype), with_grace_note=True)
+    names = ("Bar", "Pos", "Note", "Duration", "Grace")
+    assert [[names[t], ("BOS" if x == 1 else "EOS") if t == 0 else x] for t, x in zip(ev["type"].tolist(), ev["value"].tolist())] == c["events"]
