@@ -75,6 +75,7 @@ SIGNATURES = {
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
     "etd_frontend_destroy": (None, [C.c_void_p]),
     "etd_frontend_set_pad_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "etd_rms_frames": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p]),
     "etd_frontend_resampled_len": (C.c_longlong, [C.c_void_p, C.c_longlong]),
     "etd_frontend_num_frames": (C.c_longlong, [C.c_void_p, C.c_longlong]),
     "etd_frontend_run": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_longlong,

@@ -111,6 +111,34 @@ __global__ __launch_bounds__(256) void k_stft_mel(const float* __restrict__ x, l
 }
 
 // ------------------------------------------------------------------------------------------------
+// Frame-wise RMS energy (librosa.feature.rms, center=True, zero padding): frame t covers samples
+// [t*hop - frame/2, t*hop + frame/2); one wave per frame.            etude/utils/preprocess.py:116-152
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rms_frames(const float* __restrict__ x, long long N, int frame, int hop, float* __restrict__ out, long long T) {
+  const int lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= T) return;
+  const long long s0 = t * hop - frame / 2;
+  float acc = 0.f;
+  for (int i = lane; i < frame; i += 64) {
+    const long long idx = s0 + i;
+    const float v = (idx >= 0 && idx < N) ? x[idx] : 0.f;
+    acc = fmaf(v, v, acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) out[t] = sqrtf(acc / (float)frame);
+}
+
+extern "C" int etd_rms_frames(const float* x_dev, long long n, int frame_length, int hop_length, float* out_dev, long long n_frames, void* stream) {
+  if (!x_dev || !out_dev || n < 0 || frame_length < 1 || hop_length < 1 || n_frames < 0 || n_frames > 1 + n / hop_length)
+    ETD_FAIL(ETD_EINVAL, "rms_frames: bad arguments");
+  if (n_frames == 0) return ETD_OK;
+  hipLaunchKernelGGL(k_rms_frames, dim3((unsigned)((n_frames + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x_dev, n, frame_length, hop_length, out_dev, n_frames);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 struct etd_frontend {
   int sr_in, sr_out, orig, nw, K, width;
   int n_fft, lg, hop, n_mels;

@@ -69,6 +69,9 @@ void etd_frontend_destroy(etd_frontend*);
 /* STFT centre padding: 0 = reflect (AMTAPC_Extractor, torchaudio default), 1 = zeros (HFT_Transformer: pad_mode="constant",
  * etude/models/hft_transformer.py:124-131) */
 int etd_frontend_set_pad_mode(etd_frontend*, int constant_zero);
+/* frame-wise RMS of a mono device signal: out[t] = sqrt(mean(x[t*hop - frame/2 .. + frame)^2)), zeros outside the signal
+ * (librosa.feature.rms, center=True) -- the volume contour of analyze_volume, etude/utils/preprocess.py:116-152 */
+int etd_rms_frames(const float* x_dev, long long n, int frame_length, int hop_length, float* out_dev, long long n_frames, void* stream);
 long long etd_frontend_resampled_len(const etd_frontend*, long long n_in);
 long long etd_frontend_num_frames(const etd_frontend*, long long n_in);
 /* wav_dev: planar [channels][n_in] fp32.  resampled_dev: scratch >= resampled_len floats.

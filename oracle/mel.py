@@ -97,3 +97,20 @@ def feature_frames(n_samples_in: int, sr: int, target_sr: int = 16000, hop: int 
     g = math.gcd(sr, target_sr)
     n16 = int(math.ceil((target_sr // g) * n_samples_in / (sr // g))) if sr != target_sr else n_samples_in
     return 1 + n16 // hop
+
+
+def volume_contour(wave: torch.Tensor, sr_in: int, sr: int = 22050, resolution: int = 20) -> torch.Tensor:
+    """analyze_volume, etude/utils/preprocess.py:116-152, on an in-memory clip [C, L]: mono mean, resample to `sr`,
+    librosa.feature.rms(frame_length = 2 * hop, hop_length = sr // resolution, center=True with zero padding), min-max
+    normalisation.  PARITY UNPINNED at the resampler: librosa.load uses soxr ("soxr_hq", third-party, absent here); this
+    restatement uses the torchaudio-style sinc resampler of `resample` above."""
+    y = resample(torch.mean(wave, dim=0), sr_in, sr) if sr_in != sr else torch.mean(wave, dim=0)
+    hop = sr // resolution
+    frame = 2 * hop
+    yp = torch.nn.functional.pad(y, (frame // 2, frame // 2))
+    T = 1 + y.numel() // hop
+    frames = yp.unfold(0, frame, hop)[:T]
+    rms = torch.sqrt(torch.mean(frames * frames, dim=1))
+    if rms.numel() and float(rms.max()) > float(rms.min()):
+        return (rms - rms.min()) / (rms.max() - rms.min())
+    return torch.zeros_like(rms)

@@ -50,3 +50,31 @@ def test_frontend_rejects_too_short_clip(dev):
     fe = FrontEnd(44100)
     with pytest.raises(_lib.EtudeHipError):
         fe(torch.zeros((1, 1000), device=dev))           # < n_fft/2 samples after resampling: reflect pad undefined
+
+
+def test_volume_contour_matches_oracle(dev):
+    """analyze_volume (stage 1's volume map): GPU mono + resample + frame RMS vs the oracle's restatement"""
+    from etude_amd.preprocess import volume_contour_tensor
+    from oracle import mel
+    wav = synth.clip_audio(seed=9, seconds=4.0)
+    wav = wav * np.linspace(0.1, 1.0, wav.shape[1], dtype=np.float32)[None]          # a crescendo: the contour must rise
+    got = volume_contour_tensor(wav, 44100)
+    want = mel.volume_contour(torch.from_numpy(wav), 44100).numpy()
+    assert got.shape == want.shape == (1 + (wav.shape[1] // 2) // 1102,)
+    assert got.dtype == np.float32 and got.min() == 0.0 and got.max() == 1.0
+    assert np.abs(got - want).max() < 1e-4
+    assert got[-20:].mean() > got[:20].mean() + 0.3
+    assert not volume_contour_tensor(np.zeros((2, 44100), np.float32), 44100).any()   # silence -> zeros (preprocess.py:147-149)
+
+
+def test_analyze_volume_file_surface(dev, tmp_path):
+    from etude_amd.extractor import write_wav_f32
+    from etude_amd.preprocess import analyze_volume, save_volume_map
+    import json
+    wav = synth.clip_audio(seed=2, seconds=1.0)
+    write_wav_f32(tmp_path / "a.wav", wav, 44100)
+    v = analyze_volume(tmp_path / "a.wav")
+    save_volume_map(v, tmp_path / "out" / "volume.json")
+    assert json.loads((tmp_path / "out" / "volume.json").read_text()) == v.tolist()
+    with pytest.raises(FileNotFoundError):
+        analyze_volume(tmp_path / "missing.wav")
