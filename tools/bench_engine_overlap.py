@@ -23,8 +23,25 @@ if __name__ == "__main__":
     rng = np.random.default_rng(0)
     tg = np.asarray([2, 1, 1, 1], np.int32)
     decs = []
+    mask_mode = sys.argv[4] if len(sys.argv) > 4 else "none"      # none | thirds | interleave : CU masks per engine stream (hipExtStreamCreateWithCUMask)
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
     for e in range(4):
         dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=1024)
+        if mask_mode != "none":
+            bits = [0] * 256
+            if mask_mode == "thirds":
+                lo, hi = [(0, 88), (88, 176), (176, 256), (0, 256)][e]
+                for i in range(lo, hi):
+                    bits[i] = 1
+            else:                                   # every third CU
+                for i in range(256):
+                    bits[i] = 1 if (e == 3 or i % 3 == e) else 0
+            words = (C.c_uint32 * 8)(*[sum(bits[w * 32 + b] << b for b in range(32)) for w in range(8)])
+            hs = C.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(C.byref(hs), 8, words)
+            assert rc == 0, rc
+            dec._ts = torch.cuda.ExternalStream(hs.value, device=dev)
         st = dec._stream()
         for s in range(S):
             ids = rng.integers(6, 154, ctx0).astype(np.int32)
