@@ -141,3 +141,25 @@ def test_checkpoint_loader_contract(dev, tmp_path):
     torch.save(bad, tmp_path / "bad.pth")
     with pytest.raises(RuntimeError, match="missing keys"):
         load_etude_decoder(tmp_path / "etude_decoder_config.json", tmp_path / "bad.pth", "cuda")
+
+
+def test_many_jobs_slot_reuse_and_split_prefill_passes(dev):
+    """70 jobs on 24 streams with a prefill row budget that forces several batched-prefill passes per bar: every job's ids equal
+    the single-stream result (fp32 mode: logits do not depend on the batch shape)"""
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    v = _vocab()
+    cfgd = EtudeDecoderConfig(**synth.decoder_dims())
+    sd = synth.decoder_state_dict(1, {})
+    one = EtudeDecoder(cfgd, sd, "cuda", precision="fp32", max_streams=1)
+    many = EtudeDecoder(cfgd, sd, "cuda", precision="fp32", max_streams=24, max_prefill_rows=1100)
+    jobs = []
+    for s_ in range(70):
+        bars = synth.song_bars(seed=200 + s_ % 9, n_bars=2 + s_ % 3)
+        jobs.append((bars, [synth.attrs(s_ % 3, (s_ // 3) % 3, (s_ // 9) % 3, 2)] * len(bars)))
+    got = many.generate_many(jobs, v, max_bar_token_limit=10)
+    memo = {}
+    for (bars, at), g in zip(jobs, got):
+        key = (tuple(map(tuple, bars)), tuple(sorted(at[0].items())))
+        if key not in memo:
+            memo[key] = one.generate_ids(v, bars, at, max_bar_token_limit=10, temperature=0.0)
+        assert g == memo[key]

@@ -160,3 +160,27 @@ def test_extract_end_to_end_writes_reference_json(dev, tmp_path):
     on, off, mp, ve = [t.cpu().numpy() for t in ex.transcript(dev_feat)]
     assert notes == mpe2note.notes_for_json(mpe2note.mpe2note(on, off, mp, ve, 0.5, 1.0, 0.5), 0.08)
     assert abs(len(notes) - len(ref_notes)) <= max(3, len(ref_notes) // 10)
+
+
+def test_short_mono_16k_clip_single_partial_window(dev, tmp_path):
+    """edge of the input space: 16 kHz mono (no resampling), 0.35 s -> 22 frames, less than one window, ragged tail"""
+    from etude_amd.extractor import write_wav_f32
+    from oracle import hft, mel, mpe2note
+    nf = 32
+    ex = _extractor(nf, seed=4)
+    wav = synth.clip_audio(seed=8, seconds=0.35, sr=16000)[:1]
+    write_wav_f32(tmp_path / "m.wav", wav, 16000)
+    ex.extract(str(tmp_path / "m.wav"), str(tmp_path / "m.json"))
+    notes = json.loads((tmp_path / "m.json").read_text())
+    feat = mel.wav2feature(torch.from_numpy(wav), 16000).numpy()
+    assert feat.shape == (1 + wav.shape[1] // 256, 256)
+    got = ex._transcript(feat)
+    assert got[4].shape == (nf, 88)                               # padded to one whole window
+    sd, d = _oracle(nf, seed=4)
+    o = hft.transcript(sd, feat, d)
+    for i in (4, 5, 6):
+        assert np.abs(got[i] - o[i]).max() < P_TOL
+    dev_feat = ex.wav2feature_tensor(wav, 16000)
+    assert np.abs(dev_feat.cpu().numpy() - feat).max() < 2e-3
+    on, off, mp, ve = [t.cpu().numpy() for t in ex.transcript(dev_feat)]
+    assert notes == mpe2note.notes_for_json(mpe2note.mpe2note(on, off, mp, ve, 0.5, 1.0, 0.5), 0.08)
