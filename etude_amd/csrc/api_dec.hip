@@ -42,7 +42,7 @@ struct etd_dec {
   long long slot_stride = 0, layer_stride = 0;   // elements
   // workspaces
   float *h = nullptr, *h2 = nullptr, *Q = nullptr, *AO = nullptr, *DO = nullptr, *M1 = nullptr, *logits = nullptr;
-  int *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *ids = nullptr, *slots_dev = nullptr;
+  int *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *row_sp = nullptr, *ids = nullptr, *slots_dev = nullptr;
   // stream state
   int *cur_tok = nullptr, *len = nullptr, *done = nullptr, *n_out = nullptr, *eos = nullptr, *limit = nullptr, *tgt_attrs = nullptr, *out_tok = nullptr;
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
@@ -174,7 +174,9 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     } else {
       DAttnArgs at = {};
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
-      at.rows = rows; at.M = M; at.O = d->AO; at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+      at.rows = rows; at.M = M; at.O = d->AO;
+      at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+      if (rows.slot == d->row_slot) at.row_sp = d->row_sp;     // decode step: the step's (slot, pos) pairs
       if (catk) { at.Ob = d->Xcat + d->I; at.ldob = d->I + d->H; }
       ETD_TRY(launch_dattn(at, d->bf16w, st));
     }
@@ -422,6 +424,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
     rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)
   }
   rc = rc ? rc : d->alloc(&d->samp_dev, (size_t)1, true); rc = rc ? rc : d->alloc(&d->rng_key, (size_t)d->S, true);
+  rc = rc ? rc : d->alloc(&d->row_sp, (size_t)2 * d->Mmax, true);
   rc = rc ? rc : d->alloc(&d->row_slot, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_pos, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_active, (size_t)d->Mmax);
   rc = rc ? rc : d->alloc(&d->ids, 10 * M + 13 * (size_t)d->S); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
   const size_t S = d->S;
@@ -510,7 +513,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
                      vpad <= d->head.Npad && !getenv("ETD_NO_FUSED_STEP");
   auto embed = [&](hipStream_t s_) -> int {
     DEmbedArgs e = {};
-    e.slots = d->slots_dev; e.len = d->len; e.done = d->done; e.row_slot_out = d->row_slot; e.row_pos_out = d->row_pos; e.row_active_out = d->row_active;
+    e.slots = d->slots_dev; e.len = d->len; e.done = d->done; e.row_slot_out = d->row_slot; e.row_pos_out = d->row_pos; e.row_active_out = d->row_active; e.row_sp_out = d->row_sp;
     e.cur_tok = d->cur_tok; e.tgt_attrs = d->tgt_attrs; e.tgt_cls = 2 /* TGT_CLASS_ID, etude/data/dataset.py:19 */;
     e.M = n_active; e.H = d->H; e.n_bins = d->cfg.num_attribute_bins;
     e.word = d->word; e.cls_emb = d->cls_emb; e.attr_tab = d->attr_tab; e.h = d->h;
@@ -530,7 +533,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
       DHeadArgs hd = {};
       hd.hfin = hf; hd.M = n_active; hd.H = d->H; hd.V = d->V; hd.Vpad = vpad;
       hd.lnf_g = d->lnfg; hd.lnf_b = d->lnfb; hd.eps = d->cfg.layer_norm_eps; hd.Whead = (const bf16*)d->head.W;
-      hd.row_slot = d->row_slot; hd.row_pos = d->row_pos; hd.row_active = d->row_active;
+      hd.row_slot = d->row_slot; hd.row_pos = d->row_pos; hd.row_active = d->row_active; hd.row_sp = d->row_sp;
       hd.cur_tok = d->cur_tok; hd.len = d->len; hd.done = d->done; hd.n_out = d->n_out; hd.out_tok = d->out_tok; hd.out_cap = d->out_cap;
       hd.eos = d->eos; hd.limit = d->limit; hd.tgt_attrs = d->tgt_attrs; hd.tgt_cls = 2; hd.n_bins = d->cfg.num_attribute_bins;
       hd.word = d->word; hd.cls_emb = d->cls_emb; hd.attr_tab = d->attr_tab;

@@ -54,7 +54,7 @@ struct DHeadArgs {
   const float* hfin; int M, H, V, Vpad;       // last layer's residual stream [M][H]
   const float* lnf_g; const float* lnf_b; float eps;
   const bf16* Whead;                           // [Vpad][H]
-  int* row_slot; int* row_pos; int* row_active;   // in: this step's rows; out: next step's
+  int* row_slot; int* row_pos; int* row_active; int* row_sp;   // in: this step's rows; out: next step's (row_sp: (slot, pos) pairs)
   int* cur_tok; int* len; int* done; int* n_out; int* out_tok; int out_cap; const int* eos; const int* limit;
   const int* tgt_attrs; int tgt_cls; int n_bins;
   const float* word; const float* cls_emb; const float* attr_tab;
@@ -68,6 +68,7 @@ struct DAttnArgs {
   const float* Q;                // [M][hidden]
   const void* Kc; const void* Vc; long long slot_stride; int max_ctx, n_heads;
   DecRows rows; int M;
+  const int* row_sp;             // optional [M][2] = (slot, position) pairs: one scalar load instead of two dependent ones
   float* O;                      // [M][hidden]
   bf16* Ob; int ldob;            // optional bf16 copy of O (input of the dense GEMM in the bf16 pipeline), row stride ldob (0 = hidden)
   float scale;
@@ -90,7 +91,7 @@ struct DEmbedArgs {
   int tgt_cls;
   DecRows rows; int M, H, n_bins;
   const int* slots; const int* len; const int* done;  // decode mode, optional: derive the rows from the slot list and WRITE them to
-  int* row_slot_out; int* row_pos_out; int* row_active_out;   //   these arrays
+  int* row_slot_out; int* row_pos_out; int* row_active_out; int* row_sp_out;   //   these arrays ((slot, pos) pairs too)
   const float* word; const float* cls_emb; const float* attr_tab;  // [V][H], [C][H], [4][n_bins][H] (+bias in tab 0)
   float* h;
 };

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
       dn = fin;
     }
     // next step's row: position = new length, active = not done
-    if (lane == 0) { a.row_pos[m] = ln; a.row_active[m] = dn ? 0 : 1; }
+    if (lane == 0) { a.row_pos[m] = ln; a.row_active[m] = dn ? 0 : 1; if (a.row_sp) a.row_sp[2 * m + 1] = ln; }
   }
   // next embeddings, two rows at a time: all their table rows in flight together (one round trip per pair)
   f32x4 r_c[2], pg1[2], pb1[2], pg2[2], pb2[2];
@@ -784,7 +784,10 @@ __global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
   __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
   const int m = blockIdx.x, head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
-  const int slot = a.rows.slot[m], pos = a.rows.pos[m];
+  int slot, pos;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  if (a.row_sp) { const i32x2 sp = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(a.row_sp + 2 * m)); slot = sp[0]; pos = sp[1]; }   // one 8-byte load
+  else { slot = a.rows.slot[m]; pos = a.rows.pos[m]; }
   const int ctx = (pos < a.max_ctx ? pos : a.max_ctx - 1) + 1;
   const int hidden = a.n_heads * 64;
   // bf16 serving mode: scores pre-scaled by log2(e) and v_exp_f32 (exp2) -- softmax is base-invariant; the fp32
@@ -1069,7 +1072,11 @@ __global__ void k_dembed(DEmbedArgs a) {
   } else {
     // decode step: this kernel also materialises the row metadata the rest of the step reads (slot, position, active)
     const int slot = a.slots ? a.slots[m] : a.rows.slot[m];
-    if (a.slots && threadIdx.x == 0) { a.row_slot_out[m] = slot; a.row_pos_out[m] = a.len[slot]; a.row_active_out[m] = a.done[slot] ? 0 : 1; }
+    if (a.slots && threadIdx.x == 0) {
+      const int ps = a.len[slot];
+      a.row_slot_out[m] = slot; a.row_pos_out[m] = ps; a.row_active_out[m] = a.done[slot] ? 0 : 1;
+      if (a.row_sp_out) { a.row_sp_out[2 * m] = slot; a.row_sp_out[2 * m + 1] = ps; }
+    }
     id = a.cur_tok[slot]; cl = a.tgt_cls;
 #pragma unroll
     for (int k = 0; k < 4; ++k) at[k] = a.tgt_attrs[slot * 4 + k];
