@@ -462,7 +462,6 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
   // trips that now overlap the LayerNorm and logits phases instead of following each argmax)
   const int k8 = lane * 8;
   int r_slot[4], r_tok[4], r_len[4], r_done[4], r_nout[4], r_eos[4], r_lim[4], r_act[4], r_pos[4], r_at[4][4];
-  unsigned long long r_key[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     int m = m0 + wave * 4 + j; m = m < a.M ? m : a.M - 1;
@@ -472,11 +471,12 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
   for (int j = 0; j < 4; ++j) {
     const int sl = r_slot[j];
     r_tok[j] = a.cur_tok[sl]; r_len[j] = a.len[sl]; r_done[j] = a.done[sl]; r_nout[j] = a.n_out[sl]; r_eos[j] = a.eos[sl]; r_lim[j] = a.limit[sl];
-    r_key[j] = (inv_temp > 0.f) ? a.rng_key[sl] : 0ull;
 #pragma unroll
     for (int k = 0; k < 4; ++k) r_at[j][k] = a.tgt_attrs[sl * 4 + k];
   }
-  // ---- final LayerNorm of 4 rows per wave (summation order of k_dgemm_s's LayerNorm prologue)
+  // ---- final LayerNorm of 4 rows per wave (summation order of k_dgemm_s's LayerNorm prologue); unrolled: the four rows'
+  // loads are in flight together
+#pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int rl = wave * 4 + j;
     int gm = m0 + rl; gm = gm < a.M ? gm : a.M - 1;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
     if (m >= a.M) continue;
     const int slot = r_slot[j];
     int bi;
-    if (inv_temp > 0.f) bi = wave_sample(Ls + rl * DH_LDL, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, r_key[j], (unsigned)r_nout[j], sps[wave], sss[wave], sis[wave]);
+    if (inv_temp > 0.f) bi = wave_sample(Ls + rl * DH_LDL, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, a.rng_key[slot], (unsigned)r_nout[j], sps[wave], sss[wave], sis[wave]);   // (the key is fetched only on the sampling path: prefetching it made the compiler drain all loads per row)
     else bi = wave_argmax(Ls + rl * DH_LDL, a.V, lane);
     int ln = r_len[j], dn = r_done[j];
     if (r_act[j] && !dn) {
@@ -962,7 +962,8 @@ int launch_ln_rows(const float* hsrc, int M, int H, const float* g1, const float
 }
 
 // hout = ((sum_z P[z] + bias) + add) + hin, then the next layer's two LayerNorms -> bf16.  One wave per row, single pass.
-__global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__ P, int ks, const float* __restrict__ bias, const float* __restrict__ add,
+template <int KS>   // KS > 0: slab count known at compile time -> all slab loads of a row are in flight together (a runtime loop makes them dependent round trips)
+__global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__ P, int ks_rt, const float* __restrict__ bias, const float* __restrict__ add,
                                                        const float* __restrict__ hin, float* __restrict__ hout, int M, int H,
                                                        const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2,
                                                        const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
@@ -989,11 +990,24 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
       float acc[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-      for (int z = 0; z < ks; ++z) {
-        const float* pp = P + (long long)z * M * H + ro + k;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(pp), b = *reinterpret_cast<const f32x4*>(pp + 4);
+      if constexpr (KS > 0) {
+        f32x4 pa[KS], pb[KS];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+        for (int z = 0; z < KS; ++z) {
+          const float* pp = P + (long long)z * M * H + ro + k;
+          pa[z] = *reinterpret_cast<const f32x4*>(pp); pb[z] = *reinterpret_cast<const f32x4*>(pp + 4);
+        }
+#pragma unroll
+        for (int z = 0; z < KS; ++z)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[j] += pa[z][j]; acc[4 + j] += pb[z][j]; }
+      } else {
+        for (int z = 0; z < ks_rt; ++z) {
+          const float* pp = P + (long long)z * M * H + ro + k;
+          const f32x4 a = *reinterpret_cast<const f32x4*>(pp), b = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { acc[j] += a[j]; acc[4 + j] += b[j]; }
+        }
       }
       const f32x4 ba = *reinterpret_cast<const f32x4*>(bias + k), bb = *reinterpret_cast<const f32x4*>(bias + k + 4);
       f32x4 da = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
@@ -1042,7 +1056,8 @@ int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const 
                          const float* g1, const float* b1, const float* g2, const float* b2, float eps, bf16* x1, bf16* x2, hipStream_t st) {
   if (M <= 0 || H % 8 || H > 2048 || k_splits < 1) ETD_FAIL(ETD_EINVAL, "resid_ln_rows: bad shape");
   ProfScope ps("k_resid_ln_rows", st, 0, (double)M * H * 4 * (k_splits + 3));
-  hipLaunchKernelGGL(k_resid_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
+  if (k_splits == 5) hipLaunchKernelGGL(k_resid_ln_rows<5>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
+  else hipLaunchKernelGGL(k_resid_ln_rows<0>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
