@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
           wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
           xf[s4] = *reinterpret_cast<const bf16x8*>(xbrow + k + s4 * 16 + h * 8);
         }
+        __builtin_amdgcn_sched_barrier(0);     // all 8 loads of the slice are issued before the first MFMA waits: ONE round trip, not two
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
       }
@@ -282,11 +283,12 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGe
   // Wave 0 owns the epilogue.  Its row metadata and bias are requested BEFORE the weight stream and the RoPE factors
   // (which depend on the row's position) right after it, so these dependent round trips overlap the K loop and the LDS
   // reduction instead of following them.
+  // (Every wave issues these few loads, unconditionally: putting them under `if (wave == 0)` / `if (isq)` makes the compiler merge
+  // the loaded values with the defaults right behind the branch, i.e. wait a full round trip BEFORE the weight stream is issued.)
   f32x4 bq[4];
-  int pos = 0, slot = 0, act = 0;
+  const int pos = q.rows.pos[gm], slot = q.rows.slot[gm], act = q.rows.active[gm];
   f32x4 rc = {1.f, 1.f, 1.f, 1.f}, rs = {0.f, 0.f, 0.f, 0.f};
-  if (wave == 0) {
-    if (isq) { pos = q.rows.pos[gm]; slot = q.rows.slot[gm]; act = q.rows.active[gm]; }
+  {
     const float* bp = (isq ? q.bias : up.bias) + n0 + 4 * h;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) bq[q4] = *reinterpret_cast<const f32x4*>(bp + 8 * q4);
