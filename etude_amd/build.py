@@ -17,6 +17,10 @@ LIB = HERE / "libetude_hip.so"
 SOURCES = ["ext_kernels.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result",
          "-I", str(HERE.parent / "include")]
+# gfx950 can hand the first kernel arguments to a wave in SGPRs at launch (kernarg preload): kernels whose hot arguments are
+# leading scalars / pointers then start without the initial s_load round trip.  ETD_KERNARG_PRELOAD=0 turns it off.
+if os.environ.get("ETD_KERNARG_PRELOAD", "1") != "0":
+    FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 # -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
 
 

@@ -136,14 +136,14 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 #define DS_MAX_ROWS 512   // up to this many rows a GEMM runs on the weight-streaming skinny tile (decode steps of <= 512 streams)
 #define DS_WAVES 8   // K is split over 8 waves: one L2 round trip covers K = 512, four (fully unrolled) K = 2048
 template <bool WBF16, int EPI>
-__global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
+__global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, int p_ks, int p_K, const void* p_W, const bf16* p_Xb, int p_ldx, DGemmArgs a) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   __shared__ float stat[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   // Workgroup -> tile: the row tiles that stream the SAME weight tile (feature block x K slice) take consecutive slots of
   // ONE XCD (id = 8*slot + xcd), so the weights come from HBM / the Infinity Cache once and from that XCD's L2 afterwards
   // (FETCH_SIZE before: 12.9 MB per QKV|up launch at 72 rows for 3.7 MB of weights).
-  const int RT = (a.M + 31) / 32, FT = a.Npad / 32, KS = a.k_splits > 1 ? a.k_splits : 1;
+  const int RT = (p_M + 31) / 32, FT = p_Npad / 32, KS = p_ks > 1 ? p_ks : 1;
   const int bid = blockIdx.x, wt = ((bid >> 3) / RT) * 8 + (bid & 7);
   if (wt >= FT * KS) return;
   const int bz = wt / FT;
@@ -169,18 +169,18 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
     }
     __syncthreads();
   }
-  int gm = m0 + r; gm = gm < a.M ? gm : a.M - 1;
+  int gm = m0 + r; gm = gm < p_M ? gm : p_M - 1;
   const float mean = ln ? stat[r] : 0.f, rstd = ln ? stat[32 + r] : 1.f;
   const float* xrow = a.X + (long long)gm * a.ldx;
-  const int Kz = a.K / KS;                             // split-K over workgroups (DEPI_PARTIAL), then over the waves
+  const int Kz = p_K / KS;                             // split-K over workgroups (DEPI_PARTIAL), then over the waves
   const int kq = Kz / DS_WAVES, kb = bz * Kz + wave * kq, ke = kb + kq;
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   if constexpr (WBF16) {
-    const bf16* wrow = reinterpret_cast<const bf16*>(a.W) + (long long)(n0 + r) * a.K;
-    if (a.Xb) {
-      const bf16* xbrow = a.Xb + (long long)gm * a.ldx;
+    const bf16* wrow = reinterpret_cast<const bf16*>(p_W) + (long long)(n0 + r) * p_K;
+    if (p_Xb) {
+      const bf16* xbrow = p_Xb + (long long)gm * p_ldx;
 #pragma unroll 4
       for (int k = kb; k < ke; k += 64) {
         bf16x8 wf[4], xf[4];
@@ -267,13 +267,14 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(DGemmArgs a) {
 // [0, split) belong to the first problem, the rest to the second.  Same 32x32 / 8-wave K-split body as k_dgemm_s
 // (bf16 inputs, K = hidden).  One dependent kernel boundary less per layer of a latency-bound chain.
 // ================================================================================================
-__global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGemmArgs up, int split) {
+__global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K, int split, int p_ftiles, const void* p_Wq, const void* p_Wu, const bf16* p_Xq,
+                                                               const bf16* p_Xu, int p_ldxq, int p_ldxu, DGemmArgs q, DGemmArgs up) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int M = q.M, K = q.K;
+  const int M = p_M, K = p_K;
   // workgroup -> tile as in k_dgemm_s: the row tiles of one weight tile run back to back on one XCD
   const int RT = (M + 31) / 32, bid = blockIdx.x, ft = ((bid >> 3) / RT) * 8 + (bid & 7);
-  if (ft >= split + up.Npad / 32) return;
+  if (ft >= p_ftiles) return;
   const bool isq = ft < split;
   const int m0 = ((bid >> 3) % RT) * 32, n0 = (isq ? ft : ft - split) * 32;
   int gm = m0 + r; gm = gm < M ? gm : M - 1;
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(DGemmArgs q, DGe
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) bq[q4] = *reinterpret_cast<const f32x4*>(bp + 8 * q4);
   }
-  const bf16* wrow = reinterpret_cast<const bf16*>(isq ? q.W : up.W) + (long long)(n0 + r) * K;
-  const bf16* xbrow = (isq ? q.Xb : up.Xb) + (long long)gm * (isq ? q.ldx : up.ldx);
+  const bf16* wrow = reinterpret_cast<const bf16*>(isq ? p_Wq : p_Wu) + (long long)(n0 + r) * K;
+  const bf16* xbrow = (isq ? p_Xq : p_Xu) + (long long)gm * (isq ? p_ldxq : p_ldxu);
   const int kq = K / DS_WAVES, kb = wave * kq, ke = kb + kq;
   f32x16 acc;
 #pragma unroll
@@ -367,7 +368,7 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
   const int split = q.Npad / 32;
   const int ftiles = split + up.Npad / 32;
-  hipLaunchKernelGGL(k_dstep_qkv_up, dim3((unsigned)(((ftiles + 7) / 8) * 8 * ((q.M + 31) / 32))), dim3(64 * DS_WAVES), 0, st, q, up, split);
+  hipLaunchKernelGGL(k_dstep_qkv_up, dim3((unsigned)(((ftiles + 7) / 8) * 8 * ((q.M + 31) / 32))), dim3(64 * DS_WAVES), 0, st, q.M, q.K, split, ftiles, q.W, up.W, q.Xb, up.Xb, q.ldx, up.ldx, q, up);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
@@ -452,7 +453,7 @@ __device__ int wave_sample(const float* lg, int V, int lane, float inv_temp, flo
 // ================================================================================================
 #define DH_LDX 520   // LayerNorm'ed rows in LDS: 512 + 8 bf16 (1040 B rows: conflict-free 16-byte fragment reads)
 #define DH_LDL 257   // logits rows in LDS (floats): up to 256 vocabulary entries + 1
-__global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
+__global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M, const int* p_row_slot, const int* p_row_active, const int* p_row_pos, DHeadArgs a) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) bf16 Xs[32 * DH_LDX];
   __shared__ float Ls[32 * DH_LDL];
   __shared__ float sps[8][256], sss[8][256];
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
   int r_slot[4], r_tok[4], r_len[4], r_done[4], r_nout[4], r_eos[4], r_lim[4], r_act[4], r_pos[4], r_at[4][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    int m = m0 + wave * 4 + j; m = m < a.M ? m : a.M - 1;
-    r_slot[j] = a.row_slot[m]; r_act[j] = a.row_active[m]; r_pos[j] = a.row_pos[m];
+    int m = m0 + wave * 4 + j; m = m < p_M ? m : p_M - 1;
+    r_slot[j] = p_row_slot[m]; r_act[j] = p_row_active[m]; r_pos[j] = p_row_pos[m];
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -481,8 +482,8 @@ __global__ __launch_bounds__(512) void k_dstep_head(DHeadArgs a) {
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int rl = wave * 4 + j;
-    int gm = m0 + rl; gm = gm < a.M ? gm : a.M - 1;
-    const float* xp = a.hfin + (long long)gm * H;
+    int gm = m0 + rl; gm = gm < p_M ? gm : p_M - 1;
+    const float* xp = p_hfin + (long long)gm * H;
     const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + lane * 4), v1 = *reinterpret_cast<const f32x4*>(xp + lane * 4 + 256);
     float s = 0.f;
     s += v0[0] + v0[1] + v0[2] + v0[3];
@@ -623,7 +624,7 @@ int launch_dstep_head(const DHeadArgs& a, hipStream_t st) {
   if (a.M < 1 || a.H != 512 || a.V < 1 || a.V > a.Vpad || a.Vpad % 32 || a.Vpad > 256 || !a.hfin || !a.Whead || !a.h || !a.x1 || !a.x2)
     ETD_FAIL(ETD_EINVAL, "dstep_head: bad arguments (needs hidden 512, vocabulary <= 256)");
   ProfScope ps("k_dstep_head", st, 2.0 * a.M * a.V * a.H, (double)a.Vpad * a.H * 2);
-  hipLaunchKernelGGL(k_dstep_head, dim3((a.M + 31) / 32), dim3(512), 0, st, a);
+  hipLaunchKernelGGL(k_dstep_head, dim3((a.M + 31) / 32), dim3(512), 0, st, a.hfin, a.M, a.row_slot, a.row_active, a.row_pos, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
@@ -726,17 +727,17 @@ static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st
   const dim3 g0((a.M + 31) / 32, a.Npad / 128), g1((unsigned)(((wtiles + 7) / 8) * 8 * ((a.M + 31) / 32))), g2(a.Npad / 16);
 #define ETD_DG(E)                                                                                   \
   if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, E>), g0, dim3(256), 0, st, a);                  \
-  else if (path == 1) hipLaunchKernelGGL((k_dgemm_s<WBF16, E>), g1, dim3(64 * DS_WAVES), 0, st, a);  \
+  else if (path == 1) hipLaunchKernelGGL((k_dgemm_s<WBF16, E>), g1, dim3(64 * DS_WAVES), 0, st, a.M, a.Npad, a.k_splits, a.K, a.W, a.Xb, a.ldx, a);  \
   else hipLaunchKernelGGL((k_dgemv<WBF16, E>), g2, dim3(256), 0, st, a);
   switch (epi) {
     case DEPI_BIAS: ETD_DG(DEPI_BIAS) break;
     case DEPI_GELU: ETD_DG(DEPI_GELU) break;
     case DEPI_RESID: ETD_DG(DEPI_RESID) break;
     case DEPI_LOGITS: ETD_DG(DEPI_LOGITS) break;
-    case DEPI_PARTIAL: hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_PARTIAL>), g1, dim3(64 * DS_WAVES), 0, st, a); break;
+    case DEPI_PARTIAL: hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_PARTIAL>), g1, dim3(64 * DS_WAVES), 0, st, a.M, a.Npad, a.k_splits, a.K, a.W, a.Xb, a.ldx, a); break;
     default:
       if (path == 0) hipLaunchKernelGGL((k_dgemm<WBF16, DEPI_QKV>), g0, dim3(256), 0, st, a);
-      else hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_QKV>), g1, dim3(64 * DS_WAVES), 0, st, a);
+      else hipLaunchKernelGGL((k_dgemm_s<WBF16, DEPI_QKV>), g1, dim3(64 * DS_WAVES), 0, st, a.M, a.Npad, a.k_splits, a.K, a.W, a.Xb, a.ldx, a);
       break;
   }
 #undef ETD_DG
@@ -782,29 +783,32 @@ template <> struct Raw8<bf16> {
 
 #define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
 template <typename KVT>
-__global__ __launch_bounds__(256) void k_dattn(DAttnArgs a) {
+// (leading scalar arguments: gfx950 preloads the first 16 kernarg dwords into SGPRs at wave launch, so the prologue's address
+// arithmetic starts without the kernarg s_load round trip; the struct carries everything that is needed later)
+__global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+                                               int p_max_ctx, int p_n_heads, float p_scale, DAttnArgs a) {
   __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
   const int m = blockIdx.x, head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
   int slot, pos;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
-  if (a.row_sp) { const i32x2 sp = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(a.row_sp + 2 * m)); slot = sp[0]; pos = sp[1]; }   // one 8-byte load
+  if (p_row_sp) { const i32x2 sp = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(p_row_sp + 2 * m)); slot = sp[0]; pos = sp[1]; }   // one 8-byte load
   else { slot = a.rows.slot[m]; pos = a.rows.pos[m]; }
-  const int ctx = (pos < a.max_ctx ? pos : a.max_ctx - 1) + 1;
-  const int hidden = a.n_heads * 64;
+  const int ctx = (pos < p_max_ctx ? pos : p_max_ctx - 1) + 1;
+  const int hidden = p_n_heads * 64;
   // bf16 serving mode: scores pre-scaled by log2(e) and v_exp_f32 (exp2) -- softmax is base-invariant; the fp32
   // parity mode keeps the accurate expf like torch's softmax
   constexpr bool FAST = sizeof(KVT) == 2;
-  const float qs = FAST ? a.scale * 1.4426950408889634f : a.scale;
+  const float qs = FAST ? p_scale * 1.4426950408889634f : p_scale;
   float q[8];
   {
-    const float* qp = a.Q + (long long)m * hidden + head * 64 + c * 8;
+    const float* qp = p_Q + (long long)m * hidden + head * 64 + c * 8;
     const f32x4 x = *reinterpret_cast<const f32x4*>(qp), y = *reinterpret_cast<const f32x4*>(qp + 4);
     q[0] = x[0] * qs; q[1] = x[1] * qs; q[2] = x[2] * qs; q[3] = x[3] * qs;
     q[4] = y[0] * qs; q[5] = y[1] * qs; q[6] = y[2] * qs; q[7] = y[3] * qs;
   }
-  const KVT* kb = reinterpret_cast<const KVT*>(a.Kc) + (long long)slot * a.slot_stride + (long long)head * a.max_ctx * 64;
-  const KVT* vb = reinterpret_cast<const KVT*>(a.Vc) + (long long)slot * a.slot_stride + (long long)head * a.max_ctx * 64;
+  const KVT* kb = reinterpret_cast<const KVT*>(p_Kc) + (long long)slot * p_slot_stride + (long long)head * p_max_ctx * 64;
+  const KVT* vb = reinterpret_cast<const KVT*>(p_Vc) + (long long)slot * p_slot_stride + (long long)head * p_max_ctx * 64;
   float mr = -INFINITY, lr = 0.f, o[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
@@ -894,8 +898,8 @@ int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "dattn: bad M");
   ProfScope ps(a.M > 512 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
   dim3 g(a.M, a.n_heads);
-  if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a);
+  if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, a);
+  else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
