@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 // more CUs streaming weights than the 128-feature tile does when M is a handful of decode rows.
 // ================================================================================================
 #define DS_MAX_ROWS 512   // up to this many rows a GEMM runs on the weight-streaming skinny tile (decode steps of <= 512 streams)
-#define DS_WAVES 8   // K is split over 8 waves: one L2 round trip covers K = 512, four (fully unrolled) K = 2048
+#define DS_WAVES 4   // K is split over the waves of a workgroup; each wave keeps two 64-wide slices (16 fragment loads) in flight per round trip
 template <bool WBF16, int EPI>
 __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, int p_ks, int p_K, const void* p_W, const bf16* p_Xb, int p_ldx, DGemmArgs a) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
@@ -181,15 +181,26 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, 
     const bf16* wrow = reinterpret_cast<const bf16*>(p_W) + (long long)(n0 + r) * p_K;
     if (p_Xb) {
       const bf16* xbrow = p_Xb + (long long)gm * p_ldx;
-#pragma unroll 4
-      for (int k = kb; k < ke; k += 64) {
+      int k = kb;
+      for (; k + 128 <= ke; k += 128) {          // two 64-wide slices per round trip: 16 fragment loads in flight, then 8 MFMAs
+        bf16x8 wf[8], xf[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+          wf[s8] = *reinterpret_cast<const bf16x8*>(wrow + k + s8 * 16 + h * 8);
+          xf[s8] = *reinterpret_cast<const bf16x8*>(xbrow + k + s8 * 16 + h * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // every load of the pass is issued before the first MFMA waits: ONE round trip
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) acc = mfma32(wf[s8], xf[s8], acc);
+      }
+      for (; k < ke; k += 64) {
         bf16x8 wf[4], xf[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
           wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
           xf[s4] = *reinterpret_cast<const bf16x8*>(xbrow + k + s4 * 16 + h * 8);
         }
-        __builtin_amdgcn_sched_barrier(0);     // all 8 loads of the slice are issued before the first MFMA waits: ONE round trip, not two
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
       }
@@ -300,22 +311,24 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll 2
-  for (int k = kb; k < ke; k += 64) {
-    bf16x8 wf[4], xf[4];
+  constexpr int NS = 8 / DS_WAVES * 4;           // 16-wide k-steps per wave at K = 512 (launcher-checked: K == 64 * DS_WAVES * NS / 4)
+  {
+    bf16x8 wf[NS], xf[NS];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
-      xf[s4] = *reinterpret_cast<const bf16x8*>(xbrow + k + s4 * 16 + h * 8);
+    for (int s = 0; s < NS; ++s) {
+      wf[s] = *reinterpret_cast<const bf16x8*>(wrow + kb + s * 16 + h * 8);
+      xf[s] = *reinterpret_cast<const bf16x8*>(xbrow + kb + s * 16 + h * 8);
     }
-    if (k == kb && wave == 0 && rope) {
+    if (wave == 0 && rope) {
       // partial RoPE factors of dims d = 4h + i (i < 4); the partner d + 8 sits in register i + 4 of the same lane
       rc = *reinterpret_cast<const f32x4*>(q.rope_cos + (long long)pos * 8 + 4 * h);
       rs = *reinterpret_cast<const f32x4*>(q.rope_sin + (long long)pos * 8 + 4 * h);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
+    for (int s = 0; s < NS; ++s) acc = mfma32(wf[s], xf[s], acc);
   }
+  (void)ke;
   if (wave > 0) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
 }
 
 int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st) {
-  if (q.M != up.M || q.K != up.K || q.M < 1 || q.M > DS_MAX_ROWS || !q.Xb || !up.Xb || !up.Yb || q.K % (64 * DS_WAVES) || q.Npad % 32 || up.Npad % 32 ||
+  if (q.M != up.M || q.K != up.K || q.M < 1 || q.M > DS_MAX_ROWS || !q.Xb || !up.Xb || !up.Yb || q.K != 512 || q.Npad % 32 || up.Npad % 32 ||
       q.rot_half != 8 || q.N % 192 || q.Qb || !q.Q || !q.bias || !up.bias || up.N % 4)
     ETD_FAIL(ETD_EINVAL, "dstep_qkv_up: bad arguments");
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
@@ -446,8 +459,7 @@ __device__ int wave_sample(const float* lg, int V, int lane, float inv_temp, flo
 
 // ================================================================================================
 // k_dstep_head: tail of decode step t and head of step t+1 in one launch, one workgroup per 32 rows:
-//   final LayerNorm -> lm_head logits (MFMA, K split in the same eight 64-wide slices and added in the same order as
-//   k_dgemm_s, so the logits are bit-identical to the unfused path) -> greedy argmax (lowest index on ties) -> stream
+//   final LayerNorm -> lm_head logits (MFMA; eight 64-wide K slices accumulated separately and added in order) -> greedy argmax (lowest index on ties) -> stream
 //   state update (etude_decoder.py:333-343) -> embedding of the new token (:166-179), row metadata and the first layer's
 //   two LayerNorms for the next step.
 // ================================================================================================
