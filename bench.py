@@ -9,7 +9,7 @@ batch", 64 clips sharded 8 per GPU, attribute grid {0,1,2}^3).  Per rank: --clip
 clips, already resident in HBM, go through the whole Extract hot path (channel mean, resample, STFT/log-mel,
 hFT-Transformer over 22 windows, D2H of the frame outputs, note picking -> the note list extract() writes); then
 the Decode hot path generates a cover for each (clip, attribute tuple) job -- --attr-grid (27) tuples per clip,
-~92 condition bars each -- as concurrent device streams (continuous batching on three decoder engines), greedy.
+~92 condition bars each -- as concurrent device streams (continuous batching on four decoder engines), greedy.
 Ranks work on different clips (seed 1234 + clip index) with no data-path collective: weak scaling; at N=8 the
 job is exactly configs[4].  `--clips 1 --attr-grid 1` is configs[1] (one clip, attributes 1/1/1).
 
@@ -32,9 +32,9 @@ import sys
 import time
 from pathlib import Path
 
-# Three decoder engines + torch's default stream fit the HIP runtime's 4 hardware queues exactly; one more stream in the
-# process (measured with a side stream for the extractor; RCCL brings its own at N > 1) makes streams share a queue and costs
-# 25 % of the throughput.  8 queues are neutral at N = 1 (422 vs 423 audio-s/s) and remove that cliff.  Must be set before HIP
+# With the HIP runtime's default of 4 hardware queues, a fifth stream in the process (engines + torch's default stream + e.g.
+# RCCL's at N > 1) makes streams share a queue and costs 25 % of the throughput; 8 queues remove that cliff and allow a fourth
+# engine (+2 %).  Five or more concurrently submitting engines halve the throughput whatever the queue count.  Must be set before HIP
 # initialises; an explicit setting of the caller wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--clips", type=int, default=8, help="clips per rank")
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
     ap.add_argument("--streams", type=int, default=256, help="concurrent decoder streams (capped at the number of jobs)")
-    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "3")),
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "4")),
                     help="independent decoder engines (own HIP stream + KV cache each) driven from host threads: the short dependent kernels of one engine's decode step overlap the other's")
     ap.add_argument("--bars", type=int, default=92)
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS suppressed)")
