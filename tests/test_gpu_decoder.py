@@ -163,3 +163,36 @@ def test_many_jobs_slot_reuse_and_split_prefill_passes(dev):
         if key not in memo:
             memo[key] = one.generate_ids(v, bars, at, max_bar_token_limit=10, temperature=0.0)
         assert g == memo[key]
+
+
+def test_concurrent_engines_on_host_threads_equal_one_engine(dev):
+    """what bench.py does: several decoder engines (own stream, KV cache, captured graphs) driven from host threads at the same
+    time; every job's ids equal the ones a single engine produces (bf16 mode, same per-engine batch shape as the reference run)"""
+    import threading
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    v = _vocab()
+    cfgd = EtudeDecoderConfig(**synth.decoder_dims())
+    sd = synth.decoder_state_dict(1, {})
+    jobs = []
+    for s_ in range(24):
+        bars = synth.song_bars(seed=300 + s_ % 5, n_bars=3)
+        jobs.append((bars, [synth.attrs(s_ % 3, (s_ // 3) % 3, 1, 2)] * len(bars)))
+    n_eng = 3
+    ref = EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=8)
+    want = [ref.generate_many(jobs[i::n_eng], v, force_bar_tokens=16) for i in range(n_eng)]
+    engs = [EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=8) for _ in range(n_eng)]
+    got, errs = [None] * n_eng, []
+
+    def run(i):
+        try:
+            torch.cuda.set_device(0)
+            got[i] = engs[i].generate_many(jobs[i::n_eng], v, force_bar_tokens=16)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=run, args=(i,)) for i in range(n_eng)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    assert got == want
