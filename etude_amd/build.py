@@ -21,6 +21,7 @@ FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=o
 # leading scalars / pointers then start without the initial s_load round trip.  ETD_KERNARG_PRELOAD=0 turns it off.
 if os.environ.get("ETD_KERNARG_PRELOAD", "1") != "0":
     FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+FLAGS += os.environ.get("ETD_EXTRA_FLAGS", "").split()      # diagnostic builds (e.g. -DETD_HEAD_STAMP, -DETD_LIN_STAMP)
 # -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
 
 

@@ -37,6 +37,7 @@ struct etd_dec {
   std::vector<Layer> layers;
   float *lnfg = nullptr, *lnfb = nullptr;
   Lin head;
+  void* head_frag = nullptr;                     // lm_head in MFMA-fragment order for k_dstep_head: [tile][k-step][lane][8] (bf16 weights, H == 512)
   float *rope_cos = nullptr, *rope_sin = nullptr;
   void *Kc = nullptr, *Vc = nullptr;             // [layer][slot][head][ctx][64]
   long long slot_stride = 0, layer_stride = 0;   // elements
@@ -45,6 +46,7 @@ struct etd_dec {
   int *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *row_sp = nullptr, *ids = nullptr, *slots_dev = nullptr;
   // stream state
   int *cur_tok = nullptr, *len = nullptr, *done = nullptr, *n_out = nullptr, *eos = nullptr, *limit = nullptr, *tgt_attrs = nullptr, *out_tok = nullptr;
+  float* tgt_proj = nullptr;                     // [slot][H]: attribute projection of the slot's target attributes (k_slot_proj)
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
   float* qkv_raw = nullptr;                      // [3H] scratch row of the M == 1 QKV path
   bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
@@ -251,6 +253,23 @@ __global__ void k_init_slots(const int* __restrict__ init, int n, int* tgt_attrs
   cur_tok[s] = 0; len[s] = 0; done[s] = 0; n_out[s] = 0; eos[s] = p[5]; limit[s] = p[6];
 }
 
+// The attribute projection of a slot's TARGET attributes, ((t0 + t1) + t2) + t3 exactly as k_dembed / k_dstep_head add it
+// (etude_decoder.py:171-176): fixed for the whole bar, so it is formed once here and every decode step reads one row
+// instead of four.
+__global__ __launch_bounds__(128) void k_slot_proj(const int* __restrict__ init, const float* __restrict__ attr_tab, int n_bins, int H, float* proj) {
+  const int* p = init + blockIdx.x * 7;
+  const int s = p[0];
+  for (int k = threadIdx.x * 4; k < H; k += 128 * 4) {
+    f32x4 t[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) t[a] = *reinterpret_cast<const f32x4*>(attr_tab + (long long)(a * n_bins + p[1 + a]) * H + k);
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) o[c] = ((t[0][c] + t[1][c]) + t[2][c]) + t[3][c];
+    *reinterpret_cast<f32x4*>(proj + (long long)s * H + k) = o;
+  }
+}
+
 // Stage a batch of n prompts (concatenated) on the device, embed them, run the model.  On return *hfinal holds
 // the hidden states of all Mtot rows; the staged row metadata lives in d->ids (layout below).
 struct Staged { int Mtot; const int *ids, *cls, *attrs, *row_slot, *row_pos, *row_active, *last_idx, *last_slot, *last_pos, *last_active, *init, *row_seq, *seq_row0, *seq_len; };
@@ -299,6 +318,8 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
                b + 9 * (size_t)M + 11 * n, b + 10 * (size_t)M + 11 * n, b + 10 * (size_t)M + 12 * n};
   if (init7) {
     hipLaunchKernelGGL(k_init_slots, dim3((n + 63) / 64), dim3(64), 0, st, sg->init, n, d->tgt_attrs, d->cur_tok, d->len, d->done, d->n_out, d->eos, d->limit);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_slot_proj, dim3(n), dim3(128), 0, st, sg->init, d->attr_tab, d->cfg.num_attribute_bins, d->H, d->tgt_proj);
     HIP_TRY(hipGetLastError());
   }
   DEmbedArgs e = {};
@@ -392,6 +413,25 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.weight", H, &d->lnfg))) return fail(rc);
   if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.bias", H, &d->lnfb))) return fail(rc);
   if ((rc = load_lin(d, Ld, "lm_head", d->V, H, false, &d->head))) return fail(rc);
+  if (d->bf16w && H % 16 == 0) {
+    // the same bf16 values in the order one wave's A-operand loads want them: (tile t, k-step s, lane l) holds row
+    // 32 t + (l & 31), columns 16 s + 8 (l >> 5) .. +8 -- each load instruction then reads one contiguous 1 KiB block
+    // instead of 32 B out of 32 different rows (the decode-step head kernel lives on one CU per 32 streams: its L1 traffic counts)
+    const float* W = Ld.get("lm_head.weight", (int64_t)d->V * H);
+    if (!W) return fail(ETD_EINVAL);
+    const int tiles = d->head.Npad / 32, ks = H / 16;
+    std::vector<uint16_t> hp((size_t)tiles * ks * 64 * 8, 0);
+    for (int t = 0; t < tiles; ++t)
+      for (int sx = 0; sx < ks; ++sx)
+        for (int l = 0; l < 64; ++l) {
+          const int row = t * 32 + (l & 31);
+          if (row >= d->V) continue;
+          for (int e = 0; e < 8; ++e) hp[(((size_t)t * ks + sx) * 64 + l) * 8 + e] = f2bf_h(W[(size_t)row * H + sx * 16 + (l >> 5) * 8 + e]);
+        }
+    uint16_t* pp; if ((rc = d->alloc(&pp, hp.size()))) return fail(rc);
+    if (hipMemcpy(pp, hp.data(), hp.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return fail(ETD_EHIP);
+    d->head_frag = pp;
+  }
   {
     // RoPE tables as HF builds them in fp32: inv_freq = 1/theta^(2i/rot), angle = pos * inv_freq (modeling_gpt_neox.py:72-107)
     std::vector<float> cs((size_t)d->ctx * 8), sn((size_t)d->ctx * 8);
@@ -430,6 +470,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   const size_t S = d->S;
   rc = rc ? rc : d->alloc(&d->cur_tok, S, true); rc = rc ? rc : d->alloc(&d->len, S, true); rc = rc ? rc : d->alloc(&d->done, S, true);
   rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
+  rc = rc ? rc : d->alloc(&d->tgt_proj, S * (size_t)d->H, true);
   rc = rc ? rc : d->alloc(&d->tgt_attrs, 4 * S, true); rc = rc ? rc : d->alloc(&d->out_tok, S * d->out_cap, true);
   if (rc) return fail(rc);
   HIP_TRY(hipDeviceSynchronize());
@@ -510,7 +551,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   // (QKV|up, attention, down|dense, residual + LayerNorm) and one head launch that also prepares the next step's rows
   const int vpad = (d->V + 31) / 32 * 32;
   const bool fused = d->bf16w && n_active > 1 && n_active <= 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
-                     vpad <= d->head.Npad && !getenv("ETD_NO_FUSED_STEP");
+                     vpad <= d->head.Npad && d->head_frag && !getenv("ETD_NO_FUSED_STEP");
   auto embed = [&](hipStream_t s_) -> int {
     DEmbedArgs e = {};
     e.slots = d->slots_dev; e.len = d->len; e.done = d->done; e.row_slot_out = d->row_slot; e.row_pos_out = d->row_pos; e.row_active_out = d->row_active; e.row_sp_out = d->row_sp;
@@ -532,10 +573,10 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
       const Layer& w0 = d->layers[0];
       DHeadArgs hd = {};
       hd.hfin = hf; hd.M = n_active; hd.H = d->H; hd.V = d->V; hd.Vpad = vpad;
-      hd.lnf_g = d->lnfg; hd.lnf_b = d->lnfb; hd.eps = d->cfg.layer_norm_eps; hd.Whead = (const bf16*)d->head.W;
+      hd.lnf_g = d->lnfg; hd.lnf_b = d->lnfb; hd.eps = d->cfg.layer_norm_eps; hd.Whead = (const bf16*)d->head_frag;
       hd.row_slot = d->row_slot; hd.row_pos = d->row_pos; hd.row_active = d->row_active; hd.row_sp = d->row_sp;
       hd.cur_tok = d->cur_tok; hd.len = d->len; hd.done = d->done; hd.n_out = d->n_out; hd.out_tok = d->out_tok; hd.out_cap = d->out_cap;
-      hd.eos = d->eos; hd.limit = d->limit; hd.tgt_attrs = d->tgt_attrs; hd.tgt_cls = 2; hd.n_bins = d->cfg.num_attribute_bins;
+      hd.eos = d->eos; hd.limit = d->limit; hd.tgt_attrs = d->tgt_attrs; hd.tgt_proj = d->tgt_proj; hd.tgt_cls = 2; hd.n_bins = d->cfg.num_attribute_bins;
       hd.word = d->word; hd.cls_emb = d->cls_emb; hd.attr_tab = d->attr_tab;
       hd.g1 = w0.ln1g; hd.b1 = w0.ln1b; hd.g2 = w0.ln2g; hd.b2 = w0.ln2b;
       hd.h = d->h; hd.x1 = d->X1b; hd.x2 = d->X2b;

@@ -53,10 +53,10 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
 struct DHeadArgs {
   const float* hfin; int M, H, V, Vpad;       // last layer's residual stream [M][H]
   const float* lnf_g; const float* lnf_b; float eps;
-  const bf16* Whead;                           // [Vpad][H]
+  const bf16* Whead;                           // lm_head in fragment order [Vpad/32][H/16][64][8] (api_dec.hip: head_frag)
   int* row_slot; int* row_pos; int* row_active; int* row_sp;   // in: this step's rows; out: next step's (row_sp: (slot, pos) pairs)
   int* cur_tok; int* len; int* done; int* n_out; int* out_tok; int out_cap; const int* eos; const int* limit;
-  const int* tgt_attrs; int tgt_cls; int n_bins;
+  const int* tgt_attrs; const float* tgt_proj /* [slot][H]: attribute projection of the target attributes */; int tgt_cls; int n_bins;
   const float* word; const float* cls_emb; const float* attr_tab;
   const float* g1; const float* b1; const float* g2; const float* b2;   // layer 0 LayerNorms
   float* h; bf16* x1; bf16* x2;                // next step's embeddings [M][H] and their LayerNorms

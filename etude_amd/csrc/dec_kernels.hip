@@ -406,20 +406,43 @@ __device__ __forceinline__ int wave_argmax(const float* lg, int V, int lane) {
     const float x = lg[v];
     if (x > best || (x == best && v < bi)) { best = x; bi = v; }
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-  }
+#define ETD_AMAX_STAGE(O) { const float ob = lane_xor<O>(best); const int oi = lane_xor<O>(bi); \
+    const bool take = (ob > best) | ((ob == best) & (oi < bi)); best = take ? ob : best; bi = take ? oi : bi; }
+  ETD_AMAX_STAGE(32) ETD_AMAX_STAGE(16) ETD_AMAX_STAGE(8) ETD_AMAX_STAGE(4) ETD_AMAX_STAGE(2) ETD_AMAX_STAGE(1)
+#undef ETD_AMAX_STAGE
   return bi;
 }
-__device__ int wave_sample(const float* lg, int V, int lane, float inv_temp, float top_p, unsigned long long seed, unsigned long long key,
+// Four rows at once: the same comparisons as wave_argmax, branch-free and interleaved so that the rows' LDS reads and
+// cross-lane exchanges overlap (one row at a time is a chain of ~14 dependent LDS round trips).  V <= 256.
+__device__ __forceinline__ void wave_argmax4(const float* lg, int ld, int V, int lane, int (&out)[4]) {
+  float best[4]; int bi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { best[j] = -INFINITY; bi[j] = 0x7fffffff; }
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int v = lane + 64 * it;
+    float x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = lg[j * ld + (v < V ? v : 0)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool take = (v < V) & ((x[j] > best[j]) | ((x[j] == best[j]) & (v < bi[j])));      // bitwise on purpose: && / || became branch ladders
+      best[j] = take ? x[j] : best[j]; bi[j] = take ? v : bi[j];
+    }
+  }
+#define ETD_AMAX_STAGE(O) _Pragma("unroll") for (int j = 0; j < 4; ++j) { const float ob = lane_xor<O>(best[j]); const int oi = lane_xor<O>(bi[j]); \
+    const bool take = (ob > best[j]) | ((ob == best[j]) & (oi < bi[j])); best[j] = take ? ob : best[j]; bi[j] = take ? oi : bi[j]; }
+  ETD_AMAX_STAGE(32) ETD_AMAX_STAGE(16) ETD_AMAX_STAGE(8) ETD_AMAX_STAGE(4) ETD_AMAX_STAGE(2) ETD_AMAX_STAGE(1)
+#undef ETD_AMAX_STAGE
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[j] = bi[j];
+}
+__device__ __attribute__((noinline)) int wave_sample(const float* lg, int V, int lane, float inv_temp, float top_p, unsigned long long seed, unsigned long long key,
                            unsigned ctr, float* sp, float* ss, int* si) {
   // softmax(logits / T) in fp32
   float mx = -INFINITY;
   for (int v = lane; v < V; v += 64) mx = fmaxf(mx, lg[v] * inv_temp);
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  mx = wave_max(mx);
   float sum = 0.f;
   for (int v = lane; v < V; v += 64) { const float e = expf(lg[v] * inv_temp - mx); sp[v] = e; sum += e; }
   sum = wave_sum(sum);
@@ -465,6 +488,14 @@ __device__ int wave_sample(const float* lg, int V, int lane, float inv_temp, flo
 //   state update (etude_decoder.py:333-343) -> embedding of the new token (:166-179), row metadata and the first layer's
 //   two LayerNorms for the next step.
 // ================================================================================================
+// Diagnostic build (-DETD_HEAD_STAMP, tools/head_stamp.py): s_memtime stamps at the phase boundaries of workgroups 0..7,
+// read back with etd_debug_head_stamps.  Each stamp costs ~900 clk, so the shipped build has none.
+#ifdef ETD_HEAD_STAMP
+__device__ long long g_head_stamp[8 * 16];
+#define HSTAMP(i) do { if (tid == 0 && blockIdx.x < 8) g_head_stamp[blockIdx.x * 16 + (i)] = clock64(); } while (0)
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
 #define DH_LDX 520   // LayerNorm'ed rows in LDS: 512 + 8 bf16 (1040 B rows: conflict-free 16-byte fragment reads)
 #define DH_LDL 257   // logits rows in LDS (floats): up to 256 vocabulary entries + 1
 __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M, const int* p_row_slot, const int* p_row_active, const int* p_row_pos, DHeadArgs a) {   // leading scalars: kernarg preload
@@ -472,56 +503,100 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
   __shared__ float Ls[32 * DH_LDL];
   __shared__ float sps[8][256], sss[8][256];
   __shared__ int sis[8][256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // wave: provably uniform, so the per-row state below is fetched by scalar loads into SGPRs
   const int m0 = blockIdx.x * 32, H = a.H;     // H == 512 (checked by the launcher)
   const float inv_temp = a.samp ? a.samp->inv_temp : 0.f;
-  // ---- requested first, used last: the stream state of this wave's four rows (row -> slot -> state: two dependent round
-  // trips that now overlap the LayerNorm and logits phases instead of following each argmax)
+  HSTAMP(0);
+  // ---- load order (loads return in order; sched barriers pin it): the rows to normalise and the row maps, then the
+  // lm_head fragments, LayerNorm, then -- behind the row->slot lookup that has long arrived -- the stream state, whose
+  // round trip overlaps the logits phase
   const int k8 = lane * 8;
-  int r_slot[4], r_tok[4], r_len[4], r_done[4], r_nout[4], r_eos[4], r_lim[4], r_act[4], r_pos[4], r_at[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    int m = m0 + wave * 4 + j; m = m < p_M ? m : p_M - 1;
-    r_slot[j] = p_row_slot[m]; r_act[j] = p_row_active[m]; r_pos[j] = p_row_pos[m];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int sl = r_slot[j];
-    r_tok[j] = a.cur_tok[sl]; r_len[j] = a.len[sl]; r_done[j] = a.done[sl]; r_nout[j] = a.n_out[sl]; r_eos[j] = a.eos[sl]; r_lim[j] = a.limit[sl];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) r_at[j][k] = a.tgt_attrs[sl * 4 + k];
-  }
   // ---- final LayerNorm of 4 rows per wave (summation order of k_dgemm_s's LayerNorm prologue); unrolled: the four rows'
   // loads are in flight together
+  f32x4 hv0[4], hv1[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int rl = wave * 4 + j;
-    int gm = m0 + rl; gm = gm < p_M ? gm : p_M - 1;
+    int gm = m0 + wave * 4 + j; gm = gm < p_M ? gm : p_M - 1;
     const float* xp = p_hfin + (long long)gm * H;
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(xp + lane * 4), v1 = *reinterpret_cast<const f32x4*>(xp + lane * 4 + 256);
-    float s = 0.f;
-    s += v0[0] + v0[1] + v0[2] + v0[3];
-    s += v1[0] + v1[1] + v1[2] + v1[3];
-    s = wave_sum(s);
-    const float mean = s / (float)H;
-    float q = 0.f;
-    { const float d0 = v0[0] - mean, d1 = v0[1] - mean, d2 = v0[2] - mean, d3 = v0[3] - mean; q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3; }
-    { const float d0 = v1[0] - mean, d1 = v1[1] - mean, d2 = v1[2] - mean, d3 = v1[3] - mean; q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3; }
-    q = wave_sum(q);
-    const float rstd = rsqrtf(q / (float)H + a.eps);
+    hv0[j] = *reinterpret_cast<const f32x4*>(xp + lane * 4); hv1[j] = *reinterpret_cast<const f32x4*>(xp + lane * 4 + 256);
+  }
+  // row maps of the wave's four rows in ONE load instruction: lane = 4 * field + row (slot, active, position); read back
+  // with v_readlane into SGPRs.  (Per-row scalar-style loads were issued and awaited one after the other.)
+  int mapv;
+  {
+    const int j = lane & 3, f = lane >> 2;
+    int gm = m0 + wave * 4 + j; gm = gm < p_M ? gm : p_M - 1;
+    const int* mp = f == 0 ? p_row_slot : (f == 1 ? p_row_active : p_row_pos);
+    mapv = mp[gm];
+  }
+  f32x4 lg_[2], lb_[2];
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      const int k = lane * 4 + half * 256;
-      const f32x4 x = half ? v1 : v0;
-      const f32x4 g = *reinterpret_cast<const f32x4*>(a.lnf_g + k), b = *reinterpret_cast<const f32x4*>(a.lnf_b + k);
-      *reinterpret_cast<bf16x4*>(Xs + rl * DH_LDX + k) =
-          pack4((x[0] - mean) * rstd * g[0] + b[0], (x[1] - mean) * rstd * g[1] + b[1], (x[2] - mean) * rstd * g[2] + b[2], (x[3] - mean) * rstd * g[3] + b[3]);
+  for (int half = 0; half < 2; ++half) {
+    lg_[half] = *reinterpret_cast<const f32x4*>(a.lnf_g + lane * 4 + half * 256); lb_[half] = *reinterpret_cast<const f32x4*>(a.lnf_b + lane * 4 + half * 256);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // the lm_head fragments of this wave's 32 vocabulary entries depend on nothing: all 32 requested here, behind the rows
+  // above (loads return in order), and consumed after the LayerNorm -- left to the compiler they were 20 serial round trips
+  bf16x8 wf[32];
+  {
+    const bool own = wave * 32 < a.Vpad;                // waves without a tile load one broadcast address (unconditional loads: no merge waits, next to no traffic)
+    const bf16* wfr = a.Whead + (own ? ((long long)wave * 32 * 64 + lane) * 8 : 0);       // fragment order: [tile][k-step][lane][8], 1 KiB per instruction
+#pragma unroll
+    for (int s4 = 0; s4 < 32; ++s4) wf[s4] = *reinterpret_cast<const bf16x8*>(wfr + s4 * 64 * 8);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    float s4[4], q4[4], mean[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v0 = hv0[j], v1 = hv1[j];
+      float s = 0.f;
+      s += v0[0] + v0[1] + v0[2] + v0[3];
+      s += v1[0] + v1[1] + v1[2] + v1[3];
+      s4[j] = s;
+    }
+    wave_sum_n<4>(s4);
+    HSTAMP(6);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const f32x4 v0 = hv0[j], v1 = hv1[j];
+      mean[j] = s4[j] / (float)H;
+      float q = 0.f;
+      { const float d0 = v0[0] - mean[j], d1 = v0[1] - mean[j], d2 = v0[2] - mean[j], d3 = v0[3] - mean[j]; q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3; }
+      { const float d0 = v1[0] - mean[j], d1 = v1[1] - mean[j], d2 = v1[2] - mean[j], d3 = v1[3] - mean[j]; q += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3; }
+      q4[j] = q;
+    }
+    wave_sum_n<4>(q4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rl = wave * 4 + j;
+      const float rstd = rsqrtf(q4[j] / (float)H + a.eps);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int k = lane * 4 + half * 256;
+        const f32x4 x = half ? hv1[j] : hv0[j];
+        const f32x4 g = lg_[half], b = lb_[half];
+        *reinterpret_cast<bf16x4*>(Xs + rl * DH_LDX + k) =
+            pack4((x[0] - mean[j]) * rstd * g[0] + b[0], (x[1] - mean[j]) * rstd * g[1] + b[1], (x[2] - mean[j]) * rstd * g[2] + b[2], (x[3] - mean[j]) * rstd * g[3] + b[3]);
+      }
     }
   }
+  __builtin_amdgcn_sched_barrier(0);
+  // stream state of the four rows, again one load instruction: lane = 4 * field + row, fields cur_tok, len, done, n_out,
+  // eos, limit; its round trip overlaps the logits phase
+  int statev;
+  {
+    const int j = lane & 3, f = (lane >> 2) < 5 ? (lane >> 2) : 5;
+    const int sl = __shfl(mapv, j, 64);
+    const int* sp = f == 0 ? a.cur_tok : f == 1 ? a.len : f == 2 ? a.done : f == 3 ? a.n_out : f == 4 ? a.eos : a.limit;
+    statev = sp[sl];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  HSTAMP(7);
   __syncthreads();
+  HSTAMP(1);
   // ---- logits: wave w < Vpad/32 owns features [32w, 32w+32)
   if (wave * 32 < a.Vpad) {
-    const bf16* wrow = a.Whead + (long long)(wave * 32 + r) * H;
     const bf16* xrow = Xs + r * DH_LDX;
     f32x16 tot;
 #pragma unroll
@@ -532,7 +607,7 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int k = sl * 64 + s4 * 16 + h * 8;
-        acc = mfma32(*reinterpret_cast<const bf16x8*>(wrow + k), *reinterpret_cast<const bf16x8*>(xrow + k), acc);
+        acc = mfma32(wf[sl * 4 + s4], *reinterpret_cast<const bf16x8*>(xrow + k), acc);
       }
       if (sl == 0) tot = acc;
       else {
@@ -547,23 +622,34 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
     }
   }
   __syncthreads();
+  HSTAMP(2);
   // ---- per row: token choice and state update (registers + LDS only), then ONE round trip for the four word-embedding rows
-  int n_tok[4];
+  // ---- token choice, then the state update with ONE LANE PER ROW (lanes 0..3): the fields are gathered from the two
+  // load registers by cross-lane reads, and the stores go out per lane.  (Four scalar copies of this ran the kernel out of SGPRs.)
+  int gbi[4] = {0, 0, 0, 0};
+  if (inv_temp > 0.f) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rl = wave * 4 + j, m = m0 + rl;
-    n_tok[j] = r_tok[j];
-    if (m >= a.M) continue;
-    const int slot = r_slot[j];
-    int bi;
-    if (inv_temp > 0.f) bi = wave_sample(Ls + rl * DH_LDL, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, a.rng_key[slot], (unsigned)r_nout[j], sps[wave], sss[wave], sis[wave]);   // (the key is fetched only on the sampling path: prefetching it made the compiler drain all loads per row)
-    else bi = wave_argmax(Ls + rl * DH_LDL, a.V, lane);
-    int ln = r_len[j], dn = r_done[j];
-    if (r_act[j] && !dn) {
-      const int n = r_nout[j];
-      n_tok[j] = bi; ln = r_pos[j] + 1;
-      const int fin = (bi == r_eos[j] || n + 1 >= r_lim[j]) ? 1 : 0;
-      if (lane == 0) {
+    for (int j = 0; j < 4; ++j) {
+      if (m0 + wave * 4 + j >= a.M) continue;
+      gbi[j] = wave_sample(Ls + (wave * 4 + j) * DH_LDL, a.V, lane, inv_temp, a.samp->top_p, a.samp->seed, a.rng_key[__builtin_amdgcn_readlane(mapv, j)],
+                           (unsigned)__builtin_amdgcn_readlane(statev, 12 + j), sps[wave], sss[wave], sis[wave]);
+    }
+  } else {
+    wave_argmax4(Ls + wave * 4 * DH_LDL, DH_LDL, a.V, lane, gbi);
+  }
+  int n_tok[4], r_slot[4];
+  {
+    const int jr = lane & 3, m = m0 + wave * 4 + jr;
+    const int slot = __shfl(mapv, jr, 64), act = __shfl(mapv, 4 + jr, 64), pos = __shfl(mapv, 8 + jr, 64);
+    const int tok = __shfl(statev, jr, 64), len0 = __shfl(statev, 4 + jr, 64), done0 = __shfl(statev, 8 + jr, 64);
+    const int n = __shfl(statev, 12 + jr, 64), eos = __shfl(statev, 16 + jr, 64), lim = __shfl(statev, 20 + jr, 64);
+    const int bi = jr == 0 ? gbi[0] : jr == 1 ? gbi[1] : jr == 2 ? gbi[2] : gbi[3];
+    int ntok = tok, ln = len0, dn = done0;
+    const bool mine = (lane < 4) & (m < a.M);
+    if (act && !done0) {
+      ntok = bi; ln = pos + 1;
+      const int fin = ((bi == eos) | (n + 1 >= lim)) ? 1 : 0;
+      if (mine) {
         if (n < a.out_cap) a.out_tok[(long long)slot * a.out_cap + n] = bi;
         a.n_out[slot] = n + 1;
         a.cur_tok[slot] = bi;
@@ -573,69 +659,82 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
       dn = fin;
     }
     // next step's row: position = new length, active = not done
-    if (lane == 0) { a.row_pos[m] = ln; a.row_active[m] = dn ? 0 : 1; if (a.row_sp) a.row_sp[2 * m + 1] = ln; }
+    if (mine) { a.row_pos[m] = ln; a.row_active[m] = dn ? 0 : 1; if (a.row_sp) a.row_sp[2 * m + 1] = ln; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      n_tok[j] = __builtin_amdgcn_readlane(ntok, j); r_slot[j] = __builtin_amdgcn_readlane(mapv, j);
+    }
   }
-  // next embeddings, two rows at a time: all their table rows in flight together (one round trip per pair)
-  f32x4 r_c[2], pg1[2], pb1[2], pg2[2], pb2[2];
+  HSTAMP(3);
+  // next embeddings of the four rows: word row + the slot's target projection (k_slot_proj), all in flight together
+  f32x4 r_c[2], pg1[2], pb1[2], pg2[2], pb2[2], wv[4][2], pv[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      wv[j][hh] = *reinterpret_cast<const f32x4*>(a.word + (long long)n_tok[j] * H + k8 + 4 * hh);
+      pv[j][hh] = *reinterpret_cast<const f32x4*>(a.tgt_proj + (long long)r_slot[j] * H + k8 + 4 * hh);
+    }
 #pragma unroll
   for (int hh = 0; hh < 2; ++hh) {
     r_c[hh] = *reinterpret_cast<const f32x4*>(a.cls_emb + (long long)a.tgt_cls * H + k8 + 4 * hh);
     pg1[hh] = *reinterpret_cast<const f32x4*>(a.g1 + k8 + 4 * hh); pb1[hh] = *reinterpret_cast<const f32x4*>(a.b1 + k8 + 4 * hh);
     pg2[hh] = *reinterpret_cast<const f32x4*>(a.g2 + k8 + 4 * hh); pb2[hh] = *reinterpret_cast<const f32x4*>(a.b2 + k8 + 4 * hh);
   }
+  {
+    float v[4][8], s4[4], q4[4], mean[4];
 #pragma unroll
-  for (int pr = 0; pr < 2; ++pr) {
-    f32x4 wv[2][2], tv[2][4][2];
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int j = pr * 2 + jj;
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int i = k8 + 4 * hh;
-        wv[jj][hh] = *reinterpret_cast<const f32x4*>(a.word + (long long)n_tok[j] * H + i);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) tv[jj][t][hh] = *reinterpret_cast<const f32x4*>(a.attr_tab + (long long)(t * a.n_bins + r_at[j][t]) * H + i);
-      }
-    }
-#pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-      const int j = pr * 2 + jj, m = m0 + wave * 4 + j;
-      if (m >= a.M) continue;
-      float v[8];
+    for (int j = 0; j < 4; ++j) {
+      float s1 = 0.f;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int hh = e >> 2, c = e & 3;
-        const float pj = ((tv[jj][0][hh][c] + tv[jj][1][hh][c]) + tv[jj][2][hh][c]) + tv[jj][3][hh][c];      // attribute projection (etude_decoder.py:171-176)
-        v[e] = (wv[jj][hh][c] + r_c[hh][c]) + pj;
+        v[j][e] = (wv[j][hh][c] + r_c[hh][c]) + pv[j][hh][c];          // (word + class) + attribute projection (etude_decoder.py:171-176)
+        s1 += v[j][e];
       }
-      const long long ro = (long long)m * H;
-      { const f32x4 oa = {v[0], v[1], v[2], v[3]}, ob = {v[4], v[5], v[6], v[7]};
-        *reinterpret_cast<f32x4*>(a.h + ro + k8) = oa; *reinterpret_cast<f32x4*>(a.h + ro + k8 + 4) = ob; }
-      float s1 = 0.f;
+      s4[j] = s1;
+    }
+    wave_sum_n<4>(s4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s1 += v[e];
-      s1 = wave_sum(s1);
-      const float mean = s1 / (float)H;
+    for (int j = 0; j < 4; ++j) {
+      mean[j] = s4[j] / (float)H;
       float q = 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d0 = v[e] - mean; q += d0 * d0; }
-      q = wave_sum(q);
-      const float rstd = rsqrtf(q / (float)H + a.eps);
+      for (int e = 0; e < 8; ++e) { const float d0 = v[j][e] - mean[j]; q += d0 * d0; }
+      q4[j] = q;
+    }
+    wave_sum_n<4>(q4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = m0 + wave * 4 + j;
+      if (m >= a.M) continue;
+      const long long ro = (long long)m * H;
+      { const f32x4 oa = {v[j][0], v[j][1], v[j][2], v[j][3]}, ob = {v[j][4], v[j][5], v[j][6], v[j][7]};
+        *reinterpret_cast<f32x4*>(a.h + ro + k8) = oa; *reinterpret_cast<f32x4*>(a.h + ro + k8 + 4) = ob; }
+      const float rstd = rsqrtf(q4[j] / (float)H + a.eps);
       bf16x8 o1, o2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        o1[e] = (bf16)((v[e] - mean) * rstd * pg1[e >> 2][e & 3] + pb1[e >> 2][e & 3]);
-        o2[e] = (bf16)((v[e] - mean) * rstd * pg2[e >> 2][e & 3] + pb2[e >> 2][e & 3]);
+        o1[e] = (bf16)((v[j][e] - mean[j]) * rstd * pg1[e >> 2][e & 3] + pb1[e >> 2][e & 3]);
+        o2[e] = (bf16)((v[j][e] - mean[j]) * rstd * pg2[e >> 2][e & 3] + pb2[e >> 2][e & 3]);
       }
       *reinterpret_cast<bf16x8*>(a.x1 + ro + k8) = o1;
       *reinterpret_cast<bf16x8*>(a.x2 + ro + k8) = o2;
     }
   }
+  HSTAMP(4);
 }
 
+#ifdef ETD_HEAD_STAMP
+extern "C" int etd_debug_head_stamps(long long* out) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_head_stamp), sizeof(long long) * 8 * 16));
+  return ETD_OK;
+}
+#endif
 int launch_dstep_head(const DHeadArgs& a, hipStream_t st) {
   if (a.samp && !a.rng_key) ETD_FAIL(ETD_EINVAL, "dstep_head: sampling needs stream keys");
-  if (a.M < 1 || a.H != 512 || a.V < 1 || a.V > a.Vpad || a.Vpad % 32 || a.Vpad > 256 || !a.hfin || !a.Whead || !a.h || !a.x1 || !a.x2)
+  if (a.M < 1 || a.H != 512 || a.V < 1 || a.V > a.Vpad || a.Vpad % 32 || a.Vpad > 256 || !a.hfin || !a.Whead || !a.tgt_proj || !a.h || !a.x1 || !a.x2)
     ETD_FAIL(ETD_EINVAL, "dstep_head: bad arguments (needs hidden 512, vocabulary <= 256)");
   ProfScope ps("k_dstep_head", st, 2.0 * a.M * a.V * a.H, (double)a.Vpad * a.H * 2);
   hipLaunchKernelGGL(k_dstep_head, dim3((a.M + 31) / 32), dim3(512), 0, st, a.hfin, a.M, a.row_slot, a.row_active, a.row_pos, a);
@@ -846,7 +945,7 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
     float sA = 0.f, sB = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sA = fmaf(q[e], kA.get(e), sA); sB = fmaf(q[e], kB.get(e), sB); }
-    sA += __shfl_xor(sA, 1, 64); sB += __shfl_xor(sB, 1, 64);
+    sA += __shfl_xor(sA, 1, 64); sB += __shfl_xor(sB, 1, 64);      // ds_bpermute on purpose: the LDS pipe is idle here and the VALU is not (DPP measured 6 % slower)
     sA += __shfl_xor(sA, 2, 64); sB += __shfl_xor(sB, 2, 64);
     sA += __shfl_xor(sA, 4, 64); sB += __shfl_xor(sB, 4, 64);
     if (vA) {
