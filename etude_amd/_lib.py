@@ -103,6 +103,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_longlong)]),
     "etd_tok_decode": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong, C.c_void_p, C.c_longlong,
                                  C.POINTER(C.c_longlong)]),
+    "etd_midi_write": (C.c_int, [C.c_void_p, C.c_longlong, C.c_char_p]),
     "etd_decoder_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_i64_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),
     "etd_decoder_destroy": (None, [C.c_void_p]),

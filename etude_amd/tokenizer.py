@@ -166,17 +166,20 @@ class TinyREMITokenizer:
         return ev[: k.value]
 
     @staticmethod
-    def note_to_midi(note_list: list, output_path: Union[str, Path]):
-        """tokenizer.py:499-524 (needs pretty_midi, exactly like the reference)."""
-        import pretty_midi
+    def note_to_midi(note_list, output_path: Union[str, Path]):
+        """tokenizer.py:499-524: notes -> .mid, laid out as pretty_midi writes `PrettyMIDI()` + one `Instrument(program=0)`.
+
+        Native writer (csrc/midi.cpp, ``etd_midi_write``): pretty_midi / mido are not needed.  ``note_list`` is the list of
+        {pitch, onset, offset, velocity} dicts `decode_to_notes` returns, or a NOTE_DTYPE array."""
         output_path = Path(output_path)
         output_path.parent.mkdir(parents=True, exist_ok=True)
-        midi = pretty_midi.PrettyMIDI()
-        instrument = pretty_midi.Instrument(program=0)
-        for nd in note_list:
-            instrument.notes.append(pretty_midi.Note(velocity=int(nd["velocity"]), pitch=int(nd["pitch"]), start=nd["onset"], end=nd["offset"]))
-        midi.instruments.append(instrument)
-        midi.write(str(output_path))
+        if isinstance(note_list, np.ndarray) and note_list.dtype == NOTE_DTYPE:
+            notes = np.ascontiguousarray(note_list)
+        else:
+            notes = np.empty(len(note_list), dtype=NOTE_DTYPE)
+            for i, nd in enumerate(note_list):
+                notes[i] = (nd["onset"], nd["offset"], int(nd["pitch"]), int(nd["velocity"]))
+        _lib.check(_lib.lib().etd_midi_write(notes.ctypes.data if notes.size else None, int(notes.size), str(output_path).encode()), "etd_midi_write")
 
     def close(self):
         if getattr(self, "_h", None):

@@ -39,6 +39,7 @@ extern "C" {
 #define ETD_EINVAL (-22)
 #define ETD_ENOMEM (-12)
 #define ETD_EHIP (-5)
+#define ETD_EIO (-6)      /* host file I/O failed (etd_midi_write) */
 
 int etd_version(void);
 const char* etd_last_error(void);
@@ -223,6 +224,12 @@ int etd_tok_split_bars(const int32_t* ids, long long n, int bar_bos_id, int bar_
                        long long* bar_offsets, long long cap_bars, long long* n_bars);
 int etd_tok_decode(const etd_tok*, const etd_event* events, long long n, const double* volume /* or NULL */, long long n_volume,
                    etd_note* out, long long cap, long long* n_out);
+
+/* ------------------------------------------------------------------ MIDI output (host)
+ * TinyREMITokenizer.note_to_midi, etude/data/tokenizer.py:499-524 (infer.py:207): the notes as a format-1 Standard MIDI
+ * File exactly as `pretty_midi.PrettyMIDI()` + one `Instrument(program=0)` + `.write()` lays it out (220 ticks per beat,
+ * 120 bpm, tick = round(time * 440)).  pitch / velocity outside 0..127 fail with ETD_EINVAL (mido raises there). */
+int etd_midi_write(const etd_note* notes, long long n, const char* path);
 
 #ifdef __cplusplus
 }
