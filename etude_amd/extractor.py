@@ -231,16 +231,12 @@ class AMTAPC_Extractor:
             json.dump(filtered, f, ensure_ascii=False, indent=2)
 
     def _note2midi(self, notes, path_output, min_length=0.0):
-        """extractor.py:421-429 -- needs pretty_midi exactly like the reference."""
-        import pretty_midi
-        midi = pretty_midi.PrettyMIDI()
-        instrument = pretty_midi.Instrument(program=0)
-        for note in notes:
-            if note["offset"] - note["onset"] < min_length:
-                continue
-            instrument.notes.append(pretty_midi.Note(velocity=note["velocity"], pitch=note["pitch"], start=note["onset"], end=note["offset"]))
-        midi.instruments.append(instrument)
-        midi.write(path_output)
+        """extractor.py:421-429, through the native writer (csrc/midi.cpp: the file pretty_midi would write; no pretty_midi needed)."""
+        kept = [n for n in notes if not (n["offset"] - n["onset"] < min_length)]
+        arr = np.empty(len(kept), dtype=NOTE_DTYPE)
+        for i, n in enumerate(kept):
+            arr[i] = (n["onset"], n["offset"], int(n["pitch"]), int(n["velocity"]))
+        _lib.check(_lib.lib().etd_midi_write(arr.ctypes.data if arr.size else None, int(arr.size), str(path_output).encode()), "etd_midi_write")
 
     # ------------------------------------------------------------------ device-level API
     def _front(self, sr: int) -> FrontEnd:

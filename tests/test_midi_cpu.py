@@ -94,3 +94,12 @@ def test_midi_rejects_out_of_range(tmp_path):
         TinyREMITokenizer.note_to_midi([{"pitch": 128, "onset": 0.0, "offset": 1.0, "velocity": 64}], tmp_path / "bad.mid")
     with pytest.raises(RuntimeError):
         TinyREMITokenizer.note_to_midi([{"pitch": 60, "onset": 0.0, "offset": 1.0, "velocity": 200}], tmp_path / "bad.mid")
+
+
+def test_extractor_note2midi_filters_short_notes(tmp_path):
+    """AMTAPC_Extractor._note2midi (extractor.py:421-429): notes shorter than min_length are dropped, the rest written."""
+    from etude_amd.extractor import AMTAPC_Extractor
+    notes = [{"onset": 0.1, "offset": 0.5, "pitch": 60, "velocity": 90}, {"onset": 0.2, "offset": 0.21, "pitch": 61, "velocity": 90}]
+    AMTAPC_Extractor._note2midi(None, notes, str(tmp_path / "a.mid"), 0.05)
+    _, _, (_, t1) = parse_smf((tmp_path / "a.mid").read_bytes())
+    assert [e for e in t1 if e[1] == "msg" and e[2] == 0x90] == [(44, "msg", 0x90, (60, 90)), (220, "msg", 0x90, (60, 0))]
