@@ -71,6 +71,7 @@ SIGNATURES = {
     "etd_prof_entry": (C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "etd_debug_boundary_cost": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "etd_debug_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
     "etd_frontend_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
     "etd_frontend_destroy": (None, [C.c_void_p]),

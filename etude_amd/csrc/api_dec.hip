@@ -22,7 +22,8 @@ inline uint16_t f2bf_h(float f) {
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
-struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0; };
+struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0;
+             void* Wf = nullptr; };   // bf16 weights: a second copy in MFMA-fragment order for k_linear (the batched prefill); W stays row-major for the step kernels
 struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
                Lin cat; };   // decode step: [dense_4h_to_h | attention.dense] along K, so mlp + attn come out of ONE GEMM
 
@@ -104,6 +105,13 @@ int load_lin(etd_dec* d, Loader& L, const std::string& pfx, int N, int K, bool h
     uint16_t* p; ETD_TRY(d->alloc(&p, hb.size()));
     HIP_TRY(hipMemcpy(p, hb.data(), hb.size() * 2, hipMemcpyHostToDevice));
     w->W = p;
+    if (K % 16 == 0) {
+      std::vector<uint16_t> hp(hb.size());
+      pack_wfrag_host(hb.data(), Npad, K, hp.data());
+      uint16_t* pf; ETD_TRY(d->alloc(&pf, hp.size()));
+      HIP_TRY(hipMemcpy(pf, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+      w->Wf = pf;
+    }
   } else {
     std::vector<float> hf((size_t)Npad * K, 0.f);
     memcpy(hf.data(), W, (size_t)N * K * 4);
@@ -135,7 +143,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && M > 1;
-  const bool big = bpipe && M > 512;            // must match DS_MAX_ROWS in dec_kernels.hip
+  const bool big = bpipe && M > 512 && d->layers[0].qkv.Wf && d->layers[0].up.Wf && d->layers[0].cat.Wf;   // M: must match DS_MAX_ROWS in dec_kernels.hip
   for (int l = 0; l < d->L; ++l) {
     const Layer& w = d->layers[l];
     void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * esz;
@@ -154,7 +162,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     if (mfma_attn) { q.Qb = d->Qb; q.Kp = d->Kp; q.VTp = d->VTp; q.vt_spad = d->vt_spad; }
     if (big) {
       LinArgs a = {};
-      a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
+      a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.Wf; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
       ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
     } else if (small) {
       // decode step: QKV (+RoPE, KV append) and MLP up (+GELU -> Xcat) share one launch
@@ -197,7 +205,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; if (catk) { up.Yb = d->Xcat; up.ldy = d->I + d->H; } } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
     if (big) {
       LinArgs a = {};
-      a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.W; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
+      a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.Wf; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
       ETD_TRY(launch_linear_dec(a, DEPI_GELU, st));
     } else if (!small) {        // (decode step: already issued together with QKV)
       ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
@@ -210,7 +218,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     if (big) {
       dn.add = nullptr;
       LinArgs a = {};
-      a.X = d->Xcat; a.ldx = d->I + d->H; a.W = (const bf16*)w.cat.W; a.bias = w.cat.b; a.M = M; a.N = d->H; a.K = d->I + d->H; a.vt_block = -1; a.dec = dn;
+      a.X = d->Xcat; a.ldx = d->I + d->H; a.W = (const bf16*)w.cat.Wf; a.bias = w.cat.b; a.M = M; a.N = d->H; a.K = d->I + d->H; a.vt_block = -1; a.dec = dn;
       ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
     } else if (small) {
       // (down | dense) projection with K split over workgroups, then ONE row kernel: partial sums + bias + residual and the
@@ -407,6 +415,13 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
       std::vector<float> bc(H);
       for (int o = 0; o < H; ++o) bc[o] = b2[o] + bd[o];
       w.cat.W = pw; w.cat.N = H; w.cat.Npad = H; w.cat.K = Kc;
+      if (H % 32 == 0 && Kc % 16 == 0) {
+        std::vector<uint16_t> wp(wc.size());
+        pack_wfrag_host(wc.data(), H, Kc, wp.data());
+        uint16_t* pf; if ((rc = d->alloc(&pf, wp.size()))) return fail(rc);
+        HIP_TRY(hipMemcpy(pf, wp.data(), wp.size() * 2, hipMemcpyHostToDevice));
+        w.cat.Wf = pf;
+      }
       if ((rc = up_f32(d, &w.cat.b, bc.data(), H))) return fail(rc);
     }
   }

@@ -6,9 +6,26 @@
 // ---- generic token-major linear layer:  Y = epi(X[M,K] * W[N,K]^T + bias) -----------------------
 // All activations are bf16 row-major with 256-multiple feature counts; weights keep nn.Linear's
 // [out][in] layout (K contiguous), which is exactly the MFMA operand layout for both operands.
+// Weight layout for k_linear's decoder modes (launch_linear_dec): MFMA-fragment order.  Block (t, s) -- n-tile t of 32 output features, k-step s of 16 inputs --
+// is 512 elements at ((t * (K / 16) + s) * 512); inside it lane l (0..63) owns 8 consecutive elements: row 32 t + (l & 31),
+// columns 16 s + 8 (l >> 5) .. + 8.  Same element count as [N][K]; feature-block and z-batch offsets (n0 * K, z * N * K)
+// are unchanged.  N % 32 == 0, K % 16 == 0.
+#include <cstdint>
+#include <vector>
+inline void pack_wfrag_host(const uint16_t* src, int N, int K, uint16_t* dst) {
+  const int kb = K / 16;
+  for (int t = 0; t < N / 32; ++t)
+    for (int sx = 0; sx < kb; ++sx)
+      for (int l = 0; l < 64; ++l) {
+        const uint16_t* sp = src + (size_t)(t * 32 + (l & 31)) * K + sx * 16 + (l >> 5) * 8;
+        uint16_t* dp = dst + (((size_t)t * kb + sx) * 64 + l) * 8;
+        for (int e = 0; e < 8; ++e) dp[e] = sp[e];
+      }
+}
+
 struct LinArgs {
   const bf16* X; int ldx;            // [M, K]
-  const bf16* W;                     // [N, K]
+  const bf16* W;                     // [N, K] weights: row-major for the extractor modes (0, 1, 2); FRAGMENT ORDER (pack_wfrag_host above) for the decoder modes (launch_linear_dec)
   const float* bias;                 // [N]
   int M, N, K;                       // K % 64 == 0, N % 256 == 0
   bf16* Y; int ldy;                  // row-major destination for n-blocks < vt_block (may be null if all go to VT)

@@ -29,15 +29,16 @@ typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t lin_rsrc(const void* p, long long bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes), 0x00020000);
 }
-__device__ __forceinline__ void lin_gload_x(rsrc_t xs, const int (&xo)[4], int kc, u32x4 (&xr)[4]) {
+// ---- loop A (extractor, K = 256 / 512): X and W both staged through LDS
+__device__ __forceinline__ void lin_gload_x4(rsrc_t xs, const int (&xo)[4], int kc, u32x4 (&xr)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, xo[i], kc * 128, 0));
 }
-__device__ __forceinline__ void lin_gload_w(rsrc_t ws, const int (&wo)[8], int kc, u32x4 (&wr)[8]) {
+__device__ __forceinline__ void lin_gload_w8(rsrc_t ws, const int (&wo)[8], int kc, u32x4 (&wr)[8]) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) wr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, wo[i], kc * 128, 0));
 }
-__device__ __forceinline__ void lin_lstore(bf16* Xs, bf16* Ws, int tid, const u32x4 (&xr)[4], const u32x4 (&wr)[8]) {
+__device__ __forceinline__ void lin_lstore_xw(bf16* Xs, bf16* Ws, int tid, const u32x4 (&xr)[4], const u32x4 (&wr)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + i * 256, row = c >> 3, ch = c & 7;
@@ -50,13 +51,13 @@ __device__ __forceinline__ void lin_lstore(bf16* Xs, bf16* Ws, int tid, const u3
   }
 }
 
-// MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm;
+// (LDS-staged weights: the extractor's loop)  MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm;
 // MODE 10 + DEPI_x: EtudeDecoder epilogue x on the same tile (batched prefill of the Decode stage).
 // Each of the 4 waves owns 64 tokens x 128 features (2 x 4 accumulator tiles): per 16-deep k-step it reads
 // 2 X + 4 W fragments for 8 MFMAs (0.75 KB of LDS per MFMA; a 32 x 256 per-wave layout needs 1.125 KB and
 // measured 2 % slower).
 template <bool NORMAL_ORIENT>
-__device__ __forceinline__ void lin_chunk(const bf16* Xs, const bf16* Ws, int wm, int wn, int r, int h, f32x16 (&acc)[2][4]) {
+__device__ __forceinline__ void lin_chunk_lds(const bf16* Xs, const bf16* Ws, int wm, int wn, int r, int h, f32x16 (&acc)[2][4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     bf16x8 xf[2], wf[4];
@@ -74,6 +75,60 @@ __device__ __forceinline__ void lin_chunk(const bf16* Xs, const bf16* Ws, int wm
   }
 }
 
+// ---- loop B (decoder prefill, K = 512 / 2560): W from fragment-ordered global memory straight into operand registers
+__device__ __forceinline__ void lin_gload_x(rsrc_t xs, int xo, int row32_bytes, int kc, u32x4 (&xr)[4]) {   // rows (tid >> 3) + 32 i: per-lane offset + scalar offset
+#pragma unroll
+  for (int i = 0; i < 4; ++i) xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, xo, kc * 128 + i * row32_bytes, 0));
+}
+__device__ __forceinline__ void lin_lstore_x(bf16* Xs, int tid, const u32x4 (&xr)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256, row = c >> 3, ch = c & 7;
+    *reinterpret_cast<u32x4*>(Xs + row * LDK + ch * 8) = xr[i];
+  }
+}
+// Weights come in MFMA-FRAGMENT ORDER (pack_wfrag below / etd host loaders): block (n-tile t of 32 features, k-step s of 16)
+// is 1 KiB, lane l holding row 32 t + (l & 31), columns 16 s + 8 (l >> 5) .. +8.  One load instruction per fragment reads
+// one contiguous KiB straight into the operand registers: the weights never touch LDS (they were 2/3 of its traffic).
+__device__ __forceinline__ bf16x8 lin_wfrag(rsrc_t ws, int lane16, int blk) {
+  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ws, lane16, blk * 1024, 0));
+}
+
+// MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm;
+// MODE 10 + DEPI_x: EtudeDecoder epilogue x on the same tile (batched prefill of the Decode stage).
+// Each of the 4 waves owns 64 tokens x 128 features (2 x 4 accumulator tiles): per 16-deep k-step it reads 2 X fragments
+// from LDS and holds 4 W fragments in registers for 8 MFMAs.
+// One 64-deep chunk: k-step s multiplies with wf[s][*], then re-requests those registers for the NEXT chunk's k-step s.
+template <bool NORMAL_ORIENT>
+__device__ __forceinline__ void lin_chunk(const bf16* Xs, int wm, int r, int h, f32x16 (&acc)[2][4], bf16x8 (&wf)[4][4],
+                                          rsrc_t ws, int lane16, int wblk_next, int kblocks, bool more) {
+  const bf16* xp = Xs + (wm * 64 + r) * LDK + h * 8;
+  bf16x8 xf[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) xf[0][mt] = *reinterpret_cast<const bf16x8*>(xp + mt * 32 * LDK);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    // the next k-step's X fragments are requested before this k-step's MFMAs (a k-step is 8 MFMAs = 256 clk; an LDS read
+    // takes about that long to come back, and with the weights out of LDS nothing else hides it)
+    if (s < 3) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) xf[(s + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(xp + mt * 32 * LDK + (s + 1) * 16);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (NORMAL_ORIENT) acc[mt][nt] = mfma32(xf[s & 1][mt], wf[s][nt], acc[mt][nt]);
+        else               acc[mt][nt] = mfma32(wf[s][nt], xf[s & 1][mt], acc[mt][nt]);
+      }
+    if (more) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) wf[s][nt] = lin_wfrag(ws, lane16, wblk_next + nt * kblocks + s);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   constexpr bool LN = MODE == 2;
@@ -81,7 +136,6 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   constexpr bool DEC = MODE >= 10;
   __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 256) * LDK * 2 + 3 * 256 * 4];
   bf16* Xs = reinterpret_cast<bf16*>(smem);
-  bf16* Ws = Xs + 128 * LDK;
   float* sb = reinterpret_cast<float*>(smem + (128 + 256) * LDK * 2);   // bias | gamma | beta
   float* lnred = reinterpret_cast<float*>(smem + 4 * 32 * EPP * 2);      // [2][128] after the K loop (LN mode), behind the epilogue staging tiles
 
@@ -107,11 +161,56 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
 
+#define LIN_STAMP(i) do { if (a.tbuf && tid == 0) a.tbuf[(long long)blockIdx.x * 16 + (i)] = clock64(); } while (0)
+  // Two K loops, chosen per mode by measurement.  The decoder prefill (K = 512 and 2560, weights in fragment order) runs
+  // loop B: -12 ... -18 % on its GEMMs.  The extractor (K = 256 / 512, two workgroups per CU) keeps loop A: with loop B both
+  // token-halves of the workgroup fetch the same weight fragments through the CU's L1 and its windows took 5 % longer.
+  if constexpr (DEC) {
+  // K loop, 64-deep chunks.  X goes global -> registers -> LDS (two LDS buffers: one barrier per chunk); W goes global ->
+  // operand registers, one chunk ahead.  Request order per chunk: W(c+1, s) behind k-step s, then X(c+3) at the end --
+  // vmcnt retires in order, so the wait for a W fragment never forces the younger X requests.
+  LIN_STAMP(0);
+  u32x4 xa[4], xb[4];
+  bf16x8 wf[4][4];
+  const int nk = (a.dbg & 2) ? 0 : a.K >> 6;       // even: K % 128 == 0 is checked by the launchers
+  const int kblocks = a.K >> 4;                    // 16-deep k-steps per feature row block
+  const rsrc_t xs = lin_rsrc(a.X + (long long)m0 * a.ldx, ((long long)(a.M - m0) * a.ldx) * 2);
+  const rsrc_t ws = lin_rsrc(W, (long long)256 * a.K * 2);
+  const int lane16 = lane * 16;
+  const int wblk0 = __builtin_amdgcn_readfirstlane(wn) * 4 * kblocks;        // this wave's first fragment block (its 4 n-tiles are kblocks apart)
+  const int xo = ((tid >> 3) * a.ldx + (tid & 7) * 8) * 2, xr32 = 32 * a.ldx * 2;
+  bf16* Xs1 = Xs + 128 * LDK;
+  lin_gload_x(xs, xo, xr32, 0, xa);
+#pragma unroll
+  for (int sx = 0; sx < 4; ++sx)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[sx][nt] = lin_wfrag(ws, lane16, wblk0 + nt * kblocks + sx);
+  lin_gload_x(xs, xo, xr32, nk > 1 ? 1 : 0, xb);
+  __builtin_amdgcn_sched_barrier(0);
+  lin_lstore_x(Xs, tid, xa);
+  if (nk > 2) lin_gload_x(xs, xo, xr32, 2, xa);
+  __syncthreads();
+  LIN_STAMP(1);
+  for (int kc = 0; kc < nk; kc += 2) {
+    lin_chunk<vt>(Xs, wm, r, h, acc, wf, ws, lane16, wblk0 + (kc + 1) * 4, kblocks, true);       // kc + 1 < nk always (nk even)
+    lin_lstore_x(Xs1, tid, xb);
+    if (kc + 3 < nk) lin_gload_x(xs, xo, xr32, kc + 3, xb);
+    __syncthreads();
+    if (kc == 0) LIN_STAMP(2);
+    lin_chunk<vt>(Xs1, wm, r, h, acc, wf, ws, lane16, wblk0 + (kc + 2) * 4, kblocks, kc + 2 < nk);
+    if (kc + 2 < nk) {
+      lin_lstore_x(Xs, tid, xa);
+      if (kc + 4 < nk) lin_gload_x(xs, xo, xr32, kc + 4, xa);
+    }
+    __syncthreads();
+    if (kc == 0) { LIN_STAMP(3); LIN_STAMP(4); }
+  }
+  } else {
+    bf16* Ws = Xs + 128 * LDK;
   // K loop, 64-deep chunks through one LDS buffer.  The activation rows come from HBM / the Infinity Cache with ~2-3 us of
   // latency under load while a chunk's 32 MFMAs per wave take 0.4 us, so X is requested TWO chunks ahead (two register
   // sets, alternating); the weight chunk (L2-resident) one ahead, and before the X request of the same step so that the
   // in-order vmcnt wait for it leaves the younger X loads in flight.
-#define LIN_STAMP(i) do { if (a.tbuf && tid == 0) a.tbuf[(long long)blockIdx.x * 16 + (i)] = clock64(); } while (0)
   LIN_STAMP(0);
   u32x4 xa[4], xb[4], wr[8];
   const int nk = (a.dbg & 2) ? 0 : a.K >> 6;       // even: K % 128 == 0 is checked by the launchers
@@ -122,26 +221,27 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   for (int i = 0; i < 4; ++i) { const int c = tid + i * 256; xo[i] = ((c >> 3) * a.ldx + (c & 7) * 8) * 2; }
 #pragma unroll
   for (int i = 0; i < 8; ++i) { const int c = tid + i * 256; wo[i] = ((c >> 3) * a.K + (c & 7) * 8) * 2; }
-  lin_gload_x(xs, xo, 0, xa);
-  lin_gload_w(ws, wo, 0, wr);
-  lin_gload_x(xs, xo, nk > 1 ? 1 : 0, xb);
+  lin_gload_x4(xs, xo, 0, xa);
+  lin_gload_w8(ws, wo, 0, wr);
+  lin_gload_x4(xs, xo, nk > 1 ? 1 : 0, xb);
   for (int kc = 0; kc < nk; kc += 2) {
-    lin_lstore(Xs, Ws, tid, xa, wr);
+    lin_lstore_xw(Xs, Ws, tid, xa, wr);
     __syncthreads();
     if (kc == 0) LIN_STAMP(1);
-    lin_gload_w(ws, wo, kc + 1, wr);                                        // kc + 1 < nk always (nk even)
-    if (kc + 2 < nk) lin_gload_x(xs, xo, kc + 2, xa);
-    lin_chunk<vt>(Xs, Ws, wm, wn, r, h, acc);
+    lin_gload_w8(ws, wo, kc + 1, wr);                                        // kc + 1 < nk always (nk even)
+    if (kc + 2 < nk) lin_gload_x4(xs, xo, kc + 2, xa);
+    lin_chunk_lds<vt>(Xs, Ws, wm, wn, r, h, acc);
     __syncthreads();
     if (kc == 0) LIN_STAMP(2);
-    lin_lstore(Xs, Ws, tid, xb, wr);
+    lin_lstore_xw(Xs, Ws, tid, xb, wr);
     __syncthreads();
     if (kc == 0) LIN_STAMP(3);
-    if (kc + 2 < nk) lin_gload_w(ws, wo, kc + 2, wr);
-    if (kc + 3 < nk) lin_gload_x(xs, xo, kc + 3, xb);
-    lin_chunk<vt>(Xs, Ws, wm, wn, r, h, acc);
+    if (kc + 2 < nk) lin_gload_w8(ws, wo, kc + 2, wr);
+    if (kc + 3 < nk) lin_gload_x4(xs, xo, kc + 3, xb);
+    lin_chunk_lds<vt>(Xs, Ws, wm, wn, r, h, acc);
     __syncthreads();
     if (kc == 0) LIN_STAMP(4);
+  }
   }
   LIN_STAMP(5);
 

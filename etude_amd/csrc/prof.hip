@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "../../include/etude_hip.h"
+#include "ext_kernels.h"
 
 namespace {
 struct Entry { double ms = 0; long long n = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -111,4 +112,38 @@ extern "C" int etd_debug_boundary_cost(int n_nodes, int iters, int big_args, voi
   *graph_us = 1e3 * ms / ((double)iters * n_nodes);
   (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return ETD_OK;
+}
+
+// ---- measurement hook: the token-major GEMM (k_linear, plain bf16 epilogue) on a synthetic [M,K] x [N,K]^T problem.
+// tools/bench_linear.py sweeps the shapes the extractor and the decoder prefill use; with ETD_LIN_STAMP=n in the
+// environment the first n launches print the in-kernel phase stamps instead of being timed.
+__global__ void k_fill_bf16(bf16* p, long long n, unsigned seed) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    unsigned x = (unsigned)i * 2654435761u + seed; x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+    p[i] = (bf16)(((int)(x & 0xffff) - 32768) * (1.f / 262144.f));
+  }
+}
+extern "C" int etd_debug_linear(int M, int N, int K, int iters, void* stream, double* us) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M < 1 || N % 256 || K % 128 || iters < 1 || !us) ETD_FAIL(ETD_EINVAL, "debug_linear: bad shape");
+  bf16 *X = nullptr, *W = nullptr, *Y = nullptr; float* b = nullptr;
+  HIP_TRY(hipMalloc(&X, (size_t)M * K * 2 + 256)); HIP_TRY(hipMalloc(&W, (size_t)N * K * 2 + 256));
+  HIP_TRY(hipMalloc(&Y, (size_t)M * N * 2 + 256)); HIP_TRY(hipMalloc(&b, (size_t)N * 4));
+  HIP_TRY(hipMemsetAsync(b, 0, (size_t)N * 4, st));
+  hipLaunchKernelGGL(k_fill_bf16, dim3(1024), dim3(256), 0, st, X, (long long)M * K, 1u);
+  hipLaunchKernelGGL(k_fill_bf16, dim3(1024), dim3(256), 0, st, W, (long long)N * K, 2u);      // (random values: the layout does not matter for timing)
+  LinArgs a = {};
+  a.X = X; a.ldx = K; a.W = W; a.bias = b; a.M = M; a.N = N; a.K = K; a.Y = Y; a.ldy = N; a.vt_block = -1;
+  int rc = launch_linear(a, 1, st);
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventRecord(e0, st));
+  for (int it = 0; it < iters && rc == ETD_OK; ++it) rc = launch_linear(a, 1, st);
+  HIP_TRY(hipEventRecord(e1, st)); HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0; HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  *us = 1e3 * ms / iters;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(b);
+  return rc;
 }

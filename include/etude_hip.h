@@ -55,6 +55,8 @@ int etd_prof_entry(int i, char* name, int name_cap, double* total_ms, long long*
 
 /* measurement hook: device time per dependent (empty) kernel, launched eagerly vs replayed from a hipGraph */
 int etd_debug_boundary_cost(int n_nodes, int iters, int big_args, void* stream, double* eager_us, double* graph_us);
+/* measurement hook: average time (us) of the token-major bf16 GEMM kernel on a synthetic [M,K] x [N,K]^T problem (N % 256 == 0, K % 128 == 0) */
+int etd_debug_linear(int M, int N, int K, int iters, void* stream, double* us);
 
 /* ------------------------------------------------------------------ audio front end */
 typedef struct etd_frontend etd_frontend;
