@@ -67,6 +67,20 @@ def main():
         print(f"{k:40s} {max(nf,nw):9d} {fb/1e6:12.3f} {wb/1e6:12.3f} {(fb+wb)/1e6:12.3f}")
     with open(os.path.join(root, "traffic.json"), "w") as fh:
         json.dump(traffic, fh, indent=1)
+    # the same table under the names bench.py's launch profiler uses (template instances merged, launch-weighted):
+    # profiles/traffic.json, read by bench.py for `roofline.traffic`
+    groups = {"k_linear": ("k_linear<0>", "k_linear<1>"), "k_linear_ln": ("k_linear<2>",), "k_linear_dec": ("k_linear<10>", "k_linear<11>", "k_linear<12>", "k_linear<14>"),
+              "k_dgemm_s": ("k_dgemm_s<true, 5>", "k_dgemm_s<true, 3>")}
+    bench = {}
+    for k, v in traffic.items():
+        name = next((g for g, members in groups.items() if k in members), k)
+        b = bench.setdefault(name, [0.0, 0])
+        b[0] += v["bytes_per_launch"] * v["launches"]; b[1] += v["launches"]
+    out = {k: b[0] / max(b[1], 1) for k, b in bench.items() if k and not k.startswith("__amd")}
+    out["_note"] = ("HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc passes) of `bench.py --clips 8 --attr-grid 27 "
+                    "--bars 24` (same rows per engine and, after 4 bars, the same contexts as the full 92-bar run); see the round's profile_summary.txt")
+    with open(os.path.join(root, "traffic_bench.json"), "w") as fh:
+        json.dump(out, fh, indent=1)
 
 
 if __name__ == "__main__":
