@@ -59,7 +59,8 @@ struct etd_dec {
   float* Pk = nullptr;                           // [5][512][H] split-K partials of the decode-step (down | dense) projection
   bf16* Xcat = nullptr;                          // [512][I + H] bf16: GELU(up) | attention output, the K-concatenated input of that GEMM
   std::vector<int> stage;                        // host staging of a prefill batch
-  std::map<int, hipGraphExec_t> graphs;          // captured decode step per n_active
+  std::map<int, hipGraphExec_t> graphs;          // captured decode step per (n_active, rows_identity): key 2 * n_active + identity
+  bool rows_identity = false;                    // the step's slot list is 0, 1, ..., n_active - 1
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
   double attn_bytes_hint = 0;
 
@@ -186,7 +187,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = rows; at.M = M; at.O = d->AO;
       at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
-      if (rows.slot == d->row_slot) at.row_sp = d->row_sp;     // decode step: the step's (slot, pos) pairs
+      if (rows.slot == d->row_slot) { at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0; }     // decode step: the step's (slot, pos) pairs
       if (catk) { at.Ob = d->Xcat + d->I; at.ldob = d->I + d->H; }
       ETD_TRY(launch_dattn(at, d->bf16w, st));
     }
@@ -562,6 +563,8 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     d->last_slots.assign(slots, slots + n_active);
     HIP_TRY(hipMemcpyAsync(d->slots_dev, d->last_slots.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, st));
   }
+  d->rows_identity = true;
+  for (int i = 0; i < n_active; ++i) if (slots[i] != i) { d->rows_identity = false; break; }
   // bf16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
   // (QKV|up, attention, down|dense, residual + LayerNorm) and one head launch that also prepares the next step's rows
   const int vpad = (d->V + 31) / 32 * 32;
@@ -620,7 +623,8 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   // a non-default stream and must not contain the profiler's event records.
   const bool use_graph = st != nullptr && !prof_enabled() && !getenv("ETD_NO_GRAPH");
   if (use_graph) {
-    auto it = d->graphs.find(n_active);
+    const int gkey = 2 * n_active + (d->rows_identity ? 1 : 0);
+    auto it = d->graphs.find(gkey);
     if (it == d->graphs.end()) {
       hipGraph_t g = nullptr;
       HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
@@ -632,7 +636,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
       const hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
       (void)hipGraphDestroy(g);
       if (ie != hipSuccess) ETD_FAIL(ETD_EHIP, "decoder_step: graph instantiate failed: %s", hipGetErrorString(ie));
-      it = d->graphs.emplace(n_active, ge).first;
+      it = d->graphs.emplace(gkey, ge).first;
     }
     for (int s = 0; s < n_steps; ++s) HIP_TRY(hipGraphLaunch(it->second, st));
   } else {

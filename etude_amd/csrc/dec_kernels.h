@@ -69,6 +69,7 @@ struct DAttnArgs {
   const void* Kc; const void* Vc; long long slot_stride; int max_ctx, n_heads;
   DecRows rows; int M;
   const int* row_sp;             // optional [M][2] = (slot, position) pairs: one scalar load instead of two dependent ones
+  int identity;                  // row i uses slot i (host knowledge): the first K/V block is requested before the row metadata arrives
   float* O;                      // [M][hidden]
   bf16* Ob; int ldob;            // optional bf16 copy of O (input of the dense GEMM in the bf16 pipeline), row stride ldob (0 = hidden)
   float scale;

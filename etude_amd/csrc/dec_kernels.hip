@@ -899,13 +899,24 @@ template <typename KVT>
 // (leading scalar arguments: gfx950 preloads the first 16 kernarg dwords into SGPRs at wave launch, so the prologue's address
 // arithmetic starts without the kernarg s_load round trip; the struct carries everything that is needed later)
 __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
-                                               int p_max_ctx, int p_n_heads, float p_scale, DAttnArgs a) {
+                                               int p_max_ctx, int p_n_heads, float p_scale, int p_identity, DAttnArgs a) {
   __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
   const int m = blockIdx.x, head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
   int slot, pos;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
-  if (p_row_sp) { const i32x2 sp = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(p_row_sp + 2 * m)); slot = sp[0]; pos = sp[1]; }   // one 8-byte load
+  // p_identity (row i is slot i, known on the host): the K/V addresses of the first key block then depend on nothing in
+  // memory, so that block is requested BEFORE the position arrives -- the row-metadata round trip and the first K/V round
+  // trip overlap instead of following each other (keys past the context are fetched from the slot's own cache and ignored).
+  Raw8<KVT> kA, kB, wA, wB, nkA, nkB, nwA, nwB;
+  if (p_identity) {
+    const KVT* kb0 = reinterpret_cast<const KVT*>(p_Kc) + (long long)m * p_slot_stride + (long long)head * p_max_ctx * 64;
+    const KVT* vb0 = reinterpret_cast<const KVT*>(p_Vc) + (long long)m * p_slot_stride + (long long)head * p_max_ctx * 64;
+    const int ka = wave * 8 + j, kbb = ka + 32;                        // < 64 <= max_ctx (checked by the launcher)
+    kA.load(kb0 + (long long)ka * 64 + c * 8); kB.load(kb0 + (long long)kbb * 64 + c * 8);
+    wA.load(vb0 + (long long)ka * 64 + c * 8); wB.load(vb0 + (long long)kbb * 64 + c * 8);
+    slot = m; pos = __builtin_nontemporal_load(p_row_sp + 2 * m + 1);
+  } else if (p_row_sp) { const i32x2 sp = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(p_row_sp + 2 * m)); slot = sp[0]; pos = sp[1]; }   // one 8-byte load
   else { slot = a.rows.slot[m]; pos = a.rows.pos[m]; }
   const int ctx = (pos < p_max_ctx ? pos : p_max_ctx - 1) + 1;
   const int hidden = p_n_heads * 64;
@@ -927,7 +938,6 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
   for (int e = 0; e < 8; ++e) o[e] = 0.f;
   // Software-pipelined KV stream: a wave-iteration covers two 8-key groups (16 keys); the K/V pieces of iteration i+1
   // are requested before iteration i is consumed, so ~8 KB per wave are always in flight.
-  Raw8<KVT> kA, kB, wA, wB, nkA, nkB, nwA, nwB;
   auto issue = [&](int k0, Raw8<KVT>& a_, Raw8<KVT>& b_, Raw8<KVT>& c_, Raw8<KVT>& d_) {
     int ka = k0 + j, kbb = k0 + 32 + j;
     ka = ka < ctx ? ka : ctx - 1; kbb = kbb < ctx ? kbb : ctx - 1;
@@ -937,7 +947,7 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
     d_.load(vb + (long long)kbb * 64 + c * 8);
   };
   int k0 = wave * 8;
-  if (k0 < ctx) issue(k0, kA, kB, wA, wB);
+  if (!p_identity && k0 < ctx) issue(k0, kA, kB, wA, wB);
   for (; k0 < ctx; k0 += 64) {
     const bool more = k0 + 64 < ctx;
     if (more) issue(k0 + 64, nkA, nkB, nwA, nwB);
@@ -1011,8 +1021,9 @@ int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "dattn: bad M");
   ProfScope ps(a.M > 512 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
   dim3 g(a.M, a.n_heads);
-  if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, a);
-  else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, a);
+  const int ident = a.identity && a.row_sp && a.max_ctx >= 64 ? 1 : 0;
+  if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, ident, a);
+  else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, ident, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
