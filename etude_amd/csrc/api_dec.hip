@@ -139,8 +139,13 @@ int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst)
 // bf16 weights, M > 1:     k_ln_rows -> bf16 activations -> big-tile MFMA GEMM (k_linear decoder modes, M > 512, the
 //                          batched prefill) or the K-split skinny GEMM (M <= 512, the batched decode step).
 struct PrefillInfo { int n; const int* seq_row0; const int* seq_len; int max_len; double attn_flops; };
+// "Only each prompt's last position is needed" (begin_bars): the last layer then runs its attention, MLP and residual for
+// those n rows only -- on the decode-step kernels -- after the big QKV GEMM has put every position's K/V into the cache.
+struct LastOnly { int n; const int* idx; DecRows rows; };
 
-int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false) {
+int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false,
+                 const LastOnly* lo = nullptr, bool* compact = nullptr) {
+  if (compact) *compact = false;
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && M > 1;
@@ -165,6 +170,31 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       LinArgs a = {};
       a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.Wf; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
       ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
+      if (l == d->L - 1 && lo && mfma_attn && lo->n > 1 && lo->n <= 512 && d->H == 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && !getenv("ETD_NO_LAST_ONLY")) {
+        // last layer, last positions only: every position's K/V is in the cache now; what remains of the layer is needed for
+        // n rows, not M (attention, MLP up, (down | dense), residual = 9 % of the prefill's FLOPs at 8 layers)
+        const int n = lo->n;
+        ETD_TRY(launch_gather_rows(hin, lo->idx, n, d->H, d->hlast, st));
+        ETD_TRY(launch_ln_rows(d->hlast, n, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
+        DGemmArgs q2 = q;
+        q2.X = d->hlast; q2.M = n; q2.rows = lo->rows; q2.Xb = d->X1b; q2.Qb = nullptr; q2.Kp = nullptr; q2.VTp = nullptr;
+        DGemmArgs up2 = {};
+        up2.X = d->hlast; up2.ldx = d->H; up2.W = w.up.W; up2.bias = w.up.b; up2.M = n; up2.N = d->I; up2.Npad = w.up.Npad; up2.K = d->H;
+        up2.Y = d->M1; up2.Xb = d->X2b; up2.Yb = d->Xcat; up2.ldy = d->I + d->H;
+        ETD_TRY(launch_dstep_qkv_up(q2, up2, st));
+        DAttnArgs at = {};
+        at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
+        at.rows = lo->rows; at.M = n; at.O = d->AO; at.Ob = d->Xcat + d->I; at.ldob = d->I + d->H; at.scale = 0.125f; at.bytes_hint = 0;
+        ETD_TRY(launch_dattn(at, d->bf16w, st));
+        DGemmArgs dn2 = {};
+        dn2.X = d->M1; dn2.Xb = d->Xcat; dn2.ldx = d->I + d->H; dn2.W = w.cat.W; dn2.bias = w.cat.b; dn2.M = n; dn2.N = d->H; dn2.Npad = w.cat.Npad; dn2.K = d->I + d->H;
+        dn2.hin = d->hlast; dn2.hout = hout; dn2.k_splits = 5; dn2.Y = d->Pk; dn2.ldy = d->H;
+        ETD_TRY(launch_dgemm(dn2, DEPI_PARTIAL, true, st));
+        ETD_TRY(launch_resid_ln_rows(d->Pk, 5, w.cat.b, nullptr, d->hlast, hout, n, d->H, nullptr, nullptr, nullptr, nullptr, d->cfg.layer_norm_eps, nullptr, nullptr, st));
+        *hfinal = hout;                        // rows 0 .. n-1 = the prompts' last positions, in prompt order
+        if (compact) *compact = true;
+        return ETD_OK;
+      }
     } else if (small) {
       // decode step: QKV (+RoPE, KV append) and MLP up (+GELU -> Xcat) share one launch
       DGemmArgs up = {};
@@ -284,7 +314,7 @@ __global__ __launch_bounds__(128) void k_slot_proj(const int* __restrict__ init,
 struct Staged { int Mtot; const int *ids, *cls, *attrs, *row_slot, *row_pos, *row_active, *last_idx, *last_slot, *last_pos, *last_active, *init, *row_seq, *seq_row0, *seq_len; };
 
 int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T, const int32_t* ids, const int32_t* cls,
-                      const int32_t* attrs4, const int32_t* init7 /* [n][7] or null */, Staged* sg, float** hfinal, hipStream_t st) {
+                      const int32_t* attrs4, const int32_t* init7 /* [n][7] or null */, Staged* sg, float** hfinal, hipStream_t st, bool* last_only = nullptr) {
   if (!d || n < 1 || n > d->S || !slots || !T || !ids || !cls || !attrs4) ETD_FAIL(ETD_EINVAL, "prefill: bad arguments");
   long long Mtot = 0;
   for (int i = 0; i < n; ++i) {
@@ -338,7 +368,8 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   ETD_TRY(launch_dembed(e, st));
   PrefillInfo pf{n, sg->seq_row0, sg->seq_len, max_len, aflops};
   const bool can_mfma_attn = d->VTp != nullptr && max_len <= d->vt_spad && !getenv("ETD_NO_MFMA_PREFILL_ATTN");
-  ETD_TRY(forward_body(d, M, e.rows, hfinal, st, can_mfma_attn ? &pf : nullptr));
+  LastOnly lo{n, sg->last_idx, DecRows{sg->last_slot, sg->last_pos, sg->last_active}};
+  ETD_TRY(forward_body(d, M, e.rows, hfinal, st, can_mfma_attn ? &pf : nullptr, false, last_only ? &lo : nullptr, last_only));
   return ETD_OK;
 }
 
@@ -519,10 +550,15 @@ extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, c
     d->keys_dirty = false;
   }
   Staged sg; float* hf = nullptr;
-  ETD_TRY(stage_and_forward(d, n, slots, T, ids, cls, attrs4, init.data(), &sg, &hf, st));
+  bool compact = false;
+  ETD_TRY(stage_and_forward(d, n, slots, T, ids, cls, attrs4, init.data(), &sg, &hf, st, &compact));
   // only each prompt's last position feeds the first generated token (etude_decoder.py:317)
-  ETD_TRY(launch_gather_rows(hf, sg.last_idx, n, d->H, d->hlast, st));
-  ETD_TRY(head_logits(d, d->hlast, n, d->logits, st));
+  if (compact) {
+    ETD_TRY(head_logits(d, hf, n, d->logits, st));           // (the last layer already ran on those rows alone)
+  } else {
+    ETD_TRY(launch_gather_rows(hf, sg.last_idx, n, d->H, d->hlast, st));
+    ETD_TRY(head_logits(d, d->hlast, n, d->logits, st));
+  }
   DArgmaxArgs am = {};
   am.logits = d->logits; am.ldl = d->V; am.V = d->V; am.M = n;
   am.rows = DecRows{sg.last_slot, sg.last_pos, sg.last_active};
