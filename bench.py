@@ -151,7 +151,8 @@ def main():
     n_jobs = args.clips * args.attr_grid
     n_eng = max(1, min(args.engines, n_jobs))
     per_eng = (min(args.streams, n_jobs) + n_eng - 1) // n_eng
-    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng) for _ in range(n_eng)]
+    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng)]
+    decs += [decs[0].clone() for _ in range(n_eng - 1)]            # engines share one weight set (own KV caches and state)
     vocab = make_vocab()
     clip_ids = [rank * args.clips + c for c in range(args.clips)]                      # global clip index = rank-major shard
     base = synth.clip_audio(seed=1234, seconds=args.seconds)

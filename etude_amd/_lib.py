@@ -108,6 +108,7 @@ SIGNATURES = {
     "etd_decoder_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), c_i64_p, C.c_int,
                                      C.POINTER(C.c_void_p)]),
     "etd_decoder_destroy": (None, [C.c_void_p]),
+    "etd_decoder_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "etd_decoder_set_sampling": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_ulonglong, C.c_void_p]),
     "etd_decoder_set_keys": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "etd_decoder_begin_bar": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

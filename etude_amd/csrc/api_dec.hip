@@ -63,6 +63,11 @@ struct etd_dec {
   bool rows_identity = false;                    // the step's slot list is 0, 1, ..., n_active - 1
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
   double attn_bytes_hint = 0;
+  // weight sharing (etd_decoder_clone): a clone reads the owner's weight buffers and has its own KV cache, workspaces and
+  // stream state.  `allocs` of an owner = weights first (n_weight_allocs of them), then its workspaces; a clone's = workspaces only.
+  etd_dec* weights_owner = nullptr;              // null: this handle owns its weights
+  size_t n_weight_allocs = 0;
+  int n_clones = 0; bool zombie = false;         // owner destroyed while clones are alive: weights freed with the last clone
 
   template <typename T> int alloc(T** p, size_t n, bool zero = false) {
     void* q = nullptr;
@@ -373,6 +378,43 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   return ETD_OK;
 }
 
+// KV cache, activation workspaces and stream state of one handle (everything that is not a weight)
+int alloc_workspaces(etd_dec* d) {
+  const int H = d->H;
+  int rc = 0;
+  d->slot_stride = (long long)d->nh * d->ctx * 64;
+  d->layer_stride = d->slot_stride * d->S;
+  const size_t kv_elems = (size_t)d->layer_stride * d->L;
+  if (d->bf16w) { uint16_t *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return rc; d->Kc = k; d->Vc = v; }
+  else { float *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return rc; d->Kc = k; d->Vc = v; }
+  const size_t M = d->Mcap;
+  const size_t Mf = d->bf16w ? (size_t)(d->S > 1 ? d->S : 1) : M;     // rows that can take the fp32-activation path
+  rc = 0;
+  rc = rc ? rc : d->alloc(&d->h, M * H); rc = rc ? rc : d->alloc(&d->h2, M * H);
+  rc = rc ? rc : d->alloc(&d->Q, M * H); rc = rc ? rc : d->alloc(&d->AO, M * H); rc = rc ? rc : d->alloc(&d->DO, M * H);
+  rc = rc ? rc : d->alloc(&d->M1, Mf * d->I); rc = rc ? rc : d->alloc(&d->logits, (size_t)d->Mmax * d->V);
+  rc = rc ? rc : d->alloc(&d->qkv_raw, (size_t)3 * H); rc = rc ? rc : d->alloc(&d->hlast, (size_t)d->S * H);
+  if (d->bf16w) {
+    rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
+    rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
+    rc = rc ? rc : d->alloc(&d->Pk, (size_t)5 * 512 * H);
+    rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
+    rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
+    d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
+    rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)
+  }
+  rc = rc ? rc : d->alloc(&d->samp_dev, (size_t)1, true); rc = rc ? rc : d->alloc(&d->rng_key, (size_t)d->S, true);
+  rc = rc ? rc : d->alloc(&d->row_sp, (size_t)2 * d->Mmax, true);
+  rc = rc ? rc : d->alloc(&d->row_slot, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_pos, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_active, (size_t)d->Mmax);
+  rc = rc ? rc : d->alloc(&d->ids, 10 * M + 13 * (size_t)d->S); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
+  const size_t S = d->S;
+  rc = rc ? rc : d->alloc(&d->cur_tok, S, true); rc = rc ? rc : d->alloc(&d->len, S, true); rc = rc ? rc : d->alloc(&d->done, S, true);
+  rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
+  rc = rc ? rc : d->alloc(&d->tgt_proj, S * (size_t)d->H, true);
+  rc = rc ? rc : d->alloc(&d->tgt_attrs, 4 * S, true); rc = rc ? rc : d->alloc(&d->out_tok, S * d->out_cap, true);
+  return rc;
+}
+
 }  // namespace
 
 extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
@@ -489,38 +531,33 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
     if ((rc = up_f32(d, &d->rope_cos, cs.data(), cs.size()))) return fail(rc);
     if ((rc = up_f32(d, &d->rope_sin, sn.data(), sn.size()))) return fail(rc);
   }
-  d->slot_stride = (long long)d->nh * d->ctx * 64;
-  d->layer_stride = d->slot_stride * d->S;
-  const size_t kv_elems = (size_t)d->layer_stride * d->L;
-  if (d->bf16w) { uint16_t *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return fail(rc); d->Kc = k; d->Vc = v; }
-  else { float *k, *v; if ((rc = d->alloc(&k, kv_elems, true)) || (rc = d->alloc(&v, kv_elems, true))) return fail(rc); d->Kc = k; d->Vc = v; }
-  const size_t M = d->Mcap;
-  const size_t Mf = d->bf16w ? (size_t)(d->S > 1 ? d->S : 1) : M;     // rows that can take the fp32-activation path
-  rc = 0;
-  rc = rc ? rc : d->alloc(&d->h, M * H); rc = rc ? rc : d->alloc(&d->h2, M * H);
-  rc = rc ? rc : d->alloc(&d->Q, M * H); rc = rc ? rc : d->alloc(&d->AO, M * H); rc = rc ? rc : d->alloc(&d->DO, M * H);
-  rc = rc ? rc : d->alloc(&d->M1, Mf * d->I); rc = rc ? rc : d->alloc(&d->logits, (size_t)d->Mmax * d->V);
-  rc = rc ? rc : d->alloc(&d->qkv_raw, (size_t)3 * H); rc = rc ? rc : d->alloc(&d->hlast, (size_t)d->S * H);
-  if (d->bf16w) {
-    rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
-    rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
-    rc = rc ? rc : d->alloc(&d->Pk, (size_t)5 * 512 * H);
-    rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
-    rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
-    d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
-    rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)
-  }
-  rc = rc ? rc : d->alloc(&d->samp_dev, (size_t)1, true); rc = rc ? rc : d->alloc(&d->rng_key, (size_t)d->S, true);
-  rc = rc ? rc : d->alloc(&d->row_sp, (size_t)2 * d->Mmax, true);
-  rc = rc ? rc : d->alloc(&d->row_slot, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_pos, (size_t)d->Mmax); rc = rc ? rc : d->alloc(&d->row_active, (size_t)d->Mmax);
-  rc = rc ? rc : d->alloc(&d->ids, 10 * M + 13 * (size_t)d->S); rc = rc ? rc : d->alloc(&d->slots_dev, (size_t)d->S);
-  const size_t S = d->S;
-  rc = rc ? rc : d->alloc(&d->cur_tok, S, true); rc = rc ? rc : d->alloc(&d->len, S, true); rc = rc ? rc : d->alloc(&d->done, S, true);
-  rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
-  rc = rc ? rc : d->alloc(&d->tgt_proj, S * (size_t)d->H, true);
-  rc = rc ? rc : d->alloc(&d->tgt_attrs, 4 * S, true); rc = rc ? rc : d->alloc(&d->out_tok, S * d->out_cap, true);
+  d->n_weight_allocs = d->allocs.size();
+  rc = alloc_workspaces(d);
   if (rc) return fail(rc);
   HIP_TRY(hipDeviceSynchronize());
+  *out = d;
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
+  if (!src || !out) ETD_FAIL(ETD_EINVAL, "decoder_clone: null argument");
+  etd_dec* own = src->weights_owner ? src->weights_owner : src;
+  if (own->zombie) ETD_FAIL(ETD_EINVAL, "decoder_clone: the source handle was destroyed");
+  etd_dec* d = new etd_dec();
+  d->cfg = own->cfg; d->bf16w = own->bf16w;
+  d->H = own->H; d->I = own->I; d->V = own->V; d->L = own->L; d->nh = own->nh; d->S = own->S; d->ctx = own->ctx;
+  d->Mmax = own->Mmax; d->Mcap = own->Mcap; d->out_cap = own->out_cap;
+  d->word = own->word; d->cls_emb = own->cls_emb; d->attr_tab = own->attr_tab; d->layers = own->layers;
+  d->lnfg = own->lnfg; d->lnfb = own->lnfb; d->head = own->head; d->head_frag = own->head_frag;
+  d->rope_cos = own->rope_cos; d->rope_sin = own->rope_sin;
+  d->host_len.assign(d->S, 0);
+  d->host_key.resize(d->S);
+  for (int i = 0; i < d->S; ++i) d->host_key[i] = (unsigned long long)i;
+  d->weights_owner = own;
+  const int rc = alloc_workspaces(d);
+  if (rc) { for (void* p : d->allocs) (void)hipFree(p); delete d; return rc; }
+  HIP_TRY(hipDeviceSynchronize());
+  ++own->n_clones;
   *out = d;
   return ETD_OK;
 }
@@ -529,6 +566,21 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
   if (!d) return;
   (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
+  d->graphs.clear();
+  if (d->weights_owner) {
+    etd_dec* own = d->weights_owner;
+    for (void* p : d->allocs) (void)hipFree(p);
+    delete d;
+    if (--own->n_clones == 0 && own->zombie) { for (void* p : own->allocs) (void)hipFree(p); delete own; }
+    return;
+  }
+  if (d->n_clones > 0) {
+    // clones still read the weights: release this handle's own workspaces now, the weights with the last clone
+    for (size_t i = d->n_weight_allocs; i < d->allocs.size(); ++i) (void)hipFree(d->allocs[i]);
+    d->allocs.resize(d->n_weight_allocs);
+    d->zombie = true;
+    return;
+  }
   for (void* p : d->allocs) (void)hipFree(p);
   delete d;
 }

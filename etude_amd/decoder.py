@@ -97,6 +97,19 @@ class EtudeDecoder:
         # decode steps are replayed as hipGraphs, which cannot be captured on the default stream
         self._ts = torch.cuda.Stream(device=self.device)
 
+    def clone(self) -> "EtudeDecoder":
+        """A second engine over the same device weights (own KV cache / workspaces / stream state): what `generate_many`
+        callers use to run several engines side by side without one weight copy per engine."""
+        other = object.__new__(EtudeDecoder)
+        for k in ("device", "config", "precision", "max_streams", "max_ctx", "max_prefill_rows"):
+            setattr(other, k, getattr(self, k))
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().etd_decoder_clone(self._h, C.byref(h)), "etd_decoder_clone")
+        other._h = h
+        other._ts = torch.cuda.Stream(device=self.device)
+        return other
+
     # ------------------------------------------------------------------ reference surface
     def eval(self):
         return self

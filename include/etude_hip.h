@@ -146,6 +146,10 @@ typedef struct {
 int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                        const int64_t* numels, int n, etd_dec** out);
 void etd_decoder_destroy(etd_dec*);
+/* A second engine over the SAME weights: own KV cache, workspaces and stream state (same cfg), the weight buffers of `src`
+ * (or of the handle `src` was cloned from) are shared, not copied -- concurrent engines then stream one weight set through
+ * the caches instead of one copy each.  Handles may be destroyed in any order; the weights go with the last one. */
+int etd_decoder_clone(etd_dec* src, etd_dec** out);
 /* Start one bar on stream `slot` (etude_decoder.py:291-297 + first loop iteration): reset the slot's KV
  * cache and generation state, run the prompt (ids/cls: int32 host [T]; attrs4: int32 host [4][T] in the
  * concat order of etude_decoder.py:171-176 = pitch_overlap, polyphony, note_sustain, rhythm_intensity)

@@ -180,7 +180,8 @@ def test_concurrent_engines_on_host_threads_equal_one_engine(dev):
     n_eng = 3
     ref = EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=8)
     want = [ref.generate_many(jobs[i::n_eng], v, force_bar_tokens=16) for i in range(n_eng)]
-    engs = [EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=8) for _ in range(n_eng)]
+    engs = [EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=8)]
+    engs += [engs[0].clone() for _ in range(n_eng - 1)]        # engines 1.. share engine 0's device weights (etd_decoder_clone)
     got, errs = [None] * n_eng, []
 
     def run(i):
@@ -196,3 +197,7 @@ def test_concurrent_engines_on_host_threads_equal_one_engine(dev):
         t.join()
     assert not errs, errs
     assert got == want
+    # the weight owner may go first: its clones keep the weights alive and still decode
+    engs[0].close()
+    assert engs[1].generate_many(jobs[1::n_eng], v, force_bar_tokens=16) == want[1]
+    engs[2].close(); engs[1].close()
