@@ -25,6 +25,7 @@ inline uint16_t f2bf_h(float f) {
 struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0;
              void* Wf = nullptr; };   // bf16 weights: a second copy in MFMA-fragment order for k_linear (the batched prefill); W stays row-major for the step kernels
 struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
+               void* dense_hw = nullptr;   // bf16 [heads][H][64]: attention.dense regrouped per head for k_dstep_attn_down
                Lin cat; };   // decode step: [dense_4h_to_h | attention.dense] along K, so mlp + attn come out of ONE GEMM
 
 }  // namespace
@@ -208,6 +209,26 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       ETD_TRY(launch_dstep_qkv_up(q, up, st));
     } else {
       ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
+    }
+    // ---- decode step: attention (+ its share of attention.dense) and the MLP down projection in ONE launch, then the row kernel
+    const bool attn_down = small && rows.slot == d->row_slot && d->H == 512 && d->nh == 8 && d->I % 512 == 0 && d->I / 512 + d->nh <= 12 && w.dense_hw &&
+                           d->ctx >= 64 && !getenv("ETD_NO_ATTN_DOWN");
+    if (attn_down) {
+      DAttnArgs at = {};
+      at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
+      at.rows = rows; at.M = M; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+      at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0;
+      const int ksd = d->I / 512;
+      at.dense_w = (const bf16*)w.dense_hw; at.dense_out = d->Pk + (size_t)ksd * M * d->H;
+      DGemmArgs dn = {};
+      dn.Xb = d->Xcat; dn.ldx = d->I + d->H; dn.W = w.cat.W; dn.K = d->I + d->H; dn.M = M; dn.N = d->H; dn.Npad = d->H;
+      dn.k_splits = ksd; dn.Y = d->Pk; dn.ldy = d->H;
+      ETD_TRY(launch_dstep_attn_down(at, dn, st));
+      const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
+      ETD_TRY(launch_resid_ln_rows(d->Pk, ksd + d->nh, w.cat.b, nullptr, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
+                                   nx ? nx->ln2g : nullptr, nx ? nx->ln2b : nullptr, d->cfg.layer_norm_eps, nx ? d->X1b : nullptr, nx ? d->X2b : nullptr, st));
+      float* t = hin; hin = hout; hout = t;
+      continue;
     }
     // ---- causal attention against the slot's KV cache
     if (mfma_attn) {
@@ -397,7 +418,7 @@ int alloc_workspaces(etd_dec* d) {
   if (d->bf16w) {
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
-    rc = rc ? rc : d->alloc(&d->Pk, (size_t)5 * 512 * H);
+    rc = rc ? rc : d->alloc(&d->Pk, (size_t)12 * 512 * H);     // split-K slabs of the decode step: 5 (down | dense) or 4 (down) + one per head (dense inside the attention workgroups)
     rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
     rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
@@ -489,6 +510,15 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
       std::vector<float> bc(H);
       for (int o = 0; o < H; ++o) bc[o] = b2[o] + bd[o];
       w.cat.W = pw; w.cat.N = H; w.cat.Npad = H; w.cat.K = Kc;
+      {
+        std::vector<uint16_t> dh((size_t)d->nh * H * 64);
+        for (int hd = 0; hd < d->nh; ++hd)
+          for (int o = 0; o < H; ++o)
+            for (int dd = 0; dd < 64; ++dd) dh[((size_t)hd * H + o) * 64 + dd] = f2bf_h(Wd[(size_t)o * H + hd * 64 + dd]);
+        uint16_t* pd; if ((rc = d->alloc(&pd, dh.size()))) return fail(rc);
+        HIP_TRY(hipMemcpy(pd, dh.data(), dh.size() * 2, hipMemcpyHostToDevice));
+        w.dense_hw = pd;
+      }
       if (H % 32 == 0 && Kc % 16 == 0) {
         std::vector<uint16_t> wp(wc.size());
         pack_wfrag_host(wc.data(), H, Kc, wp.data());

@@ -74,8 +74,15 @@ struct DAttnArgs {
   bf16* Ob; int ldob;            // optional bf16 copy of O (input of the dense GEMM in the bf16 pipeline), row stride ldob (0 = hidden)
   float scale;
   double bytes_hint;             // algorithmic K+V bytes this launch reads (host estimate, profiler only)
+  // k_dstep_attn_down only: attention.dense applied inside the attention workgroup
+  const bf16* dense_w;           // [heads][512][64]: per head, the [out][64] slice of attention.dense (contiguous 64 KiB)
+  float* dense_out;              // [heads][M][512] fp32 partial sums = split-K slabs of k_resid_ln_rows
 };
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
+// decode step, bf16: attention of every (row, head) WITH its share of attention.dense, and -- in the same launch, on other
+// workgroups -- the MLP down projection (which depends on the QKV|up launch only): `down` is a DEPI_PARTIAL request
+// (k_splits slabs of K / k_splits each, over the first K columns of the (down | dense) weight).
+int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& down, hipStream_t st);
 
 // h fp32 [M,H] -> LayerNorm with (g1,b1) and (g2,b2) -> two bf16 matrices (the two parallel-residual branches read the same h)
 int launch_ln_rows(const float* h, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,

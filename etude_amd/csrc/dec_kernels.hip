@@ -895,13 +895,13 @@ template <> struct Raw8<bf16> {
 };
 
 #define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
-template <typename KVT>
-// (leading scalar arguments: gfx950 preloads the first 16 kernarg dwords into SGPRs at wave launch, so the prologue's address
-// arithmetic starts without the kernarg s_load round trip; the struct carries everything that is needed later)
-__global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
-                                               int p_max_ctx, int p_n_heads, float p_scale, int p_identity, DAttnArgs a) {
-  __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
-  const int m = blockIdx.x, head = blockIdx.y;
+// DENSE: instead of storing the head's 64 outputs, multiply them (rounded to bf16, as the projection GEMM would read them)
+// with this head's [512][64] slice of attention.dense and store the 512 partial sums as one more split-K slab for
+// k_resid_ln_rows -- the attention-output projection needs no launch of its own (k_dstep_attn_down below).
+template <typename KVT, bool DENSE>
+__device__ __forceinline__ void dattn_core(const int m, const int head, float (&red)[4][8][10], float* osh, float* outsh,
+                                           const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+                                           int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
   int slot, pos;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
@@ -976,6 +976,7 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
     }
     if (more) { kA = nkA; kB = nkB; wA = nwA; wB = nwB; }
   }
+
   // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the 4 waves through LDS
 #pragma unroll
   for (int off = 8; off < 64; off <<= 1) {
@@ -1005,18 +1006,147 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
       for (int e = 0; e < 8; ++e) acc[e] += red[w][c][2 + e] * f;
     }
     const float inv = 1.f / L;
-    float* op = a.O + (long long)m * hidden + head * 64 + c * 8;
     const f32x4 x = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv}, y = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
-    *reinterpret_cast<f32x4*>(op) = x;
-    *reinterpret_cast<f32x4*>(op + 4) = y;
-    if (a.Ob) {
-      const bf16x8 ob = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
-      *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * (a.ldob > 0 ? a.ldob : hidden) + head * 64 + c * 8) = ob;
+    if constexpr (DENSE) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { osh[c * 8 + e] = (float)(bf16)x[e]; osh[c * 8 + 4 + e] = (float)(bf16)y[e]; }
+    } else {
+      float* op = a.O + (long long)m * hidden + head * 64 + c * 8;
+      *reinterpret_cast<f32x4*>(op) = x;
+      *reinterpret_cast<f32x4*>(op + 4) = y;
+      if (a.Ob) {
+        const bf16x8 ob = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+        *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * (a.ldob > 0 ? a.ldob : hidden) + head * 64 + c * 8) = ob;
+      }
     }
   }
+  if constexpr (DENSE) {
+    // out[n] = sum_d Wd[n][64 head + d] * o[d] for the 512 outputs: 8 lanes share a weight row (128 contiguous bytes), a wave
+    // instruction covers 8 consecutive rows = 1 KiB; 16 such loads per wave are in flight together (requested above, before
+    // the merge), the 8-lane sums use DPP exchanges.  The weights of a head are one contiguous 64 KiB block (dense_w).
+    // (register budget: this kernel streams K/V at 6-7 waves per SIMD, so the dense weights are requested only here, after the
+    // key loop's registers are dead, in two passes of 8 fragments; other workgroups' streaming hides the extra L2 round trip)
+    const bf16* dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * 128 + (lane >> 3)) * 64 + (lane & 7) * 8;
+    bf16x8 dwv[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + it * 8 * 64);
+    __syncthreads();
+    const int g8 = lane >> 3, sub = lane & 7;
+    float ov[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov[e] = osh[sub * 8 + e];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + (8 + it) * 8 * 64);
+      }
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sacc = fmaf(bf2f(dwv[it][e]), ov[e], sacc);
+        sacc += lane_xor<1>(sacc); sacc += lane_xor<2>(sacc); sacc += lane_xor<4>(sacc);
+        if (sub == 0) outsh[wave * 128 + (pass * 8 + it) * 8 + g8] = sacc;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 o2 = {outsh[2 * tid], outsh[2 * tid + 1]};
+    *reinterpret_cast<f32x2*>(a.dense_out + ((long long)head * a.M + m) * 512 + 2 * tid) = o2;
+  }
+}
+template <typename KVT>
+// (leading scalar arguments: gfx950 preloads the first 16 kernarg dwords into SGPRs at wave launch, so the prologue's address
+// arithmetic starts without the kernarg s_load round trip; the struct carries everything that is needed later)
+__global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+                                               int p_max_ctx, int p_n_heads, float p_scale, int p_identity, DAttnArgs a) {
+  __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
+  dattn_core<KVT, false>(blockIdx.x, blockIdx.y, red, nullptr, nullptr, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
 }
 
 #undef EXPF
+// ================================================================================================
+// k_dstep_attn_down: one launch for the two things that depend on the QKV|up launch only
+//   * workgroups [0, p_gemm_wgs): the MLP down projection as split-K partial slabs.  A workgroup is two independent
+//     2-wave units of k_dgemm_s's bf16 path (32x32 tile, one K slab of 512, K halved over the unit's two waves); the two
+//     units of a workgroup are consecutive slots of one XCD, i.e. row tiles of the same weight tile where there are several.
+//   * the others: attention per (row, head) with the head's slice of attention.dense applied in place (dattn_core<DENSE>).
+// k_resid_ln_rows then sums k_splits + n_heads slabs.  A decode-step layer is 3 launches instead of 4.
+// ================================================================================================
+#ifndef ETD_AD_WAVES_MIN
+#define ETD_AD_WAVES_MIN 7       // keeps the MFMA accumulator out of AGPRs: 72 registers, 7 waves per SIMD like k_dattn (5 without the hint)
+#define ETD_AD_WAVES_MAX 8
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ETD_AD_WAVES_MIN, ETD_AD_WAVES_MAX))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+                                                         int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
+                                                         DAttnArgs a, DGemmArgs g) {
+  __shared__ float red[4][8][10];
+  __shared__ float osh[64];
+  __shared__ __attribute__((aligned(16))) float sh[2 * 16 * 64];      // attention: 512 staged outputs; GEMM: the two units' cross-wave sums
+  if ((int)blockIdx.x >= p_gemm_wgs) {
+    const int lid = blockIdx.x - p_gemm_wgs;
+    dattn_core<bf16, true>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
+    return;
+  }
+  // ---- GEMM role
+  const int tid = threadIdx.x, half = tid >> 7, tl = tid & 127, lane = tl & 63, wave = tl >> 6, r = lane & 31, h = lane >> 5;
+  const int RT = (p_M + 31) / 32, FT = g.Npad / 32, KS = g.k_splits;
+  const int bid = blockIdx.x, slot = (bid >> 3) * 2 + half, wt = (slot / RT) * 8 + (bid & 7);
+  const bool valid = wt < FT * KS;
+  const int wtc = valid ? wt : 0;
+  const int bz = wtc / FT, m0 = (slot % RT) * 32, n0 = (wtc - bz * FT) * 32;
+  int gm = m0 + r; gm = gm < p_M ? gm : p_M - 1;
+  const int Kz = 512;                                  // one slab = 512 input columns (checked by the launcher)
+  const int kb = bz * Kz + wave * 256;
+  const bf16* wrow = reinterpret_cast<const bf16*>(g.W) + (long long)(n0 + r) * g.K + kb + h * 8;
+  const bf16* xrow = g.Xb + (long long)gm * g.ldx + kb + h * 8;
+  // (the same 16 MFMAs in the same order as k_dgemm_s, but fed in four passes of 4 k-steps: this role shares the launch -- and
+  // so the register allocation -- with the attention role, which needs its 6-7 waves per SIMD; four short round trips of
+  // 64 workgroups hide behind the attention workgroups)
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    bf16x8 wf[4], xf[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + (ps * 4 + s4) * 16); xf[s4] = *reinterpret_cast<const bf16x8*>(xrow + (ps * 4 + s4) * 16); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
+  }
+  float* redg = sh + half * (16 * 64);
+  if (wave == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) redg[i * 64 + lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave != 0 || !valid) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] += redg[i * 64 + lane];
+  const int m = m0 + r;
+  if (m >= p_M) return;
+  DGemmArgs b = g;
+  b.Y = g.Y + (long long)bz * p_M * g.ldy;
+  dgemm_epilogue<true, DEPI_PARTIAL>(b, acc, m, n0, h);
+}
+
+int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, hipStream_t st) {
+  if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 64 ||
+      g.M != a.M || !g.Xb || !g.W || !g.Y || g.ldy != 512 || g.N != 512 || g.Npad != 512 || g.k_splits < 1 || g.k_splits * 512 > g.K || (g.K % 8) || a.n_heads * 64 != 512)
+    ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad arguments");
+  const int RT = (a.M + 31) / 32, FT = g.Npad / 32;
+  const int slots = ((FT * g.k_splits + 7) / 8) * RT;               // per XCD
+  const int gemm_wgs = ((slots + 1) / 2) * 8;
+  ProfScope ps("k_dstep_attn_down", st, 2.0 * a.M * 512 * (512.0 * g.k_splits + 512.0), a.bytes_hint + 512.0 * (512.0 * g.k_splits + 512.0) * 2);
+  hipLaunchKernelGGL(k_dstep_attn_down, dim3(gemm_wgs + a.M * a.n_heads), dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale,
+                     a.identity ? 1 : 0, gemm_wgs, a.M, a, g);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "dattn: bad M");
   ProfScope ps(a.M > 512 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
@@ -1187,6 +1317,7 @@ int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const 
   if (M <= 0 || H % 8 || H > 2048 || k_splits < 1) ETD_FAIL(ETD_EINVAL, "resid_ln_rows: bad shape");
   ProfScope ps("k_resid_ln_rows", st, 0, (double)M * H * 4 * (k_splits + 3));
   if (k_splits == 5) hipLaunchKernelGGL(k_resid_ln_rows<5>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
+  else if (k_splits == 12) hipLaunchKernelGGL(k_resid_ln_rows<12>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
   else hipLaunchKernelGGL(k_resid_ln_rows<0>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
   HIP_TRY(hipGetLastError());
   return ETD_OK;

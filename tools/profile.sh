@@ -14,6 +14,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -- python3 $ROOT/bench.py $PARGS > $OUT/prof_write.json 2> $OUT/prof_write.err
 cd $ROOT
 python3 tools/summarize_profile.py $OUT > $OUT/profile_summary.txt 2>&1
+python3 tools/trace_overlap.py $OUT/prof_trace >> $OUT/profile_summary.txt 2>&1
 tail -40 $OUT/profile_summary.txt
 du -sh $OUT/prof_trace $OUT/prof_fetch $OUT/prof_write 2>/dev/null
 find $OUT/prof_trace -name "*.csv" | head
