@@ -12,7 +12,7 @@ import re
 import sys
 
 PREFILL = ("k_linear", "k_attn", "k_ln_rows", "k_dembed", "k_dgemm_s<true, 3>", "k_gather_rows", "k_dargmax")
-STEP = ("k_dattn", "k_dstep_qkv_up", "k_dgemm_s<true, 5>", "k_resid_ln_rows", "k_dstep_head")
+STEP = ("k_dattn", "k_dstep_attn_down", "k_dstep_qkv_up", "k_dgemm_s<true, 5>", "k_resid_ln_rows", "k_dstep_head")
 
 
 def short(name):
