@@ -59,7 +59,12 @@ struct etd_dec {
   std::vector<unsigned long long> host_key; bool keys_dirty = true; bool sampling = false;
   float* Pk = nullptr;                           // [5][512][H] split-K partials of the decode-step (down | dense) projection
   bf16* Xcat = nullptr;                          // [512][I + H] bf16: GELU(up) | attention output, the K-concatenated input of that GEMM
-  std::vector<int> stage;                        // host staging of a prefill batch
+  std::vector<int> stage;                        // host staging of a prefill batch (fallback when the pinned buffer is absent)
+  // pinned host memory (hipHostMalloc): copies to / from it are true async DMAs -- a pageable source or destination costs a
+  // staging pass and ~100 us per call at these sizes, all of it with this engine's queue empty (bar boundaries)
+  int* pin_stage = nullptr; size_t pin_stage_ints = 0; hipEvent_t pin_stage_evt = nullptr;   // prefill upload; the event = "the last upload has left the buffer"
+  int* pin_rb = nullptr;                         // read-back: [done S][n_out S][tokens S * out_cap]
+  std::vector<int> host_n_out; bool host_n_out_valid = false;   // n_out as of the last poll; valid until the next step / begin_bars
   std::map<int, hipGraphExec_t> graphs;          // captured decode step per (n_active, rows_identity): key 2 * n_active + identity
   bool rows_identity = false;                    // the step's slot list is 0, 1, ..., n_active - 1
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
@@ -357,12 +362,21 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   }
   // staging layout: [ids M][cls M][attrs 4M][row_slot M][row_pos M][row_active M][last_idx n][last_slot n][last_pos n][last_active n][init 7n]
   //                 [row_seq M][seq_row0 n][seq_len n]
-  std::vector<int>& sv = d->stage;
-  sv.assign((size_t)10 * M + 13 * n, 0);
-  memcpy(sv.data(), ids, (size_t)M * 4);
-  memcpy(sv.data() + M, cls, (size_t)M * 4);
-  memcpy(sv.data() + 2 * (size_t)M, attrs4, (size_t)4 * M * 4);
-  int* rs = sv.data() + 6 * (size_t)M; int* rp = rs + M; int* ra = rp + M;
+  const size_t sv_ints = (size_t)10 * M + 13 * n;
+  int* svp;
+  const bool pinned = d->pin_stage && sv_ints <= d->pin_stage_ints;
+  if (pinned) {
+    HIP_TRY(hipEventSynchronize(d->pin_stage_evt));            // the previous upload (if any) has been read out of the buffer
+    svp = d->pin_stage;
+    memset(svp, 0, sv_ints * 4);
+  } else {
+    d->stage.assign(sv_ints, 0);
+    svp = d->stage.data();
+  }
+  memcpy(svp, ids, (size_t)M * 4);
+  memcpy(svp + M, cls, (size_t)M * 4);
+  memcpy(svp + 2 * (size_t)M, attrs4, (size_t)4 * M * 4);
+  int* rs = svp + 6 * (size_t)M; int* rp = rs + M; int* ra = rp + M;
   int* li = ra + M; int* ls = li + n; int* lp = ls + n; int* la = lp + n; int* in7 = la + n;
   int* rq = in7 + 7 * n; int* sr0 = rq + M; int* sln = sr0 + n;
   int row = 0, max_len = 0; double kvb = 0, aflops = 0;
@@ -376,7 +390,9 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   }
   if (init7) memcpy(in7, init7, (size_t)7 * n * 4);
   d->attn_bytes_hint = kvb;
-  HIP_TRY(hipMemcpyAsync(d->ids, sv.data(), sv.size() * 4, hipMemcpyHostToDevice, st));   // pageable source: returns after staging
+  HIP_TRY(hipMemcpyAsync(d->ids, svp, sv_ints * 4, hipMemcpyHostToDevice, st));   // pinned: an async DMA; pageable fallback: returns after staging
+  if (pinned) HIP_TRY(hipEventRecord(d->pin_stage_evt, st));
+  d->host_n_out_valid = false;
   const int* b = d->ids;
   *sg = Staged{M, b, b + M, b + 2 * (size_t)M, b + 6 * (size_t)M, b + 7 * (size_t)M, b + 8 * (size_t)M, b + 9 * (size_t)M, b + 9 * (size_t)M + n,
                b + 9 * (size_t)M + 2 * n, b + 9 * (size_t)M + 3 * n, b + 9 * (size_t)M + 4 * n,
@@ -433,6 +449,13 @@ int alloc_workspaces(etd_dec* d) {
   rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
   rc = rc ? rc : d->alloc(&d->tgt_proj, S * (size_t)d->H, true);
   rc = rc ? rc : d->alloc(&d->tgt_attrs, 4 * S, true); rc = rc ? rc : d->alloc(&d->out_tok, S * d->out_cap, true);
+  if (!rc && !getenv("ETD_NO_PINNED")) {
+    d->pin_stage_ints = 10 * M + 13 * S;
+    if (hipHostMalloc((void**)&d->pin_stage, d->pin_stage_ints * 4, hipHostMallocDefault) != hipSuccess) { d->pin_stage = nullptr; (void)hipGetLastError(); }
+    if (hipHostMalloc((void**)&d->pin_rb, (2 * S + S * (size_t)d->out_cap) * 4, hipHostMallocDefault) != hipSuccess) { d->pin_rb = nullptr; (void)hipGetLastError(); }
+    if (d->pin_stage && hipEventCreateWithFlags(&d->pin_stage_evt, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(d->pin_stage); d->pin_stage = nullptr; d->pin_stage_evt = nullptr; }
+  }
+  d->host_n_out.assign(S, 0);
   return rc;
 }
 
@@ -597,6 +620,9 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
   (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
   d->graphs.clear();
+  if (d->pin_stage) { (void)hipHostFree(d->pin_stage); d->pin_stage = nullptr; }
+  if (d->pin_rb) { (void)hipHostFree(d->pin_rb); d->pin_rb = nullptr; }
+  if (d->pin_stage_evt) { (void)hipEventDestroy(d->pin_stage_evt); d->pin_stage_evt = nullptr; }
   if (d->weights_owner) {
     etd_dec* own = d->weights_owner;
     for (void* p : d->allocs) (void)hipFree(p);
@@ -681,6 +707,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     d->last_slots.assign(slots, slots + n_active);
     HIP_TRY(hipMemcpyAsync(d->slots_dev, d->last_slots.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, st));
   }
+  d->host_n_out_valid = false;
   d->rows_identity = true;
   for (int i = 0; i < n_active; ++i) if (slots[i] != i) { d->rows_identity = false; break; }
   // bf16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
@@ -766,11 +793,16 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
 extern "C" int etd_decoder_poll(etd_dec* d, const int32_t* slots, int n, int32_t* done_out, int32_t* n_out_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!d || !slots || n < 1 || !done_out || !n_out_out) ETD_FAIL(ETD_EINVAL, "decoder_poll: bad args");
-  std::vector<int> dn(d->S), no(d->S);
-  HIP_TRY(hipMemcpyAsync(dn.data(), d->done, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(no.data(), d->n_out, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
+  std::vector<int> dnv, nov;
+  int *dn, *no;
+  if (d->pin_rb) { dn = d->pin_rb; no = d->pin_rb + d->S; }
+  else { dnv.resize(d->S); nov.resize(d->S); dn = dnv.data(); no = nov.data(); }
+  HIP_TRY(hipMemcpyAsync(dn, d->done, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(no, d->n_out, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   for (int i = 0; i < n; ++i) { ETD_TRY(check_slot(d, slots[i])); done_out[i] = dn[slots[i]]; n_out_out[i] = no[slots[i]]; }
+  memcpy(d->host_n_out.data(), no, (size_t)d->S * 4);
+  d->host_n_out_valid = true;                     // nothing has been launched on this handle's streams since: read_many can size its copy
   return ETD_OK;
 }
 
@@ -794,17 +826,26 @@ extern "C" int etd_decoder_read_tokens(etd_dec* d, int slot, int32_t* out, int c
 extern "C" int etd_decoder_read_many(etd_dec* d, int n, const int32_t* slots, int32_t* out, int cap, int32_t* counts, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!d || n < 1 || !slots || !out || !counts || cap < 1) ETD_FAIL(ETD_EINVAL, "read_many: bad args");
-  std::vector<int> no(d->S);
-  std::vector<int> all((size_t)d->S * d->out_cap);
-  HIP_TRY(hipMemcpyAsync(no.data(), d->n_out, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(all.data(), d->out_tok, all.size() * 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) ETD_TRY(check_slot(d, slots[i]));
+  if (!d->host_n_out_valid) {
+    HIP_TRY(hipMemcpyAsync(d->host_n_out.data(), d->n_out, (size_t)d->S * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  // only the columns that hold tokens travel: [S rows][widest requested count] out of [S][out_cap]
+  int wmax = 0;
+  for (int i = 0; i < n; ++i) { int c = d->host_n_out[slots[i]]; if (c > d->out_cap) c = d->out_cap; if (c > wmax) wmax = c; }
+  std::vector<int> allv;
+  int* all;
+  if (d->pin_rb) all = d->pin_rb + 2 * (size_t)d->S; else { allv.resize((size_t)d->S * (wmax > 0 ? wmax : 1)); all = allv.data(); }
+  if (wmax > 0) {
+    HIP_TRY(hipMemcpy2DAsync(all, (size_t)wmax * 4, d->out_tok, (size_t)d->out_cap * 4, (size_t)wmax * 4, (size_t)d->S, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   for (int i = 0; i < n; ++i) {
-    ETD_TRY(check_slot(d, slots[i]));
-    int c = no[slots[i]]; if (c > d->out_cap) c = d->out_cap;
+    int c = d->host_n_out[slots[i]]; if (c > d->out_cap) c = d->out_cap;
     if (c > cap) ETD_FAIL(ETD_ENOMEM, "read_many: slot %d holds %d tokens (cap %d)", slots[i], c, cap);
     counts[i] = c;
-    memcpy(out + (size_t)i * cap, all.data() + (size_t)slots[i] * d->out_cap, (size_t)c * 4);
+    memcpy(out + (size_t)i * cap, all + (size_t)slots[i] * wmax, (size_t)c * 4);
   }
   return ETD_OK;
 }

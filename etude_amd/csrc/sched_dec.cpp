@@ -21,6 +21,7 @@ struct Pair { const int32_t* x; int xn; std::vector<int32_t> y; int a[4]; };
 struct Job {
   const etd_job* j;
   int bar = 0; long long total = 0; int slot = -1; int limit = 0;
+  int n_out_known = 0;                    // tokens of the current bar the host knows of (last poll; 1 right after the bar's prefill)
   std::vector<Pair> hist;                 // <= n_ctx most recent (X, Y, attrs)
   std::vector<int32_t> out;               // [n_bars_done, len_0.., tokens...] built at the end
   std::vector<std::vector<int32_t>> bars; // generated bars ([Bar_BOS] + tokens)
@@ -105,6 +106,11 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
   long long n_steps = 0;
   std::vector<int32_t> ids, cls, at[4], a4cat, slots, Ts, tg, eos, lim, dn, no, rd, cnt;
 
+  // ETD_SCHED_STATS=1: host time this engine spends with its queue EMPTY at bar boundaries (from the moment the poll reports
+  // finished bars to the moment the next bars' launches have been issued), printed once per call
+  const bool want_stats = getenv("ETD_SCHED_STATS") != nullptr;
+  double host_gap_us = 0, poll_us = 0, read_us = 0, begin_us = 0; long long n_gaps = 0;
+  auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   // start the next bar of the given jobs (prefill in as few passes as the row budget allows); jobs that are finished are retired
   auto start_bars = [&](std::vector<int>& batch) -> int {
     std::vector<int> pend;
@@ -151,11 +157,14 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
       const size_t M = ids.size();
       a4cat.resize(4 * M);
       for (int k = 0; k < 4; ++k) memcpy(a4cat.data() + (size_t)k * M, at[k].data(), M * 4);
+      const double tb0 = want_stats ? now_us() : 0;
       ETD_TRY(etd_decoder_begin_bars(d, (int)slots.size(), slots.data(), Ts.data(), ids.data(), cls.data(), a4cat.data(), tg.data(), eos.data(), lim.data(), stream));
+      if (want_stats) begin_us += now_us() - tb0;
     }
     return ETD_OK;
   };
 
+  bool skip_poll = false;           // the bars of every active stream were (re)started or polled since the last step launch: nothing new to learn from a poll
   while (next_job < n_jobs || !active.empty()) {
     std::vector<int> fresh;
     while (next_job < n_jobs && !free_slots.empty() && is_ready(next_job)) {
@@ -164,7 +173,7 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
       active.push_back(next_job);
       fresh.push_back(next_job++);
     }
-    if (!fresh.empty()) ETD_TRY(start_bars(fresh));
+    if (!fresh.empty()) { ETD_TRY(start_bars(fresh)); for (int ji : fresh) J[ji].n_out_known = 1; }
     if (active.empty()) {
       if (next_job < n_jobs && !is_ready(next_job)) std::this_thread::sleep_for(std::chrono::microseconds(100));   // idle until upstream delivers
       continue;
@@ -173,7 +182,19 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
     std::sort(active.begin(), active.end(), [&](int a, int b) { return J[a].slot < J[b].slot; });
     slots.resize(na); dn.resize(na); no.resize(na);
     for (int i = 0; i < na; ++i) slots[i] = J[active[i]].slot;
-    ETD_TRY(etd_decoder_poll(d, slots.data(), na, dn.data(), no.data(), stream));
+    const double t_poll0 = want_stats ? now_us() : 0;
+    if (skip_poll) {
+      // right after start_bars: a restarted stream has produced exactly its first token (the prefill's), the others are where
+      // the last poll left them -- the step launches go out behind the prefill without a host round trip in between.  (A first
+      // token that is already Bar_EOS just makes that row idle until the next poll.)
+      for (int i = 0; i < na; ++i) { dn[i] = 0; no[i] = J[active[i]].n_out_known; }
+      skip_poll = false;
+    } else {
+      ETD_TRY(etd_decoder_poll(d, slots.data(), na, dn.data(), no.data(), stream));
+      for (int i = 0; i < na; ++i) J[active[i]].n_out_known = no[i];
+    }
+    const double t_poll1 = want_stats ? now_us() : 0;
+    poll_us += t_poll1 - t_poll0;
     std::vector<int> done_jobs;
     for (int i = 0; i < na; ++i) if (dn[i]) done_jobs.push_back(active[i]);
     if (!done_jobs.empty()) {
@@ -182,6 +203,7 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
       for (int i = 0; i < nd; ++i) ds[i] = J[done_jobs[i]].slot;
       rd.resize((size_t)nd * cap); cnt.resize(nd);
       ETD_TRY(etd_decoder_read_many(d, nd, ds.data(), rd.data(), cap, cnt.data(), stream));
+      if (want_stats) read_us += now_us() - t_poll1;
       std::vector<int> again;
       for (int i = 0; i < nd; ++i) {
         Job& jb = J[done_jobs[i]];
@@ -200,7 +222,10 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
         again.push_back(done_jobs[i]);
       }
       ETD_TRY(start_bars(again));
-      continue;                                   // re-poll / refill before stepping
+      for (int ji : again) J[ji].n_out_known = 1;
+      if (want_stats) { host_gap_us += now_us() - t_poll1; ++n_gaps; }
+      skip_poll = true;
+      continue;                                   // refill, then step without another poll
     }
     int nstep = c.steps_per_poll;
     if (c.force_bar_tokens > 0) {                 // no early EOS possible: run to the nearest bar end in one call
@@ -211,6 +236,8 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
     ETD_TRY(etd_decoder_step(d, slots.data(), na, nstep, stream));
     n_steps += nstep;
   }
+  if (want_stats) fprintf(stderr, "[sched] %lld bar boundaries: queue empty on the host side for %.0f us each on average (token read-back %.0f us, begin_bars call %.0f us, rest = prompt assembly); %.1f ms waiting in polls\n",
+                          n_gaps, n_gaps ? host_gap_us / n_gaps : 0.0, n_gaps ? read_us / n_gaps : 0.0, n_gaps ? begin_us / n_gaps : 0.0, poll_us / 1e3);
   // pack results: per job [n_bars_done, len_0 .. len_{n-1}, tokens of bar 0, tokens of bar 1, ...]
   long long pos = 0;
   for (int i = 0; i < n_jobs; ++i) {

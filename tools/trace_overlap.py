@@ -85,6 +85,25 @@ def main():
     print(f"window {wall/1e6:.1f} ms, {len(sel)} kernels; average kernels in flight {busy/wall:.2f}")
     print(f"some prefill kernel running {100*up/wall:.1f} %   some step kernel running {100*us/wall:.1f} %   both {100*both/wall:.1f} %   neither {100*(wall-ua)/wall:.1f} %")
     print(f"prefill kernel time {sum(e-s for s,e in pre)/1e6:.1f} ms   step kernel time {sum(e-s for s,e in stp)/1e6:.1f} ms")
+    # gaps between consecutive step kernels of one queue (end -> next start, host stalls > 50 us excluded): with four
+    # engines submitting vs the window before/after in which a single queue runs (the event pass)
+    def gaps(lo, hi):
+        byq = {}
+        for s_, e_, k, q in rows:
+            if s_ >= lo and e_ <= hi and k in STEP:
+                byq.setdefault(q, []).append((s_, e_, k))
+        g, d = [], []
+        for q, lst in byq.items():
+            for (s0, e0, k0), (s1, e1, k1) in zip(lst[:-1], lst[1:]):
+                if 0 <= s1 - e0 < 50_000:
+                    g.append(s1 - e0)
+                d.append(e0 - s0)
+        g.sort(); d.sort()
+        return (sum(g) / max(len(g), 1), g[len(g) // 2] if g else 0, sum(d) / max(len(d), 1), len(g))
+    g4 = gaps(span_s, span_e)
+    g1 = gaps(span_e, rows[-1][1])
+    print(f"step-kernel gap on one queue: four engines mean {g4[0]/1e3:.2f} us (median {g4[1]/1e3:.2f}), mean kernel {g4[2]/1e3:.2f} us, n={g4[3]}")
+    print(f"                              single engine (event pass) mean {g1[0]/1e3:.2f} us (median {g1[1]/1e3:.2f}), mean kernel {g1[2]/1e3:.2f} us, n={g1[3]}")
 
 
 if __name__ == "__main__":
