@@ -201,3 +201,39 @@ def test_concurrent_engines_on_host_threads_equal_one_engine(dev):
     engs[0].close()
     assert engs[1].generate_many(jobs[1::n_eng], v, force_bar_tokens=16) == want[1]
     engs[2].close(); engs[1].close()
+
+
+def _agreement(a, b):
+    tot = same = 0
+    for ja, jb in zip(a, b):
+        for ba, bb in zip(ja, jb):
+            n = min(len(ba), len(bb))
+            tot += max(len(ba), len(bb))
+            same += sum(1 for x, y in zip(ba[:n], bb[:n]) if x == y)
+    return same / max(tot, 1)
+
+
+@pytest.mark.parametrize("switch", ["ETD_NO_LAST_ONLY", "ETD_NO_ATTN_DOWN"])
+def test_bf16_fast_paths_agree_with_the_plain_kernel_sequence(dev, switch, monkeypatch):
+    """The bf16 serving path has two restructurings whose arithmetic order differs from the plain kernel sequence: the last
+    prefill layer restricted to the prompts' last positions (ETD_NO_LAST_ONLY=1 turns it off) and attention + dense + MLP down
+    in one launch (ETD_NO_ATTN_DOWN=1).  Same jobs with the switch on and off: greedy ids may differ where two logits tie
+    within bf16 rounding, nowhere else -- a wrong slab, row or head would give near-zero agreement.  48 streams x ~60-token
+    prompts = the big-tile prefill path (M > 512)."""
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    v = _vocab()
+    cfgd = EtudeDecoderConfig(**synth.decoder_dims())
+    sd = synth.decoder_state_dict(1, {})
+    jobs = []
+    for s_ in range(48):
+        bars = synth.song_bars(seed=400 + s_ % 7, n_bars=3)
+        jobs.append((bars, [synth.attrs(s_ % 3, (s_ // 3) % 3, (s_ // 9) % 3, 2)] * len(bars)))
+    fast = EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=48)
+    got_fast = fast.generate_many(jobs, v, force_bar_tokens=12)
+    fast.close()
+    monkeypatch.setenv(switch, "1")
+    plain = EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=48)
+    got_plain = plain.generate_many(jobs, v, force_bar_tokens=12)
+    plain.close()
+    agree = _agreement(got_fast, got_plain)
+    assert agree > 0.9, f"{switch}: only {agree:.3f} of the generated ids agree"
