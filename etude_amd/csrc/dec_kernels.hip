@@ -977,6 +977,15 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     if (more) { kA = nkA; kB = nkB; wA = nwA; wB = nwB; }
   }
 
+  // DENSE: the first 8 of this wave's 16 dense-weight fragments are requested here -- the key loop's K/V registers are dead, and
+  // the merge below (shuffles, LDS, a barrier) covers their round trip
+  bf16x8 dwv[DENSE ? 8 : 1];
+  const bf16* dwb = nullptr;
+  if constexpr (DENSE) {
+    dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * 128 + (lane >> 3)) * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + it * 8 * 64);
+  }
   // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the 4 waves through LDS
 #pragma unroll
   for (int off = 8; off < 64; off <<= 1) {
@@ -1024,12 +1033,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     // out[n] = sum_d Wd[n][64 head + d] * o[d] for the 512 outputs: 8 lanes share a weight row (128 contiguous bytes), a wave
     // instruction covers 8 consecutive rows = 1 KiB; 16 such loads per wave are in flight together (requested above, before
     // the merge), the 8-lane sums use DPP exchanges.  The weights of a head are one contiguous 64 KiB block (dense_w).
-    // (register budget: this kernel streams K/V at 6-7 waves per SIMD, so the dense weights are requested only here, after the
-    // key loop's registers are dead, in two passes of 8 fragments; other workgroups' streaming hides the extra L2 round trip)
-    const bf16* dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * 128 + (lane >> 3)) * 64 + (lane & 7) * 8;
-    bf16x8 dwv[8];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + it * 8 * 64);
+    // (register budget: this kernel streams K/V at 7 waves per SIMD, so the 16 fragments come in two passes of 8)
     __syncthreads();
     const int g8 = lane >> 3, sub = lane & 7;
     float ov[8];

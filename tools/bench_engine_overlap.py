@@ -42,17 +42,20 @@ if __name__ == "__main__":
             rc = hip.hipExtStreamCreateWithCUMask(C.byref(hs), 8, words)
             assert rc == 0, rc
             dec._ts = torch.cuda.ExternalStream(hs.value, device=dev)
-        st = dec._stream()
-        for s in range(S):
-            ids = rng.integers(6, 154, ctx0).astype(np.int32)
-            cls = rng.integers(1, 3, ctx0).astype(np.int32)
-            a4 = rng.integers(0, 3, (4, ctx0)).astype(np.int32)
-            _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, 1000, st), "begin_bar")
         decs.append(dec)
     slots = np.arange(S, dtype=np.int32)
-    for dec in decs:
-        _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, S, 4, dec._stream()), "step")
-    torch.cuda.synchronize(dev)
+    prompts = [(rng.integers(6, 154, ctx0).astype(np.int32), rng.integers(1, 3, ctx0).astype(np.int32), rng.integers(0, 3, (4, ctx0)).astype(np.int32)) for _ in range(S)]
+
+    def reset():
+        """every stream of every engine back to a ctx0-token context (each timed run then covers the same contexts)"""
+        for dec in decs:
+            st = dec._stream()
+            for s, (ids, cls, a4) in enumerate(prompts):
+                _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, 1000, st), "begin_bar")
+            _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, S, 4, st), "step")
+        torch.cuda.synchronize(dev)
+
+    reset()
 
     def run(dec):
         torch.cuda.set_device(0)
@@ -60,6 +63,7 @@ if __name__ == "__main__":
         torch.cuda.current_stream().synchronize()
 
     for E in (1, 2, 3, 4, 1):
+        reset()
         th = [threading.Thread(target=run, args=(decs[i],)) for i in range(E)]
         torch.cuda.synchronize(dev)
         t = time.perf_counter()
