@@ -890,7 +890,10 @@ template <> struct Raw8<float> {
 };
 template <> struct Raw8<bf16> {
   bf16x8 v;
-  __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  // K/V rows are read once per step and never again before they are overwritten in the caches by the next row's stream: the
+  // nontemporal hint keeps them from evicting the weights (shared by all engines) from L2 / the Infinity Cache -- measured
+  // -5.5 % per step with one engine and with four (tools/bench_engine_overlap.py)
+  __device__ __forceinline__ void load(const bf16* p) { v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
   __device__ __forceinline__ float get(int j) const { return bf2f(v[j]); }
 };
 
@@ -1259,7 +1262,7 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
 #pragma unroll
         for (int z = 0; z < KS; ++z) {
           const float* pp = P + (long long)z * M * H + ro + k;
-          pa[z] = *reinterpret_cast<const f32x4*>(pp); pb[z] = *reinterpret_cast<const f32x4*>(pp + 4);
+          pa[z] = *reinterpret_cast<const f32x4*>(pp); pb[z] = *reinterpret_cast<const f32x4*>(pp + 4);   // (a nontemporal hint here measured 2 % slower)
         }
 #pragma unroll
         for (int z = 0; z < KS; ++z)
