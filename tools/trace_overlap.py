@@ -59,7 +59,8 @@ def main():
     rows.sort()
     # decoder kernels only, inside the decode stage of the LAST step of the run (the eager event pass runs engines one at a
     # time, so take the window in which >= 3 queues launch k_dattn: the graph-replayed step)
-    datt = [(s, e, q) for s, e, k, q in rows if k == "k_dattn"]
+    anchor = "k_dstep_attn_down" if any(k == "k_dstep_attn_down" for _, _, k, _ in rows) else "k_dattn"
+    datt = [(s, e, q) for s, e, k, q in rows if k == anchor]
     t0, t1 = datt[0][0], datt[-1][1]
     # find the longest span where four distinct queues are active within any 2 ms window
     import bisect
