@@ -480,7 +480,13 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   for (int i = 0; i < d->S; ++i) d->host_key[i] = (unsigned long long)i;
   Loader Ld;
   for (int i = 0; i < n; ++i) Ld.t[names[i]] = {host_ptrs[i], numels[i]};
-  auto fail = [&](int rc) { for (void* p : d->allocs) (void)hipFree(p); delete d; return rc; };
+  auto fail = [&](int rc) {
+    for (void* p : d->allocs) (void)hipFree(p);
+    if (d->pin_stage) (void)hipHostFree(d->pin_stage);
+    if (d->pin_rb) (void)hipHostFree(d->pin_rb);
+    if (d->pin_stage_evt) (void)hipEventDestroy(d->pin_stage_evt);
+    delete d; return rc;
+  };
   const int H = d->H, E = c.attribute_emb_dim, NB = c.num_attribute_bins;
   int rc;
   if ((rc = load_vec(d, Ld, "word_embeddings.weight", d->V * H, &d->word))) return fail(rc);
@@ -608,7 +614,13 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
   for (int i = 0; i < d->S; ++i) d->host_key[i] = (unsigned long long)i;
   d->weights_owner = own;
   const int rc = alloc_workspaces(d);
-  if (rc) { for (void* p : d->allocs) (void)hipFree(p); delete d; return rc; }
+  if (rc) {
+    for (void* p : d->allocs) (void)hipFree(p);
+    if (d->pin_stage) (void)hipHostFree(d->pin_stage);
+    if (d->pin_rb) (void)hipHostFree(d->pin_rb);
+    if (d->pin_stage_evt) (void)hipEventDestroy(d->pin_stage_evt);
+    delete d; return rc;
+  }
   HIP_TRY(hipDeviceSynchronize());
   ++own->n_clones;
   *out = d;
