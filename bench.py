@@ -331,44 +331,17 @@ def main():
 
 
 def decode_jobs_async(decs, jobs, vocab, bar_tokens, ready, one_at_a_time=False):
-    """Greedy-decode all jobs: the job list is dealt round-robin over the engines and each engine runs its share from its
-    own host thread (ctypes releases the GIL inside the library calls).  `ready` = (flags, job -> flag index) gates the
-    admission of each job on its clip's upstream stages.  Returns a function that joins and yields (results, n_tokens)."""
-    import threading
-    n = len(decs)
-    outs = [None] * n
-    stats = [dict() for _ in decs]
-    errs = []
-    flags, idx = ready
+    """Greedy-decode all jobs on the engines (etude_amd.decoder.run_engines: jobs dealt round-robin, one host thread per
+    engine).  `ready` = (flags, job -> flag index) gates the admission of each job on its clip's upstream stages.  Returns
+    a function that joins and yields (results, n_tokens)."""
+    from etude_amd.decoder import run_engines
+    join = run_engines(decs, jobs, vocab, one_at_a_time=one_at_a_time, ready=ready, force_bar_tokens=bar_tokens)
 
-    def run(i):
-        try:
-            torch.cuda.set_device(decs[i].device)
-            outs[i] = decs[i].generate_many(jobs[i::n], vocab, stats=stats[i], force_bar_tokens=bar_tokens, ready=(flags, idx[i::n]))
-        except Exception as e:  # surfaced by the join
-            errs.append(e)
-
-    th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
-    if one_at_a_time:                       # per-kernel profiling pass: engines do not share the device
-        for t in th:
-            t.start()
-            t.join()
-    else:
-        for t in th:
-            t.start()
-
-    def join():
-        if not one_at_a_time:
-            for t in th:
-                t.join()
-        if errs:
-            raise errs[0]
-        out = [None] * len(jobs)
-        for i in range(n):
-            out[i::n] = outs[i]
+    def join_tokens():
+        out, stats = join()
         return out, sum(s["tokens"] for s in stats)
 
-    return join
+    return join_tokens
 
 
 def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64):

@@ -11,14 +11,14 @@ All arithmetic runs in libetude_hip.so (hand-written HIP, see csrc/); importing 
 modules is lazy so that `import etude_amd` works on a box without a GPU.
 """
 __all__ = ["AMTAPC_Extractor", "EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder", "Vocab", "Event",
-           "ExtractorConfig", "DecoderConfig", "HFT_Transformer", "HFTConfig", "TinyREMITokenizer"]
+           "ExtractorConfig", "DecoderConfig", "HFT_Transformer", "HFTConfig", "TinyREMITokenizer", "run_engines"]
 
 
 def __getattr__(name):
     if name == "AMTAPC_Extractor":
         from .extractor import AMTAPC_Extractor
         return AMTAPC_Extractor
-    if name in ("EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder"):
+    if name in ("EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder", "run_engines"):
         from . import decoder
         return getattr(decoder, name)
     if name in ("Vocab", "Event"):

@@ -272,6 +272,51 @@ class EtudeDecoder:
             pass
 
 
+def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: bool = False, ready=None, **generate_many_kwargs):
+    """`generate_many` over several engines at once: the job list is dealt round-robin over ``engines`` (normally one
+    EtudeDecoder and its ``clone()``s, which share the device weights) and each engine runs its share from its own host
+    thread -- ctypes releases the GIL inside the library calls.  On MI355X four engines is the useful maximum: a GPU has
+    four compute pipes, and a fifth chain of dependent kernels halves the one it shares a pipe with.
+
+    ``ready=(flags, job_index_to_flag)`` is split per engine like the jobs.  Returns ``join``: calling it waits for the
+    engines and returns ``(results in job order, per-engine stats dicts)``; exceptions of the workers are re-raised there.
+    ``one_at_a_time`` runs the engines one after the other (profiling passes)."""
+    import threading
+    n = len(engines)
+    outs = [None] * n
+    stats = [dict() for _ in engines]
+    errs: list = []
+
+    def run(i):
+        try:
+            torch.cuda.set_device(engines[i].device)
+            kw = dict(generate_many_kwargs)
+            if ready is not None:
+                kw["ready"] = (ready[0], ready[1][i::n])
+            outs[i] = engines[i].generate_many(jobs[i::n], vocab, stats=stats[i], **kw)
+        except Exception as e:      # noqa: BLE001 -- surfaced by join()
+            errs.append(e)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(n)]
+    for t in th:
+        t.start()
+        if one_at_a_time:
+            t.join()
+
+    def join():
+        if not one_at_a_time:
+            for t in th:
+                t.join()
+        if errs:
+            raise errs[0]
+        out = [None] * len(jobs)
+        for i in range(n):
+            out[i::n] = outs[i]
+        return out, stats
+
+    return join
+
+
 def load_decoder_state(checkpoint_path: Union[str, Path]) -> Dict[str, np.ndarray]:
     """Checkpoint -> name->fp32 array: accepts a bare state dict or the training payload
     ``{"model_state_dict": ...}`` and strips ``_orig_mod.`` (model_loader.py:44-53)."""

@@ -182,21 +182,10 @@ def test_concurrent_engines_on_host_threads_equal_one_engine(dev):
     want = [ref.generate_many(jobs[i::n_eng], v, force_bar_tokens=16) for i in range(n_eng)]
     engs = [EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=8)]
     engs += [engs[0].clone() for _ in range(n_eng - 1)]        # engines 1.. share engine 0's device weights (etd_decoder_clone)
-    got, errs = [None] * n_eng, []
-
-    def run(i):
-        try:
-            torch.cuda.set_device(0)
-            got[i] = engs[i].generate_many(jobs[i::n_eng], v, force_bar_tokens=16)
-        except Exception as e:      # noqa: BLE001
-            errs.append(e)
-    th = [threading.Thread(target=run, args=(i,)) for i in range(n_eng)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert not errs, errs
-    assert got == want
+    from etude_amd import run_engines
+    got_flat, stats = run_engines(engs, jobs, v, force_bar_tokens=16)()
+    got = [got_flat[i::n_eng] for i in range(n_eng)]
+    assert got == want and len(stats) == n_eng and all(s["tokens"] > 0 for s in stats)
     # the weight owner may go first: its clones keep the weights alive and still decode
     engs[0].close()
     assert engs[1].generate_many(jobs[1::n_eng], v, force_bar_tokens=16) == want[1]
