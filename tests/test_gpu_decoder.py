@@ -225,4 +225,5 @@ def test_bf16_fast_paths_agree_with_the_plain_kernel_sequence(dev, switch, monke
     got_plain = plain.generate_many(jobs, v, force_bar_tokens=12)
     plain.close()
     agree = _agreement(got_fast, got_plain)
+    print(f"{switch}: agreement {agree:.4f}")
     assert agree > 0.9, f"{switch}: only {agree:.3f} of the generated ids agree"
