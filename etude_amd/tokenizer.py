@@ -56,6 +56,8 @@ class TinyREMITokenizer:
             regs[i] = _lib.TempoRegion(float(r["bpm"]) if db.size else float(r.get("bpm", 120.0)), int(r["time_sig"]) if db.size else int(r.get("time_sig", 4)),
                                        float(r.get("start", 0.0)), db.ctypes.data if db.size else None, int(db.size))
         h = C.c_void_p()
+        if self.tempo_data and (not self.tempo_data[0].get("downbeats") or not self.tempo_data[-1].get("downbeats")):
+            raise IndexError("list index out of range")           # what the reference's _create_measures does with an empty first / last region (tokenizer.py:166-229)
         _lib.check(lib.etd_tok_create(C.cast(regs, C.c_void_p), len(self.tempo_data), C.byref(h)), "etd_tok_create")
         self._h = h
         n = lib.etd_tok_num_measures(h)

@@ -93,3 +93,19 @@ def test_array_fast_path_equals_object_path(gold, tmp_path):
     ev = tk.encode_note_array_to_events(np.asarray([(n["onset"], n["offset"], n["pitch"], n["velocity"]) for n in c["notes"]], dtype=arr.dtype), with_grace_note=True)
     names = ("Bar", "Pos", "Note", "Duration", "Grace")
     assert [[names[t], ("BOS" if x == 1 else "EOS") if t == 0 else x] for t, x in zip(ev["type"].tolist(), ev["value"].tolist())] == c["events"]
+
+
+def test_empty_first_or_last_tempo_region_raises_like_the_reference(tmp_path):
+    """tokenizer.py:166-229: `_create_measures` indexes the first / last region's downbeats -> IndexError when one is empty
+    (an empty region in the middle is skipped).  Found by a differential run against the reference class over random tempo maps."""
+    import json
+    from etude_amd.tokenizer import TinyREMITokenizer
+    good = {"start": 0.0, "bpm": 120, "time_sig": 4, "downbeats": [0.0, 2.0, 4.0]}
+    empty = {"start": 5.0, "bpm": 100, "time_sig": 4, "downbeats": []}
+    for regions in ([good, empty], [empty, dict(good, start=6.0, downbeats=[6.0, 8.0])]):
+        p = tmp_path / "t.json"
+        p.write_text(json.dumps(regions))
+        with pytest.raises(IndexError):
+            TinyREMITokenizer(str(p))
+    p.write_text(json.dumps([good, empty, dict(good, start=9.0, downbeats=[9.0, 11.0])]))
+    assert len(TinyREMITokenizer(str(p)).global_measures) > 0
