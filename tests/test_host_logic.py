@@ -60,6 +60,19 @@ def test_native_prompt_assembly_matches_oracle_incl_truncation():
     hist = [(list(range(6, 90)), list(range(10, 140)), {k: 2 for k in keys})] * 3
     x, y = list(range(20, 60)), {k: 0 for k in keys}
     assert _native_prompt(hist, x, y, n_ctx=2, max_pos=256, limit=100, ratio=0.25) == tuple(neox.build_bar_prompt(hist, x, y, keys, 4, 5, d2, 100, 0.25))
+    # random knobs: history depth, position budget, bar limit and overlap ratio all varied (the oracle itself was checked against
+    # the reference's generate() over random configurations of the same knobs; see oracle/README or DESIGN.md section 3)
+    for trial in range(80):
+        n_ctx = int(rng.integers(1, 6)); max_pos = int(rng.choice([64, 96, 128, 256, 512, 1024])); ratio = float(rng.choice([0.25, 0.3, 0.5, 0.7]))
+        limit = int(rng.integers(3, max(4, max_pos // 2)))
+        dd = neox.NeoxDims(max_position_embeddings=max_pos, context_num_past_xy_pairs=n_ctx)
+        hist = []
+        for _ in range(int(rng.integers(0, 8))):
+            hist.append((rng.integers(4, 150, int(rng.integers(2, 60))).tolist(), rng.integers(4, 150, int(rng.integers(1, 90))).tolist(),
+                         {k: int(rng.integers(0, 3)) for k in keys}))
+        x = rng.integers(4, 150, int(rng.integers(2, 50))).tolist()
+        y = {k: int(rng.integers(0, 3)) for k in keys}
+        assert _native_prompt(hist, x, y, n_ctx=n_ctx, max_pos=max_pos, limit=limit, ratio=ratio) == tuple(neox.build_bar_prompt(hist, x, y, keys, 4, 5, dd, limit, ratio)), trial
 
 
 def test_vocab_roundtrip_and_event_decoding(tmp_path):
