@@ -23,7 +23,7 @@ if __name__ == "__main__":
     rng = np.random.default_rng(0)
     tg = np.asarray([2, 1, 1, 1], np.int32)
     decs = []
-    mask_mode = sys.argv[4] if len(sys.argv) > 4 else "none"      # none | thirds | interleave : CU masks per engine stream (hipExtStreamCreateWithCUMask)
+    mask_mode = sys.argv[4] if len(sys.argv) > 4 else "none"      # none | thirds | interleave | halves | halves8 : CU masks per engine stream (hipExtStreamCreateWithCUMask)
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     for e in range(4):
@@ -34,6 +34,12 @@ if __name__ == "__main__":
                 lo, hi = [(0, 88), (88, 176), (176, 256), (0, 256)][e]
                 for i in range(lo, hi):
                     bits[i] = 1
+            elif mask_mode == "halves":              # every CU hosts exactly two of the four engines, each engine has half the chip
+                for i in range(256):
+                    bits[i] = 1 if ((i + e) % 4) < 2 else 0
+            elif mask_mode == "halves8":             # the same in groups of 8 CUs
+                for i in range(256):
+                    bits[i] = 1 if (((i // 8) + e) % 4) < 2 else 0
             else:                                   # every third CU
                 for i in range(256):
                     bits[i] = 1 if (e == 3 or i % 3 == e) else 0
