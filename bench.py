@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--clips", type=int, default=8, help="clips per rank")
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
     ap.add_argument("--streams", type=int, default=256, help="concurrent decoder streams (capped at the number of jobs)")
+    ap.add_argument("--ext-engines", type=int, default=int(os.environ.get("ETD_EXT_ENGINES", "2")),
+                    help="extractor instances that transcribe different clips at the same time (own stream + host thread each)")
     ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "4")),
                     help="independent decoder engines (own HIP stream + KV cache each) driven from host threads: the short dependent kernels of one engine's decode step overlap the other's")
     ap.add_argument("--bars", type=int, default=92)
@@ -147,6 +149,8 @@ def main():
 
     cfg = ExtractorConfig()
     ex = AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=int(os.environ.get("ETD_WB", "4")))
+    exs = [ex] + [AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=int(os.environ.get("ETD_WB", "4"))) for _ in range(max(1, args.ext_engines) - 1)]
+    ex_streams = [torch.cuda.Stream(device=dev) for _ in exs]
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
     n_jobs = args.clips * args.attr_grid
     n_eng = max(1, min(args.engines, n_jobs))
@@ -189,12 +193,36 @@ def main():
         n_notes = 0
         bg = None if serial else decode_jobs_async(decs, jobs, vocab, args.bar_tokens, (ready, job_clip))
         try:
-            with torch.cuda.stream(ext_stream):
-                for c, wav in enumerate(wavs):
-                    notes = ex.extract_notes(wav, 44100, inf.min_duration)      # device wav -> the note list extract() writes (host)
-                    n_notes += len(notes)
-                    ready[c] = 1
-            ext_stream.synchronize()
+            if len(exs) > 1 and not profiling:
+                # several extractor instances, one host thread and stream each, clips dealt round-robin
+                import threading
+                cnt = [0] * len(exs); errs = []
+
+                def run_ex(i):
+                    try:
+                        torch.cuda.set_device(dev)
+                        with torch.cuda.stream(ex_streams[i]):
+                            for c in range(i, len(wavs), len(exs)):
+                                cnt[i] += len(exs[i].extract_notes(wavs[c], 44100, inf.min_duration))
+                                ready[c] = 1
+                        ex_streams[i].synchronize()
+                    except Exception as e:      # noqa: BLE001
+                        errs.append(e)
+                th = [threading.Thread(target=run_ex, args=(i,)) for i in range(len(exs))]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                if errs:
+                    raise errs[0]
+                n_notes += sum(cnt)
+            else:
+                with torch.cuda.stream(ext_stream):
+                    for c, wav in enumerate(wavs):
+                        notes = ex.extract_notes(wav, 44100, inf.min_duration)      # device wav -> the note list extract() writes (host)
+                        n_notes += len(notes)
+                        ready[c] = 1
+                ext_stream.synchronize()
         finally:
             ready[:] = 1                                                         # never leave a scheduler waiting
         t1 = time.perf_counter()
@@ -256,7 +284,7 @@ def main():
         "config": {"workload": f"BASELINE configs[4] share per rank: {args.clips} x 3-min 44.1 kHz stereo clips, full extract (wav->notes) each, + greedy decode of "
                                f"{args.clips}x{args.attr_grid} (clip, attribute tuple) jobs, {args.bars} synthetic condition bars x {args.bar_tokens} generated tokens each "
                                "(Bar_EOS suppressed: synthetic weights carry no musical EOS statistics), overlap bin 2, bf16 compute / fp32 accumulate; synthetic seeded weights",
-                   "clips_per_gpu": args.clips, "attr_tuples_per_clip": args.attr_grid, "decode_jobs_per_gpu": n_jobs, "decoder_streams": per_eng * n_eng, "decoder_engines": n_eng,
+                   "clips_per_gpu": args.clips, "attr_tuples_per_clip": args.attr_grid, "decode_jobs_per_gpu": n_jobs, "decoder_streams": per_eng * n_eng, "decoder_engines": n_eng, "extractor_engines": len(exs),
                    "clip_seconds": args.seconds, "windows_per_clip": int(np.ceil((1 + int(np.ceil(160 * wavs[0].shape[1] / 441)) // 256) / 512)),
                    "bars": args.bars, "bar_tokens": args.bar_tokens, "parallelism": f"clip-sharded x{world}",
                    "stage_overlap": "pipelined per clip (jobs of clip c admitted when its extraction is done; extraction of c+1 overlaps)" if args.pipeline else "stages back to back"},
