@@ -34,7 +34,7 @@ struct LinArgs {
   bf16* VT; int S, Spad;             // VT[((seq*4+head)*64+d)*Spad + pos], seq = m / S, pos = m % S
   int relu;
   long long* tbuf;                   // ETD_LIN_STAMP: per-workgroup clock64 stamps [grid][16] (wave 0)
-  int dbg;                           // timing ablations (ETD_LIN_DBG): 1 = skip the epilogue, 2 = skip the K loop; results are garbage
+  int dbg;                           // timing ablations (ETD_LIN_DBG): 1 = skip the epilogue, 2 = skip the K loop (results are garbage); 4 = V^T block with direct 8-byte stores (correct, slower)
   // z-batching (several weight sets over the same X): per-blockIdx.z element offsets
   long long wz, bz, yz, vtz;
   // LayerNorm epilogue (N == 256): Y = LN(acc + bias + R) * gamma + beta

@@ -400,6 +400,33 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
     }
   } else if constexpr (!LN) {
     if constexpr (vt) {
+      // V^T rows: with the feature on the lane a direct store puts 8 bytes into each of 32 different rows per instruction.  When a
+      // wave's 64 tokens are consecutive positions of ONE sequence (S % 64 == 0), the 32-feature x 64-token sub-tile goes through the
+      // wave's LDS region instead and leaves as full 128-byte row segments (8 rows per instruction).
+      const bool rowseg = (a.S % 64 == 0) && (a.M % 64 == 0) && (a.Spad % 8 == 0) && (a.vtz % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.VT) & 15) == 0) && !(a.dbg & 4);
+      if (rowseg) {
+        const int mb = m0 + wm * 64, seq = mb / a.S, pos0 = mb - seq * a.S;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const float b = sb[wn * 128 + nt * 32 + r];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              *reinterpret_cast<bf16x4*>(stg + r * 72 + mt * 32 + 8 * q + 4 * h) =
+                  pack4(acc[mt][nt][4 * q] + b, acc[mt][nt][4 * q + 1] + b, acc[mt][nt][4 * q + 2] + b, acc[mt][nt][4 * q + 3] + b);
+          __syncthreads();
+          if (mb < a.M) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+              const int row = it * 8 + (lane >> 3), ch = lane & 7, fr = wn * 128 + nt * 32 + row;
+              bf16* dst = a.VT + (long long)z * a.vtz + ((long long)(seq * 4 + (fr >> 6)) * 64 + (fr & 63)) * a.Spad + pos0 + ch * 8;
+              *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(stg + row * 72 + ch * 8);
+            }
+          }
+          __syncthreads();
+        }
+      } else
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const int f = wn * 128 + nt * 32 + r;
