@@ -65,7 +65,8 @@ def make_vocab():
     return v
 
 
-def cpu_baseline(seconds_budget: float = 25.0):
+def cpu_baseline(seconds_budget: float = 25.0, clip_seconds: float = 180.0, windows_per_clip: int = 22, attr_tuples: int = 27, bars_per_job: int = 92,
+                 bar_tokens: int = 48):
     """The CPU oracle (a restatement of the reference, pinned by golden vectors) on this node's host cores."""
     from etude_amd import synth
     from oracle import hft, neox
@@ -90,12 +91,22 @@ def cpu_baseline(seconds_budget: float = 25.0):
     torch.set_num_threads(dthreads)
     bars = synth.song_bars(seed=1234, n_bars=2)
     t0 = time.time()
+    # synthetic weights reach Bar_EOS after ~7 tokens; id 5 (Bar_EOS) is pushed out of reach so that both bars run the full 24
+    # tokens, like the GPU workload (Bar_EOS suppressed)
+    tsd = dict(tsd); tsd["lm_head.weight"] = tsd["lm_head.weight"].clone(); tsd["lm_head.weight"][5] = 0
     out = neox.generate_ids(tsd, neox.NeoxDims(), 4, 5, bars, [synth.attrs()] * 2, max_bar_token_limit=24)
     t_dec = time.time() - t0
     ntok = sum(len(b) - 1 for b in out)
-    return {"value": round(nwin * 8.192 / t_ext, 4), "unit": "audio-s/s", "cores": cores, "kind": "port",
-            "sample": f"oracle hFT forward on {nwin} window(s) of 512 frames (8.192 s audio each) in {t_ext:.1f}s; "
-                      f"oracle greedy generate on 2 bars: {ntok} tokens in {t_dec:.1f}s on {dthreads} threads",
+    # the headline's unit: audio seconds taken through BOTH stages (extract once, decode for every attribute tuple) per wall second.
+    # Extrapolated from the bounded sample: extract = windows_per_clip x (time per window); decode = tuples x bars x (time per bar of
+    # bar_tokens tokens, prompt pass included).
+    ext_s_per_clip = (t_ext / nwin) * windows_per_clip
+    dec_s_per_clip = attr_tuples * bars_per_job * (t_dec / 2.0) * (bar_tokens / 24.0)
+    return {"value": round(clip_seconds / (ext_s_per_clip + dec_s_per_clip), 4),
+            "unit": "audio-s/s (each clip extracted and decoded for every attribute tuple; extrapolated from the sample)", "cores": cores, "kind": "port",
+            "sample": f"oracle hFT forward on {nwin} window(s) of 512 frames (8.192 s audio each) in {t_ext:.1f}s on {cores} threads; "
+                      f"oracle greedy generate on 2 bars of 24 tokens ({ntok} tokens) in {t_dec:.1f}s on {dthreads} threads",
+            "extract_audio_s_per_s": round(nwin * 8.192 / t_ext, 4),
             "decoder_tokens_per_s": round(ntok / t_dec, 2), "decoder_cores": dthreads}
 
 
@@ -121,17 +132,26 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # ---- N > 1 without a launcher: start the N ranks ourselves.  Nothing in this process has touched the GPU yet
+    # (torch.cuda.device_count() does not initialise HIP), the ranks are fresh child processes of torch.distributed.run, their
+    # stdout (rank 0's ONE JSON line) is relayed and their exit status becomes ours.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a mislabelled number", file=sys.stderr)
+        sys.exit(2)
+    if torch.cuda.device_count() < max(1, min(world, local + 1)):
+        print(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
+        sys.exit(3)
+
     # Keep stdout clean for the ONE JSON line: RCCL prints its version banner to stdout from C code, so fd 1 is
     # pointed at stderr for the whole run and the result is written to the saved descriptor at the end.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("ETD_FORCE_DIST") == "1"      # ETD_FORCE_DIST: exercise the RCCL path on one GPU
@@ -313,10 +333,25 @@ def main():
         if tp.exists():
             try:
                 result["roofline"]["traffic"] = json.loads(tp.read_text()).get(name)
+                result["roofline"]["traffic_source"] = ("static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch from separate "
+                                                        "profiling passes of this same command, committed with the tree; NOT measured in this run")
             except Exception:
                 pass
-        result["roofline"]["measured"] = "HIP events around every launch of the library during one extra step over the same inputs right after the timed region (stages and engines run one at a time in that step)"
+        result["roofline"]["frac_source"] = ("serial event pass: HIP events around every launch of the library during ONE extra step over the same inputs right after "
+                                             "the timed region, stages and engines one at a time (event records cannot sit inside the hipGraph replays of the timed "
+                                             "steps; with four engines running, an event pair also counts queueing behind the other engines' kernels).  The rocprofv3 "
+                                             "kernel-trace average of the timed configuration is in profiles/ (tools/profile.sh).")
         result["kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        # the whole decode stage as ONE figure that needs no per-kernel timing: algorithmic bytes of every decode-step launch of the
+        # step (host-side counts: K/V of every (row, head) + the weights each launch streams) over the stage's wall time in the TIMED steps
+        step_k = ("k_dstep_attn_down", "k_dstep_qkv_up", "k_resid_ln_rows", "k_dstep_head", "k_dattn", "k_dgemm_s", "k_ln_rows")
+        dec_bytes = sum(prof[k]["bytes"] for k in step_k if k in prof) / prof_steps
+        t_dec_step = t_dec / args.steps
+        if t_dec_step > 0:
+            result["roofline"]["decode_stage"] = {"alg_bytes_per_step": dec_bytes, "stage_s_per_step": round(t_dec_step, 4),
+                                                  "achieved": round(dec_bytes / t_dec_step / 1e9, 1), "unit": "GB/s",
+                                                  "frac": round(dec_bytes / t_dec_step / 1e9 / PEAK_HBM_GBS, 4),
+                                                  "note": "sum of algorithmic decode-step bytes / wall time of the decode stage in the timed steps (prefill passes included in the time, not in the bytes)"}
 
     # ---- extras outside the timed region
     if not args.no_extras and rank == 0:
@@ -338,6 +373,24 @@ def main():
                                         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}}
         except Exception as e:      # extras must never take the headline down
             extras["extractor_only"] = {"error": repr(e)}
+        try:
+            # configs[1]: ONE 3-min clip, full extract + greedy decode with the default attributes (1/1/1, overlap 2) on one engine
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            with torch.cuda.stream(ext_stream):
+                n1 = len(ex.extract_notes(wavs[0], 44100, inf.min_duration))
+            ext_stream.synchronize()
+            t_e = time.perf_counter() - t
+            t = time.perf_counter()
+            st1 = {}
+            decs[0].generate_many([(jobs[0][0], [synth.attrs(1, 1, 1, 2)] * len(jobs[0][0]))], vocab, stats=st1, force_bar_tokens=args.bar_tokens)
+            torch.cuda.synchronize(dev)
+            t_d = time.perf_counter() - t
+            extras["single_clip"] = {"workload": f"BASELINE configs[1]: one 3-min 44.1 kHz clip, extract (wav -> {n1} notes) + greedy decode of {len(jobs[0][0])} bars x {args.bar_tokens} tokens, attributes 1/1/1, bf16",
+                                     "extract_s": round(t_e, 4), "decode_s": round(t_d, 4), "wall_s": round(t_e + t_d, 4),
+                                     "audio_s_per_s": round(args.seconds / (t_e + t_d), 1), "decoder_tokens_per_s": round(st1.get("tokens", 0) / t_d, 1)}
+        except Exception as e:
+            extras["single_clip"] = {"error": repr(e)}
         for key, c0 in (("decoder_streams", 512), ("decoder_streams_4k", 3500)):     # reference-faithful context / 4k stress
             try:
                 extras[key] = decoder_stream_bench(dcfg, dev, ctx0=c0)
@@ -347,7 +400,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline()
+            result["cpu_baseline"] = cpu_baseline(clip_seconds=args.seconds, windows_per_clip=result["config"]["windows_per_clip"], attr_tuples=args.attr_grid,
+                                                  bars_per_job=args.bars, bar_tokens=args.bar_tokens)
         except Exception as e:
             result["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
@@ -356,6 +410,26 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` (no launcher): run N ranks of this script under torch.distributed.run, one per GPU, over
+    RCCL on 127.0.0.1.  Fails loudly -- non-zero exit, no JSON line -- when the node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible on this node; not reporting a {n}-GPU number", file=sys.stderr)
+        return 3
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    log("bench.py: starting", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
 
 
 def decode_jobs_async(decs, jobs, vocab, bar_tokens, ready, one_at_a_time=False):
@@ -388,7 +462,7 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
         cls = rng.integers(1, 3, ctx0).astype(np.int32)
         a4 = rng.integers(0, 3, (4, ctx0)).astype(np.int32)
         _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data,
-                                             -1, 1000, st), "begin_bar")
+                                             -1, min(1000, 4096 - ctx0), st), "begin_bar")
     slots = np.arange(n_streams, dtype=np.int32)
     _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, 4, st), "step")
     torch.cuda.synchronize(dev)

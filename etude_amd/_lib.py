@@ -45,7 +45,7 @@ class SchedCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("bar_bos_id", "bar_eos_id", "n_ctx_pairs", "max_position_embeddings", "max_output_tokens",
                                        "max_bar_token_limit")] + [("context_overlap_ratio", C.c_float)] + \
                [(n, C.c_int) for n in ("force_bar_tokens", "max_streams", "max_prefill_rows", "steps_per_poll")] + \
-               [("temperature", C.c_float), ("top_p", C.c_float), ("seed", C.c_ulonglong)]
+               [("temperature", C.c_float), ("top_p", C.c_float), ("seed", C.c_ulonglong), ("job_key_offset", C.c_int), ("job_key_stride", C.c_int)]
 
 
 class TempoRegion(C.Structure):
@@ -64,6 +64,7 @@ class Note(C.Structure):
 SIGNATURES = {
     "etd_version": (C.c_int, []),
     "etd_last_error": (C.c_char_p, []),
+    "etd_build_id": (C.c_char_p, []),
     "etd_prof_enable": (C.c_int, [C.c_int]),
     "etd_prof_reset": (C.c_int, []),
     "etd_prof_collect": (C.c_int, []),
@@ -150,6 +151,12 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)          # AttributeError if the .so does not export it: fail loudly
             fn.restype = res
             fn.argtypes = args
+        # provenance: the binary must have been built from the sources it sits next to (diagnostic builds opt out explicitly)
+        if not os.environ.get("ETD_PARTIAL") and not os.environ.get("ETD_ALLOW_STALE_LIB"):
+            from .build import src_hash
+            have, want = (l.etd_build_id() or b"").decode(), src_hash()
+            if have != want:
+                raise EtudeHipError(f"{LIB_PATH} is stale: built from sources {have}, the tree is {want}; rebuild with `python -m etude_amd.build`")
         _lib = l
     return _lib
 

@@ -25,6 +25,19 @@ FLAGS += os.environ.get("ETD_EXTRA_FLAGS", "").split()      # diagnostic builds 
 # -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
 
 
+def src_hash() -> str:
+    """sha256 over every source and header the library is built from.  build() bakes it into the .so (`etd_build_id`) and
+    `_lib.lib()` compares it with the tree it is loaded from: a stale binary next to newer sources fails loudly instead of
+    passing the GPU tests with yesterday's kernels."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + [HERE.parent / "include" / "etude_hip.h"], key=lambda p: p.name)
+    for f in files:
+        if f.exists():
+            h.update(f.name.encode()); h.update(b"\0"); h.update(f.read_bytes()); h.update(b"\0")
+    return h.hexdigest()[:32]
+
+
 def _hipcc() -> str:
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (Path(c).exists() or c == "hipcc"):
@@ -52,6 +65,15 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
             rebuilt = True
+    # the build id: a generated translation unit holding the hash of the sources this binary was made from
+    bid_src, bid_obj = OBJ / "build_id.cpp", OBJ / "build_id.cpp.o"
+    want = 'extern "C" const char* etd_build_id(void) { return "%s"; }\n' % src_hash()
+    if force or not bid_obj.exists() or not bid_src.exists() or bid_src.read_text() != want:
+        bid_src.write_text(want)
+        procs.append(("build_id.cpp", subprocess.Popen([hipcc, "-O1", "-fPIC", "-c", "-x", "c++", str(bid_src), "-o", str(bid_obj)],
+                                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        rebuilt = True
+    objs.append(bid_obj)
     for s, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:

@@ -217,7 +217,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     }
     // ---- decode step: attention (+ its share of attention.dense) and the MLP down projection in ONE launch, then the row kernel
     const bool attn_down = small && rows.slot == d->row_slot && d->H == 512 && d->nh == 8 && d->I % 512 == 0 && d->I / 512 + d->nh <= 12 && w.dense_hw &&
-                           d->ctx >= 64 && !getenv("ETD_NO_ATTN_DOWN");
+                           d->ctx >= 256 && !getenv("ETD_NO_ATTN_DOWN");
     if (attn_down) {
       DAttnArgs at = {};
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
@@ -656,10 +656,13 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
 extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, const int32_t* T, const int32_t* ids, const int32_t* cls,
                                       const int32_t* attrs4, const int32_t* tgt_attrs4, const int32_t* eos_ids, const int32_t* limits, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!d || n < 1 || !tgt_attrs4 || !eos_ids || !limits) ETD_FAIL(ETD_EINVAL, "begin_bars: bad arguments");
+  if (!d || n < 1 || !T || !tgt_attrs4 || !eos_ids || !limits) ETD_FAIL(ETD_EINVAL, "begin_bars: bad arguments");
   std::vector<int> init((size_t)7 * n);
   for (int i = 0; i < n; ++i) {
     if (limits[i] < 1 || limits[i] > d->out_cap) ETD_FAIL(ETD_EINVAL, "begin_bars: limit %d outside [1, %d]", limits[i], d->out_cap);
+    // positions a bar touches: the prompt's T, then one per generated token that is fed back (all but the last) -- past max_ctx the
+    // K/V rows could not be stored and the RoPE table would be read out of bounds
+    if ((long long)T[i] + limits[i] - 1 > d->ctx) ETD_FAIL(ETD_EINVAL, "begin_bars: prompt of %d tokens + limit %d needs %d KV positions, max_ctx is %d", T[i], limits[i], T[i] + limits[i] - 1, d->ctx);
     for (int k = 0; k < 4; ++k) if (tgt_attrs4[4 * i + k] < 0 || tgt_attrs4[4 * i + k] >= d->cfg.num_attribute_bins) ETD_FAIL(ETD_EINVAL, "begin_bars: target attribute out of range");
     init[7 * i] = slots ? slots[i] : 0;
     for (int k = 0; k < 4; ++k) init[7 * i + 1 + k] = tgt_attrs4[4 * i + k];

@@ -901,11 +901,18 @@ template <> struct Raw8<bf16> {
 // DENSE: instead of storing the head's 64 outputs, multiply them (rounded to bf16, as the projection GEMM would read them)
 // with this head's [512][64] slice of attention.dense and store the 512 partial sums as one more split-K slab for
 // k_resid_ln_rows -- the attention-output projection needs no launch of its own (k_dstep_attn_down below).
-template <typename KVT, bool DENSE>
-__device__ __forceinline__ void dattn_core(const int m, const int head, float (&red)[4][8][10], float* osh, float* outsh,
+//
+// NW = waves per (row, head) workgroup.  A wave-iteration covers 16 keys and keeps the next iteration's K/V requested, so a
+// workgroup has 2 x 16 NW keys x 256 B in flight and walks the context in ceil(ctx / (16 NW)) dependent round trips: at the
+// serving shape (54 rows per engine, ctx ~340) NW = 4 is six round trips of ~1-2 us each with ~30 KiB in flight per CU (the
+// 0.29-of-peak kernel of round 1); NW = 16 requests the whole context of a (row, head) at once (2 iterations, both in flight).
+template <typename KVT, bool DENSE, int NW>
+__device__ __forceinline__ void dattn_core(const int m, const int head, float (&red)[NW][8][10], float* osh, float* outsh,
                                            const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                            int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
+  constexpr int G2 = 8 * NW;         // offset of a wave's second 8-key group inside an iteration
+  constexpr int KI = 16 * NW;        // keys per workgroup iteration
   int slot, pos;
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   // p_identity (row i is slot i, known on the host): the K/V addresses of the first key block then depend on nothing in
@@ -915,7 +922,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   if (p_identity) {
     const KVT* kb0 = reinterpret_cast<const KVT*>(p_Kc) + (long long)m * p_slot_stride + (long long)head * p_max_ctx * 64;
     const KVT* vb0 = reinterpret_cast<const KVT*>(p_Vc) + (long long)m * p_slot_stride + (long long)head * p_max_ctx * 64;
-    const int ka = wave * 8 + j, kbb = ka + 32;                        // < 64 <= max_ctx (checked by the launcher)
+    const int ka = wave * 8 + j, kbb = ka + G2;                        // < 16 NW <= max_ctx (checked by the launcher)
     kA.load(kb0 + (long long)ka * 64 + c * 8); kB.load(kb0 + (long long)kbb * 64 + c * 8);
     wA.load(vb0 + (long long)ka * 64 + c * 8); wB.load(vb0 + (long long)kbb * 64 + c * 8);
     slot = m; pos = __builtin_nontemporal_load(p_row_sp + 2 * m + 1);
@@ -942,7 +949,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   // Software-pipelined KV stream: a wave-iteration covers two 8-key groups (16 keys); the K/V pieces of iteration i+1
   // are requested before iteration i is consumed, so ~8 KB per wave are always in flight.
   auto issue = [&](int k0, Raw8<KVT>& a_, Raw8<KVT>& b_, Raw8<KVT>& c_, Raw8<KVT>& d_) {
-    int ka = k0 + j, kbb = k0 + 32 + j;
+    int ka = k0 + j, kbb = k0 + G2 + j;
     ka = ka < ctx ? ka : ctx - 1; kbb = kbb < ctx ? kbb : ctx - 1;
     a_.load(kb + (long long)ka * 64 + c * 8);
     b_.load(kb + (long long)kbb * 64 + c * 8);
@@ -951,10 +958,10 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   };
   int k0 = wave * 8;
   if (!p_identity && k0 < ctx) issue(k0, kA, kB, wA, wB);
-  for (; k0 < ctx; k0 += 64) {
-    const bool more = k0 + 64 < ctx;
-    if (more) issue(k0 + 64, nkA, nkB, nwA, nwB);
-    const bool vA = k0 + j < ctx, vB = k0 + 32 + j < ctx;
+  for (; k0 < ctx; k0 += KI) {
+    const bool more = k0 + KI < ctx;
+    if (more) issue(k0 + KI, nkA, nkB, nwA, nwB);
+    const bool vA = k0 + j < ctx, vB = k0 + G2 + j < ctx;
     float sA = 0.f, sB = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sA = fmaf(q[e], kA.get(e), sA); sB = fmaf(q[e], kB.get(e), sB); }
@@ -980,88 +987,118 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     if (more) { kA = nkA; kB = nkB; wA = nwA; wB = nwB; }
   }
 
-  // DENSE: the first 8 of this wave's 16 dense-weight fragments are requested here -- the key loop's K/V registers are dead, and
-  // the merge below (shuffles, LDS, a barrier) covers their round trip
-  bf16x8 dwv[DENSE ? 8 : 1];
+  // DENSE: this wave's dense-weight fragments (512 / NW rows = 64 / NW one-KiB fragments; the first 8 of them at most) are
+  // requested here -- the key loop's K/V registers are dead, and the merge below (shuffles, LDS, a barrier) covers their round trip
+  constexpr int FR = 64 / NW, FP = FR > 8 ? 8 : FR, NPASS = FR / FP;
+  bf16x8 dwv[DENSE ? FP : 1];
   const bf16* dwb = nullptr;
   if constexpr (DENSE) {
-    dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * 128 + (lane >> 3)) * 64 + (lane & 7) * 8;
+    dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * (512 / NW) + (lane >> 3)) * 64 + (lane & 7) * 8;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + it * 8 * 64);
+    for (int it = 0; it < FP; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + it * 8 * 64);
   }
-  // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the 4 waves through LDS
-#pragma unroll
-  for (int off = 8; off < 64; off <<= 1) {
-    const float m2 = __shfl_xor(mr, off, 64), l2 = __shfl_xor(lr, off, 64);
-    const float mn = fmaxf(mr, m2);
-    const float f1 = (mr == -INFINITY) ? 0.f : EXPF(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : EXPF(m2 - mn);
-    lr = lr * f1 + l2 * f2;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { const float o2 = __shfl_xor(o[e], off, 64); o[e] = o[e] * f1 + o2 * f2; }
-    mr = mn;
+  // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the NW waves through LDS
+#define ETD_MERGE_STAGES()                                                                                                  \
+  _Pragma("unroll") for (int off = 8; off < 64; off <<= 1) {                                                                \
+    const float m2 = __shfl_xor(mr, off, 64), l2 = __shfl_xor(lr, off, 64);                                                 \
+    const float mn = fmaxf(mr, m2);                                                                                         \
+    const float f1 = (mr == -INFINITY) ? 0.f : EXPF(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : EXPF(m2 - mn);                 \
+    lr = lr * f1 + l2 * f2;                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float o2 = __shfl_xor(o[e], off, 64); o[e] = o[e] * f1 + o2 * f2; } \
+    mr = mn;                                                                                                                \
   }
+  ETD_MERGE_STAGES()
   if (j == 0) {
     red[wave][c][0] = mr; red[wave][c][1] = lr;
 #pragma unroll
     for (int e = 0; e < 8; ++e) red[wave][c][2 + e] = o[e];
   }
   __syncthreads();
-  if (wave == 0 && j == 0) {
-    float M2 = -INFINITY;
-    for (int w = 0; w < 4; ++w) M2 = fmaxf(M2, red[w][c][0]);
-    float L = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int w = 0; w < 4; ++w) {
-      const float mw = red[w][c][0];
-      const float f = (mw == -INFINITY) ? 0.f : EXPF(mw - M2);
-      L += red[w][c][1] * f;
+  if (wave == 0) {
+    if constexpr (NW <= 4) {
+      // (the round-1 order of operations, kept bit for bit: NW = 4 is what the goldens of the bf16 mode were taken with)
+      if (j == 0) {
+        float M2 = -INFINITY;
+        for (int w = 0; w < NW; ++w) M2 = fmaxf(M2, red[w][c][0]);
+        float L = 0.f, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < NW; ++w) {
+          const float mw = red[w][c][0];
+          const float f = (mw == -INFINITY) ? 0.f : EXPF(mw - M2);
+          L += red[w][c][1] * f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += red[w][c][2 + e] * f;
-    }
-    const float inv = 1.f / L;
-    const f32x4 x = {acc[0] * inv, acc[1] * inv, acc[2] * inv, acc[3] * inv}, y = {acc[4] * inv, acc[5] * inv, acc[6] * inv, acc[7] * inv};
-    if constexpr (DENSE) {
+          for (int e = 0; e < 8; ++e) acc[e] += red[w][c][2 + e] * f;
+        }
+        lr = L;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { osh[c * 8 + e] = (float)(bf16)x[e]; osh[c * 8 + 4 + e] = (float)(bf16)y[e]; }
+        for (int e = 0; e < 8; ++e) o[e] = acc[e];
+      }
     } else {
-      float* op = a.O + (long long)m * hidden + head * 64 + c * 8;
-      *reinterpret_cast<f32x4*>(op) = x;
-      *reinterpret_cast<f32x4*>(op + 4) = y;
-      if (a.Ob) {
-        const bf16x8 ob = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
-        *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * (a.ldob > 0 ? a.ldob : hidden) + head * 64 + c * 8) = ob;
+      // lane (j, c) folds waves j, j + 8 (fixed order), then the same three exchange stages as above fold the 8 partial results
+      mr = red[j][c][0]; lr = red[j][c][1];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = red[j][c][2 + e];
+#pragma unroll
+      for (int w = j + 8; w < NW; w += 8) {
+        const float m2 = red[w][c][0], l2 = red[w][c][1];
+        const float mn = fmaxf(mr, m2);
+        const float f1 = (mr == -INFINITY) ? 0.f : EXPF(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : EXPF(m2 - mn);
+        lr = lr * f1 + l2 * f2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * f1 + red[w][c][2 + e] * f2;
+        mr = mn;
+      }
+      ETD_MERGE_STAGES()
+    }
+    if (j == 0) {
+      const float inv = 1.f / lr;
+      const f32x4 x = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}, y = {o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv};
+      if constexpr (DENSE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { osh[c * 8 + e] = (float)(bf16)x[e]; osh[c * 8 + 4 + e] = (float)(bf16)y[e]; }
+      } else {
+        float* op = a.O + (long long)m * hidden + head * 64 + c * 8;
+        *reinterpret_cast<f32x4*>(op) = x;
+        *reinterpret_cast<f32x4*>(op + 4) = y;
+        if (a.Ob) {
+          const bf16x8 ob = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
+          *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * (a.ldob > 0 ? a.ldob : hidden) + head * 64 + c * 8) = ob;
+        }
       }
     }
   }
+#undef ETD_MERGE_STAGES
   if constexpr (DENSE) {
     // out[n] = sum_d Wd[n][64 head + d] * o[d] for the 512 outputs: 8 lanes share a weight row (128 contiguous bytes), a wave
-    // instruction covers 8 consecutive rows = 1 KiB; 16 such loads per wave are in flight together (requested above, before
+    // instruction covers 8 consecutive rows = 1 KiB; the wave's fragments are in flight together (requested above, before
     // the merge), the 8-lane sums use DPP exchanges.  The weights of a head are one contiguous 64 KiB block (dense_w).
-    // (register budget: this kernel streams K/V at 7 waves per SIMD, so the 16 fragments come in two passes of 8)
+    // (register budget at NW = 4: the kernel streams K/V at 7 waves per SIMD, so its 16 fragments come in two passes of 8)
     __syncthreads();
     const int g8 = lane >> 3, sub = lane & 7;
     float ov[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) ov[e] = osh[sub * 8 + e];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
       if (pass == 1) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + (8 + it) * 8 * 64);
+        for (int it = 0; it < FP; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + (FP + it) * 8 * 64);
       }
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
+      for (int it = 0; it < FP; ++it) {
         float sacc = 0.f;
 #pragma unroll
         for (int e = 0; e < 8; ++e) sacc = fmaf(bf2f(dwv[it][e]), ov[e], sacc);
         sacc += lane_xor<1>(sacc); sacc += lane_xor<2>(sacc); sacc += lane_xor<4>(sacc);
-        if (sub == 0) outsh[wave * 128 + (pass * 8 + it) * 8 + g8] = sacc;
+        if (sub == 0) outsh[wave * (512 / NW) + (pass * FP + it) * 8 + g8] = sacc;
       }
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 o2 = {outsh[2 * tid], outsh[2 * tid + 1]};
-    *reinterpret_cast<f32x2*>(a.dense_out + ((long long)head * a.M + m) * 512 + 2 * tid) = o2;
+    if (tid < 256) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 o2 = {outsh[2 * tid], outsh[2 * tid + 1]};
+      *reinterpret_cast<f32x2*>(a.dense_out + ((long long)head * a.M + m) * 512 + 2 * tid) = o2;
+    }
   }
 }
 template <typename KVT>
@@ -1070,37 +1107,37 @@ template <typename KVT>
 __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                                int p_max_ctx, int p_n_heads, float p_scale, int p_identity, DAttnArgs a) {
   __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
-  dattn_core<KVT, false>(blockIdx.x, blockIdx.y, red, nullptr, nullptr, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
+  dattn_core<KVT, false, 4>(blockIdx.x, blockIdx.y, red, nullptr, nullptr, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
 }
 
 #undef EXPF
 // ================================================================================================
-// k_dstep_attn_down: one launch for the two things that depend on the QKV|up launch only
-//   * workgroups [0, p_gemm_wgs): the MLP down projection as split-K partial slabs.  A workgroup is two independent
-//     2-wave units of k_dgemm_s's bf16 path (32x32 tile, one K slab of 512, K halved over the unit's two waves); the two
+// k_dstep_attn_down<NW>: one launch for the two things that depend on the QKV|up launch only
+//   * workgroups [0, p_gemm_wgs): the MLP down projection as split-K partial slabs.  A workgroup is NW / 2 independent
+//     2-wave units of k_dgemm_s's bf16 path (32x32 tile, one K slab of 512, K halved over the unit's two waves); the
 //     units of a workgroup are consecutive slots of one XCD, i.e. row tiles of the same weight tile where there are several.
-//   * the others: attention per (row, head) with the head's slice of attention.dense applied in place (dattn_core<DENSE>).
+//   * the others: attention per (row, head), NW waves, with the head's slice of attention.dense applied in place (dattn_core<DENSE>).
 // k_resid_ln_rows then sums k_splits + n_heads slabs.  A decode-step layer is 3 launches instead of 4.
 // ================================================================================================
-#ifndef ETD_AD_WAVES_MIN
-#define ETD_AD_WAVES_MIN 7       // keeps the MFMA accumulator out of AGPRs: 72 registers, 7 waves per SIMD like k_dattn (5 without the hint)
-#define ETD_AD_WAVES_MAX 8
-#endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ETD_AD_WAVES_MIN, ETD_AD_WAVES_MAX))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+template <int NW> struct AdOcc { static constexpr int lo = 7, hi = 8; };      // 72 registers; forcing 64 (8 waves per SIMD) spills inside the key loop, and a scratch reload there drains the K/V stream
+template <> struct AdOcc<4> { static constexpr int lo = 7, hi = 8; };      // keeps the MFMA accumulator out of AGPRs: 72 registers, 7 waves per SIMD like k_dattn (5 without the hint)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(AdOcc<NW>::lo, AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                                          int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
                                                          DAttnArgs a, DGemmArgs g) {
-  __shared__ float red[4][8][10];
+  constexpr int UNITS = NW / 2;
+  __shared__ float red[NW][8][10];
   __shared__ float osh[64];
-  __shared__ __attribute__((aligned(16))) float sh[2 * 16 * 64];      // attention: 512 staged outputs; GEMM: the two units' cross-wave sums
+  __shared__ __attribute__((aligned(16))) float sh[UNITS * 16 * 64 > 512 ? UNITS * 16 * 64 : 512];      // attention: 512 staged outputs; GEMM: the units' cross-wave sums
   if ((int)blockIdx.x >= p_gemm_wgs) {
     const int lid = blockIdx.x - p_gemm_wgs;
-    dattn_core<bf16, true>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
+    dattn_core<bf16, true, NW>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
     return;
   }
   // ---- GEMM role
-  const int tid = threadIdx.x, half = tid >> 7, tl = tid & 127, lane = tl & 63, wave = tl >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, unit = tid >> 7, tl = tid & 127, lane = tl & 63, wave = tl >> 6, r = lane & 31, h = lane >> 5;
   const int RT = (p_M + 31) / 32, FT = g.Npad / 32, KS = g.k_splits;
-  const int bid = blockIdx.x, slot = (bid >> 3) * 2 + half, wt = (slot / RT) * 8 + (bid & 7);
+  const int bid = blockIdx.x, slot = (bid >> 3) * UNITS + unit, wt = (slot / RT) * 8 + (bid & 7);
   const bool valid = wt < FT * KS;
   const int wtc = valid ? wt : 0;
   const int bz = wtc / FT, m0 = (slot % RT) * 32, n0 = (wtc - bz * FT) * 32;
@@ -1110,8 +1147,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ETD_AD_WAVE
   const bf16* wrow = reinterpret_cast<const bf16*>(g.W) + (long long)(n0 + r) * g.K + kb + h * 8;
   const bf16* xrow = g.Xb + (long long)gm * g.ldx + kb + h * 8;
   // (the same 16 MFMAs in the same order as k_dgemm_s, but fed in four passes of 4 k-steps: this role shares the launch -- and
-  // so the register allocation -- with the attention role, which needs its 6-7 waves per SIMD; four short round trips of
-  // 64 workgroups hide behind the attention workgroups)
+  // so the register allocation -- with the attention role; four short round trips of a few dozen workgroups hide behind the
+  // attention workgroups)
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1124,7 +1161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ETD_AD_WAVE
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
   }
-  float* redg = sh + half * (16 * 64);
+  float* redg = sh + unit * (16 * 64);
   if (wave == 1) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) redg[i * 64 + lane] = acc[i];
@@ -1140,16 +1177,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ETD_AD_WAVE
   dgemm_epilogue<true, DEPI_PARTIAL>(b, acc, m, n0, h);
 }
 
+// waves per attention workgroup: ETD_AD_WAVES (4 / 8 / 16) overrides; default by the launch's row count -- few rows leave
+// wave slots free, so each (row, head) takes more of them and requests its whole context at once
+static int ad_waves(int M) {
+  static const int env = getenv("ETD_AD_WAVES") ? atoi(getenv("ETD_AD_WAVES")) : 0;
+  if (env == 4 || env == 8 || env == 16) return env;
+  return M <= 96 ? 16 : (M <= 192 ? 8 : 4);
+}
 int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, hipStream_t st) {
-  if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 64 ||
+  if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 256 ||
       g.M != a.M || !g.Xb || !g.W || !g.Y || g.ldy != 512 || g.N != 512 || g.Npad != 512 || g.k_splits < 1 || g.k_splits * 512 > g.K || (g.K % 8) || a.n_heads * 64 != 512)
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad arguments");
+  const int nw = ad_waves(a.M), units = nw / 2;
   const int RT = (a.M + 31) / 32, FT = g.Npad / 32;
   const int slots = ((FT * g.k_splits + 7) / 8) * RT;               // per XCD
-  const int gemm_wgs = ((slots + 1) / 2) * 8;
+  const int gemm_wgs = ((slots + units - 1) / units) * 8;
   ProfScope ps("k_dstep_attn_down", st, 2.0 * a.M * 512 * (512.0 * g.k_splits + 512.0), a.bytes_hint + 512.0 * (512.0 * g.k_splits + 512.0) * 2);
-  hipLaunchKernelGGL(k_dstep_attn_down, dim3(gemm_wgs + a.M * a.n_heads), dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale,
-                     a.identity ? 1 : 0, gemm_wgs, a.M, a, g);
+#define ETD_AD_LAUNCH(NW_) hipLaunchKernelGGL(k_dstep_attn_down<NW_>, dim3(gemm_wgs + a.M * a.n_heads), dim3(64 * NW_), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, \
+                                              a.identity ? 1 : 0, gemm_wgs, a.M, a, g)
+  if (nw == 16) ETD_AD_LAUNCH(16); else if (nw == 8) ETD_AD_LAUNCH(8); else ETD_AD_LAUNCH(4);
+#undef ETD_AD_LAUNCH
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }

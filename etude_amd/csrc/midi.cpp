@@ -74,8 +74,10 @@ extern "C" int etd_midi_write(const etd_note* notes, long long n, const char* pa
   }
   put_varint(trk1, 1); trk1.push_back(0xFF); trk1.push_back(0x2F); trk1.push_back(0x00);   // end_of_track at last tick + 1
 
-  static const unsigned char trk0[] = {0x00, 0xFF, 0x58, 0x04, 0x04, 0x02, 0x18, 0x08,       // time_signature 4/4, 24 clocks/click, 8 32nds/beat
-                                       0x00, 0xFF, 0x51, 0x03, 0x07, 0xA1, 0x20,             // set_tempo 500000 us/beat (120 bpm)
+  // pretty_midi.write() sorts the timing track with the same event_compare as track 1: at equal ticks set_tempo (rank 1) comes
+  // before time_signature (rank 2)
+  static const unsigned char trk0[] = {0x00, 0xFF, 0x51, 0x03, 0x07, 0xA1, 0x20,             // set_tempo 500000 us/beat (120 bpm)
+                                       0x00, 0xFF, 0x58, 0x04, 0x04, 0x02, 0x18, 0x08,       // time_signature 4/4, 24 clocks/click, 8 32nds/beat
                                        0x01, 0xFF, 0x2F, 0x00};                              // end_of_track at tick 1
   std::vector<unsigned char> out;
   out.insert(out.end(), {'M', 'T', 'h', 'd'}); put_be32(out, 6); put_be16(out, 1); put_be16(out, 2); put_be16(out, 220);

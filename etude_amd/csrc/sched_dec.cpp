@@ -151,7 +151,8 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
       if (c.temperature > 0.f) {           // draw key of a stream = (job, bar): the same tokens whatever slot / pass the job lands in
         std::vector<unsigned long long> keys(slots.size());
         size_t q = p - slots.size();
-        for (size_t i = 0; i < slots.size(); ++i, ++q) keys[i] = ((unsigned long long)(uint32_t)pend[q] << 32) | (uint32_t)J[pend[q]].bar;
+        const int kstride = c.job_key_stride > 0 ? c.job_key_stride : 1;
+        for (size_t i = 0; i < slots.size(); ++i, ++q) keys[i] = ((unsigned long long)(uint32_t)(c.job_key_offset + pend[q] * kstride) << 32) | (uint32_t)J[pend[q]].bar;
         ETD_TRY(etd_decoder_set_keys(d, (int)slots.size(), slots.data(), keys.data()));
       }
       const size_t M = ids.size();

@@ -77,8 +77,13 @@ class EtudeDecoder:
             raise ValueError("precision must be 'fp32' (token-parity mode) or 'bf16'")
         self.precision = precision
         self.max_streams = int(max_streams)
-        # the reference never exceeds ~max_position_embeddings + 1 positions per bar (etude_decoder.py:285-300)
-        self.max_ctx = int(max_ctx) if max_ctx else int(config.max_position_embeddings) + 64
+        # KV positions per stream.  A bar touches prompt + limit - 1 positions, and the prompt (after the truncation rule of
+        # etude_decoder.py:285-289, + Bar_BOS) is at most max(max_pos - limit, int(max_pos * ratio)) + 1 tokens: with the reference's
+        # default arguments that is ~max_pos + 1 positions, with context_overlap_ratio up to 1 and max_bar_token_limit up to
+        # 1024 (the output ring of a stream) up to 2 * max_pos.  HF's GPT-NeoX has no such bound (dynamic cache, rotary computed
+        # on the fly), so the default covers every such call; `ctx_needed` below rejects what does not fit instead of
+        # truncating silently.
+        self.max_ctx = int(max_ctx) if max_ctx else 2 * int(config.max_position_embeddings) + 64
         # one begin_bars call carries up to this many prompt rows (a prompt is <= max_pos/2 + 1 tokens after truncation)
         self.max_prefill_rows = int(max_prefill_rows) if max_prefill_rows else self.max_streams * (int(config.max_position_embeddings) // 2 + 8)
         self.max_prefill_rows = max(self.max_prefill_rows, self.max_ctx)
@@ -164,7 +169,7 @@ class EtudeDecoder:
                       max_bar_token_limit: int = 512, context_overlap_ratio: float = 0.5, steps_per_poll: int = 8,
                       _validate: bool = True, stats: Optional[dict] = None, force_bar_tokens: int = 0,
                       ready: Optional[Tuple[np.ndarray, Sequence[int]]] = None, temperature: float = 0.0, top_p: float = 0.9,
-                      seed: Optional[int] = None) -> List[List[List[int]]]:
+                      seed: Optional[int] = None, _job_key: Tuple[int, int] = (0, 1)) -> List[List[List[int]]]:
         """Greedy-decode many independent jobs on up to ``max_streams`` concurrent device streams.
 
         The bar loop (prompt assembly, history, truncation, token budget, EOS stop) runs in the library's native
@@ -177,6 +182,11 @@ class EtudeDecoder:
         lib = _lib.lib()
         if not temperature >= 0:
             raise ValueError("temperature must be >= 0")
+        lim = int(force_bar_tokens or max_bar_token_limit)
+        need = self.ctx_needed(lim, context_overlap_ratio)
+        if need > self.max_ctx:
+            raise _lib.EtudeHipError(f"generate: max_bar_token_limit={lim} with context_overlap_ratio={context_overlap_ratio} needs {need} KV positions "
+                                     f"per stream, this decoder was created with max_ctx={self.max_ctx}; pass max_ctx>={need} to EtudeDecoder / load_etude_decoder")
         if seed is None:
             self._draw_calls = getattr(self, "_draw_calls", 0) + 1
             seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + self._draw_calls) & 0xFFFFFFFFFFFFFFFF
@@ -222,7 +232,8 @@ class EtudeDecoder:
                                max_bar_token_limit=max_bar_token_limit, context_overlap_ratio=context_overlap_ratio,
                                force_bar_tokens=force_bar_tokens, max_streams=self.max_streams,
                                max_prefill_rows=self.max_prefill_rows, steps_per_poll=steps_per_poll,
-                               temperature=float(temperature), top_p=float(top_p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF)
+                               temperature=float(temperature), top_p=float(top_p), seed=int(seed) & 0xFFFFFFFFFFFFFFFF,
+                               job_key_offset=int(_job_key[0]), job_key_stride=int(_job_key[1]))
             out = np.zeros(cap, np.int32)
             offs_out = np.zeros(len(live) + 1, np.int64)
             nsteps = C.c_longlong()
@@ -244,6 +255,12 @@ class EtudeDecoder:
         elif stats is not None:
             stats["steps"] = stats["tokens"] = 0
         return results  # type: ignore[return-value]
+
+    def ctx_needed(self, max_bar_token_limit: int, context_overlap_ratio: float) -> int:
+        """KV positions a bar can touch under generate()'s truncation rule (etude_decoder.py:285-300)."""
+        mp = int(self.config.max_position_embeddings)
+        prompt = max(mp - int(max_bar_token_limit), int(mp * float(context_overlap_ratio))) + 1
+        return prompt + int(max_bar_token_limit) - 1
 
     # ------------------------------------------------------------------ test / bench hooks
     def prefill_logits(self, ids, cls, attrs4, slot: int = 0) -> np.ndarray:
@@ -283,6 +300,13 @@ def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: b
     ``one_at_a_time`` runs the engines one after the other (profiling passes)."""
     import threading
     n = len(engines)
+    seed = generate_many_kwargs.pop("seed", None)
+    if seed is None and float(generate_many_kwargs.get("temperature", 0.0) or 0.0) > 0:
+        # sampled covers: one seed per call for every engine (each engine deriving its own from its private call counter gave all
+        # engines the same seed AND the same engine-local job indices, i.e. identical draw streams for job k of every engine)
+        e0 = engines[0]
+        e0._draw_calls = getattr(e0, "_draw_calls", 0) + 1
+        seed = (int(torch.initial_seed()) * 0x9E3779B97F4A7C15 + e0._draw_calls) & 0xFFFFFFFFFFFFFFFF
     outs = [None] * n
     stats = [dict() for _ in engines]
     errs: list = []
@@ -291,6 +315,8 @@ def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: b
         try:
             torch.cuda.set_device(engines[i].device)
             kw = dict(generate_many_kwargs)
+            kw["seed"] = seed                         # ONE seed for the whole job list ...
+            kw["_job_key"] = (i, n)                   # ... and GLOBAL job indices in the draw keys: engine i holds jobs i, i + n, ...
             if ready is not None:
                 kw["ready"] = (ready[0], ready[1][i::n])
             outs[i] = engines[i].generate_many(jobs[i::n], vocab, stats=stats[i], **kw)
@@ -344,7 +370,7 @@ def expected_state_keys(cfg: EtudeDecoderConfig) -> List[str]:
 
 
 def load_etude_decoder(config_path: Union[str, Path], checkpoint_path: Union[str, Path], device: str = "auto",
-                       precision: Optional[str] = None, max_streams: int = 1) -> EtudeDecoder:
+                       precision: Optional[str] = None, max_streams: int = 1, max_ctx: Optional[int] = None) -> EtudeDecoder:
     """model_loader.py:12-60: JSON config -> model -> checkpoint (strict key match) -> eval."""
     config = EtudeDecoderConfig.from_json_file(str(config_path))
     state = load_decoder_state(checkpoint_path)
@@ -353,4 +379,4 @@ def load_etude_decoder(config_path: Union[str, Path], checkpoint_path: Union[str
     missing, unexpected = sorted(exp - got), sorted(got - exp)
     if missing or unexpected:     # load_state_dict(strict=True) semantics (model_loader.py:56)
         raise RuntimeError(f"Error(s) in loading state_dict for EtudeDecoder: missing keys {missing}; unexpected keys {unexpected}")
-    return EtudeDecoder(config, state, device=device, precision=precision, max_streams=max_streams)
+    return EtudeDecoder(config, state, device=device, precision=precision, max_streams=max_streams, max_ctx=max_ctx)

@@ -243,7 +243,8 @@ class AMTAPC_Extractor:
         if sr not in self._fronts:
             f = self.config.feature
             with torch.cuda.device(self.device):
-                self._fronts[sr] = FrontEnd(sr, f.sr, f.fft_bins, f.hop_sample, f.mel_bins, f.log_offset, pad_mode=self._stft_pad_mode)
+                self._fronts[sr] = FrontEnd(sr, f.sr, f.fft_bins, f.hop_sample, f.mel_bins, f.log_offset, pad_mode=self._stft_pad_mode,
+                                            win_length=f.window_length)
         return self._fronts[sr]
 
     def wav2feature_tensor(self, wave: Union[np.ndarray, torch.Tensor], sr: int) -> torch.Tensor:

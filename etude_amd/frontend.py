@@ -61,14 +61,21 @@ class FrontEnd:
     """wav (device, planar [C][L] fp32) -> log-mel features (device, [T][n_mels] fp32)."""
 
     def __init__(self, sr_in: int, sr_out: int = 16000, n_fft: int = 2048, hop: int = 256, n_mels: int = 256,
-                 log_offset: float = 1e-8, pad_mode: str = "reflect"):
+                 log_offset: float = 1e-8, pad_mode: str = "reflect", win_length: int | None = None):
         self.sr_in, self.sr_out, self.hop, self.n_mels = int(sr_in), int(sr_out), hop, n_mels
+        win_length = int(win_length) if win_length else int(n_fft)
+        if win_length < 1 or win_length > n_fft:
+            raise _lib.EtudeHipError(f"FrontEnd: win_length {win_length} must be in [1, n_fft={n_fft}] (torch.stft's rule)")
         lib = _lib.lib()
         if self.sr_in != self.sr_out:
             kt, width, orig, new = _resample_table(self.sr_in, self.sr_out)
         else:
             kt, width, orig, new = np.zeros((1, 1), np.float32), 0, 1, 1
-        win = torch.hann_window(n_fft, periodic=True).numpy().astype(np.float32)
+        # MelSpectrogram(win_length=w) -> torch.stft: a periodic Hann window of w samples, zero-padded on both sides to n_fft
+        # (extractor.py:186-193 passes win_length=feature.window_length)
+        win = np.zeros(n_fft, np.float32)
+        lpad = (n_fft - win_length) // 2
+        win[lpad:lpad + win_length] = torch.hann_window(win_length, periodic=True).numpy().astype(np.float32)
         ms, ml, mw = _mel_csr(n_fft // 2 + 1, float(self.sr_out // 2), n_mels, self.sr_out)
         h = C.c_void_p()
         _lib.check(lib.etd_frontend_create(self.sr_in, self.sr_out, orig, new, kt.shape[0], width, kt.ctypes.data, n_fft, hop,

@@ -43,6 +43,9 @@ extern "C" {
 
 int etd_version(void);
 const char* etd_last_error(void);
+/* Hash of the sources this binary was built from (etude_amd/build.py: src_hash); the Python binding refuses a library whose
+ * id differs from the tree it sits in, so a stale in-tree .so cannot stand in for the current kernels. */
+const char* etd_build_id(void);
 
 /* ------------------------------------------------------------------ launch profiler (measurement only)
  * When enabled, every kernel launch of the library is bracketed by HIP events on its own stream;
@@ -156,7 +159,9 @@ int etd_decoder_clone(etd_dec* src, etd_dec** out);
  * cache and generation state, run the prompt (ids/cls: int32 host [T]; attrs4: int32 host [4][T] in the
  * concat order of etude_decoder.py:171-176 = pitch_overlap, polyphony, note_sustain, rhythm_intensity)
  * through the model and leave the greedy first token in the slot's device-side state.  tgt_attrs4 (same
- * order) condition the generated tokens; generation stops at eos_id or after `limit` tokens. */
+ * order) condition the generated tokens; generation stops at eos_id or after `limit` tokens.  The bar needs T + limit - 1
+ * KV positions: ETD_EINVAL when that exceeds max_ctx (the reference's dynamic cache / on-the-fly rotary has no such bound,
+ * etude_decoder.py:285-300; EtudeDecoder sizes max_ctx so that every legal generate() argument set fits). */
 /* Sampling branch of generate() (etude_decoder.py:321-331): temperature > 0 -> softmax(logits / T), top-p filter when
  * 0 < top_p < 1, one draw per token; temperature == 0 -> greedy argmax (the default).  Draws are a pure function of (seed, the
  * stream's key, index of the token inside its bar) -- reproducible, independent of slot / engine placement; the reference
@@ -197,6 +202,8 @@ typedef struct {
   int max_streams, max_prefill_rows, steps_per_poll;
   float temperature, top_p;            /* etude_decoder.py:213-214; temperature 0 = greedy */
   unsigned long long seed;
+  int job_key_offset, job_key_stride;  /* sampling keys: job k of THIS call is global job job_key_offset + k * max(job_key_stride, 1), so that several
+                                          engines sharing one job list (run_engines deals it round-robin) draw independent streams */
 } etd_sched_cfg;
 int etd_decoder_run_jobs(etd_dec*, const etd_sched_cfg* cfg, const etd_job* jobs, int n_jobs, int32_t* out, long long out_cap,
                          long long* job_offsets, long long* n_steps_out, void* stream);

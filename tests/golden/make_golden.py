@@ -360,7 +360,56 @@ def gen_tokenizer():
     (HERE / "tokenizer.json").write_text(json.dumps(dict(cases=cases, splits=splits)))
 
 
-ALL = dict(tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
+def gen_clip_full():
+    """BASELINE configs[1]: ONE 3-min 44.1 kHz stereo clip (synth.clip_audio seed 1234) through the reference chain at the
+    default configuration (n_frame 512 -> 22 windows, ragged tail):
+        features (oracle/mel.py: the torchaudio front end is absent from this image -- parity-unpinned)
+        -> reference AMTAPC_Extractor._transcript -> reference _mpe2note (0.5 / 1.0 / 0.5) -> reference _note2json (0.08 s)
+        -> reference TinyREMITokenizer(synthetic tempo.json: 120 bpm, 4/4, 90 downbeats from 0.5 s).encode -> Vocab.encode_sequence
+        -> split_sequence_into_bars -> reference EtudeDecoder.generate (greedy, attrs 1/1/1 + overlap 2, default limits).
+    Extractor weights = synth.extractor_state_dict(0), decoder weights = synth.decoder_state_dict(1): what bench.py runs.
+    Takes ~6 min of CPU (22 reference forward passes).  Stored: every 8th frame of the B outputs (fp16 is 5e-4 abs, far below the
+    test tolerance), the full velocity argmax + top-2 gap of every 8th frame, the full note list, the bars and the generated ids."""
+    import tempfile
+    from oracle import mel
+    from etude.data.tokenizer import TinyREMITokenizer
+    wav = synth.clip_audio(seed=1234, seconds=180.0)
+    feat = mel.wav2feature(torch.from_numpy(wav), 44100).numpy()
+    ex, d = ref_extractor({}, seed=0)
+    torch.set_num_threads(8)
+    out = ex._transcript(feat)
+    on, off, mpe, vel = out[4], out[5], out[6], out[7]
+    notes = ex._mpe2note(on, off, mpe, vel, thred_onset=0.5, thred_offset=1.0, thred_mpe=0.5)
+    tmp = Path(tempfile.mkdtemp())
+    ex._note2json(notes, str(tmp / "extract.json"), 0.08)
+    kept = json.loads((tmp / "extract.json").read_text())
+    tempo = [{"start": 0.5, "bpm": 120, "time_sig": 4, "downbeats": [round(0.5 + 2.0 * i, 6) for i in range(90)]}]
+    (tmp / "tempo.json").write_text(json.dumps(tempo))
+    vocab = _Vocab().v
+    tk = TinyREMITokenizer(tempo_path=str(tmp / "tempo.json"))
+    ev = tk.encode(str(tmp / "extract.json"))
+    ids = vocab.encode_sequence(ev)
+    bars = tk.split_sequence_into_bars(ids, vocab.get_bar_bos_id(), vocab.get_bar_eos_id())
+    model, _ = ref_decoder({}, 1)
+    attrs = synth.attrs(1, 1, 1, 2)
+    gev = model.generate(vocab, bars, [attrs] * len(bars), temperature=0.0, top_p=0.9)
+    gen_ids = [vocab.encode(e) if e.type_ not in vocab.special_tokens else vocab.token_to_id[e.type_] for e in gev]
+    print(f"  clip_full: {feat.shape[0]} frames, {len(notes)} notes ({len(kept)} after the 0.08 s filter), {len(bars)} bars, "
+          f"{sum(len(b) for b in bars)} condition ids (UNK {sum(1 for i in ids if i == 1)}), {len(gen_ids)} generated ids, "
+          f"{int((np.asarray(gen_ids) == vocab.get_bar_eos_id()).sum())} Bar_EOS")
+    sub = slice(None, None, 8)
+    arr = lambda key: np.asarray([n[key] for n in notes])       # noqa: E731
+    np.savez_compressed(HERE / "clip_full.npz", n_frames=np.int64(feat.shape[0]), feat_rows=feat[::512],
+                        onset_B=on[sub].astype(np.float16), offset_B=off[sub].astype(np.float16), mpe_B=mpe[sub].astype(np.float16),
+                        offset_B_sat=np.packbits(off >= 1.0), velocity_B=vel,
+                        note_onset=arr("onset").astype(np.float64), note_offset=arr("offset").astype(np.float64),
+                        note_pitch=arr("pitch").astype(np.int32), note_velocity=arr("velocity").astype(np.int32),
+                        n_kept=np.int64(len(kept)),
+                        bar_ids=np.asarray([t for b in bars for t in b], np.int32), bar_lens=np.asarray([len(b) for b in bars], np.int32),
+                        gen_ids=np.asarray(gen_ids, np.int32))
+
+
+ALL = dict(clip_full=gen_clip_full, tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
            decoder_tiny=gen_decoder_tiny, decoder_full=gen_decoder_full)
 
 if __name__ == "__main__":

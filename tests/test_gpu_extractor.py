@@ -184,3 +184,32 @@ def test_short_mono_16k_clip_single_partial_window(dev, tmp_path):
     assert np.abs(dev_feat.cpu().numpy() - feat).max() < 2e-3
     on, off, mp, ve = [t.cpu().numpy() for t in ex.transcript(dev_feat)]
     assert notes == mpe2note.notes_for_json(mpe2note.mpe2note(on, off, mp, ve, 0.5, 1.0, 0.5), 0.08)
+
+
+def test_checkpoint_file_contract(dev, tmp_path):
+    """_load_model (extractor.py:78-113): `checkpoints/extractor/latest.pth` is a FLAT state dict read with
+    torch.load(weights_only=True).  The reference loads it with strict=False (extra keys ignored, missing keys silently left at
+    their random init); this build ignores extra keys too but treats a MISSING key as an error (stricter on purpose: a silently
+    random layer is never what a caller wants -- INTEGRATION.md section 3)."""
+    from etude_amd import _lib
+    from etude_amd.extractor import AMTAPC_Extractor
+    nf = 32
+    cfg = ExtractorConfig()
+    cfg.input.num_frame = nf
+    sd = synth.extractor_state_dict(7, dict(n_frame=nf))
+    tsd = {k: torch.from_numpy(v) for k, v in sd.items()}
+    tsd["encoder.some_buffer_the_reference_would_ignore"] = torch.zeros(3)
+    tsd["fc_style.weight"] = torch.zeros(4, 4)
+    torch.save(tsd, tmp_path / "latest.pth")
+    x = torch.from_numpy(synth.window_features(5, 1, 256, nf + 64)).to(dev)
+    a = AMTAPC_Extractor(cfg, str(tmp_path / "latest.pth"), "cuda")
+    b = AMTAPC_Extractor(cfg, sd, "cuda")
+    for p, q in zip(a.transcript_windows(x), b.transcript_windows(x)):
+        assert torch.equal(p, q)
+    a.close(); b.close()
+    del tsd["decoder.fc_onset_time.weight"]
+    torch.save(tsd, tmp_path / "bad.pth")
+    with pytest.raises(_lib.EtudeHipError, match="missing weight"):
+        AMTAPC_Extractor(cfg, str(tmp_path / "bad.pth"), "cuda")
+    with pytest.raises(FileNotFoundError):
+        AMTAPC_Extractor(cfg, str(tmp_path / "nope.pth"), "cuda")

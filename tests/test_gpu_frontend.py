@@ -78,3 +78,35 @@ def test_analyze_volume_file_surface(dev, tmp_path):
     assert json.loads((tmp_path / "out" / "volume.json").read_text()) == v.tolist()
     with pytest.raises(FileNotFoundError):
         analyze_volume(tmp_path / "missing.wav")
+
+
+def test_frontend_against_real_torchaudio_when_present(dev):
+    """The oracle's front end restates torchaudio's published algorithm because torchaudio is neither vendored by the reference
+    nor installed in the build image (parity unpinned).  Where a box does have it, pin the HIP front end to the
+    real thing: the exact calls of etude/data/extractor.py:181-197."""
+    torchaudio = pytest.importorskip("torchaudio")
+    wav = synth.clip_audio(seed=3, seconds=2.0)
+    w = torch.mean(torch.from_numpy(wav), dim=0)
+    w = torchaudio.transforms.Resample(44100, 16000)(w)
+    ms = torchaudio.transforms.MelSpectrogram(sample_rate=16000, n_fft=2048, win_length=2048, hop_length=256, n_mels=256, norm="slaney")(w)
+    want = torch.log(ms + 1e-8).T.numpy()
+    feat, res = _run(wav, 44100, dev)
+    np.testing.assert_allclose(res, w.numpy(), rtol=0, atol=2e-6)
+    assert feat.shape == want.shape and np.abs(feat - want).max() < 2e-3
+
+
+def test_frontend_window_shorter_than_fft(dev):
+    """feature.window_length != feature.fft_bins: MelSpectrogram(win_length=w) centres a w-sample Hann window in the n_fft frame
+    (torch.stft); extractor.py:186-193 passes the config's value."""
+    from etude_amd import _lib
+    from etude_amd.frontend import FrontEnd
+    from oracle import mel
+    wav = synth.clip_audio(seed=12, seconds=1.0, sr=16000)
+    fe = FrontEnd(16000, win_length=1024)
+    feat = fe(torch.from_numpy(wav).to(dev)).cpu().numpy()
+    ref = mel.log_mel(torch.mean(torch.from_numpy(wav), 0), win_length=1024).numpy()
+    if ref.shape != feat.shape:
+        ref = ref.T
+    assert feat.shape == ref.shape and np.abs(feat - ref).max() < 2e-3
+    with pytest.raises(_lib.EtudeHipError):
+        FrontEnd(16000, win_length=4096)

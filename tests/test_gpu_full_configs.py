@@ -1,0 +1,287 @@
+"""Parity at the FULL size of BASELINE.json's configurations (the other GPU tests run reduced sizes).
+
+configs[1]  one 3-min 44.1 kHz clip, default n_frame = 512 (22 windows, ragged tail), windows batched four at a time, then
+            notes -> tokenizer -> greedy decode -> MIDI: against tests/golden/clip_full.npz, which make_golden.py produced by
+            running the REFERENCE chain on the same clip (extractor.py:199-446, tokenizer.py, etude_decoder.py:209-354).
+configs[3]  128 concurrent streams at a 3.5 k-token context (KV ring of 4096): fp32 ids against the oracle's greedy
+            continuation, bf16 streams against each other and against the fp32 ids.
+Also here because they need the full geometry: the KV-window bound of generate() (context_overlap_ratio 0.9) and the bf16
+greedy divergence rate over the whole configs[0] song and all 27 attribute tuples.
+"""
+import ctypes as C
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from etude_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+P_TOL, P_MEAN = 8e-2, 6e-3          # bf16 compute vs the fp32 reference (same bounds as tests/test_gpu_extractor.py)
+HOP_S = 256 / 16000.0
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _vocab():
+    from etude_amd.vocab import Vocab
+    v = Vocab()
+    v.token_to_id = synth.vocab_json()["token_to_id"]
+    v.id_to_token = [""] * len(v.token_to_id)
+    for t, i in v.token_to_id.items():
+        v.id_to_token[i] = t
+    return v
+
+
+def match_notes(ref, got, tol_frames=1):
+    """(recall, precision): a note matches when pitch is equal and the onset is within tol_frames hops; one-to-one, greedy in time"""
+    tol = tol_frames * HOP_S + 1e-9
+    import bisect
+    by_pitch = {}
+    for n in got:
+        by_pitch.setdefault(n["pitch"], []).append(n["onset"])
+    for v in by_pitch.values():
+        v.sort()
+    used = {p: [False] * len(v) for p, v in by_pitch.items()}
+    hit = 0
+    for n in sorted(ref, key=lambda n: n["onset"]):
+        cand = by_pitch.get(n["pitch"], [])
+        lo = bisect.bisect_left(cand, n["onset"] - tol)
+        best, bd = -1, tol
+        for i in range(lo, len(cand)):
+            d = abs(cand[i] - n["onset"])
+            if cand[i] > n["onset"] + tol:
+                break
+            if not used[n["pitch"]][i] and d <= bd:
+                best, bd = i, d
+        if best >= 0:
+            used[n["pitch"]][best] = True
+            hit += 1
+    return hit / max(1, len(ref)), hit / max(1, len(got))
+
+
+def test_config1_single_clip_full_chain(dev, golden_dir, tmp_path):
+    from etude_amd.config import ExtractorConfig
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    from etude_amd.extractor import AMTAPC_Extractor, write_wav_f32
+    from etude_amd.tokenizer import TinyREMITokenizer
+    from oracle import mel
+    g = np.load(golden_dir / "clip_full.npz")
+    wav = synth.clip_audio(seed=1234, seconds=180.0)
+    # ---- the features the golden was made from, rebuilt here (CPU, oracle/mel.py) and checked against the stored rows
+    feat_o = mel.wav2feature(torch.from_numpy(wav), 44100).numpy()
+    T = int(g["n_frames"])
+    assert feat_o.shape == (T, 256) and T == 11251
+    assert np.abs(feat_o[::512] - g["feat_rows"]).max() < 1e-3
+    cfg = ExtractorConfig()
+    sd = synth.extractor_state_dict(0)
+    ex4 = AMTAPC_Extractor(cfg, sd, "cuda", max_windows=4)
+    ex1 = AMTAPC_Extractor(cfg, sd, "cuda", max_windows=1)
+    feat_d = ex4.wav2feature_tensor(wav, 44100)
+    assert tuple(feat_d.shape) == (T, 256) and np.abs(feat_d.cpu().numpy() - feat_o).max() < 2e-3
+    # ---- 22 windows of 512 frames, ragged tail, four windows per batch vs one: not a bit may differ
+    fo = torch.from_numpy(feat_o).to(dev)
+    out4 = [t.cpu().numpy() for t in ex4.transcript(fo)]
+    out1 = [t.cpu().numpy() for t in ex1.transcript(fo)]
+    assert out4[0].shape == (11264, 88)
+    for a, b in zip(out4, out1):
+        assert np.array_equal(a, b)
+    on, off, mpe, vel = out4
+    # ---- frames against the reference (every 8th frame of the golden)
+    worst = 0.0
+    for name, got in (("onset_B", on), ("offset_B", off), ("mpe_B", mpe)):
+        ref = g[name].astype(np.float32)
+        e = np.abs(got[::8] - ref)
+        worst = max(worst, float(e.max()))
+        assert e.max() < P_TOL and e.mean() < P_MEAN, (name, float(e.max()), float(e.mean()))
+    vel_ref = g["velocity_B"]
+    vel_agree = float((vel == vel_ref).mean())
+    sat_ref = np.unpackbits(g["offset_B_sat"])[: off.size].reshape(off.shape).astype(bool)
+    sat_agree = float(((off >= 1.0) == sat_ref).mean())
+    # ---- notes: the reference's _mpe2note on the reference's frames (golden) vs ours on our frames, +-1 frame on the onset
+    ref_notes = [dict(onset=float(a), offset=float(b), pitch=int(p), velocity=int(v))
+                 for a, b, p, v in zip(g["note_onset"], g["note_offset"], g["note_pitch"], g["note_velocity"])]
+    arr = ex4.mpe2note_device(*[torch.from_numpy(x).to(dev) for x in (on, off, mpe, vel)], 0.5, 1.0, 0.5)
+    got_notes = ex4._notes_from_array(arr)
+    assert got_notes == ex4._mpe2note(on, off, mpe, vel, 0.5, 1.0, 0.5)              # device == host note picking on 11 264 frames
+    keep = lambda ns: [n for n in ns if not (n["offset"] - n["onset"] < 0.08)]       # noqa: E731  (what _note2json writes, extractor.py:435-437)
+    recall_all, precision_all = match_notes(ref_notes, got_notes)
+    recall, precision = match_notes(keep(ref_notes), keep(got_notes))
+    print(f"configs[1] extract: max frame error {worst:.3e}, velocity argmax agreement {vel_agree:.4f}, offset saturation agreement {sat_agree:.6f}; "
+          f"notes written to extract.json (>= 0.08 s): {len(keep(got_notes))} vs {len(keep(ref_notes))} reference, recall {recall:.4f} precision {precision:.4f} (+-1 frame); "
+          f"all raw notes incl. sub-80-ms fragments: {len(got_notes)} vs {len(ref_notes)}, recall {recall_all:.4f} precision {precision_all:.4f}")
+    assert recall >= 0.97 and precision >= 0.97
+    assert vel_agree > 0.97 and sat_agree > 0.999
+    # ---- extract() itself: wav file -> JSON (device front end); same note population
+    write_wav_f32(tmp_path / "origin.wav", wav, 44100)
+    ex4.extract(str(tmp_path / "origin.wav"), str(tmp_path / "extract.json"), str(tmp_path / "extract.mid"))
+    js = json.loads((tmp_path / "extract.json").read_text())
+    assert abs(len(js) - int(g["n_kept"])) <= max(3, int(g["n_kept"]) // 50)
+    assert (tmp_path / "extract.mid").read_bytes()[:4] == b"MThd"
+    ex4.close(); ex1.close()
+    # ---- tokenizer (native) on the REFERENCE notes -> exactly the reference's condition bars
+    kept = [n for n in ref_notes if not (n["offset"] - n["onset"] < 0.08)]
+    assert len(kept) == int(g["n_kept"])
+    tempo = [{"start": 0.5, "bpm": 120, "time_sig": 4, "downbeats": [round(0.5 + 2.0 * i, 6) for i in range(90)]}]
+    (tmp_path / "tempo.json").write_text(json.dumps(tempo))
+    (tmp_path / "ref_extract.json").write_text(json.dumps(kept))
+    v = _vocab()
+    tk = TinyREMITokenizer(str(tmp_path / "tempo.json"))
+    ids = v.encode_sequence(tk.encode(str(tmp_path / "ref_extract.json")))
+    bars = tk.split_sequence_into_bars(ids, v.get_bar_bos_id(), v.get_bar_eos_id())
+    lens = g["bar_lens"].tolist()
+    assert [len(b) for b in bars] == lens and [t for b in bars for t in b] == g["bar_ids"].tolist()
+    # ---- decode: greedy ids of the whole song, fp32 mode == the reference's generate(); bf16 agreement reported
+    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+    dsd = synth.decoder_state_dict(1, {})
+    attrs = [synth.attrs(1, 1, 1, 2)] * len(bars)
+    d32 = EtudeDecoder(dcfg, dsd, "cuda", precision="fp32")
+    ev = d32.generate(v, bars, attrs, temperature=0.0, top_p=0.9)
+    gen = [v.encode(e) if e.type_ not in v.special_tokens else v.token_to_id[e.type_] for e in ev]
+    assert gen == g["gen_ids"].tolist()                                              # bit-exact integer parity over the whole song
+    ids32 = d32.generate_ids(v, bars, attrs, temperature=0.0)
+    d32.close()
+    d16 = EtudeDecoder(dcfg, dsd, "cuda", precision="bf16")
+    ids16 = d16.generate_ids(v, bars, attrs, temperature=0.0)
+    d16.close()
+    same_bars = sum(1 for a, b in zip(ids32, ids16) if a == b)
+    print(f"configs[1] decode: {len(gen)} ids identical to the reference in fp32; bf16: {same_bars}/{len(ids32)} bars identical")
+    # ---- and out to MIDI (tokenizer.py:446-524)
+    notes_out = tk.decode_to_notes(ev)
+    TinyREMITokenizer.note_to_midi(notes_out, tmp_path / "output.mid")
+    assert (tmp_path / "output.mid").stat().st_size > 22
+
+
+def _raw_generate(dec, prompts, tgt4, n_steps):
+    """begin_bar per stream (raw prompts, no bar logic) + n_steps batched decode steps; returns [stream][1 + n_steps] ids"""
+    from etude_amd import _lib
+    lib = _lib.lib()
+    st = dec._stream()
+    tg = np.asarray(tgt4, np.int32)
+    for s, (ids, cls, a4) in enumerate(prompts):
+        ids = np.ascontiguousarray(ids, np.int32); cls = np.ascontiguousarray(cls, np.int32); a4 = np.ascontiguousarray(a4, np.int32)
+        _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, len(ids), tg.ctypes.data, -1, n_steps + 1, st), "begin_bar")
+    slots = np.arange(len(prompts), dtype=np.int32)
+    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, len(prompts), n_steps, st), "step")
+    out = np.zeros((len(prompts), n_steps + 1), np.int32)
+    cnt = np.zeros(len(prompts), np.int32)
+    _lib.check(lib.etd_decoder_read_many(dec._h, len(prompts), slots.ctypes.data, out.ctypes.data, n_steps + 1, cnt.ctypes.data, st), "read_many")
+    assert (cnt == n_steps + 1).all()
+    return out
+
+
+def test_config3_128_streams_at_4k_context(dev):
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    from oracle import neox
+    from tests._util import neox_dims, torch_sd
+    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+    sd_np = synth.decoder_state_dict(1, {})
+    sd = torch_sd(sd_np)
+    nd = neox_dims({})
+    ctx0, steps = 3500, 64
+    rng = np.random.default_rng(17)
+    tgt = [2, 1, 0, 1]                                                      # ABI order: overlap, polyphony, sustain, rhythm
+    base = [(rng.integers(6, 154, ctx0), rng.integers(1, 3, ctx0), rng.integers(0, 3, (4, ctx0))) for _ in range(2)]
+    # ---- oracle: greedy continuation of the two prompts (positions 3500 .. 3500 + n: far beyond max_position_embeddings = 1024,
+    # where HF's rotary embedding is computed on the fly, modeling_gpt_neox.py:72-107)
+    n_chk = 12
+    want = []
+    for ids, cls, a4 in base:
+        at = {"pitch_overlap": torch.from_numpy(a4[0])[None], "polyphony": torch.from_numpy(a4[1])[None],
+              "note_sustain": torch.from_numpy(a4[2])[None], "rhythm_intensity": torch.from_numpy(a4[3])[None]}
+        lg, kv = neox.forward_logits(sd, nd, torch.from_numpy(ids)[None], torch.from_numpy(cls)[None], at)
+        seq = []
+        for _ in range(n_chk + 1):
+            nxt = int(torch.argmax(lg[:, -1, :], -1))
+            seq.append(nxt)
+            one = lambda x: torch.tensor([[x]])                             # noqa: E731
+            lg, kv = neox.forward_logits(sd, nd, one(nxt), one(2), {"pitch_overlap": one(tgt[0]), "polyphony": one(tgt[1]),
+                                                                    "note_sustain": one(tgt[2]), "rhythm_intensity": one(tgt[3])}, kv)
+        want.append(seq)
+    # ---- fp32 engine, the two prompts side by side: ids identical to the oracle
+    d32 = EtudeDecoder(dcfg, sd_np, "cuda", precision="fp32", max_streams=2, max_ctx=4096)
+    got32 = _raw_generate(d32, base, tgt, n_chk)
+    d32.close()
+    assert got32.tolist() == want
+    # ---- bf16, 128 streams (64 copies of each prompt, interleaved), 64 steps through the captured decode step: streams
+    # with equal prompts must produce equal tokens whatever slot they sit in, and the start agrees with the fp32 ids
+    d16 = EtudeDecoder(dcfg, sd_np, "cuda", precision="bf16", max_streams=128, max_ctx=4096)
+    got16 = _raw_generate(d16, [base[s % 2] for s in range(128)], tgt, steps)
+    d16.close()
+    for s in range(2, 128):
+        assert np.array_equal(got16[s], got16[s % 2]), s
+    agree = [int(np.argmax(np.r_[got16[k][: n_chk + 1] != np.asarray(want[k]), True])) for k in range(2)]
+    print(f"configs[3]: fp32 ids == oracle over {n_chk + 1} tokens at ctx {ctx0}; bf16 first divergence from fp32 after {agree} tokens")
+    assert min(agree) >= 1                                                   # at least the prefill's token (greedy paths may part later)
+
+
+def test_generate_kv_window_bound_with_large_overlap_ratio(dev):
+    """context_overlap_ratio = 0.9: prompts keep int(1024 * 0.9) = 921 tokens (+ Bar_BOS), plus up to max_bar_token_limit
+    generated ones -- beyond the 1088 positions round 1 allocated.  The KV window is now sized for it: ids == oracle; and a
+    decoder created with a window that is too small refuses instead of wrapping silently."""
+    from etude_amd import _lib
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    from oracle import neox
+    from tests._util import neox_dims, torch_sd
+    v = _vocab()
+    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+    sd_np = synth.decoder_state_dict(1, {})
+    bars = synth.song_bars(seed=8, n_bars=5, notes_per_bar=70)
+    at = [synth.attrs(2, 2, 0, 2)] * len(bars)
+    limit = 260
+    want = neox.generate_ids(torch_sd(sd_np), neox_dims({}), 4, 5, bars, at, max_bar_token_limit=limit, context_overlap_ratio=0.9)
+    dec = EtudeDecoder(dcfg, sd_np, "cuda", precision="fp32")
+    assert dec.ctx_needed(limit, 0.9) == 922 + limit - 1 and dec.max_ctx >= 2048
+    assert dec.generate_ids(v, bars, at, max_bar_token_limit=limit, context_overlap_ratio=0.9, temperature=0.0) == want
+    dec.close()
+    small = EtudeDecoder(dcfg, sd_np, "cuda", precision="fp32", max_ctx=1088)
+    with pytest.raises(_lib.EtudeHipError, match="KV positions"):
+        small.generate_ids(v, bars, at, max_bar_token_limit=limit, context_overlap_ratio=0.9, temperature=0.0)
+    # the C ABI refuses too: prompt + limit beyond max_ctx
+    ids = np.full(1000, 7, np.int32); cls = np.ones(1000, np.int32); a4 = np.ones((4, 1000), np.int32); tg = np.ones(4, np.int32)
+    rc = _lib.lib().etd_decoder_begin_bar(small._h, 0, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, 1000, tg.ctypes.data, 5, 512, small._stream())
+    assert rc == -22 and b"KV positions" in _lib.lib().etd_last_error()
+    small.close()
+
+
+def test_bf16_greedy_divergence_rate_full_song_all_tuples(dev):
+    """SURVEY.md section 7 hard part 2: the reference decodes in fp32; bf16 weights / KV flip near-tie argmaxes.  Whole configs[0]
+    song (92 bars) x all 27 attribute tuples, fp32 engine vs bf16 engine, same scheduler: per-bar comparison.  A bar can only be
+    compared while the two histories are still equal, so the rate is 'bars identical among bars whose context was identical'."""
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    v = _vocab()
+    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+    sd_np = synth.decoder_state_dict(1, {})
+    bars = synth.song_bars(seed=1234, n_bars=92)
+    jobs = [(bars, [synth.attrs(p, r, s, 2)] * len(bars)) for p in range(3) for r in range(3) for s in range(3)]
+    d32 = EtudeDecoder(dcfg, sd_np, "cuda", precision="fp32", max_streams=27)
+    r32 = d32.generate_many(jobs, v)
+    d32.close()
+    d16 = EtudeDecoder(dcfg, sd_np, "cuda", precision="bf16", max_streams=27)
+    r16 = d16.generate_many(jobs, v)
+    d16.close()
+    comparable = same = tok = tok_same = 0
+    first_div = []
+    for a, b in zip(r32, r16):
+        k = 0
+        while k < min(len(a), len(b)) and a[k] == b[k]:
+            k += 1
+        first_div.append(k)
+        n_cmp = min(k + 1, len(a), len(b))          # the bars before the first difference + the one that differs
+        comparable += n_cmp
+        same += k
+        for i in range(n_cmp):
+            m = min(len(a[i]), len(b[i]))
+            tok += max(len(a[i]), len(b[i]))
+            tok_same += sum(1 for x, y in zip(a[i][:m], b[i][:m]) if x == y)
+    rate = 1.0 - same / max(1, comparable)
+    print(f"bf16 vs fp32 greedy: {same}/{comparable} comparable bars identical (divergence rate {rate:.4f} per bar), token agreement "
+          f"{tok_same / max(1, tok):.4f} on those bars; jobs identical end to end: {sum(1 for k, a in zip(first_div, r32) if k == len(a))}/27; "
+          f"first differing bar per job: min {min(first_div)} median {int(np.median(first_div))}")
+    assert same / max(1, comparable) >= 0.90

@@ -128,3 +128,20 @@ def test_frontend_tables_match_oracle_definitions():
         dense[start[m]:start[m] + length[m], m] = w[p:p + length[m]]
         p += length[m]
     assert np.array_equal(dense, fb)
+
+
+def test_decoder_kv_window_requirement_formula():
+    """EtudeDecoder.ctx_needed: positions a bar can touch under generate()'s truncation rule (etude_decoder.py:285-300); the
+    default window (2 * max_pos + 64) covers ratio <= 1 with limits up to the 1024-token output ring."""
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    d = object.__new__(EtudeDecoder)
+    d.config = EtudeDecoderConfig()
+    assert d.ctx_needed(512, 0.5) == 513 + 511                  # the reference's defaults: prompt <= 512 (+ Bar_BOS), 512 generated
+    assert d.ctx_needed(512, 0.9) == 922 + 511
+    assert d.ctx_needed(100, 0.5) == 925 + 99                   # short limit: untruncated prompts up to max_pos - limit
+    assert max(d.ctx_needed(l, r) for l in (1, 64, 512, 1024) for r in (0.0, 0.5, 0.9, 1.0)) <= 2 * 1024 + 64
+
+
+def test_library_build_id_matches_the_tree():
+    from etude_amd import _lib, build
+    assert _lib.lib().etd_build_id().decode() == build.src_hash()

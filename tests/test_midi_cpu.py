@@ -56,7 +56,8 @@ def test_midi_layout_and_ticks(tmp_path):
     TinyREMITokenizer.note_to_midi(notes, out)
     fmt, div, (t0, t1) = parse_smf(out.read_bytes())
     assert (fmt, div) == (1, 220)
-    assert t0 == [(0, "meta", 0x58, bytes([4, 2, 24, 8])), (0, "meta", 0x51, (500000).to_bytes(3, "big")), (1, "meta", 0x2F, b"")]
+    # pretty_midi sorts the timing track with event_compare: set_tempo (rank 1) before time_signature (rank 2) at tick 0
+    assert t0 == [(0, "meta", 0x51, (500000).to_bytes(3, "big")), (0, "meta", 0x58, bytes([4, 2, 24, 8])), (1, "meta", 0x2F, b"")]
     assert t1[0] == (0, "msg", 0xC0, (0,))
     assert t1[-1][1:] == ("meta", 0x2F, b"") and t1[-1][0] == t1[-2][0] + 1
     body = t1[1:-1]
@@ -81,7 +82,7 @@ def test_midi_small_case_bytes_and_array_input(tmp_path):
                   0x6E, 64, 0,                          # +110 -> tick 330: 64 off
                   0x6E, 60, 0,                          # +110 -> tick 440: 60 off
                   0x01, 0xFF, 0x2F, 0x00])
-    trk0 = bytes([0, 0xFF, 0x58, 4, 4, 2, 24, 8, 0, 0xFF, 0x51, 3, 0x07, 0xA1, 0x20, 1, 0xFF, 0x2F, 0])
+    trk0 = bytes([0, 0xFF, 0x51, 3, 0x07, 0xA1, 0x20, 0, 0xFF, 0x58, 4, 4, 2, 24, 8, 1, 0xFF, 0x2F, 0])
     want = b"MThd" + (6).to_bytes(4, "big") + bytes([0, 1, 0, 2, 0, 220]) + b"MTrk" + len(trk0).to_bytes(4, "big") + trk0 + b"MTrk" + len(trk1).to_bytes(4, "big") + trk1
     assert out.read_bytes() == want
     TinyREMITokenizer.note_to_midi([], tmp_path / "empty.mid")

@@ -109,3 +109,35 @@ def test_empty_first_or_last_tempo_region_raises_like_the_reference(tmp_path):
             TinyREMITokenizer(str(p))
     p.write_text(json.dumps([good, empty, dict(good, start=9.0, downbeats=[9.0, 11.0])]))
     assert len(TinyREMITokenizer(str(p)).global_measures) > 0
+
+
+def test_full_clip_notes_to_bars_match_reference(golden_dir, tmp_path):
+    """configs[1] chain, host part: the reference's note list of the 3-min clip (tests/golden/clip_full.npz) -> native tokenizer
+    -> exactly the condition bars the reference's TinyREMITokenizer + Vocab produced."""
+    import json
+    import numpy as np
+    from etude_amd import synth
+    from etude_amd.tokenizer import TinyREMITokenizer
+    from etude_amd.vocab import Vocab
+    p = golden_dir / "clip_full.npz"
+    if not p.exists():
+        import pytest
+        pytest.skip("clip_full.npz not generated")
+    g = np.load(p)
+    notes = [dict(onset=float(a), offset=float(b), pitch=int(q), velocity=int(v))
+             for a, b, q, v in zip(g["note_onset"], g["note_offset"], g["note_pitch"], g["note_velocity"])]
+    kept = [n for n in notes if not (n["offset"] - n["onset"] < 0.08)]
+    assert len(kept) == int(g["n_kept"])
+    tempo = [{"start": 0.5, "bpm": 120, "time_sig": 4, "downbeats": [round(0.5 + 2.0 * i, 6) for i in range(90)]}]
+    (tmp_path / "tempo.json").write_text(json.dumps(tempo))
+    (tmp_path / "extract.json").write_text(json.dumps(kept))
+    v = Vocab()
+    v.token_to_id = synth.vocab_json()["token_to_id"]
+    v.id_to_token = [""] * len(v.token_to_id)
+    for t, i in v.token_to_id.items():
+        v.id_to_token[i] = t
+    tk = TinyREMITokenizer(str(tmp_path / "tempo.json"))
+    ids = v.encode_sequence(tk.encode(str(tmp_path / "extract.json")))
+    bars = tk.split_sequence_into_bars(ids, v.get_bar_bos_id(), v.get_bar_eos_id())
+    assert [len(b) for b in bars] == g["bar_lens"].tolist()
+    assert [t for b in bars for t in b] == g["bar_ids"].tolist()

@@ -57,7 +57,7 @@ if __name__ == "__main__":
         for dec in decs:
             st = dec._stream()
             for s, (ids, cls, a4) in enumerate(prompts):
-                _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, 1000, st), "begin_bar")
+                _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, min(1000, 1024 - ctx0), st), "begin_bar")
             _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, S, 4, st), "step")
         torch.cuda.synchronize(dev)
 

@@ -14,7 +14,7 @@ prompts = [(rng.integers(6, 154, ctx0).astype(np.int32), rng.integers(1, 3, ctx0
 def reset():
     st = dec._stream()
     for s, (ids, cls, a4) in enumerate(prompts):
-        _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, 1000, st), "bb")
+        _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, min(1000, 1024 - ctx0), st), "bb")
     _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, S, 4, st), "step"); torch.cuda.synchronize(dev)
 streams = [torch.cuda.Stream() for _ in range(3)]
 stop = False
