@@ -26,7 +26,7 @@ c_f32_p = C.POINTER(C.c_float)
 class ExtCfg(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n_margin", "n_frame", "n_bin", "cnn_channel", "cnn_kernel", "hid_dim", "pf_dim",
                                        "n_heads", "n_layers_enc", "n_layers_dec", "n_note", "n_velocity")] + \
-               [("min_value", C.c_float), ("max_windows", C.c_int), ("chunk_frames", C.c_int)]
+               [("min_value", C.c_float), ("max_windows", C.c_int), ("chunk_frames", C.c_int), ("precision", C.c_int)]
 
 
 class DecCfg(C.Structure):

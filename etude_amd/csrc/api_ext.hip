@@ -10,6 +10,7 @@
 
 #include "../../include/etude_hip.h"
 #include "ext_kernels.h"
+#include "ext_fp32.h"
 
 thread_local std::string g_etd_err;
 extern "C" const char* etd_last_error(void) { return g_etd_err.c_str(); }
@@ -37,8 +38,8 @@ inline uint16_t f2bf(float f) {   // round-to-nearest-even, NaN kept
 }
 
 struct LinW { bf16* W = nullptr; float* b = nullptr; };
-struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; };
-struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; };
+struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; bf16* ffn = nullptr; /* fused-FFN weight stream (ext_fused.hip) */ };
+struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; bf16* ffn = nullptr; };
 
 }  // namespace
 
@@ -65,6 +66,7 @@ struct etd_ext {
   size_t MTe = 0;              // encoder chunk token capacity (wb*fc*256)
   float* dbg_vel = nullptr;
   void* tap[16] = {nullptr};   // test hook: device destinations for intermediate activations (first chunk only)
+  Ext32* f32 = nullptr;        // fp32 parity mode (cfg.precision == 1): its own weights and workspaces, none of the above
 };
 
 namespace {
@@ -123,7 +125,19 @@ int load_ln(DevPool& pool, Loader& L, const std::string& pfx, float** g, float**
   ETD_TRY(up_f32(pool, b, bw, 256));
   return ETD_OK;
 }
+// fc_1 / fc_2 of a position-wise feed-forward block in the fused kernel's fragment-ordered stream
+int load_ffn_stream(DevPool& pool, Loader& L, const std::string& p, bf16** dst) {
+  const float* W1 = L.get(p + ".fc_1.weight", 512 * 256);
+  const float* W2 = L.get(p + ".fc_2.weight", 256 * 512);
+  if (!W1 || !W2) return ETD_EINVAL;
+  std::vector<uint16_t> h((size_t)16 * 32 * 64 * 8);
+  pack_ffn_weights(W1, W2, h.data(), f2bf);
+  ETD_TRY(pool.alloc(dst, h.size()));
+  HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  return ETD_OK;
+}
 int load_enc_layer(DevPool& pool, Loader& L, const std::string& p, EncLayerW* w) {
+  ETD_TRY(load_ffn_stream(pool, L, p + ".positionwise_feedforward", &w->ffn));
   ETD_TRY(load_cat(pool, L, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, &w->qkv));
   ETD_TRY(load_lin(pool, L, p + ".self_attention.fc_o", 256, 256, &w->o));
   ETD_TRY(load_lin(pool, L, p + ".positionwise_feedforward.fc_1", 512, 256, &w->f1));
@@ -173,6 +187,14 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
   for (int i = 0; i < n; ++i) L.t[names[i]] = {host_ptrs[i], numels[i]};
   DevPool& P = e->pool;
   auto fail = [&](int rc) { e->pool.free_all(); delete e; return rc; };
+  if (c.precision != 0 && c.precision != 1) { delete e; ETD_FAIL(ETD_EINVAL, "extractor_create: precision must be 0 (bf16) or 1 (fp32 parity mode)"); }
+  if (c.precision == 1) {
+    const int rc = ext32_create(c, L.t, &e->f32);
+    if (rc) return fail(rc);
+    HIP_TRY(hipDeviceSynchronize());
+    *out = e;
+    return ETD_OK;
+  }
 
   // ---- front end: fold Conv2d(1,4,(1,5)) and Linear(244,256) into one [256][65] map (amt_apc.py:79-99)
   {
@@ -225,6 +247,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
     rc = load_lin(P, L, p + ".encoder_attention.fc_o", 256, 256, &w.o_c); if (rc) return fail(rc);
     rc = load_lin(P, L, p + ".positionwise_feedforward.fc_1", 512, 256, &w.f1); if (rc) return fail(rc);
     rc = load_lin(P, L, p + ".positionwise_feedforward.fc_2", 256, 512, &w.f2); if (rc) return fail(rc);
+    rc = load_ffn_stream(P, L, p + ".positionwise_feedforward", &w.ffn); if (rc) return fail(rc);
     rc = load_ln(P, L, p + ".layer_norm", &w.g, &w.be); if (rc) return fail(rc);
   }
   { int rc = up_bf16(P, &e->Wkv_all, kvW.data(), kvW.size()); if (rc) return fail(rc);
@@ -285,6 +308,7 @@ extern "C" void etd_extractor_destroy(etd_ext* e) {
   if (!e) return;
   (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   e->pool.free_all();
+  ext32_destroy(e->f32);
   delete e;
 }
 
@@ -314,6 +338,8 @@ extern "C" double etd_extractor_window_flops(const etd_ext* e) {
 namespace {
 
 const float kScaleLog2e = 0.125f * 1.4426950408889634f;
+// ETD_NO_FUSED_FFN=1: the round-1 sequence (FFN1 launch, 512-wide hidden through HBM, FFN2 + LayerNorm launch) for A/B runs
+bool fused_ffn() { static const bool on = !getenv("ETD_NO_FUSED_FFN"); return on; }
 
 int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int n_seq, int S, hipStream_t st,
                    bf16* Yfinal /* where the 2nd LN writes (X to run in place) */) {
@@ -333,6 +359,10 @@ int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int
   o.X = e->AO; o.ldx = 256; o.W = w.o.W; o.bias = w.o.b; o.M = M; o.N = 256; o.K = 256; o.vt_block = -1;
   o.R = X; o.ldr = 256; o.gamma = w.g; o.beta = w.be; o.Y = X1; o.ldy = 256;
   ETD_TRY(launch_linear_ln(o, st));
+  if (fused_ffn()) {
+    FfnArgs f = {X1, w.ffn, w.f1.b, w.f2.b, w.g, w.be, Yfinal, M};
+    return launch_ffn_fused(f, st);
+  }
   LinArgs f1 = {};
   f1.X = X1; f1.ldx = 256; f1.W = w.f1.W; f1.bias = w.f1.b; f1.M = M; f1.N = 512; f1.K = 256; f1.vt_block = -1; f1.relu = 1;
   f1.Y = e->HF; f1.ldy = 512;
@@ -420,6 +450,10 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       o.X = e->AOd; o.ldx = 256; o.W = w.o_c.W; o.bias = w.o_c.b; o.M = Mq; o.N = 256; o.K = 256; o.vt_block = -1;
       o.R = cross_in; o.ldr = 256; o.r_mod = r_mod; o.gamma = w.g; o.beta = w.be; o.Y = D2; o.ldy = 256;
       ETD_TRY(launch_linear_ln(o, st));
+      if (fused_ffn()) {
+        FfnArgs f = {D2, w.ffn, w.f1.b, w.f2.b, w.g, w.be, D0, Mq};
+        ETD_TRY(launch_ffn_fused(f, st));
+      } else {
       LinArgs f1 = {};
       f1.X = D2; f1.ldx = 256; f1.W = w.f1.W; f1.bias = w.f1.b; f1.M = Mq; f1.N = 512; f1.K = 256; f1.vt_block = -1; f1.relu = 1;
       f1.Y = e->HFd; f1.ldy = 512;
@@ -428,6 +462,7 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       f2.X = e->HFd; f2.ldx = 512; f2.W = w.f2.W; f2.bias = w.f2.b; f2.M = Mq; f2.N = 256; f2.K = 512; f2.vt_block = -1;
       f2.R = D2; f2.ldr = 256; f2.gamma = w.g; f2.beta = w.be; f2.Y = D0; f2.ldy = 256;
       ETD_TRY(launch_linear_ln(f2, st));
+      }
       ETD_TRY(tap(e, 4 + l, D0, (size_t)Mq * 512, first, st));
     }
     // freq -> time layout of this chunk, *16 + pos_embedding_time (amt_apc.py:203-205); optional A heads (:186-189)
@@ -459,6 +494,7 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
 }
 
 int run_all(etd_ext* e, EmbedArgs src, int n_windows, Outs B, Outs A, hipStream_t st) {
+  if (e->f32) return ext32_run(e->f32, src, n_windows, Outs32{B.on, B.off, B.mpe, B.vel}, Outs32{A.on, A.off, A.mpe, A.vel}, e->tap, e->dbg_vel, st);
   const bool wantA = A.on && A.off && A.mpe && A.vel;
   for (int w0 = 0; w0 < n_windows; w0 += e->wb) {
     const int nw = (n_windows - w0) < e->wb ? (n_windows - w0) : e->wb;

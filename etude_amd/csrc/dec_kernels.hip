@@ -1177,12 +1177,14 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(AdOcc<N
   dgemm_epilogue<true, DEPI_PARTIAL>(b, acc, m, n0, h);
 }
 
-// waves per attention workgroup: ETD_AD_WAVES (4 / 8 / 16) overrides; default by the launch's row count -- few rows leave
-// wave slots free, so each (row, head) takes more of them and requests its whole context at once
+// waves per attention workgroup: 4, or ETD_AD_WAVES = 8 / 16 (measurement builds).  Measured on MI355X, round 2 (tools/runs/r2_run1.sh):
+// 54 rows x ctx 320, one engine: 0.197 / 0.230 / 0.238 ms per step at 4 / 8 / 16 waves, four engines 9.98 / 9.17 / 8.21
+// engine-steps per ms; 128 rows x ctx 512: 0.356 / 0.349 / 0.419 ms; 128 rows x ctx 3.5 k: 1.290 / 1.343 / 1.362 ms.  Requesting a
+// (row, head)'s whole context at once does NOT shorten the launch: its ~8 us of fixed cost are not the key loop's round trips.
 static int ad_waves(int M) {
   static const int env = getenv("ETD_AD_WAVES") ? atoi(getenv("ETD_AD_WAVES")) : 0;
-  if (env == 4 || env == 8 || env == 16) return env;
-  return M <= 96 ? 16 : (M <= 192 ? 8 : 4);
+  (void)M;
+  return (env == 8 || env == 16) ? env : 4;
 }
 int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, hipStream_t st) {
   if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 256 ||

@@ -1,0 +1,475 @@
+// fp32 parity mode of the Extract stage -- see ext_fp32.h.  Reference ops: etude/models/amt_apc.py (cited per kernel).
+// Everything is the plain, unfused arithmetic of the reference in fp32: GEMMs on the exact-fp32 MFMA tile of the Decode
+// stage's parity mode (k_dgemm: v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain), attention / LayerNorm / heads as
+// straightforward fmaf kernels.  Activations are fp32 row-major [token][256] throughout.
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "ext_fp32.h"
+#include "dec_kernels.h"
+
+namespace {
+
+struct Lin32 { float* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0; };
+struct Enc32 { Lin32 qkv, o, f1, f2; float *g = nullptr, *be = nullptr; };
+struct Dec32 { Lin32 qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; };
+
+}  // namespace
+
+struct Ext32 {
+  etd_ext_cfg cfg;
+  int nf = 0, nn = 0, margin = 0;
+  std::vector<void*> allocs;
+  float *Wf = nullptr, *bfold = nullptr, *pos_freq_enc = nullptr;      // folded conv+linear [256][65], bias [256], [256 bins][256]
+  Enc32 enc[3], tim[3];
+  Dec32 dec[3];
+  float *q0 = nullptr, *trg0 = nullptr, *pos_time = nullptr;
+  Lin32 head_time, head_freq;
+  // one window of workspaces
+  float *X = nullptr, *X1 = nullptr, *QKV = nullptr, *AO = nullptr, *HF = nullptr, *T = nullptr, *KV = nullptr;
+  float *D0 = nullptr, *D1 = nullptr, *D2 = nullptr, *Qd = nullptr, *TI = nullptr, *HL = nullptr;
+  size_t Me = 0, Mq = 0;
+
+  template <typename Tp> int alloc(Tp** p, size_t n) {
+    void* q = nullptr;
+    HIP_TRY(hipMalloc(&q, n * sizeof(Tp) + 256));
+    allocs.push_back(q);
+    *p = (Tp*)q;
+    return ETD_OK;
+  }
+};
+
+namespace {
+
+const float* wget(const WeightMap& w, const std::string& k, int64_t numel) {
+  auto it = w.find(k);
+  if (it == w.end()) { g_etd_err = "missing weight '" + k + "'"; return nullptr; }
+  if (it->second.second != numel) { g_etd_err = "weight '" + k + "' has " + std::to_string(it->second.second) + " elements, expected " + std::to_string(numel); return nullptr; }
+  return it->second.first;
+}
+int up(Ext32* e, float** dst, const float* src, size_t n) {
+  ETD_TRY(e->alloc(dst, n));
+  HIP_TRY(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
+  return ETD_OK;
+}
+// several [out_i][K] linears stacked along the output dimension, rows padded with zeros to a multiple of 128
+int load_stack(Ext32* e, const WeightMap& w, const std::vector<std::string>& pfx, const std::vector<int>& outs, int K, Lin32* l) {
+  int N = 0;
+  for (int o : outs) N += o;
+  const int Npad = (N + 127) / 128 * 128;
+  std::vector<float> W((size_t)Npad * K, 0.f), b(Npad, 0.f);
+  int r = 0;
+  for (size_t i = 0; i < pfx.size(); ++i) {
+    const float* Wi = wget(w, pfx[i] + ".weight", (int64_t)outs[i] * K);
+    const float* bi = wget(w, pfx[i] + ".bias", outs[i]);
+    if (!Wi || !bi) return ETD_EINVAL;
+    memcpy(W.data() + (size_t)r * K, Wi, (size_t)outs[i] * K * 4);
+    memcpy(b.data() + r, bi, (size_t)outs[i] * 4);
+    r += outs[i];
+  }
+  l->N = N; l->Npad = Npad; l->K = K;
+  ETD_TRY(up(e, &l->W, W.data(), W.size()));
+  ETD_TRY(up(e, &l->b, b.data(), b.size()));
+  return ETD_OK;
+}
+int load_ln(Ext32* e, const WeightMap& w, const std::string& p, float** g, float** b) {
+  const float* gw = wget(w, p + ".weight", 256);
+  const float* bw = wget(w, p + ".bias", 256);
+  if (!gw || !bw) return ETD_EINVAL;
+  ETD_TRY(up(e, g, gw, 256));
+  ETD_TRY(up(e, b, bw, 256));
+  return ETD_OK;
+}
+int load_enc(Ext32* e, const WeightMap& w, const std::string& p, Enc32* l) {
+  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, &l->qkv));
+  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, &l->o));
+  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, &l->f1));
+  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, &l->f2));
+  return load_ln(e, w, p + ".layer_norm", &l->g, &l->be);
+}
+
+// ================================================================================================ kernels
+// unfold(2,65,1) -> Conv2d(1,4,(1,5)) -> Linear(244,256) (folded to [256][65] in double on the host) -> *16 + pos_embedding_freq
+//                                                                                                    amt_apc.py:79-109
+__global__ __launch_bounds__(256) void k32_embed(EmbedArgs a, const float* __restrict__ Wf, const float* __restrict__ bf, const float* __restrict__ pos, float* __restrict__ Y) {
+  __shared__ float xs[32][66];
+  const int f = blockIdx.x, b0 = blockIdx.y * 32, o = threadIdx.x, w = a.w0;
+  for (int c = threadIdx.x; c < 32 * 65; c += 256) {
+    const int bin = c / 65, t = c - bin * 65;
+    const int tt = f + t;                       // time index inside the window's input [0, nf + 2 * margin)
+    float v;
+    if (a.feat_mode) {
+      const long long g = (long long)w * a.nf + tt - a.margin;
+      v = (g >= 0 && g < a.T) ? a.src[g * a.s_t + (long long)(b0 + bin) * a.s_bin] : a.pad_value;
+    } else {
+      v = a.src[(long long)w * a.s_win + (long long)(b0 + bin) * a.s_bin + (long long)tt * a.s_t];
+    }
+    xs[bin][t] = v;
+  }
+  float wr[65];
+#pragma unroll
+  for (int t = 0; t < 65; ++t) wr[t] = Wf[o * 65 + t];
+  const float bo = bf[o];
+  __syncthreads();
+  for (int bin = 0; bin < 32; ++bin) {
+    float acc = 0.f;
+#pragma unroll
+    for (int t = 0; t < 65; ++t) acc = fmaf(wr[t], xs[bin][t], acc);
+    Y[((long long)f * 256 + b0 + bin) * 256 + o] = (acc + bo) * 16.f + pos[(b0 + bin) * 256 + o];
+  }
+}
+
+__global__ void k32_relu(float* __restrict__ x, long long n4) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < n4; i += stride) {
+    f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+    reinterpret_cast<f32x4*>(x)[i] = v;
+  }
+}
+
+// Y = LayerNorm(A + R) * g + b over 256 features, one wave per row; R row = r_mod > 0 ? m % r_mod : m      amt_apc.py:250,256
+__global__ __launch_bounds__(256) void k32_add_ln(const float* __restrict__ A, const float* __restrict__ R, int r_mod, const float* __restrict__ g,
+                                                  const float* __restrict__ b, float* __restrict__ Y, int M) {
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int rr = r_mod > 0 ? m % r_mod : m;
+  const f32x4 av = *reinterpret_cast<const f32x4*>(A + (long long)m * 256 + lane * 4);
+  const f32x4 rv = *reinterpret_cast<const f32x4*>(R + (long long)rr * 256 + lane * 4);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = rv[j] + av[j];                 // x + sublayer(x)
+  float s = (v[0] + v[1]) + (v[2] + v[3]);
+  s = wave_sum(s);
+  const float mean = s * (1.f / 256.f);
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const float d = v[j] - mean; q = fmaf(d, d, q); }
+  q = wave_sum(q);
+  const float rstd = 1.f / sqrtf(q * (1.f / 256.f) + 1e-5f);
+  const f32x4 gv = *reinterpret_cast<const f32x4*>(g + lane * 4), bv = *reinterpret_cast<const f32x4*>(b + lane * 4);
+  f32x4 o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (v[j] - mean) * rstd * gv[j] + bv[j];
+  *reinterpret_cast<f32x4*>(Y + (long long)m * 256 + lane * 4) = o;
+}
+
+// softmax(Q K^T / sqrt(64)) V per (sequence, head), head_dim 64, 4 heads                              amt_apc.py:349-368
+// workgroup = 32 queries (4 waves x 8), key tiles of 64 through LDS, online softmax with expf (fp32 like torch.softmax)
+struct Attn32Args {
+  const float* Q; int ldq; long long q_seq;
+  const float* K; int ldk; long long k_seq;
+  const float* V; int ldv; long long v_seq;
+  float* O; int ldo; long long o_seq;
+  int Sq, Sk;
+};
+__global__ __launch_bounds__(256) void k32_attn(Attn32Args a) {
+  __shared__ float Ks[64][65], Vs[64][65], Qs[32][64], Ps[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int seq = blockIdx.y >> 2, head = blockIdx.y & 3, q0 = blockIdx.x * 32;
+  const float* Qb = a.Q + seq * a.q_seq + head * 64;
+  const float* Kb = a.K + seq * a.k_seq + head * 64;
+  const float* Vb = a.V + seq * a.v_seq + head * 64;
+  for (int c = tid; c < 32 * 64; c += 256) {
+    const int qi = c >> 6, d = c & 63;
+    int q = q0 + qi; q = q < a.Sq ? q : a.Sq - 1;
+    Qs[qi][d] = Qb[(long long)q * a.ldq + d];
+  }
+  float mrun[8], lrun[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { mrun[i] = -INFINITY; lrun[i] = 0.f; o[i] = 0.f; }
+  for (int k0 = 0; k0 < a.Sk; k0 += 64) {
+    __syncthreads();
+    for (int c = tid; c < 64 * 64; c += 256) {
+      const int kj = c >> 6, d = c & 63;
+      int key = k0 + kj; key = key < a.Sk ? key : a.Sk - 1;
+      Ks[kj][d] = Kb[(long long)key * a.ldk + d];
+      Vs[kj][d] = Vb[(long long)key * a.ldv + d];
+    }
+    __syncthreads();
+    const bool kvalid = k0 + lane < a.Sk;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float* qrow = Qs[wave * 8 + i];
+      float s = 0.f;
+#pragma unroll 16
+      for (int d = 0; d < 64; ++d) s = fmaf(qrow[d], Ks[lane][d], s);
+      s = kvalid ? s * 0.125f : -INFINITY;
+      const float mx = wave_max(s);
+      const float mnew = fmaxf(mrun[i], mx);
+      const float alpha = expf(mrun[i] - mnew);              // first tile: exp(-inf) = 0
+      const float p = kvalid ? expf(s - mnew) : 0.f;
+      lrun[i] = lrun[i] * alpha + wave_sum(p);
+      mrun[i] = mnew;
+      Ps[wave][lane] = p;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      float acc = 0.f;
+#pragma unroll 16
+      for (int j = 0; j < 64; ++j) acc = fmaf(Ps[wave][j], Vs[j][lane], acc);
+      o[i] = o[i] * alpha + acc;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = q0 + wave * 8 + i;
+    if (q < a.Sq) a.O[seq * a.o_seq + (long long)q * a.ldo + head * 64 + lane] = o[i] / lrun[i];
+  }
+}
+
+// logits [M][ld] (0..127 velocity, 128 onset, 129 offset, 130 mpe) -> sigmoid (fp32) / argmax (lowest index on ties)
+//                                                                amt_apc.py:186-189,217-220 + extractor.py:242,248
+__global__ __launch_bounds__(256) void k32_heads_epi(const float* __restrict__ L, int ld, HeadsArgs a) {
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= a.M) return;
+  const float* lg = L + (long long)m * ld;
+  const float v0 = lg[lane], v1 = lg[lane + 64];
+  float best = v0; int bi = lane;
+  if (v1 > best) { best = v1; bi = lane + 64; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  long long oidx;
+  if (a.time_layout) {
+    const int per_w = a.nn * a.nf;
+    const int w = m / per_w, rem = m - w * per_w, note = rem / a.nf, f = rem - note * a.nf;
+    oidx = ((long long)w * a.nf + f) * a.nn + note;
+  } else {
+    oidx = m;
+  }
+  oidx += a.out_off;
+  if (lane == 0) {
+    a.vel[oidx] = (int8_t)bi;
+    a.onset[oidx] = 1.f / (1.f + expf(-lg[128]));
+    a.offset[oidx] = 1.f / (1.f + expf(-lg[129]));
+    a.mpe[oidx] = 1.f / (1.f + expf(-lg[130]));
+  }
+  if (a.vel_logit) { a.vel_logit[oidx * 128 + lane] = v0; a.vel_logit[oidx * 128 + lane + 64] = v1; }
+}
+
+// freq-major [(f*nn + note)][256] -> time-major [(note*nf + f)][256] = x*16 + pos_embedding_time[f]     amt_apc.py:203-205
+__global__ void k32_freq2time(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ pos, int nf, int nn) {
+  const long long total = (long long)nf * nn * 64;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total; i += stride) {
+    const int ch = (int)(i & 63);
+    const long long row = i >> 6;
+    const int note = (int)(row % nn), f = (int)(row / nn);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * 256 + ch * 4);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (long long)f * 256 + ch * 4);
+    const f32x4 o = {v[0] * 16.f + p[0], v[1] * 16.f + p[1], v[2] * 16.f + p[2], v[3] * 16.f + p[3]};
+    *reinterpret_cast<f32x4*>(dst + ((long long)note * nf + f) * 256 + ch * 4) = o;
+  }
+}
+
+// ================================================================================================ launch helpers
+int gemm32(const float* X, int ldx, const Lin32& w, int M, float* Y, int ldy, hipStream_t st) {
+  DGemmArgs a = {};
+  a.X = X; a.ldx = ldx; a.W = w.W; a.bias = w.b; a.M = M; a.N = w.N; a.Npad = w.Npad; a.K = w.K; a.Y = Y; a.ldy = ldy;
+  return launch_dgemm(a, DEPI_BIAS, false, st);
+}
+int add_ln(const float* A, const float* R, int r_mod, const float* g, const float* b, float* Y, int M, hipStream_t st) {
+  hipLaunchKernelGGL(k32_add_ln, dim3((M + 3) / 4), dim3(256), 0, st, A, R, r_mod, g, b, Y, M);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+int attn32(const float* Q, int ldq, long long q_seq, const float* K, int ldk, long long k_seq, const float* V, int ldv, long long v_seq,
+           float* O, int ldo, long long o_seq, int n_seq, int Sq, int Sk, hipStream_t st) {
+  Attn32Args a{Q, ldq, q_seq, K, ldk, k_seq, V, ldv, v_seq, O, ldo, o_seq, Sq, Sk};
+  hipLaunchKernelGGL(k32_attn, dim3((Sq + 31) / 32, n_seq * 4), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+int relu32(float* x, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(k32_relu, dim3(2048), dim3(256), 0, st, x, n / 4);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// x = LN(x + MHA(x)); x = LN(x + FFN(x)), one shared LayerNorm                                          amt_apc.py:244-259
+int enc_layer32(Ext32* e, const Enc32& w, float* X, int M, int n_seq, int S, hipStream_t st) {
+  ETD_TRY(gemm32(X, 256, w.qkv, M, e->QKV, 768, st));
+  ETD_TRY(attn32(e->QKV, 768, (long long)S * 768, e->QKV + 256, 768, (long long)S * 768, e->QKV + 512, 768, (long long)S * 768,
+                 e->AO, 256, (long long)S * 256, n_seq, S, S, st));
+  ETD_TRY(gemm32(e->AO, 256, w.o, M, e->T, 256, st));
+  ETD_TRY(add_ln(e->T, X, 0, w.g, w.be, e->X1, M, st));
+  ETD_TRY(gemm32(e->X1, 256, w.f1, M, e->HF, 512, st));
+  ETD_TRY(relu32(e->HF, (long long)M * 512, st));
+  ETD_TRY(gemm32(e->HF, 512, w.f2, M, e->T, 256, st));
+  ETD_TRY(add_ln(e->T, e->X1, 0, w.g, w.be, X, M, st));
+  return ETD_OK;
+}
+
+int tap32(void* const* tap, int stage, const float* src, size_t rows, bool first, hipStream_t st) {
+  if (first && tap && tap[stage]) HIP_TRY(hipMemcpyAsync(tap[stage], src, rows * 256 * 4, hipMemcpyDeviceToDevice, st));
+  return ETD_OK;
+}
+
+}  // namespace
+
+int ext32_create(const etd_ext_cfg& c, const WeightMap& w, Ext32** out) {
+  Ext32* e = new Ext32();
+  e->cfg = c; e->nf = c.n_frame; e->nn = c.n_note; e->margin = c.n_margin;
+  auto fail = [&](int rc) { ext32_destroy(e); return rc; };
+  {
+    const float* cw = wget(w, "encoder.conv.weight", 4 * 5);
+    const float* cb = wget(w, "encoder.conv.bias", 4);
+    const float* tw = wget(w, "encoder.tok_embedding_freq.weight", 256 * 244);
+    const float* tb = wget(w, "encoder.tok_embedding_freq.bias", 256);
+    const float* pe = wget(w, "encoder.pos_embedding_freq.weight", 256 * 256);
+    if (!cw || !cb || !tw || !tb || !pe) return fail(ETD_EINVAL);
+    std::vector<float> Wf(256 * 65), bf(256);
+    for (int o = 0; o < 256; ++o) {
+      double fold[65] = {0};
+      double bacc = tb[o];
+      for (int ch = 0; ch < 4; ++ch)
+        for (int p = 0; p < 61; ++p) {
+          const double wv = tw[o * 244 + ch * 61 + p];
+          bacc += wv * cb[ch];
+          for (int k = 0; k < 5; ++k) fold[p + k] += wv * cw[ch * 5 + k];
+        }
+      for (int t = 0; t < 65; ++t) Wf[o * 65 + t] = (float)fold[t];
+      bf[o] = (float)bacc;
+    }
+    int rc = up(e, &e->Wf, Wf.data(), Wf.size()); if (rc) return fail(rc);
+    rc = up(e, &e->bfold, bf.data(), 256); if (rc) return fail(rc);
+    rc = up(e, &e->pos_freq_enc, pe, 256 * 256); if (rc) return fail(rc);
+  }
+  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "encoder.layers_freq." + std::to_string(i), &e->enc[i]); if (rc) return fail(rc); }
+  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "decoder.layers_time." + std::to_string(i), &e->tim[i]); if (rc) return fail(rc); }
+  for (int i = 0; i < 3; ++i) {
+    const std::string p = i == 0 ? std::string("decoder.layer_zero_freq") : "decoder.layers_freq." + std::to_string(i - 1);
+    Dec32& d = e->dec[i];
+    d.has_self = i > 0;
+    int rc;
+    if (d.has_self) {
+      rc = load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, &d.qkv_s); if (rc) return fail(rc);
+      rc = load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, &d.o_s); if (rc) return fail(rc);
+    }
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_q"}, {256}, 256, &d.q_c); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_k", p + ".encoder_attention.fc_v"}, {256, 256}, 256, &d.kv_c); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_o"}, {256}, 256, &d.o_c); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, &d.f1); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, &d.f2); if (rc) return fail(rc);
+    rc = load_ln(e, w, p + ".layer_norm", &d.g, &d.be); if (rc) return fail(rc);
+  }
+  {
+    const int nn = e->nn;
+    const float* pe = wget(w, "decoder.pos_embedding_freq.weight", (int64_t)nn * 256);
+    const float* qw = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.weight", 256 * 256);
+    const float* qb = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.bias", 256);
+    const float* pt = wget(w, "decoder.pos_embedding_time.weight", (int64_t)e->nf * 256);
+    if (!pe || !qw || !qb || !pt) return fail(ETD_EINVAL);
+    std::vector<float> q0((size_t)nn * 256);          // layer-zero queries are input independent: fc_q(pos_embedding_freq)   amt_apc.py:168-175
+    for (int r = 0; r < nn; ++r)
+      for (int o = 0; o < 256; ++o) {
+        float s = 0.f;                                 // fp32 dot products in k order, + bias: what F.linear computes up to summation order
+        for (int k = 0; k < 256; ++k) s = fmaf(pe[r * 256 + k], qw[o * 256 + k], s);
+        q0[(size_t)r * 256 + o] = s + qb[o];
+      }
+    int rc = up(e, &e->q0, q0.data(), q0.size()); if (rc) return fail(rc);
+    rc = up(e, &e->trg0, pe, (size_t)nn * 256); if (rc) return fail(rc);
+    rc = up(e, &e->pos_time, pt, (size_t)e->nf * 256); if (rc) return fail(rc);
+  }
+  for (int t = 0; t < 2; ++t) {
+    const std::string sfx = t == 0 ? "time" : "freq";
+    int rc = load_stack(e, w, {"decoder.fc_velocity_" + sfx, "decoder.fc_onset_" + sfx, "decoder.fc_offset_" + sfx, "decoder.fc_mpe_" + sfx}, {128, 1, 1, 1}, 256,
+                        t == 0 ? &e->head_time : &e->head_freq);
+    if (rc) return fail(rc);
+  }
+  const size_t Me = (size_t)e->nf * 256, Mq = (size_t)e->nf * e->nn;
+  e->Me = Me; e->Mq = Mq;
+  int rc = 0;
+  rc = rc ? rc : e->alloc(&e->X, Me * 256); rc = rc ? rc : e->alloc(&e->X1, Me * 256); rc = rc ? rc : e->alloc(&e->QKV, Me * 768);
+  rc = rc ? rc : e->alloc(&e->AO, Me * 256); rc = rc ? rc : e->alloc(&e->HF, Me * 512); rc = rc ? rc : e->alloc(&e->T, Me * 256);
+  rc = rc ? rc : e->alloc(&e->KV, 3 * Me * 512);
+  rc = rc ? rc : e->alloc(&e->D0, Mq * 256); rc = rc ? rc : e->alloc(&e->D1, Mq * 256); rc = rc ? rc : e->alloc(&e->D2, Mq * 256);
+  rc = rc ? rc : e->alloc(&e->Qd, Mq * 256); rc = rc ? rc : e->alloc(&e->TI, Mq * 256); rc = rc ? rc : e->alloc(&e->HL, Mq * 256);
+  if (rc) return fail(rc);
+  *out = e;
+  return ETD_OK;
+}
+
+void ext32_destroy(Ext32* e) {
+  if (!e) return;
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+int ext32_run(Ext32* e, const EmbedArgs& src, int n_windows, Outs32 B, Outs32 A, void* const* tap, float* dbg_vel, hipStream_t st) {
+  const int nf = e->nf, nn = e->nn, Me = nf * 256, Mq = nf * nn;
+  const bool wantA = A.on && A.off && A.mpe && A.vel;
+  for (int w = 0; w < n_windows; ++w) {
+    const bool first = w == 0;
+    // ---- encoder                                                                                      amt_apc.py:74-120
+    EmbedArgs ea = src;
+    ea.w0 = w; ea.nf = nf; ea.margin = e->margin; ea.pad_value = e->cfg.min_value;
+    hipLaunchKernelGGL(k32_embed, dim3(nf, 8), dim3(256), 0, st, ea, e->Wf, e->bfold, e->pos_freq_enc, e->X);
+    HIP_TRY(hipGetLastError());
+    ETD_TRY(tap32(tap, 0, e->X, Me, first, st));
+    for (int l = 0; l < 3; ++l) {
+      ETD_TRY(enc_layer32(e, e->enc[l], e->X, Me, nf, 256, st));
+      ETD_TRY(tap32(tap, 1 + l, e->X, Me, first, st));
+    }
+    // ---- frequency decoder: 88 note queries per frame against the frame's 256 encoder tokens             amt_apc.py:168-177,261-320
+    float *D0 = e->D0, *D1 = e->D1, *D2 = e->D2;
+    for (int l = 0; l < 3; ++l) {
+      const Dec32& d = e->dec[l];
+      float* KVl = e->KV + (size_t)l * Me * 512;
+      ETD_TRY(gemm32(e->X, 256, d.kv_c, Me, KVl, 512, st));
+      const float* cross_in = D0; int r_mod = 0;
+      if (l == 0) { cross_in = e->trg0; r_mod = nn; }
+      if (d.has_self) {
+        ETD_TRY(gemm32(D0, 256, d.qkv_s, Mq, e->QKV, 768, st));
+        ETD_TRY(attn32(e->QKV, 768, (long long)nn * 768, e->QKV + 256, 768, (long long)nn * 768, e->QKV + 512, 768, (long long)nn * 768,
+                       e->AO, 256, (long long)nn * 256, nf, nn, nn, st));
+        ETD_TRY(gemm32(e->AO, 256, d.o_s, Mq, e->T, 256, st));
+        ETD_TRY(add_ln(e->T, D0, 0, d.g, d.be, D1, Mq, st));
+        cross_in = D1;
+      }
+      const float* Qp; long long q_seq;
+      if (l == 0) { Qp = e->q0; q_seq = 0; }
+      else { ETD_TRY(gemm32(cross_in, 256, d.q_c, Mq, e->Qd, 256, st)); Qp = e->Qd; q_seq = (long long)nn * 256; }
+      ETD_TRY(attn32(Qp, 256, q_seq, KVl, 512, 256LL * 512, KVl + 256, 512, 256LL * 512, e->AO, 256, (long long)nn * 256, nf, nn, 256, st));
+      ETD_TRY(gemm32(e->AO, 256, d.o_c, Mq, e->T, 256, st));
+      ETD_TRY(add_ln(e->T, cross_in, r_mod, d.g, d.be, D2, Mq, st));
+      ETD_TRY(gemm32(D2, 256, d.f1, Mq, e->HF, 512, st));
+      ETD_TRY(relu32(e->HF, (long long)Mq * 512, st));
+      ETD_TRY(gemm32(e->HF, 512, d.f2, Mq, e->T, 256, st));
+      ETD_TRY(add_ln(e->T, D2, 0, d.g, d.be, D0, Mq, st));
+      ETD_TRY(tap32(tap, 4 + l, D0, Mq, first, st));
+    }
+    const long long out_row0 = (long long)w * nf;
+    if (wantA) {
+      ETD_TRY(gemm32(D0, 256, e->head_freq, Mq, e->HL, 256, st));
+      HeadsArgs h = {};
+      h.M = Mq; h.time_layout = 0; h.nf = nf; h.nn = nn; h.out_off = out_row0 * nn;
+      h.onset = A.on; h.offset = A.off; h.mpe = A.mpe; h.vel = A.vel;
+      hipLaunchKernelGGL(k32_heads_epi, dim3((Mq + 3) / 4), dim3(256), 0, st, e->HL, 256, h);
+      HIP_TRY(hipGetLastError());
+    }
+    // ---- time decoder: nn sequences of nf frames                                                       amt_apc.py:203-220
+    hipLaunchKernelGGL(k32_freq2time, dim3(2048), dim3(256), 0, st, D0, e->TI, e->pos_time, nf, nn);
+    HIP_TRY(hipGetLastError());
+    ETD_TRY(tap32(tap, 7, e->TI, Mq, first, st));
+    for (int l = 0; l < 3; ++l) {
+      ETD_TRY(enc_layer32(e, e->tim[l], e->TI, Mq, nn, nf, st));
+      ETD_TRY(tap32(tap, 8 + l, e->TI, Mq, first, st));
+    }
+    ETD_TRY(gemm32(e->TI, 256, e->head_time, Mq, e->HL, 256, st));
+    HeadsArgs h = {};
+    h.M = Mq; h.time_layout = 1; h.nf = nf; h.nn = nn; h.out_off = out_row0 * nn;
+    h.onset = B.on; h.offset = B.off; h.mpe = B.mpe; h.vel = B.vel;
+    h.vel_logit = dbg_vel ? dbg_vel + out_row0 * nn * 128 : nullptr;
+    hipLaunchKernelGGL(k32_heads_epi, dim3((Mq + 3) / 4), dim3(256), 0, st, e->HL, 256, h);
+    HIP_TRY(hipGetLastError());
+  }
+  return ETD_OK;
+}

@@ -99,3 +99,15 @@ int launch_freq2time(const bf16* src, bf16* dst, const float* pos, int nw, int f
 
 // small utilities
 int launch_f32_to_bf16(const float* src, bf16* dst, long long n, hipStream_t st);
+
+// ---- fused position-wise feed-forward sub-layer (csrc/ext_fused.hip): Y = LN(X + relu(X W1^T + b1) W2^T + b2) * gamma + beta
+struct FfnArgs {
+  const bf16* X;               // [M][256] bf16 row-major (also the residual)
+  const bf16* Wf;              // packed weight stream (pack_ffn_weights): [16][32][64][8]
+  const float* b1;             // [512]
+  const float* b2; const float* gamma; const float* beta;   // [256] each
+  bf16* Y;                     // [M][256]; may alias X (a token's row is read completely before it is written, by the same lane pair)
+  int M;
+};
+int launch_ffn_fused(const FfnArgs& a, hipStream_t st);
+void pack_ffn_weights(const float* W1, const float* W2, uint16_t* dst, uint16_t (*f2bf)(float));

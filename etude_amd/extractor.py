@@ -100,7 +100,8 @@ class AMTAPC_Extractor:
     """Audio -> notes (JSON/MIDI) on one MI355X.  Signature of etude/data/extractor.py:121-146."""
 
     def __init__(self, config: Optional[ExtractorConfig], model_path: Union[str, Path, Dict[str, np.ndarray]],
-                 device: Union[str, torch.device] = "auto", max_windows: int = 4, chunk_frames: int = 0, stft_pad_mode: str = "reflect"):
+                 device: Union[str, torch.device] = "auto", max_windows: int = 4, chunk_frames: int = 0, stft_pad_mode: str = "reflect",
+                 precision: Optional[str] = None):
         if device == "auto":
             device = "cuda"
         self.device = torch.device(device)
@@ -110,13 +111,20 @@ class AMTAPC_Extractor:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.config = config if config is not None else ExtractorConfig()
         c = self.config
+        # "bf16" (default): bf16 operands, fp32 accumulate -- the serving path.  "fp32": the parity mode (csrc/ext_fp32.hip), fp32 end
+        # to end like the reference (extractor.py runs the model in fp32), ~20x slower; also selectable with ETD_EXTRACTOR_PRECISION.
+        import os
+        precision = precision or os.environ.get("ETD_EXTRACTOR_PRECISION", "bf16")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
         state = model_path if isinstance(model_path, dict) else load_extractor_state(model_path)
         cfg = _lib.ExtCfg(n_margin=c.input.margin_b, n_frame=c.input.num_frame, n_bin=c.feature.n_bins,
                           cnn_channel=c.model.cnn_channel, cnn_kernel=c.model.cnn_kernel, hid_dim=c.model.transformer_hid_dim,
                           pf_dim=c.model.transformer_pf_dim, n_heads=c.model.encoder_n_head,
                           n_layers_enc=c.model.encoder_n_layer, n_layers_dec=c.model.decoder_n_layer,
                           n_note=c.midi.num_note, n_velocity=c.midi.num_velocity, min_value=c.input.min_value,
-                          max_windows=max_windows, chunk_frames=chunk_frames)
+                          max_windows=max_windows, chunk_frames=chunk_frames, precision=1 if precision == "fp32" else 0)
         if c.input.margin_b != c.input.margin_f:
             raise _lib.EtudeHipError("margin_b != margin_f is not supported")
         if c.model.encoder_n_head != c.model.decoder_n_head:

@@ -93,6 +93,9 @@ typedef struct {
   float min_value;        /* -18.0: padding value of _transcript */
   int max_windows;        /* windows processed per internal batch (workspace size) */
   int chunk_frames;       /* frames per encoder/freq-decoder chunk (0 = default) */
+  int precision;          /* 0 = bf16 compute, fp32 accumulate / LayerNorm / softmax / sigmoid (default, the fast path);
+                             1 = fp32 parity mode: fp32 weights and activations, exact-fp32 products (csrc/ext_fp32.hip), one window
+                             at a time -- what the note-level parity tests run on */
 } etd_ext_cfg;
 /* Weights: n named fp32 host tensors with the reference checkpoint's own keys ("encoder.*",
  * "decoder.*"); every key the model needs must be present with the right element count. */

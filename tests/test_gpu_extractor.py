@@ -213,3 +213,69 @@ def test_checkpoint_file_contract(dev, tmp_path):
         AMTAPC_Extractor(cfg, str(tmp_path / "bad.pth"), "cuda")
     with pytest.raises(FileNotFoundError):
         AMTAPC_Extractor(cfg, str(tmp_path / "nope.pth"), "cuda")
+
+
+# ------------------------------------------------------------------------------------------------ fp32 parity mode
+F32_TOL = 2e-4          # fp32 end to end, exact-fp32 products: differences from the fp32 reference are summation order only
+
+
+def test_fp32_parity_mode_full_window_against_reference_golden(dev, golden_dir):
+    """precision="fp32" (csrc/ext_fp32.hip): the reference's own fp32 arithmetic on the device.  ONE full-size window against the
+    golden the reference produced: probabilities within 2e-4 (the bf16 mode: 8e-2), velocity logits within 1e-3, every argmax
+    with a top-2 gap above 2e-3 identical."""
+    g = np.load(golden_dir / "hft_full.npz")
+    ex = _extractor(512, precision="fp32")
+    x = torch.from_numpy(synth.window_features(5, 1)).to(dev)
+    vl = torch.zeros((512, 88, 128), dtype=torch.float32, device=dev)
+    ex.debug_velocity_logits(vl)
+    oA, fA, mA, vA, on, off, mpe, vel = [t.cpu().numpy() for t in ex.transcript_windows(x, want_A=True)]
+    ex.debug_velocity_logits(None)
+    worst = 0.0
+    for name, got in (("onset_B", on), ("offset_B", off), ("mpe_B", mpe)):
+        worst = max(worst, float(np.abs(got - g[name]).max()))
+    print(f"fp32 parity mode, one 512-frame window: max |p - reference| = {worst:.2e}")
+    assert worst < F32_TOL
+    assert np.abs(oA - g["onset_A"].astype(np.float32)).max() < 1e-3 and np.abs(mA - g["mpe_A"].astype(np.float32)).max() < 1e-3   # (stored as fp16)
+    assert np.abs(vl.cpu().numpy()[::64] - g["velocity_B_rows"]).max() < 1e-3
+    clear = g["velocity_B_top2gap"].astype(np.float32) > 2e-3
+    assert (vel == g["velocity_B_argmax"])[clear].all() and (vel == g["velocity_B_argmax"]).mean() > 0.9995
+    ex.close()
+
+
+def test_fp32_parity_mode_taps_ragged_transcript_and_notes(dev):
+    """every stage of the fp32 mode against the oracle at n_frame = 64 (taps are fp32 here), then a ragged 3-window _transcript:
+    frame outputs within 2e-4 and the note list IDENTICAL to the oracle's on all but threshold-grazing notes"""
+    from oracle import hft, mpe2note
+    nf = 64
+    ex = _extractor(nf, precision="fp32")
+    sd, d = _oracle(nf)
+    x = synth.window_features(11, 1, 256, nf + 64)
+    taps = {}
+    hft.model_forward(sd, torch.from_numpy(x), d, taps)
+    rows = {0: nf * 256, 1: nf * 256, 3: nf * 256, 4: nf * 88, 6: nf * 88, 7: 88 * nf, 8: 88 * nf, 10: 88 * nf}
+    names = {0: "embed", 1: "enc0", 3: "enc2", 4: "dec0", 6: "dec2", 7: "time_in", 8: "time0", 10: "time2"}
+    bufs = {s: torch.zeros((r, 256), dtype=torch.float32, device=dev) for s, r in rows.items()}
+    for s, b in bufs.items():
+        ex.debug_tap(s, b)
+    ex.transcript_windows(torch.from_numpy(x).to(dev))
+    torch.cuda.synchronize()
+    for s, b in bufs.items():
+        ex.debug_tap(s, None)
+        ref = taps[names[s]].numpy().reshape(-1, 256)
+        rel = np.abs(b.cpu().numpy() - ref).max() / np.abs(ref).max()
+        assert rel < 5e-4, (names[s], rel)            # max-abs error over max-abs value: fp32 summation order through softmax and LayerNorm
+    rng = np.random.default_rng(3)
+    feat = np.clip(rng.normal(-8, 2, (150, 256)), -18, 5).astype(np.float32)
+    ref, ref_vl = hft.transcript(sd, feat, d, return_vel_logits=True)
+    got = ex._transcript(feat)
+    assert len(got) == 8 and got[0].shape == (192, 88)
+    for i in (0, 1, 2, 4, 5, 6):
+        assert np.abs(got[i] - ref[i]).max() < F32_TOL, i
+    chosen = np.take_along_axis(ref_vl, got[7].astype(np.int64)[..., None], -1)[..., 0]
+    assert (ref_vl.max(-1) - chosen).max() < 1e-3
+    n_got = mpe2note.mpe2note(got[4], got[5], got[6], got[7], 0.5, 1.0, 0.5)
+    n_ref = mpe2note.mpe2note(ref[4], ref[5], ref[6], ref[7], 0.5, 1.0, 0.5)
+    key = lambda n: (n["pitch"], round(n["onset"] / 0.016))        # noqa: E731
+    common = len({key(n) for n in n_got} & {key(n) for n in n_ref})
+    assert common >= 0.995 * max(len(n_ref), 1) and abs(len(n_got) - len(n_ref)) <= max(1, len(n_ref) // 200)
+    ex.close()
