@@ -38,8 +38,10 @@ inline uint16_t f2bf(float f) {   // round-to-nearest-even, NaN kept
 }
 
 struct LinW { bf16* W = nullptr; float* b = nullptr; };
-struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; bf16* ffn = nullptr; /* fused-FFN weight stream (ext_fused.hip) */ };
-struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; bf16* ffn = nullptr; };
+// p*: the same Linear weights as 256 x 256 blocks in k_proj256's fragment-ordered stream (ext_fused.hip); ffn: k_ffn_fused's stream
+struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; bf16 *ffn = nullptr, *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr; };
+struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; bf16* ffn = nullptr;
+                   bf16 *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *pqc = nullptr, *pkc = nullptr, *pvc = nullptr, *poc = nullptr; };
 
 }  // namespace
 
@@ -136,8 +138,22 @@ int load_ffn_stream(DevPool& pool, Loader& L, const std::string& p, bf16** dst) 
   HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
   return ETD_OK;
 }
+// one [256][256] Linear as a k_proj256 block (rows permuted for row-major / LayerNorm blocks, natural for V^T blocks)
+int load_proj_block(DevPool& pool, Loader& L, const std::string& name, bool permute_rows, bf16** dst) {
+  const float* W = L.get(name + ".weight", 256 * 256);
+  if (!W) return ETD_EINVAL;
+  std::vector<uint16_t> h((size_t)256 * 256);
+  pack_proj_weights(W, permute_rows, h.data(), f2bf);
+  ETD_TRY(pool.alloc(dst, h.size()));
+  HIP_TRY(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  return ETD_OK;
+}
 int load_enc_layer(DevPool& pool, Loader& L, const std::string& p, EncLayerW* w) {
   ETD_TRY(load_ffn_stream(pool, L, p + ".positionwise_feedforward", &w->ffn));
+  ETD_TRY(load_proj_block(pool, L, p + ".self_attention.fc_q", true, &w->pq));
+  ETD_TRY(load_proj_block(pool, L, p + ".self_attention.fc_k", true, &w->pk));
+  ETD_TRY(load_proj_block(pool, L, p + ".self_attention.fc_v", false, &w->pv));
+  ETD_TRY(load_proj_block(pool, L, p + ".self_attention.fc_o", true, &w->po));
   ETD_TRY(load_cat(pool, L, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, &w->qkv));
   ETD_TRY(load_lin(pool, L, p + ".self_attention.fc_o", 256, 256, &w->o));
   ETD_TRY(load_lin(pool, L, p + ".positionwise_feedforward.fc_1", 512, 256, &w->f1));
@@ -239,7 +255,15 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
     if (w.has_self) {
       rc = load_cat(P, L, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, &w.qkv_s); if (rc) return fail(rc);
       rc = load_lin(P, L, p + ".self_attention.fc_o", 256, 256, &w.o_s); if (rc) return fail(rc);
+      rc = load_proj_block(P, L, p + ".self_attention.fc_q", true, &w.pq); if (rc) return fail(rc);
+      rc = load_proj_block(P, L, p + ".self_attention.fc_k", true, &w.pk); if (rc) return fail(rc);
+      rc = load_proj_block(P, L, p + ".self_attention.fc_v", false, &w.pv); if (rc) return fail(rc);
+      rc = load_proj_block(P, L, p + ".self_attention.fc_o", true, &w.po); if (rc) return fail(rc);
     }
+    rc = load_proj_block(P, L, p + ".encoder_attention.fc_q", true, &w.pqc); if (rc) return fail(rc);
+    rc = load_proj_block(P, L, p + ".encoder_attention.fc_k", true, &w.pkc); if (rc) return fail(rc);
+    rc = load_proj_block(P, L, p + ".encoder_attention.fc_v", false, &w.pvc); if (rc) return fail(rc);
+    rc = load_proj_block(P, L, p + ".encoder_attention.fc_o", true, &w.poc); if (rc) return fail(rc);
     rc = load_lin(P, L, p + ".encoder_attention.fc_q", 256, 256, &w.q_c); if (rc) return fail(rc);
     std::vector<float> W1, b1;
     rc = load_cat(P, L, {p + ".encoder_attention.fc_k", p + ".encoder_attention.fc_v"}, &w.kv_c, &W1, &b1); if (rc) return fail(rc);
@@ -340,6 +364,28 @@ namespace {
 const float kScaleLog2e = 0.125f * 1.4426950408889634f;
 // ETD_NO_FUSED_FFN=1: the round-1 sequence (FFN1 launch, 512-wide hidden through HBM, FFN2 + LayerNorm launch) for A/B runs
 bool fused_ffn() { static const bool on = !getenv("ETD_NO_FUSED_FFN"); return on; }
+// ETD_NO_FUSED_PROJ=1: the K = 256 projections on round 1's k_linear tiles instead of k_proj256
+bool fused_proj() { static const bool on = !getenv("ETD_NO_FUSED_PROJ"); return on; }
+
+ProjBlock pblock(const bf16* Wf, const float* bias, int kind, bf16* dst, int ldd, int relu = 0) {
+  ProjBlock b = {}; b.Wf = Wf; b.bias = bias; b.kind = kind; b.relu = relu; b.dst = dst; b.ldd = ldd; return b;
+}
+// Q | K row-major into QK[tok][512], V transposed into VT: ONE launch, the token tile is read once
+int proj_qkv(const bf16* X, int M, const bf16* pq, const bf16* pk, const bf16* pv, const float* bias768, bf16* QK, bf16* VT, int S, int Spad, hipStream_t st) {
+  ProjArgs a = {};
+  a.X = X; a.ldx = 256; a.M = M; a.nblk = 3; a.S = S; a.Spad = Spad;
+  a.blk[0] = pblock(pq, bias768, PROJ_ROW, QK, 512);
+  a.blk[1] = pblock(pk, bias768 + 256, PROJ_ROW, QK + 256, 512);
+  a.blk[2] = pblock(pv, bias768 + 512, PROJ_VT, VT, 0);
+  return launch_proj256(a, st);
+}
+// Y = LN(R + X Wo^T + b) * gamma + beta
+int proj_ln(const bf16* X, int M, const bf16* po, const float* bias, const bf16* R, int r_mod, const float* g, const float* be, bf16* Y, hipStream_t st) {
+  ProjArgs a = {};
+  a.X = X; a.ldx = 256; a.M = M; a.nblk = 1; a.R = R; a.r_mod = r_mod; a.gamma = g; a.beta = be;
+  a.blk[0] = pblock(po, bias, PROJ_LN, Y, 256);
+  return launch_proj256(a, st);
+}
 
 int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int n_seq, int S, hipStream_t st,
                    bf16* Yfinal /* where the 2nd LN writes (X to run in place) */) {
@@ -347,7 +393,8 @@ int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int
   LinArgs a = {};
   a.X = X; a.ldx = 256; a.W = w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = 768; a.K = 256;
   a.Y = e->QK; a.ldy = 512; a.vt_block = 2; a.VT = e->VT; a.S = S; a.Spad = ((S + 63) / 64) * 64;
-  ETD_TRY(launch_linear(a, 1, st));
+  if (fused_proj()) ETD_TRY(proj_qkv(X, M, w.pq, w.pk, w.pv, w.qkv.b, e->QK, e->VT, S, a.Spad, st));
+  else ETD_TRY(launch_linear(a, 1, st));
   AttnArgs t = {};
   t.Q = e->QK; t.ldq = 512; t.q_seq_stride = (long long)S * 512;
   t.K = e->QK + 256; t.ldk = 512; t.k_seq_stride = (long long)S * 512;
@@ -358,7 +405,8 @@ int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int
   LinArgs o = {};
   o.X = e->AO; o.ldx = 256; o.W = w.o.W; o.bias = w.o.b; o.M = M; o.N = 256; o.K = 256; o.vt_block = -1;
   o.R = X; o.ldr = 256; o.gamma = w.g; o.beta = w.be; o.Y = X1; o.ldy = 256;
-  ETD_TRY(launch_linear_ln(o, st));
+  if (fused_proj()) ETD_TRY(proj_ln(e->AO, M, w.po, w.o.b, X, 0, w.g, w.be, X1, st));
+  else ETD_TRY(launch_linear_ln(o, st));
   if (fused_ffn()) {
     FfnArgs f = {X1, w.ffn, w.f1.b, w.f2.b, w.g, w.be, Yfinal, M};
     return launch_ffn_fused(f, st);
@@ -404,7 +452,18 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       a.X = e->X; a.ldx = 256; a.W = e->Wkv_all; a.bias = e->bkv_all; a.M = Mtok; a.N = 512; a.K = 256;
       a.Y = e->Kc; a.ldy = 256; a.vt_block = 1; a.VT = e->VTc; a.S = 256; a.Spad = 256;
       a.wz = 512 * 256; a.bz = 512; a.yz = (long long)e->MTe * 256; a.vtz = (long long)e->MTe * 256;
-      ETD_TRY(launch_linear(a, 3, st));
+      if (fused_proj()) {
+        // the three decoder layers' K and V^T of the encoder output in ONE launch: six blocks over the same token tile
+        ProjArgs pa = {};
+        pa.X = e->X; pa.ldx = 256; pa.M = Mtok; pa.nblk = 6; pa.S = 256; pa.Spad = 256;
+        for (int l = 0; l < 3; ++l) {
+          pa.blk[2 * l] = pblock(e->dec[l].pkc, e->bkv_all + l * 512, PROJ_ROW, e->Kc + (size_t)l * e->MTe * 256, 256);
+          pa.blk[2 * l + 1] = pblock(e->dec[l].pvc, e->bkv_all + l * 512 + 256, PROJ_VT, e->VTc + (size_t)l * e->MTe * 256, 0);
+        }
+        ETD_TRY(launch_proj256(pa, st));
+      } else {
+        ETD_TRY(launch_linear(a, 3, st));
+      }
     }
     // ---- frequency decoder (amt_apc.py:168-177,261-320): queries = 88 note embeddings per frame
     // D0 = layer input/output, D1 = after self-attention LN, D2 = after cross-attention LN
@@ -418,7 +477,8 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
         LinArgs a = {};
         a.X = D0; a.ldx = 256; a.W = w.qkv_s.W; a.bias = w.qkv_s.b; a.M = Mq; a.N = 768; a.K = 256;
         a.Y = e->QKd; a.ldy = 512; a.vt_block = 2; a.VT = e->VTd; a.S = nn; a.Spad = 128;
-        ETD_TRY(launch_linear(a, 1, st));
+        if (fused_proj()) ETD_TRY(proj_qkv(D0, Mq, w.pq, w.pk, w.pv, w.qkv_s.b, e->QKd, e->VTd, nn, 128, st));
+        else ETD_TRY(launch_linear(a, 1, st));
         AttnArgs t = {};
         t.Q = e->QKd; t.ldq = 512; t.q_seq_stride = (long long)nn * 512;
         t.K = e->QKd + 256; t.ldk = 512; t.k_seq_stride = (long long)nn * 512;
@@ -428,7 +488,8 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
         LinArgs o = {};
         o.X = e->AOd; o.ldx = 256; o.W = w.o_s.W; o.bias = w.o_s.b; o.M = Mq; o.N = 256; o.K = 256; o.vt_block = -1;
         o.R = D0; o.ldr = 256; o.gamma = w.g; o.beta = w.be; o.Y = D1; o.ldy = 256;
-        ETD_TRY(launch_linear_ln(o, st));
+        if (fused_proj()) ETD_TRY(proj_ln(e->AOd, Mq, w.po, w.o_s.b, D0, 0, w.g, w.be, D1, st));
+        else ETD_TRY(launch_linear_ln(o, st));
         cross_in = D1;
       }
       AttnArgs t = {};
@@ -438,7 +499,14 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
         LinArgs q = {};
         q.X = cross_in; q.ldx = 256; q.W = w.q_c.W; q.bias = w.q_c.b; q.M = Mq; q.N = 256; q.K = 256; q.vt_block = -1;
         q.Y = e->Qd; q.ldy = 256;
-        ETD_TRY(launch_linear(q, 1, st));
+        if (fused_proj()) {
+          ProjArgs pa = {};
+          pa.X = cross_in; pa.ldx = 256; pa.M = Mq; pa.nblk = 1;
+          pa.blk[0] = pblock(w.pqc, w.q_c.b, PROJ_ROW, e->Qd, 256);
+          ETD_TRY(launch_proj256(pa, st));
+        } else {
+          ETD_TRY(launch_linear(q, 1, st));
+        }
         t.Q = e->Qd; t.ldq = 256; t.q_seq_stride = (long long)nn * 256;
       }
       t.K = e->Kc + (size_t)l * e->MTe * 256; t.ldk = 256; t.k_seq_stride = 256LL * 256;
@@ -449,7 +517,8 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       LinArgs o = {};
       o.X = e->AOd; o.ldx = 256; o.W = w.o_c.W; o.bias = w.o_c.b; o.M = Mq; o.N = 256; o.K = 256; o.vt_block = -1;
       o.R = cross_in; o.ldr = 256; o.r_mod = r_mod; o.gamma = w.g; o.beta = w.be; o.Y = D2; o.ldy = 256;
-      ETD_TRY(launch_linear_ln(o, st));
+      if (fused_proj()) ETD_TRY(proj_ln(e->AOd, Mq, w.poc, w.o_c.b, cross_in, r_mod, w.g, w.be, D2, st));
+      else ETD_TRY(launch_linear_ln(o, st));
       if (fused_ffn()) {
         FfnArgs f = {D2, w.ffn, w.f1.b, w.f2.b, w.g, w.be, D0, Mq};
         ETD_TRY(launch_ffn_fused(f, st));

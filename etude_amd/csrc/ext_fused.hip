@@ -71,8 +71,24 @@ __global__ __launch_bounds__(256, 2) void k_ffn_fused(FfnArgs a) {
     f32x16 acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+    // (fragments are requested four at a time, one group ahead of the MFMAs that use them: left alone, hipcc hoists all 32 reads of
+    // a sub-chunk to the top and spills; the other workgroup's wave on this SIMD covers the LDS latency of a group)
+    bf16x8 af[2][4];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) acc1 = mfma32(*reinterpret_cast<const bf16x8*>(sl + s * 512), xf[s], acc1);
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      if (g < 3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[(g + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((g + 1) * 4 + k) * 512);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + k) * 512);      // first four W2 fragments (ks 0, tiles 0..3)
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc1 = mfma32(af[g & 1][k], xf[g * 4 + k], acc1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     bf16x8 hf[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -82,9 +98,15 @@ __global__ __launch_bounds__(256, 2) void k_ffn_fused(FfnArgs a) {
     }
     // out[256] += W2[:, these 32 hidden features] . hidden   (two 16-deep k-steps, 8 output tiles)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int g = 0; g < 4; ++g) {                              // group g = fragments 16 + 4 g .. + 4: k-step g >> 1, tiles 4 (g & 1) .. + 4
+      if (g < 3) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc2[t] = mfma32(*reinterpret_cast<const bf16x8*>(sl + (16 + ks * 8 + t) * 512), hf[ks], acc2[t]);
+        for (int k = 0; k < 4; ++k) af[(g + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + (g + 1) * 4 + k) * 512);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc2[4 * (g & 1) + k] = mfma32(af[g & 1][k], hf[g >> 1], acc2[4 * (g & 1) + k]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 
   // ---- bias + residual + LayerNorm over the token's 256 features (128 in this lane, 128 in lane ^ 32)
@@ -160,4 +182,244 @@ void pack_ffn_weights(const float* W1, const float* W2, uint16_t* dst, uint16_t 
           for (int j = 0; j < 8; ++j) d[j] = f2bf(W2[(size_t)feat * 512 + 32 * sc + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)]);
         }
       }
+}
+
+
+// ================================================================================================
+// k_proj256: every K = 256 projection of the model on the same skeleton -- the wave's 32 tokens as B fragments in registers,
+// weights from the LDS ring, one 256-feature output block after another for the SAME token tile (X is read once for Q, K and V,
+// once for the three decoder layers' cross-attention K/V ...).  Block kinds:
+//   ROW  bias (+ReLU) -> bf16 row-major                                                     amt_apc.py:342-343 (fc_q, fc_k)
+//   VT   bias -> V^T[(seq, head)][d][pos] for k_attn: the MFMA is issued the other way round (A = tokens, B = weights), the
+//        accumulator then has the feature on the lane; pairs of 8-byte token groups are exchanged between the lane halves
+//        (v_permlane32_swap) and leave as 16-byte pieces                                     amt_apc.py:344 (fc_v)
+//   LN   bias + residual + LayerNorm (the layer's shared one) -> bf16 row-major            amt_apc.py:371 (fc_o), :250
+// Weight stream per block: [chunk c of 4 k-steps][k-step kk][tile t][lane][8] = 4 x 32 KiB; ROW / LN blocks have their output
+// rows permuted like k_ffn_fused's second GEMM (accumulator layout == fragment layout), VT blocks are in natural order.
+// ================================================================================================
+// one 256-feature block for the wave's 32 tokens; the ring keeps running across blocks (chunk g + 1 may belong to the next block)
+template <int KIND>
+__device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb, const ProjBlock* sblk, const int b, const int nchunk, bf16* ring,
+                                           const bf16x8 (&xf)[16], const int wave, const int lane, const int m0w, float* sbias) {
+  const int r = lane & 31, h = lane >> 5, m = m0w + r;
+  const int mc = m < a.M ? m : a.M - 1;
+  // this block's bias (and the LayerNorm parameters) go to LDS now; the K loop's barriers publish them long before the epilogue
+  // (read from global memory in the epilogue, hipcc hoists ~50 loads above it and spills the accumulators)
+  sbias[threadIdx.x] = pb.bias[threadIdx.x];
+  if constexpr (KIND == PROJ_LN) { sbias[256 + threadIdx.x] = a.gamma[threadIdx.x]; sbias[512 + threadIdx.x] = a.beta[threadIdx.x]; }
+  f32x16 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int g = b * 4 + c;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (g + 1 < nchunk) {
+      const bf16* src = sblk[(g + 1) >> 2].Wf + (long long)((g + 1) & 3) * FFN_SLOT_ELEMS + wave * (8 * 512) + lane * 8;
+      bf16* dst = ring + ((g + 1) & 1) * FFN_SLOT_ELEMS + wave * (8 * 512);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
+    }
+    const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+    bf16x8 af[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {                   // group gq = fragments 4 gq .. + 4: k-step gq >> 1, tiles 4 (gq & 1) .. + 4
+      if (gq < 7) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+      }
+      const bf16x8 xb = xf[4 * c + (gq >> 1)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if constexpr (KIND == PROJ_VT) acc[4 * (gq & 1) + k] = mfma32(xb, af[gq & 1][k], acc[4 * (gq & 1) + k]);
+        else                           acc[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], xb, acc[4 * (gq & 1) + k]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- epilogue
+  if constexpr (KIND == PROJ_VT) {
+    // acc[t][i]: token (i & 3) + 8 (i >> 2) + 4 h of the wave's 32, feature 32 t + r
+    const int seq = m0w / a.S, pos0 = m0w - seq * a.S;
+    const bool vec = (a.S % 32 == 0) && (a.Spad % 8 == 0) && (m0w + 32 <= a.M);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int f = 32 * t + r;
+      const float bv = sbias[f];
+      bf16* row = pb.dst + ((long long)(seq * 4 + (f >> 6)) * 64 + (f & 63)) * a.Spad;
+      if (vec) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const bf16x4 lo = pack4(acc[t][8 * p] + bv, acc[t][8 * p + 1] + bv, acc[t][8 * p + 2] + bv, acc[t][8 * p + 3] + bv);          // token group q = 2 p
+          const bf16x4 hi = pack4(acc[t][8 * p + 4] + bv, acc[t][8 * p + 5] + bv, acc[t][8 * p + 6] + bv, acc[t][8 * p + 7] + bv);      // q = 2 p + 1
+          const u32x2 la = __builtin_bit_cast(u32x2, lo), lb = __builtin_bit_cast(u32x2, hi);
+          // lower half keeps its q = 2 p group and takes the upper half's; the upper half takes the lower's q = 2 p + 1 and keeps its own
+          const auto s0 = __builtin_amdgcn_permlane32_swap(la[0], lb[0], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(la[1], lb[1], false, false);
+          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          *reinterpret_cast<u32x4*>(row + pos0 + 16 * p + 8 * h) = o;
+        }
+      } else {
+        // (sequence length not a multiple of 32 -- the 88-note self-attention of the frequency decoder -- or the ragged last tile)
+        float vals[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) vals[i] = acc[t][i] + bv;
+#pragma unroll 1
+        for (int q = 0; q < 4; ++q)
+#pragma unroll 1
+          for (int j = 0; j < 4; ++j) {
+            const int mt = m0w + 8 * q + 4 * h + j;
+            if (mt < a.M) {
+              const int sq = mt / a.S, ps = mt - sq * a.S;
+              float v = vals[0];
+#pragma unroll
+              for (int i = 1; i < 16; ++i) v = (i == 4 * q + j) ? vals[i] : v;
+              pb.dst[((long long)(sq * 4 + (f >> 6)) * 64 + (f & 63)) * a.Spad + ps] = (bf16)v;
+            }
+          }
+      }
+    }
+  } else if constexpr (KIND == PROJ_ROW) {
+    bf16* yp = pb.dst + (long long)m * pb.ldd + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(sbias + 32 * t + 16 * u + 8 * h + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { float v = acc[t][8 * u + 4 * q + j] + bb[j]; if (pb.relu) v = fmaxf(v, 0.f); o[4 * q + j] = (bf16)v; }
+        }
+        if (m < a.M) *reinterpret_cast<bf16x8*>(yp + 16 * (2 * t + u)) = o;
+      }
+  } else {
+    // LN: the residual row arrives in pieces of the accumulators' own layout
+    const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
+    const bf16* rp = a.R + (long long)rrow * 256 + 8 * h;
+    // (an LN block is the last block of its launch -- launch_proj256 checks -- so the X fragments are dead and the residual's 16
+    // fragments take their registers: one round trip for the whole row)
+    bf16x8 rf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) rf[s] = *reinterpret_cast<const bf16x8*>(rp + 16 * s);
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const f32x4 bb = *reinterpret_cast<const f32x4*>(sbias + 32 * t + 16 * u + 8 * h + 4 * q);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v = acc[t][8 * u + 4 * q + j] + bb[j] + bf2f(rf[2 * t + u][4 * q + j]);
+            acc[t][8 * u + 4 * q + j] = v;
+            s1 += v;
+          }
+        }
+      }
+    s1 += xhalf(s1);
+    const float mean = s1 * (1.f / 256.f);
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float d = acc[t][i] - mean; s2 += d * d; }
+    s2 += xhalf(s2);
+    const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);
+    bf16* yp = pb.dst + (long long)m * pb.ldd + 8 * h;
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        bf16x8 o;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int f0 = 32 * t + 16 * u + 8 * h + 4 * q;
+          const f32x4 gg = *reinterpret_cast<const f32x4*>(sbias + 256 + f0), be = *reinterpret_cast<const f32x4*>(sbias + 512 + f0);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[4 * q + j] = (bf16)((acc[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);
+        }
+        if (m < a.M) *reinterpret_cast<bf16x8*>(yp + 16 * (2 * t + u)) = o;
+      }
+  }
+}
+
+template <bool LNK>      // LNK: the launch is ONE LayerNorm block (its own instantiation: the X fragments die with the K loop)
+__global__ __launch_bounds__(256, 2) void k_proj256(ProjArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FFN_SLOT_ELEMS * 2 + 2 * 768 * 4 + PROJ_MAX_BLOCKS * sizeof(ProjBlock)];
+  bf16* ring = reinterpret_cast<bf16*>(smem);
+  float* sbias = reinterpret_cast<float*>(smem + 2 * FFN_SLOT_ELEMS * 2);             // bias (| gamma | beta), two copies alternating by block
+  ProjBlock* sblk = reinterpret_cast<ProjBlock*>(smem + 2 * FFN_SLOT_ELEMS * 2 + 2 * 768 * 4);      // the block list, indexable at run time (a by-value kernel argument is not)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
+  const int m0w = blockIdx.x * 128 + wave * 32, m = m0w + (lane & 31);
+  const int mc = m < a.M ? m : a.M - 1;
+  const int nchunk = a.nblk * 4;
+  if (tid == 0) {
+#pragma unroll
+    for (int i = 0; i < PROJ_MAX_BLOCKS; ++i) sblk[i] = a.blk[i];
+  }
+  {
+    const bf16* src = a.blk[0].Wf + wave * (8 * 512) + lane * 8;
+    bf16* dst = ring + wave * (8 * 512);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
+  }
+  bf16x8 xf[16];
+  {
+    const bf16* xp = a.X + (long long)mc * a.ldx + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+  }
+  __syncthreads();                                       // sblk visible
+  if constexpr (LNK) {
+    proj_block<PROJ_LN>(a, sblk[0], sblk, 0, nchunk, ring, xf, wave, lane, m0w, sbias);
+  } else {
+    for (int b = 0; b < a.nblk; ++b) {
+      const ProjBlock pb = sblk[b];
+      const int kind = __builtin_amdgcn_readfirstlane(pb.kind);
+      // (bias copies alternate: the waves that are still in block b - 1's epilogue read the other one)
+      if (kind == PROJ_VT) proj_block<PROJ_VT>(a, pb, sblk, b, nchunk, ring, xf, wave, lane, m0w, sbias + (b & 1) * 768);
+      else proj_block<PROJ_ROW>(a, pb, sblk, b, nchunk, ring, xf, wave, lane, m0w, sbias + (b & 1) * 768);
+    }
+  }
+}
+
+int launch_proj256(const ProjArgs& a, hipStream_t st) {
+  if (a.M <= 0 || !a.X || a.nblk < 1 || a.nblk > PROJ_MAX_BLOCKS || a.ldx % 8 || ((uintptr_t)a.X & 15)) ETD_FAIL(ETD_EINVAL, "proj256: bad arguments");
+  for (int b = 0; b < a.nblk; ++b) {
+    const ProjBlock& p = a.blk[b];
+    if (!p.Wf || !p.bias || !p.dst || ((uintptr_t)p.Wf & 15) || ((uintptr_t)p.dst & 15)) ETD_FAIL(ETD_EINVAL, "proj256: bad block %d", b);
+    if (p.kind == PROJ_VT && (a.S <= 0 || a.Spad < a.S)) ETD_FAIL(ETD_EINVAL, "proj256: bad V^T geometry");
+    if (p.kind != PROJ_VT && (p.ldd % 8)) ETD_FAIL(ETD_EINVAL, "proj256: row stride must be a multiple of 8");
+    if (p.kind == PROJ_LN && (!a.R || !a.gamma || !a.beta || a.nblk != 1)) ETD_FAIL(ETD_EINVAL, "proj256: an LN block needs residual + LayerNorm parameters and a launch of its own");
+  }
+  const char* pname = a.blk[0].kind == PROJ_LN ? "k_proj256_ln" : (a.nblk == 6 ? "k_proj256_kv6" : (a.nblk == 3 ? "k_proj256_qkv" : "k_proj256_row"));
+  ProfScope ps(pname, st, 2.0 * a.M * 256.0 * 256.0 * a.nblk, ((double)a.M * 256 * (1 + a.nblk) + 65536.0 * a.nblk) * 2);
+  if (a.blk[0].kind == PROJ_LN) hipLaunchKernelGGL(k_proj256<true>, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_proj256<false>, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// [256 out][256 in] fp32 (nn.Linear layout) -> one block of k_proj256's stream: [chunk 4][k-step 4][tile 8][lane 64][8]
+void pack_proj_weights(const float* W, bool permute_rows, uint16_t* dst, uint16_t (*f2bf)(float)) {
+  for (int c = 0; c < 4; ++c)
+    for (int kk = 0; kk < 4; ++kk)
+      for (int t = 0; t < 8; ++t)
+        for (int l = 0; l < 64; ++l) {
+          const int r = l & 31, h = l >> 5, s = 4 * c + kk;
+          int feat = 32 * t + r;
+          if (permute_rows) { const int i = (r & 3) + 4 * (r >> 3), hh = (r >> 2) & 1; feat = 32 * t + 16 * (i >> 3) + 8 * hh + (i & 7); }
+          uint16_t* d = dst + ((((size_t)c * 4 + kk) * 8 + t) * 64 + l) * 8;
+          for (int j = 0; j < 8; ++j) d[j] = f2bf(W[(size_t)feat * 256 + 16 * s + 8 * h + j]);
+        }
 }

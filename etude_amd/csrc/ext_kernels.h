@@ -111,3 +111,23 @@ struct FfnArgs {
 };
 int launch_ffn_fused(const FfnArgs& a, hipStream_t st);
 void pack_ffn_weights(const float* W1, const float* W2, uint16_t* dst, uint16_t (*f2bf)(float));
+
+// ---- K = 256 projections on the fused skeleton (csrc/ext_fused.hip: k_proj256)
+enum { PROJ_ROW = 0, PROJ_VT = 1, PROJ_LN = 2 };
+#define PROJ_MAX_BLOCKS 6
+struct ProjBlock {
+  const bf16* Wf;              // packed [256 out][256 in] block (pack_proj_weights; rows permuted for ROW / LN, natural for VT)
+  const float* bias;           // [256]
+  int kind;                    // PROJ_ROW / PROJ_VT / PROJ_LN
+  int relu;                    // ROW only
+  bf16* dst; int ldd;          // ROW / LN: dst[m * ldd + feature] (col offset folded into dst); VT: V^T base (z offset folded in)
+};
+struct ProjArgs {
+  const bf16* X; int ldx; int M;      // [M][256] bf16 rows, row stride ldx
+  int nblk; ProjBlock blk[PROJ_MAX_BLOCKS];
+  int S, Spad;                        // VT blocks: seq = m / S, pos = m % S; row stride of V^T
+  const bf16* R; int r_mod;           // LN blocks: residual rows [.][256] (row = r_mod > 0 ? m % r_mod : m)
+  const float* gamma; const float* beta;
+};
+int launch_proj256(const ProjArgs& a, hipStream_t st);
+void pack_proj_weights(const float* W, bool permute_rows, uint16_t* dst, uint16_t (*f2bf)(float));
