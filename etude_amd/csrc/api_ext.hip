@@ -39,7 +39,8 @@ inline uint16_t f2bf(float f) {   // round-to-nearest-even, NaN kept
 
 struct LinW { bf16* W = nullptr; float* b = nullptr; };
 // p*: the same Linear weights as 256 x 256 blocks in k_proj256's fragment-ordered stream (ext_fused.hip); ffn: k_ffn_fused's stream
-struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; bf16 *ffn = nullptr, *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr; };
+struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; bf16 *ffn = nullptr, *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr;
+                   bf16* lw = nullptr; /* k_enc_layer's whole-layer stream (32 x 32 KiB) */ };
 struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; bf16* ffn = nullptr;
                    bf16 *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *pqc = nullptr, *pkc = nullptr, *pvc = nullptr, *poc = nullptr; };
 
@@ -154,6 +155,16 @@ int load_enc_layer(DevPool& pool, Loader& L, const std::string& p, EncLayerW* w)
   ETD_TRY(load_proj_block(pool, L, p + ".self_attention.fc_k", true, &w->pk));
   ETD_TRY(load_proj_block(pool, L, p + ".self_attention.fc_v", false, &w->pv));
   ETD_TRY(load_proj_block(pool, L, p + ".self_attention.fc_o", true, &w->po));
+  {
+    const float* Wq = L.get(p + ".self_attention.fc_q.weight", 65536); const float* Wk = L.get(p + ".self_attention.fc_k.weight", 65536);
+    const float* Wv = L.get(p + ".self_attention.fc_v.weight", 65536); const float* Wo = L.get(p + ".self_attention.fc_o.weight", 65536);
+    const float* W1 = L.get(p + ".positionwise_feedforward.fc_1.weight", 512 * 256); const float* W2 = L.get(p + ".positionwise_feedforward.fc_2.weight", 256 * 512);
+    if (!Wq || !Wk || !Wv || !Wo || !W1 || !W2) return ETD_EINVAL;
+    std::vector<uint16_t> h((size_t)32 * 16384);
+    pack_enc_layer_weights(Wq, Wk, Wv, Wo, W1, W2, h.data(), f2bf);
+    ETD_TRY(pool.alloc(&w->lw, h.size()));
+    HIP_TRY(hipMemcpy(w->lw, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+  }
   ETD_TRY(load_cat(pool, L, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, &w->qkv));
   ETD_TRY(load_lin(pool, L, p + ".self_attention.fc_o", 256, 256, &w->o));
   ETD_TRY(load_lin(pool, L, p + ".positionwise_feedforward.fc_1", 512, 256, &w->f1));
@@ -366,6 +377,8 @@ const float kScaleLog2e = 0.125f * 1.4426950408889634f;
 bool fused_ffn() { static const bool on = !getenv("ETD_NO_FUSED_FFN"); return on; }
 // ETD_NO_FUSED_PROJ=1: the K = 256 projections on round 1's k_linear tiles instead of k_proj256
 bool fused_proj() { static const bool on = !getenv("ETD_NO_FUSED_PROJ"); return on; }
+// ETD_NO_FUSED_LAYER=1: encoder layers as four launches (QKV, attention, fc_o + LN, FFN) instead of k_enc_layer
+bool fused_layer() { static const bool on = !getenv("ETD_NO_FUSED_LAYER"); return on; }
 
 ProjBlock pblock(const bf16* Wf, const float* bias, int kind, bf16* dst, int ldd, int relu = 0) {
   ProjBlock b = {}; b.Wf = Wf; b.bias = bias; b.kind = kind; b.relu = relu; b.dst = dst; b.ldd = ldd; return b;
@@ -443,7 +456,13 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
     const bool first = (w0 == 0 && f0 == 0);
     ETD_TRY(tap(e, 0, e->X, (size_t)Mtok * 512, first, st));
     for (int l = 0; l < 3; ++l) {
-      ETD_TRY(enc_like_layer(e, e->enc[l], e->X, e->X1, Mtok, nfr, 256, st, e->X));
+      if (fused_layer()) {
+        const EncLayerW& w = e->enc[l];
+        EncLayerArgs la = {e->X, w.lw, w.qkv.b, w.o.b, w.g, w.be, w.f1.b, w.f2.b, e->X, nfr};
+        ETD_TRY(launch_enc_layer(la, st));
+      } else {
+        ETD_TRY(enc_like_layer(e, e->enc[l], e->X, e->X1, Mtok, nfr, 256, st, e->X));
+      }
       ETD_TRY(tap(e, 1 + l, e->X, (size_t)Mtok * 512, first, st));
     }
     // ---- cross-attention K/V of the encoder output for the 3 decoder layers, one z-batched launch pair

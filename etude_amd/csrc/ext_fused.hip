@@ -423,3 +423,342 @@ void pack_proj_weights(const float* W, bool permute_rows, uint16_t* dst, uint16_
           for (int j = 0; j < 8; ++j) d[j] = f2bf(W[(size_t)feat * 256 + 16 * s + 8 * h + j]);
         }
 }
+
+// ================================================================================================
+// k_enc_layer: one whole EncoderLayer for one 256-token sequence (a frame's 256 frequency bins) per workgroup.
+//     x = LN(x + fc_o(MHA(x)));  x = LN(x + fc_2(relu(fc_1(x))))          amt_apc.py:244-259, one shared LayerNorm
+// 8 waves x 32 tokens.  Everything between the layer's input and output lives on the CU:
+//   * per head: Q, K, V projections of the wave's own 32 tokens on the k_proj256 skeleton (X fragments from registers, weights
+//     from the LDS ring).  Q stays in registers as the B operand of S^T = K Q^T; K leaves as MFMA A-fragments into an LDS image
+//     [key tile][k-step][lane] (linear 1 KiB pieces: conflict-free writes and reads, no address arithmetic); V is produced
+//     with the operands swapped (feature on the lane), whose accumulator registers 8 ks .. 8 ks + 7 ARE the A fragment of
+//     O^T += V^T P^T for k-step ks in exactly the permuted key order in which P^T leaves the softmax (guide section 3) -- they go
+//     to a second LDS image;
+//   * flash-style softmax per 64 keys as in k_attn (query on the lane, statistics lane-local + one exchange with lane ^ 32);
+//   * the normalised O^T accumulator is the B operand of the output projection (Wo's columns are packed in its permuted order);
+//     fc_o of all four heads accumulates after the last head, then bias + residual + LayerNorm in registers, and the result --
+//     laid out as B fragments -- feeds the feed-forward block of k_ffn_fused unchanged.
+// Weight stream: 32 chunks of 32 KiB (12 QKV, 4 fc_o, 16 feed-forward) through the two-slot ring, 1 MiB per sequence from L2.
+// HBM traffic per sequence: 128 KiB in, 128 KiB out (round 1: ~2.3 MiB).
+// ================================================================================================
+#define ENC_LDS_RING 0
+#define ENC_LDS_K (2 * FFN_SLOT_ELEMS * 2)
+#define ENC_LDS_V (ENC_LDS_K + 32768)
+#define ENC_LDS_PAR (ENC_LDS_V + 32768)
+#define ENC_LDS_BYTES (ENC_LDS_PAR + (768 + 256 * 3 + 512 + 256) * 4)
+
+__global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[ENC_LDS_BYTES];
+  bf16* ring = reinterpret_cast<bf16*>(smem + ENC_LDS_RING);
+  bf16* Kimg = reinterpret_cast<bf16*>(smem + ENC_LDS_K);        // [key tile 8][k-step 4][lane 64][8]
+  bf16* Vimg = reinterpret_cast<bf16*>(smem + ENC_LDS_V);        // [key tile 8][ks 2][dt 2][lane 64][8]
+  float* sbqkv = reinterpret_cast<float*>(smem + ENC_LDS_PAR);   // bqkv[768] | bo[256] | gamma[256] | beta[256] | b1[512] | b2[256]
+  float* sbo = sbqkv + 768; float* sg = sbo + 256; float* sbe = sg + 256; float* sb1 = sbe + 256; float* sb2 = sb1 + 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const long long row = (long long)blockIdx.x * 256 + wave * 32 + r;        // this lane's token
+
+  auto issue = [&](int g) {                              // chunk g -> ring slot g & 1: 32 one-KiB pieces, 4 per wave
+    const bf16* src = a.Wl + (long long)g * FFN_SLOT_ELEMS + wave * (4 * 512) + lane * 8;
+    bf16* dst = ring + (g & 1) * FFN_SLOT_ELEMS + wave * (4 * 512);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
+  };
+  // top of a chunk: its slot has landed for everybody, everybody is done with the other slot, the next chunk is requested
+#define ENC_CHUNK_TOP(g) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if ((g) + 1 < 32) issue((g) + 1); } while (0)
+
+  issue(0);
+  for (int i = tid; i < 768; i += 512) sbqkv[i] = a.bqkv[i];
+  if (tid < 256) { sbo[tid] = a.bo[tid]; sg[tid] = a.gamma[tid]; sbe[tid] = a.beta[tid]; sb2[tid] = a.b2[tid]; }
+  sb1[tid] = a.b1[tid];
+
+  const float qscale = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) and the base-2 exponent, folded into Q
+  bf16x8 ofr[16];                                         // the four heads' normalised outputs as B fragments (k-step 4 head + ks)
+#pragma unroll
+  for (int hd = 0; hd < 4; ++hd) {
+    // ---- the wave's 32 tokens as B / A fragments (re-read per head: 16 KiB from L2 instead of 64 registers held through the attention)
+    bf16x8 xf[16];
+    {
+      const bf16* xp = a.X + row * 256 + 8 * h;
+      asm volatile("" : "+v"(xp));                        // (keeps the loads inside this head's iteration)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    }
+    bf16x8 qf[4];
+    // ---- Q (part 0), K (part 1): token on the lane; V (part 2): feature on the lane
+#pragma unroll
+    for (int part = 0; part < 3; ++part) {
+      const int g = hd * 3 + part;
+      ENC_CHUNK_TOP(g);
+      const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+      f32x16 acc[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
+      bf16x8 af[2][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+#pragma unroll
+      for (int gq = 0; gq < 8; ++gq) {                   // group gq = fragments 4 gq .. + 4 = k-steps 2 gq, 2 gq + 1 x tiles 0, 1
+        if (gq < 7) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bf16x8 xb = xf[2 * gq + (k >> 1)];
+          if (part == 2) acc[k & 1] = mfma32(xb, af[gq & 1][k], acc[k & 1]);
+          else           acc[k & 1] = mfma32(af[gq & 1][k], xb, acc[k & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (part < 2) {
+        // accumulator (tile dt, register i) of lane half h = feature 32 dt + 16 (i >> 3) + 8 h + (i & 7) of this head's 64:
+        // fragment s = 2 dt + (i >> 3), element i & 7
+        bf16x8 fr[4];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(sbqkv + part * 256 + hd * 64 + 32 * dt + 16 * u + 8 * h + 4 * q);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                float v = acc[dt][8 * u + 4 * q + j] + bb[j];
+                if (part == 0) v *= qscale;
+                fr[2 * dt + u][4 * q + j] = (bf16)v;
+              }
+            }
+        if (part == 0) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) qf[s] = fr[s];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x8*>(Kimg + ((wave * 4 + s) * 64 + lane) * 8) = fr[s];
+        }
+      } else {
+        // acc[dt][i]: key (i & 3) + 8 (i >> 2) + 4 h of the wave's 32, feature 32 dt + r; registers 8 ks .. + 8 = A fragment of k-step ks
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const float bv = sbqkv[512 + hd * 64 + 32 * dt + r];
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 fr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fr[j] = (bf16)(acc[dt][8 * ks + j] + bv);
+            *reinterpret_cast<bf16x8*>(Vimg + (((wave * 2 + ks) * 2 + dt) * 64 + lane) * 8) = fr;
+          }
+        }
+      }
+    }
+    __syncthreads();                                      // K and V images of this head complete
+    // ---- attention of the wave's 32 queries against the 256 keys, 64 keys per step
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+#pragma unroll
+    for (int kp = 0; kp < 4; ++kp) {
+      f32x16 sT[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sT[kt][i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+          sT[kt] = mfma32(*reinterpret_cast<const bf16x8*>(Kimg + (((2 * kp + kt) * 4 + s) * 64 + lane) * 8), qf[s], sT[kt]);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sT[kt][i]);
+      mx = fmaxf(mx, xhalf(mx));
+      const float mnew = fmaxf(mrun, mx);
+      const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+      mrun = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(sT[kt][i] - mnew); sT[kt][i] = p; ps += p; }
+      lrun = lrun * alpha + ps;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8 pf;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[kt][8 * ks + j];
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            o[dt] = mfma32(*reinterpret_cast<const bf16x8*>(Vimg + ((((2 * kp + kt) * 2 + ks) * 2 + dt) * 64 + lane) * 8), pf, o[dt]);
+        }
+    }
+    lrun += xhalf(lrun);
+    const float inv = 1.f / lrun;
+    // O^T[d][query]: registers 8 u .. + 8 of tile dt = B fragment of k-step 2 dt + u (d = 32 dt + 16 u + 8 (j >> 2) + 4 h + (j & 3))
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ofr[4 * hd + 2 * dt + u][j] = (bf16)(o[dt][8 * u + j] * inv);
+  }
+
+  // ---- fc_o over the four heads (chunks 12 .. 15), bias + residual + LayerNorm
+  f32x16 acc2[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
+#pragma unroll
+  for (int hd = 0; hd < 4; ++hd) {
+    const int g = 12 + hd;
+    ENC_CHUNK_TOP(g);
+    const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+    bf16x8 af[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {                     // group gq: k-step gq >> 1, tiles 4 (gq & 1) .. + 4
+      if (gq < 7) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], ofr[4 * hd + (gq >> 1)], acc2[4 * (gq & 1) + k]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  bf16x8 xf[16];
+  {
+    const bf16* xp = a.X + row * 256 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);       // residual
+  }
+  // LayerNorm of (acc2 + bias + resid) -> xf (bf16 fragments); statistics in fp32
+#define ENC_RESID_LN(BIAS)                                                                                                   \
+  {                                                                                                                          \
+    float s1 = 0.f;                                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
+      const f32x4 bb = *reinterpret_cast<const f32x4*>((BIAS) + 32 * t + 16 * u + 8 * h + 4 * q);                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
+        const float v = acc2[t][8 * u + 4 * q + j] + bb[j] + bf2f(xf[2 * t + u][4 * q + j]);                                \
+        acc2[t][8 * u + 4 * q + j] = v; s1 += v;                                                                             \
+      }                                                                                                                      \
+    }                                                                                                                        \
+    s1 += xhalf(s1);                                                                                                         \
+    const float mean = s1 * (1.f / 256.f);                                                                                   \
+    float s2 = 0.f;                                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int i = 0; i < 16; ++i) { const float d = acc2[t][i] - mean; s2 += d * d; }   \
+    s2 += xhalf(s2);                                                                                                         \
+    const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);                                                                   \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
+      const int f0 = 32 * t + 16 * u + 8 * h + 4 * q;                                                                        \
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(sg + f0), be = *reinterpret_cast<const f32x4*>(sbe + f0);            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (bf16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
+    }                                                                                                                        \
+  }
+  ENC_RESID_LN(sbo)
+
+  // ---- feed-forward block (chunks 16 .. 31): k_ffn_fused's loop on the fragments just produced
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
+  for (int sc = 0; sc < FFN_NSUB; ++sc) {
+    const int g = 16 + sc;
+    ENC_CHUNK_TOP(g);
+    const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+    f32x16 acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+    bf16x8 af[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      if (gq < 3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + k) * 512);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc1 = mfma32(af[gq & 1][k], xf[gq * 4 + k], acc1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    bf16x8 hf[2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + 32 * sc + 8 * q + 4 * h);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) hf[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
+    }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      if (gq < 3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + (gq + 1) * 4 + k) * 512);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], hf[gq >> 1], acc2[4 * (gq & 1) + k]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  ENC_RESID_LN(sb2)
+  bf16* yp = a.Y + row * 256 + 8 * h;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) *reinterpret_cast<bf16x8*>(yp + 16 * s) = xf[s];
+#undef ENC_RESID_LN
+#undef ENC_CHUNK_TOP
+}
+
+int launch_enc_layer(const EncLayerArgs& a, hipStream_t st) {
+  if (a.n_seq <= 0 || !a.X || !a.Wl || !a.bqkv || !a.bo || !a.gamma || !a.beta || !a.b1 || !a.b2 || !a.Y || (((uintptr_t)a.X | (uintptr_t)a.Y | (uintptr_t)a.Wl) & 15))
+    ETD_FAIL(ETD_EINVAL, "enc_layer: bad arguments");
+  const double tok = (double)a.n_seq * 256;
+  ProfScope ps("k_enc_layer", st, 2.0 * tok * 256 * (768 + 256 + 1024) + 4.0 * a.n_seq * 256.0 * 256 * 256, tok * 256 * 2 * 2 + 1048576.0);
+  hipLaunchKernelGGL(k_enc_layer, dim3(a.n_seq), dim3(512), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+void pack_enc_layer_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo, const float* W1, const float* W2, uint16_t* dst, uint16_t (*f2bf)(float)) {
+  auto perm = [](int r) { const int i = (r & 3) + 4 * (r >> 3), hh = (r >> 2) & 1; return 16 * (i >> 3) + 8 * hh + (i & 7); };   // A-row r -> feature offset in its 32-tile
+  for (int hd = 0; hd < 4; ++hd)
+    for (int part = 0; part < 3; ++part) {
+      const float* W = part == 0 ? Wq : (part == 1 ? Wk : Wv);
+      uint16_t* ch = dst + (size_t)(hd * 3 + part) * FFN_SLOT_ELEMS;
+      for (int s = 0; s < 16; ++s)
+        for (int dt = 0; dt < 2; ++dt)
+          for (int l = 0; l < 64; ++l) {
+            const int r = l & 31, h = l >> 5;
+            const int rowf = 64 * hd + 32 * dt + (part == 2 ? r : perm(r));
+            uint16_t* d = ch + ((size_t)(s * 2 + dt) * 64 + l) * 8;
+            for (int j = 0; j < 8; ++j) d[j] = f2bf(W[(size_t)rowf * 256 + 16 * s + 8 * h + j]);
+          }
+    }
+  for (int hd = 0; hd < 4; ++hd) {
+    uint16_t* ch = dst + (size_t)(12 + hd) * FFN_SLOT_ELEMS;
+    for (int ks = 0; ks < 4; ++ks)
+      for (int t = 0; t < 8; ++t)
+        for (int l = 0; l < 64; ++l) {
+          const int r = l & 31, h = l >> 5;
+          const int rowf = 32 * t + perm(r);
+          uint16_t* d = ch + ((size_t)(ks * 8 + t) * 64 + l) * 8;
+          for (int j = 0; j < 8; ++j) d[j] = f2bf(Wo[(size_t)rowf * 256 + 64 * hd + 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)]);
+        }
+  }
+  pack_ffn_weights(W1, W2, dst + (size_t)16 * FFN_SLOT_ELEMS, f2bf);
+}

@@ -131,3 +131,18 @@ struct ProjArgs {
 };
 int launch_proj256(const ProjArgs& a, hipStream_t st);
 void pack_proj_weights(const float* W, bool permute_rows, uint16_t* dst, uint16_t (*f2bf)(float));
+
+// ---- one whole hFT EncoderLayer (amt_apc.py:236-259) per 256-token sequence in ONE launch (csrc/ext_fused.hip: k_enc_layer):
+// QKV projection, 4-head attention, output projection + LayerNorm, feed-forward + LayerNorm; X is read once, Y written once
+struct EncLayerArgs {
+  const bf16* X;               // [n_seq * 256][256]
+  const bf16* Wl;              // packed layer stream (pack_enc_layer_weights): 32 chunks of 32 KiB
+  const float* bqkv;           // [768] q | k | v biases
+  const float* bo; const float* gamma; const float* beta;   // [256]
+  const float* b1; const float* b2;                         // [512], [256]
+  bf16* Y;                     // [n_seq * 256][256]; may alias X
+  int n_seq;
+};
+int launch_enc_layer(const EncLayerArgs& a, hipStream_t st);
+// Wq, Wk, Wv, Wo: [256][256]; W1 [512][256]; W2 [256][512] (fp32, nn.Linear layout) -> dst[32 * 16384] bf16
+void pack_enc_layer_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo, const float* W1, const float* W2, uint16_t* dst, uint16_t (*f2bf)(float));
