@@ -60,7 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         o = OBJ / (s + ".o")
         objs.append(o)
         if force or not o.exists() or o.stat().st_mtime < max(src.stat().st_mtime, newest_h):
-            cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(o)]
+            cmd = [hipcc, *FLAGS, *os.environ.get("ETD_FLAGS_" + s.split(".")[0].upper(), "").split(), "-c", str(src), "-o", str(o)]   # per-file experiment flags, e.g. ETD_FLAGS_EXT_FUSED
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

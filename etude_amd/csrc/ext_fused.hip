@@ -762,3 +762,157 @@ void pack_enc_layer_weights(const float* Wq, const float* Wk, const float* Wv, c
   }
   pack_ffn_weights(W1, W2, dst + (size_t)16 * FFN_SLOT_ELEMS, f2bf);
 }
+
+
+// ================================================================================================
+// k_post_attn: everything of a layer that follows its attention, for layers whose attention runs as its own launch (the
+// frequency decoder's self- and cross-attention blocks, the time decoder):
+//     x1 = LN(resid + AO Wo^T + bo);   [y = LN(x1 + relu(x1 W1^T + b1) W2^T + b2)]      amt_apc.py:250-259, 281-286, 306-320
+// = k_proj256's LayerNorm block whose output fragments feed k_ffn_fused's loop without leaving the registers (the tail of
+// k_enc_layer with the attention output read from memory).  4 waves x 32 tokens, two workgroups per CU.
+// ================================================================================================
+__global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FFN_SLOT_ELEMS * 2 + (256 * 3 + 512 + 256) * 4];
+  bf16* ring = reinterpret_cast<bf16*>(smem);
+  float* sbo = reinterpret_cast<float*>(smem + 2 * FFN_SLOT_ELEMS * 2);      // bo[256] | gamma[256] | beta[256] | b1[512] | b2[256]
+  float* sg = sbo + 256; float* sbe = sg + 256; float* sb1 = sbe + 256; float* sb2 = sb1 + 512;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int m = blockIdx.x * 128 + wave * 32 + r;
+  const int mc = m < a.M ? m : a.M - 1;
+  const int nstep = a.Wffn ? 20 : 4;
+  auto issue = [&](int st) {                             // steps 0..3: fc_o chunks, 4..19: feed-forward chunks; 8 pieces per wave
+    const bf16* base = st < 4 ? a.Wo + (long long)st * FFN_SLOT_ELEMS : a.Wffn + (long long)(st - 4) * FFN_SLOT_ELEMS;
+    const bf16* src = base + wave * (8 * 512) + lane * 8;
+    bf16* dst = ring + (st & 1) * FFN_SLOT_ELEMS + wave * (8 * 512);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
+  };
+#define PA_TOP(g) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if ((g) + 1 < nstep) issue((g) + 1); } while (0)
+  issue(0);
+  bf16x8 xf[16];
+  {
+    const bf16* xp = a.AO + (long long)mc * 256 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+  }
+  sbo[tid] = a.bo[tid]; sg[tid] = a.gamma[tid]; sbe[tid] = a.beta[tid];
+  if (a.Wffn) { sb1[tid] = a.b1[tid]; sb1[256 + tid] = a.b1[256 + tid]; sb2[tid] = a.b2[tid]; }
+  f32x16 acc2[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    PA_TOP(c);
+    const bf16* sl = ring + (c & 1) * FFN_SLOT_ELEMS + lane * 8;
+    bf16x8 af[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {                     // group gq: k-step 4 c + (gq >> 1), tiles 4 (gq & 1) .. + 4
+      if (gq < 7) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], xf[4 * c + (gq >> 1)], acc2[4 * (gq & 1) + k]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  {
+    const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
+    const bf16* rp = a.R + (long long)rrow * 256 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(rp + 16 * s);       // residual
+  }
+#define PA_RESID_LN(BIAS)                                                                                                    \
+  {                                                                                                                          \
+    float s1 = 0.f;                                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
+      const f32x4 bb = *reinterpret_cast<const f32x4*>((BIAS) + 32 * t + 16 * u + 8 * h + 4 * q);                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
+        const float v = acc2[t][8 * u + 4 * q + j] + bb[j] + bf2f(xf[2 * t + u][4 * q + j]);                                \
+        acc2[t][8 * u + 4 * q + j] = v; s1 += v;                                                                             \
+      }                                                                                                                      \
+    }                                                                                                                        \
+    s1 += xhalf(s1);                                                                                                         \
+    const float mean = s1 * (1.f / 256.f);                                                                                   \
+    float s2 = 0.f;                                                                                                          \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int i = 0; i < 16; ++i) { const float d = acc2[t][i] - mean; s2 += d * d; }   \
+    s2 += xhalf(s2);                                                                                                         \
+    const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);                                                                   \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
+      const int f0 = 32 * t + 16 * u + 8 * h + 4 * q;                                                                        \
+      const f32x4 gg = *reinterpret_cast<const f32x4*>(sg + f0), be = *reinterpret_cast<const f32x4*>(sbe + f0);            \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (bf16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
+    }                                                                                                                        \
+  }
+  PA_RESID_LN(sbo)
+  if (a.Wffn) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
+    for (int sc = 0; sc < FFN_NSUB; ++sc) {
+      const int g = 4 + sc;
+      PA_TOP(g);
+      const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+      f32x16 acc1;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
+      bf16x8 af[2][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        if (gq < 3) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + k) * 512);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc1 = mfma32(af[gq & 1][k], xf[gq * 4 + k], acc1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bf16x8 hf[2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + 32 * sc + 8 * q + 4 * h);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hf[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
+      }
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        if (gq < 3) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + (gq + 1) * 4 + k) * 512);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], hf[gq >> 1], acc2[4 * (gq & 1) + k]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    PA_RESID_LN(sb2)
+  }
+  if (m < a.M) {
+    bf16* yp = a.Y + (long long)m * 256 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) *reinterpret_cast<bf16x8*>(yp + 16 * s) = xf[s];
+  }
+#undef PA_RESID_LN
+#undef PA_TOP
+}
+
+int launch_post_attn(const PostAttnArgs& a, hipStream_t st) {
+  if (a.M <= 0 || !a.AO || !a.R || !a.Wo || !a.bo || !a.gamma || !a.beta || !a.Y || (a.Wffn && (!a.b1 || !a.b2)) ||
+      (((uintptr_t)a.AO | (uintptr_t)a.R | (uintptr_t)a.Y | (uintptr_t)a.Wo | (uintptr_t)a.Wffn) & 15))
+    ETD_FAIL(ETD_EINVAL, "post_attn: bad arguments");
+  ProfScope ps(a.Wffn ? "k_post_attn_ffn" : "k_post_attn", st, 2.0 * a.M * 256.0 * (256.0 + (a.Wffn ? 1024.0 : 0.0)), (double)a.M * 256 * 2 * 3 + 655360.0);
+  hipLaunchKernelGGL(k_post_attn, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}

@@ -146,3 +146,15 @@ struct EncLayerArgs {
 int launch_enc_layer(const EncLayerArgs& a, hipStream_t st);
 // Wq, Wk, Wv, Wo: [256][256]; W1 [512][256]; W2 [256][512] (fp32, nn.Linear layout) -> dst[32 * 16384] bf16
 void pack_enc_layer_weights(const float* Wq, const float* Wk, const float* Wv, const float* Wo, const float* W1, const float* W2, uint16_t* dst, uint16_t (*f2bf)(float));
+
+// ---- the part of a layer behind its attention in one launch (csrc/ext_fused.hip: k_post_attn):
+//      x1 = LN(R + AO Wo^T + bo) and, when Wffn is set, y = LN(x1 + FFN(x1)) with the same (shared) LayerNorm
+struct PostAttnArgs {
+  const bf16* AO;              // [M][256] attention output
+  const bf16* R; int r_mod;    // residual rows (row = r_mod > 0 ? m % r_mod : m)
+  const bf16* Wo;              // fc_o as a k_proj256 block (pack_proj_weights, rows permuted)
+  const bf16* Wffn;            // k_ffn_fused's stream, or null: stop after the first LayerNorm
+  const float* bo; const float* gamma; const float* beta; const float* b1; const float* b2;
+  bf16* Y; int M;
+};
+int launch_post_attn(const PostAttnArgs& a, hipStream_t st);
