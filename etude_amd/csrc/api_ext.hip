@@ -66,6 +66,7 @@ struct etd_ext {
   bf16 *Kc = nullptr, *VTc = nullptr;              // [3][MTe][256] each
   bf16 *Tq = nullptr, *T1 = nullptr, *QKd = nullptr, *VTd = nullptr, *AOd = nullptr, *HFd = nullptr, *Qd = nullptr, *Tfreq = nullptr;
   bf16* TI = nullptr;          // time-decoder input [wb*nn*nf][256]
+  bf16 *KVimg = nullptr, *KVcimg = nullptr;   // K / V MFMA-fragment images for k_attn_frag: self-attention [MT * 512], cross-attention [3][MTe * 512]
   size_t MTe = 0;              // encoder chunk token capacity (wb*fc*256)
   float* dbg_vel = nullptr;
   void* tap[16] = {nullptr};   // test hook: device destinations for intermediate activations (first chunk only)
@@ -333,6 +334,8 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
   rc = rc ? rc : P.alloc(&e->HFd, MQ * 512);
   rc = rc ? rc : P.alloc(&e->Qd, MQ * 256);
   rc = rc ? rc : P.alloc(&e->TI, MTt * 256);
+  rc = rc ? rc : P.alloc(&e->KVimg, MT * 512);
+  rc = rc ? rc : P.alloc(&e->KVcimg, 3 * MTe * 512);
   if (rc) return fail(rc);
   HIP_TRY(hipDeviceSynchronize());
   *out = e;
@@ -379,6 +382,8 @@ bool fused_ffn() { static const bool on = !getenv("ETD_NO_FUSED_FFN"); return on
 bool fused_proj() { static const bool on = !getenv("ETD_NO_FUSED_PROJ"); return on; }
 // ETD_NO_FUSED_LAYER=1: encoder layers as four launches (QKV, attention, fc_o + LN, FFN) instead of k_enc_layer
 bool fused_layer() { static const bool on = !getenv("ETD_NO_FUSED_LAYER"); return on; }
+// ETD_NO_FRAG_ATTN=1: attention on k_attn (K row-major, V^T) instead of k_attn_frag (K / V as MFMA-fragment images)
+bool frag_attn() { static const bool on = !getenv("ETD_NO_FRAG_ATTN") && !getenv("ETD_NO_FUSED_PROJ"); return on; }
 // ETD_POST_ATTN=1: fc_o + LayerNorm + feed-forward block of the decoder layers as ONE launch (k_post_attn).  Measured equal in time to the
 // two launches it replaces (0.319 vs 0.309 ms per window: its mid-kernel LayerNorm costs what the saved HBM round trip gains), so the
 // two-launch sequence stays the default
@@ -410,6 +415,18 @@ int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int
   LinArgs a = {};
   a.X = X; a.ldx = 256; a.W = w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = 768; a.K = 256;
   a.Y = e->QK; a.ldy = 512; a.vt_block = 2; a.VT = e->VT; a.S = S; a.Spad = ((S + 63) / 64) * 64;
+  if (frag_attn() && S % 64 == 0 && M % 32 == 0) {
+    ProjArgs pa = {};
+    pa.X = X; pa.ldx = 256; pa.M = M; pa.nblk = 3; pa.S = S; pa.kv_nstep = S / 64;
+    pa.blk[0] = pblock(w.pq, w.qkv.b, PROJ_ROW, e->QK, 256);
+    pa.blk[1] = pblock(w.pk, w.qkv.b + 256, PROJ_KFRAG, e->KVimg, 0);
+    pa.blk[2] = pblock(w.pv, w.qkv.b + 512, PROJ_VFRAG, e->KVimg, 0);
+    ETD_TRY(launch_proj256(pa, st));
+    AttnFragArgs f = {};
+    f.Q = e->QK; f.ldq = 256; f.q_seq_stride = (long long)S * 256; f.KV = e->KVimg;
+    f.O = e->AO; f.ldo = 256; f.o_seq_stride = (long long)S * 256; f.n_seq = n_seq; f.Sq = S; f.Sk = S; f.scale_log2e = kScaleLog2e;
+    ETD_TRY(launch_attn_frag(f, st));
+  } else {
   if (fused_proj()) ETD_TRY(proj_qkv(X, M, w.pq, w.pk, w.pv, w.qkv.b, e->QK, e->VT, S, a.Spad, st));
   else ETD_TRY(launch_linear(a, 1, st));
   AttnArgs t = {};
@@ -419,6 +436,7 @@ int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int
   t.O = e->AO; t.ldo = 256; t.o_seq_stride = (long long)S * 256;
   t.n_seq = n_seq; t.Sq = S; t.Sk = S; t.scale_log2e = kScaleLog2e;
   ETD_TRY(launch_attn(t, st));
+  }
   LinArgs o = {};
   o.X = e->AO; o.ldx = 256; o.W = w.o.W; o.bias = w.o.b; o.M = M; o.N = 256; o.K = 256; o.vt_block = -1;
   o.R = X; o.ldr = 256; o.gamma = w.g; o.beta = w.be; o.Y = X1; o.ldy = 256;
@@ -480,12 +498,17 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       a.Y = e->Kc; a.ldy = 256; a.vt_block = 1; a.VT = e->VTc; a.S = 256; a.Spad = 256;
       a.wz = 512 * 256; a.bz = 512; a.yz = (long long)e->MTe * 256; a.vtz = (long long)e->MTe * 256;
       if (fused_proj()) {
-        // the three decoder layers' K and V^T of the encoder output in ONE launch: six blocks over the same token tile
+        // the three decoder layers' K and V of the encoder output in ONE launch: six blocks over the same token tile
         ProjArgs pa = {};
-        pa.X = e->X; pa.ldx = 256; pa.M = Mtok; pa.nblk = 6; pa.S = 256; pa.Spad = 256;
+        pa.X = e->X; pa.ldx = 256; pa.M = Mtok; pa.nblk = 6; pa.S = 256; pa.Spad = 256; pa.kv_nstep = 4;
         for (int l = 0; l < 3; ++l) {
-          pa.blk[2 * l] = pblock(e->dec[l].pkc, e->bkv_all + l * 512, PROJ_ROW, e->Kc + (size_t)l * e->MTe * 256, 256);
-          pa.blk[2 * l + 1] = pblock(e->dec[l].pvc, e->bkv_all + l * 512 + 256, PROJ_VT, e->VTc + (size_t)l * e->MTe * 256, 0);
+          if (frag_attn()) {
+            pa.blk[2 * l] = pblock(e->dec[l].pkc, e->bkv_all + l * 512, PROJ_KFRAG, e->KVcimg + (size_t)l * e->MTe * 512, 0);
+            pa.blk[2 * l + 1] = pblock(e->dec[l].pvc, e->bkv_all + l * 512 + 256, PROJ_VFRAG, e->KVcimg + (size_t)l * e->MTe * 512, 0);
+          } else {
+            pa.blk[2 * l] = pblock(e->dec[l].pkc, e->bkv_all + l * 512, PROJ_ROW, e->Kc + (size_t)l * e->MTe * 256, 256);
+            pa.blk[2 * l + 1] = pblock(e->dec[l].pvc, e->bkv_all + l * 512 + 256, PROJ_VT, e->VTc + (size_t)l * e->MTe * 256, 0);
+          }
         }
         ETD_TRY(launch_proj256(pa, st));
       } else {
@@ -543,7 +566,14 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       t.VT = e->VTc + (size_t)l * e->MTe * 256; t.Spad = 256;
       t.O = e->AOd; t.ldo = 256; t.o_seq_stride = (long long)nn * 256;
       t.n_seq = nfr; t.Sq = nn; t.Sk = 256; t.scale_log2e = kScaleLog2e;
-      ETD_TRY(launch_attn(t, st));
+      if (fused_proj() && frag_attn()) {
+        AttnFragArgs f = {};
+        f.Q = t.Q; f.ldq = t.ldq; f.q_seq_stride = t.q_seq_stride; f.KV = e->KVcimg + (size_t)l * e->MTe * 512;
+        f.O = e->AOd; f.ldo = 256; f.o_seq_stride = (long long)nn * 256; f.n_seq = nfr; f.Sq = nn; f.Sk = 256; f.scale_log2e = kScaleLog2e;
+        ETD_TRY(launch_attn_frag(f, st));
+      } else {
+        ETD_TRY(launch_attn(t, st));
+      }
       LinArgs o = {};
       o.X = e->AOd; o.ldx = 256; o.W = w.o_c.W; o.bias = w.o_c.b; o.M = Mq; o.N = 256; o.K = 256; o.vt_block = -1;
       o.R = cross_in; o.ldr = 256; o.r_mod = r_mod; o.gamma = w.g; o.beta = w.be; o.Y = D2; o.ldy = 256;

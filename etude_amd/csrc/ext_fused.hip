@@ -237,14 +237,45 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
       const bf16x8 xb = xf[4 * c + (gq >> 1)];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if constexpr (KIND == PROJ_VT) acc[4 * (gq & 1) + k] = mfma32(xb, af[gq & 1][k], acc[4 * (gq & 1) + k]);
+        if constexpr (KIND == PROJ_VT || KIND == PROJ_VFRAG) acc[4 * (gq & 1) + k] = mfma32(xb, af[gq & 1][k], acc[4 * (gq & 1) + k]);
         else                           acc[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], xb, acc[4 * (gq & 1) + k]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   }
   // ---- epilogue
-  if constexpr (KIND == PROJ_VT) {
+  if constexpr (KIND == PROJ_KFRAG || KIND == PROJ_VFRAG) {
+    // K / V as the MFMA-fragment images k_attn_frag streams: per (sequence, head) and 64-key step 16 KiB =
+    // [K: key tile 2][k-step 4][lane][8] | [V: key tile 2][ks 2][dt 2][lane][8].  The wave's 32 tokens are ONE key tile, and the
+    // accumulators already hold fragments: K (token on the lane, rows permuted) registers 8 u .. + 8 of tile t = k-step 2 (t & 1) + u
+    // of head t >> 1; V (feature on the lane) registers 8 ks .. + 8 = k-step ks of d-tile t & 1.  Every store is 16 bytes per lane
+    // at lane-linear addresses: one contiguous KiB per instruction.
+    const int seq = m0w / a.S, kt = (m0w - seq * a.S) >> 5, step = kt >> 1, kt2 = kt & 1;
+    if (m0w < a.M) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        bf16* img = pb.dst + ((long long)(seq * 4 + (t >> 1)) * a.kv_nstep + step) * 8192 + lane * 8;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          bf16x8 fr;
+          if constexpr (KIND == PROJ_KFRAG) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              const f32x4 bb = *reinterpret_cast<const f32x4*>(sbias + 32 * t + 16 * u + 8 * h + 4 * q);
+#pragma unroll
+              for (int j = 0; j < 4; ++j) fr[4 * q + j] = (bf16)(acc[t][8 * u + 4 * q + j] + bb[j]);
+            }
+            *reinterpret_cast<bf16x8*>(img + (kt2 * 4 + 2 * (t & 1) + u) * 512) = fr;
+          } else {
+            const float bv = sbias[32 * t + r];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fr[j] = (bf16)(acc[t][8 * u + j] + bv);
+            *reinterpret_cast<bf16x8*>(img + 4096 + ((kt2 * 2 + u) * 2 + (t & 1)) * 512) = fr;
+          }
+        }
+      }
+    }
+  } else if constexpr (KIND == PROJ_VT) {
     // acc[t][i]: token (i & 3) + 8 (i >> 2) + 4 h of the wave's 32, feature 32 t + r
     const int seq = m0w / a.S, pos0 = m0w - seq * a.S;
     const bool vec = (a.S % 32 == 0) && (a.Spad % 8 == 0) && (m0w + 32 <= a.M);
@@ -388,6 +419,8 @@ __global__ __launch_bounds__(256, 2) void k_proj256(ProjArgs a) {
       const int kind = __builtin_amdgcn_readfirstlane(pb.kind);
       // (bias copies alternate: the waves that are still in block b - 1's epilogue read the other one)
       if (kind == PROJ_VT) proj_block<PROJ_VT>(a, pb, sblk, b, nchunk, ring, xf, wave, lane, m0w, sbias + (b & 1) * 768);
+      else if (kind == PROJ_KFRAG) proj_block<PROJ_KFRAG>(a, pb, sblk, b, nchunk, ring, xf, wave, lane, m0w, sbias + (b & 1) * 768);
+      else if (kind == PROJ_VFRAG) proj_block<PROJ_VFRAG>(a, pb, sblk, b, nchunk, ring, xf, wave, lane, m0w, sbias + (b & 1) * 768);
       else proj_block<PROJ_ROW>(a, pb, sblk, b, nchunk, ring, xf, wave, lane, m0w, sbias + (b & 1) * 768);
     }
   }
@@ -399,7 +432,8 @@ int launch_proj256(const ProjArgs& a, hipStream_t st) {
     const ProjBlock& p = a.blk[b];
     if (!p.Wf || !p.bias || !p.dst || ((uintptr_t)p.Wf & 15) || ((uintptr_t)p.dst & 15)) ETD_FAIL(ETD_EINVAL, "proj256: bad block %d", b);
     if (p.kind == PROJ_VT && (a.S <= 0 || a.Spad < a.S)) ETD_FAIL(ETD_EINVAL, "proj256: bad V^T geometry");
-    if (p.kind != PROJ_VT && (p.ldd % 8)) ETD_FAIL(ETD_EINVAL, "proj256: row stride must be a multiple of 8");
+    if ((p.kind == PROJ_ROW || p.kind == PROJ_LN) && (p.ldd % 8)) ETD_FAIL(ETD_EINVAL, "proj256: row stride must be a multiple of 8");
+    if ((p.kind == PROJ_KFRAG || p.kind == PROJ_VFRAG) && (a.S <= 0 || a.S % 64 || a.kv_nstep != a.S / 64 || a.M % 32)) ETD_FAIL(ETD_EINVAL, "proj256: fragment images need sequences of a multiple of 64 tokens");
     if (p.kind == PROJ_LN && (!a.R || !a.gamma || !a.beta || a.nblk != 1)) ETD_FAIL(ETD_EINVAL, "proj256: an LN block needs residual + LayerNorm parameters and a launch of its own");
   }
   const char* pname = a.blk[0].kind == PROJ_LN ? "k_proj256_ln" : (a.nblk == 6 ? "k_proj256_kv6" : (a.nblk == 3 ? "k_proj256_qkv" : "k_proj256_row"));
@@ -913,6 +947,112 @@ int launch_post_attn(const PostAttnArgs& a, hipStream_t st) {
     ETD_FAIL(ETD_EINVAL, "post_attn: bad arguments");
   ProfScope ps(a.Wffn ? "k_post_attn_ffn" : "k_post_attn", st, 2.0 * a.M * 256.0 * (256.0 + (a.Wffn ? 1024.0 : 0.0)), (double)a.M * 256 * 2 * 3 + 655360.0);
   hipLaunchKernelGGL(k_post_attn, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
+// ================================================================================================
+// k_attn_frag: softmax(Q K^T / 8) V per (sequence, head) with K and V arriving as MFMA-fragment images (k_proj256's KFRAG /
+// VFRAG blocks): a 64-key step is one contiguous 16 KiB piece of global memory that goes into an LDS ring by LDS-DMA and is
+// read back as linear, conflict-free ds_read_b128 fragments -- no register staging, no transposed V copy, no address
+// arithmetic in the loop.  The arithmetic is k_attn's (query on the lane, online softmax in fp32, P^T from the accumulator
+// registers).  Workgroup = 4 waves x 32 queries; three ring slots, two steps in flight.            amt_apc.py:349-368
+// ================================================================================================
+#define AF_SLOT_ELEMS 8192              // bf16 elements per ring slot (16 KiB)
+__global__ __launch_bounds__(256) void k_attn_frag(AttnFragArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * AF_SLOT_ELEMS * 2];
+  bf16* ring = reinterpret_cast<bf16*>(smem);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int seq = blockIdx.y >> 2, head = blockIdx.y & 3;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  int qi = q0 + r; const bool qvalid = qi < a.Sq; if (!qvalid) qi = a.Sq - 1;
+  const int nstep = a.Sk >> 6;
+  const bf16* img = a.KV + (long long)(seq * 4 + head) * nstep * AF_SLOT_ELEMS;
+  auto issue = [&](int st) {                             // step st -> slot st % 3: 16 one-KiB pieces, 4 per wave
+    const bf16* src = img + (long long)st * AF_SLOT_ELEMS + wave * (4 * 512) + lane * 8;
+    bf16* dst = ring + (st % 3) * AF_SLOT_ELEMS + wave * (4 * 512);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
+  };
+  const bf16* qp = a.Q + seq * a.q_seq_stride + (long long)qi * a.ldq + head * 64;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16 + h * 8);
+  issue(0);
+  if (nstep > 1) issue(1);
+  f32x16 o[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[t][i] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+  const float c = a.scale_log2e;
+  for (int st = 0; st < nstep; ++st) {
+    // the pieces of step st have landed (the 4 of step st + 1, issued after them, may still be in flight), for every wave
+    if (st + 1 < nstep) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (st + 2 < nstep) issue(st + 2);                   // into the slot of step st - 1, which every wave has left (it passed this barrier)
+    const bf16* sl = ring + (st % 3) * AF_SLOT_ELEMS + lane * 8;
+    f32x16 sT[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sT[kt][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sT[kt] = mfma32(*reinterpret_cast<const bf16x8*>(sl + (kt * 4 + s) * 512), qf[s], sT[kt]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, sT[kt][i]);
+    mx = fmaxf(mx, xhalf(mx));
+    const float mnew = fmaxf(mrun, mx);
+    const float alpha = __builtin_amdgcn_exp2f((mrun - mnew) * c);
+    mrun = mnew;
+    const float mc = -mnew * c;
+    float ps = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(fmaf(sT[kt][i], c, mc)); sT[kt][i] = p; ps += p; }
+    lrun = lrun * alpha + ps;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[t][i] *= alpha;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[kt][8 * ks + j];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          o[dt] = mfma32(*reinterpret_cast<const bf16x8*>(sl + 4096 + ((kt * 2 + ks) * 2 + dt) * 512), pf, o[dt]);
+      }
+  }
+  lrun += xhalf(lrun);
+  const float inv = 1.f / lrun;
+  if (qvalid) {
+    bf16* op = a.O + seq * a.o_seq_stride + (long long)(q0 + r) * a.ldo + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int d = dt * 32 + 8 * q + 4 * h;
+        *reinterpret_cast<bf16x4*>(op + d) = pack4(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
+      }
+  }
+}
+
+int launch_attn_frag(const AttnFragArgs& a, hipStream_t st) {
+  if (a.Sq <= 0 || a.Sk <= 0 || a.Sk % 64 || a.n_seq <= 0 || !a.Q || !a.KV || !a.O || (((uintptr_t)a.Q | (uintptr_t)a.KV) & 15) || a.ldq % 8 || a.ldo % 4)
+    ETD_FAIL(ETD_EINVAL, "attn_frag: bad arguments (Sk must be a multiple of 64)");
+  ProfScope ps("k_attn_frag", st, 1024.0 * a.n_seq * a.Sq * a.Sk, ((double)a.n_seq * (2.0 * a.Sq + 2.0 * a.Sk) * 256) * 2);
+  hipLaunchKernelGGL(k_attn_frag, dim3((a.Sq + 127) / 128, a.n_seq * 4), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }

@@ -113,7 +113,7 @@ int launch_ffn_fused(const FfnArgs& a, hipStream_t st);
 void pack_ffn_weights(const float* W1, const float* W2, uint16_t* dst, uint16_t (*f2bf)(float));
 
 // ---- K = 256 projections on the fused skeleton (csrc/ext_fused.hip: k_proj256)
-enum { PROJ_ROW = 0, PROJ_VT = 1, PROJ_LN = 2 };
+enum { PROJ_ROW = 0, PROJ_VT = 1, PROJ_LN = 2, PROJ_KFRAG = 3, PROJ_VFRAG = 4 };
 #define PROJ_MAX_BLOCKS 6
 struct ProjBlock {
   const bf16* Wf;              // packed [256 out][256 in] block (pack_proj_weights; rows permuted for ROW / LN, natural for VT)
@@ -126,6 +126,7 @@ struct ProjArgs {
   const bf16* X; int ldx; int M;      // [M][256] bf16 rows, row stride ldx
   int nblk; ProjBlock blk[PROJ_MAX_BLOCKS];
   int S, Spad;                        // VT blocks: seq = m / S, pos = m % S; row stride of V^T
+  int kv_nstep;                       // KFRAG / VFRAG blocks: S / 64; dst = fragment images [(seq * 4 + head)][kv_nstep][8192] (k_attn_frag)
   const bf16* R; int r_mod;           // LN blocks: residual rows [.][256] (row = r_mod > 0 ? m % r_mod : m)
   const float* gamma; const float* beta;
 };
@@ -158,3 +159,13 @@ struct PostAttnArgs {
   bf16* Y; int M;
 };
 int launch_post_attn(const PostAttnArgs& a, hipStream_t st);
+
+// ---- attention over K / V fragment images (csrc/ext_fused.hip: k_attn_frag); 4 heads x 64
+struct AttnFragArgs {
+  const bf16* Q; int ldq; long long q_seq_stride;   // Q + seq * q_seq_stride + q * ldq + head * 64
+  const bf16* KV;                                    // [(seq * 4 + head)][Sk / 64][8192]: k_proj256's KFRAG | VFRAG images
+  bf16* O; int ldo; long long o_seq_stride;          // O + seq * o_seq_stride + q * ldo + head * 64
+  int n_seq, Sq, Sk;                                 // Sk % 64 == 0
+  float scale_log2e;
+};
+int launch_attn_frag(const AttnFragArgs& a, hipStream_t st);
