@@ -1180,7 +1180,9 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(AdOcc<N
 // waves per attention workgroup: 4, or ETD_AD_WAVES = 8 / 16 (measurement builds).  Measured on MI355X, round 2 (tools/runs/r2_run1.sh):
 // 54 rows x ctx 320, one engine: 0.197 / 0.230 / 0.238 ms per step at 4 / 8 / 16 waves, four engines 9.98 / 9.17 / 8.21
 // engine-steps per ms; 128 rows x ctx 512: 0.356 / 0.349 / 0.419 ms; 128 rows x ctx 3.5 k: 1.290 / 1.343 / 1.362 ms.  Requesting a
-// (row, head)'s whole context at once does NOT shorten the launch: its ~8 us of fixed cost are not the key loop's round trips.
+// (row, head)'s whole context at once does NOT shorten the launch: its ~8 us of fixed cost are not the key loop's round trips.  Nor are
+// they the second pass of dense-weight fragments in the tail: with all 16 requested before the merge (100 registers, 4 waves per SIMD)
+// one engine steps in 0.199 instead of 0.198 ms and four engines reach 9.97-10.03 engine-steps per ms either way (tools/runs/r2_run12.sh).
 static int ad_waves(int M) {
   static const int env = getenv("ETD_AD_WAVES") ? atoi(getenv("ETD_AD_WAVES")) : 0;
   (void)M;
