@@ -475,8 +475,18 @@ void pack_proj_weights(const float* W, bool permute_rows, uint16_t* dst, uint16_
 // Weight stream: 32 chunks of 32 KiB (12 QKV, 4 fc_o, 16 feed-forward) through the two-slot ring, 1 MiB per sequence from L2.
 // HBM traffic per sequence: 128 KiB in, 128 KiB out (round 1: ~2.3 MiB).
 // ================================================================================================
+// The ring: five slots of 16 KiB; the 1 MiB stream is consumed as 64 half-chunks (16 fragments each: 16 MFMAs per wave), four
+// of them requested ahead.  With two 32 KiB slots (one chunk ahead, ~1000 clocks of MFMAs) every chunk top waited for its DMA -- an
+// L2 round trip under load is 2-4 k clocks and this kernel has ONE workgroup per CU, nobody else to fill the gap: SQ_WAIT_ANY was 50 %
+// of the wave cycles (profiles/r02_pmc_extractor.txt).  Each wave issues 2 one-KiB pieces per half-chunk and waits with a COUNTED
+// vmcnt: all but the 6 youngest (= the three half-chunks behind the one needed).  Other vector-memory operations between an issue and
+// its wait (the X fragment reloads, compiler spills) only make that wait stricter, never laxer: vmcnt retires in order.
+#define ENC_HC_ELEMS 8192
+#define ENC_NSLOT 5
+#define ENC_AHEAD 4
+#define ENC_NHC 64
 #define ENC_LDS_RING 0
-#define ENC_LDS_K (2 * FFN_SLOT_ELEMS * 2)
+#define ENC_LDS_K (ENC_NSLOT * ENC_HC_ELEMS * 2)
 #define ENC_LDS_V (ENC_LDS_K + 32768)
 #define ENC_LDS_PAR (ENC_LDS_V + 32768)
 #define ENC_LDS_BYTES (ENC_LDS_PAR + (768 + 256 * 3 + 512 + 256) * 4)
@@ -491,17 +501,36 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const long long row = (long long)blockIdx.x * 256 + wave * 32 + r;        // this lane's token
 
-  auto issue = [&](int g) {                              // chunk g -> ring slot g & 1: 32 one-KiB pieces, 4 per wave
-    const bf16* src = a.Wl + (long long)g * FFN_SLOT_ELEMS + wave * (4 * 512) + lane * 8;
-    bf16* dst = ring + (g & 1) * FFN_SLOT_ELEMS + wave * (4 * 512);
+  auto issue = [&](int hc) {                             // half-chunk hc -> slot hc % 5: 16 one-KiB pieces, 2 per wave
+    const bf16* src = a.Wl + (long long)hc * ENC_HC_ELEMS + wave * (2 * 512) + lane * 8;
+    bf16* dst = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + wave * (2 * 512);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
   };
-  // top of a chunk: its slot has landed for everybody, everybody is done with the other slot, the next chunk is requested
-#define ENC_CHUNK_TOP(g) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if ((g) + 1 < 32) issue((g) + 1); } while (0)
+  // top of a half-chunk: it has landed for this wave (counted wait) and, behind the barrier, for everybody; the slot of half-chunk
+  // hc - 1 is free (every wave has passed this barrier, so it is done reading it) and takes half-chunk hc + 4
+#define ENC_TOP(hc)                                                                                                    \
+  do {                                                                                                                 \
+    if ((hc) + ENC_AHEAD - 1 < ENC_NHC) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
+    __syncthreads();                                                                                                   \
+    if ((hc) + ENC_AHEAD < ENC_NHC) issue((hc) + ENC_AHEAD);                                                           \
+  } while (0)
+  // 16 fragments of a half-chunk against B (or A) operands, four at a time, one group requested ahead of the MFMAs that use it
+#define ENC_HALF(sl, BODY)                                                                                             \
+  {                                                                                                                    \
+    bf16x8 af[2][4];                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>((sl) + k * 512);          \
+    _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                                 \
+      if (gq < 3) { _Pragma("unroll") for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>((sl) + ((gq + 1) * 4 + k) * 512); }   \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) { const bf16x8 fa = af[gq & 1][k]; BODY }                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                  \
+  }
 
-  issue(0);
+#pragma unroll
+  for (int i = 0; i < ENC_AHEAD; ++i) issue(i);
   for (int i = tid; i < 768; i += 512) sbqkv[i] = a.bqkv[i];
   if (tid < 256) { sbo[tid] = a.bo[tid]; sg[tid] = a.gamma[tid]; sbe[tid] = a.beta[tid]; sb2[tid] = a.b2[tid]; }
   sb1[tid] = a.b1[tid];
@@ -519,33 +548,22 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
     }
     bf16x8 qf[4];
-    // ---- Q (part 0), K (part 1): token on the lane; V (part 2): feature on the lane
+    // ---- Q (part 0), K (part 1): token on the lane; V (part 2): feature on the lane.  A part = two half-chunks (k-steps 0..7, 8..15)
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
-      const int g = hd * 3 + part;
-      ENC_CHUNK_TOP(g);
-      const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
       f32x16 acc[2];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[dt][i] = 0.f;
-      bf16x8 af[2][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
-#pragma unroll
-      for (int gq = 0; gq < 8; ++gq) {                   // group gq = fragments 4 gq .. + 4 = k-steps 2 gq, 2 gq + 1 x tiles 0, 1
-        if (gq < 7) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bf16x8 xb = xf[2 * gq + (k >> 1)];
-          if (part == 2) acc[k & 1] = mfma32(xb, af[gq & 1][k], acc[k & 1]);
-          else           acc[k & 1] = mfma32(af[gq & 1][k], xb, acc[k & 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+      for (int hf2 = 0; hf2 < 2; ++hf2) {
+        const int hc = (hd * 3 + part) * 2 + hf2;
+        ENC_TOP(hc);
+        const bf16* sl = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
+        // fragment 4 gq + k of this half = k-step 8 hf2 + 2 gq + (k >> 1), tile k & 1
+        if (part == 2) ENC_HALF(sl, acc[k & 1] = mfma32(xf[8 * hf2 + 2 * gq + (k >> 1)], fa, acc[k & 1]);)
+        else           ENC_HALF(sl, acc[k & 1] = mfma32(fa, xf[8 * hf2 + 2 * gq + (k >> 1)], acc[k & 1]);)
       }
       if (part < 2) {
         // accumulator (tile dt, register i) of lane half h = feature 32 dt + 16 (i >> 3) + 8 h + (i & 7) of this head's 64:
@@ -621,6 +639,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) { const float p = __builtin_amdgcn_exp2f(sT[kt][i] - mnew); sT[kt][i] = p; ps += p; }
       lrun = lrun * alpha + ps;
+      // (skipping this rescale when no query of the wave raised its maximum -- a wave-uniform branch -- measured nothing: 0.630 vs 0.632 ms)
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -648,31 +667,22 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
         for (int j = 0; j < 8; ++j) ofr[4 * hd + 2 * dt + u][j] = (bf16)(o[dt][8 * u + j] * inv);
   }
 
-  // ---- fc_o over the four heads (chunks 12 .. 15), bias + residual + LayerNorm
+  // ---- fc_o over the four heads (half-chunks 24 .. 31: head hd = k-steps 4 hd .. + 4, two per half), bias + residual + LayerNorm
   f32x16 acc2[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
 #pragma unroll
-  for (int hd = 0; hd < 4; ++hd) {
-    const int g = 12 + hd;
-    ENC_CHUNK_TOP(g);
-    const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
-    bf16x8 af[2][4];
+  for (int hd = 0; hd < 4; ++hd)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
-#pragma unroll
-    for (int gq = 0; gq < 8; ++gq) {                     // group gq: k-step gq >> 1, tiles 4 (gq & 1) .. + 4
-      if (gq < 7) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], ofr[4 * hd + (gq >> 1)], acc2[4 * (gq & 1) + k]);
-      __builtin_amdgcn_sched_barrier(0);
+    for (int hf2 = 0; hf2 < 2; ++hf2) {
+      const int hc = 24 + hd * 2 + hf2;
+      ENC_TOP(hc);
+      const bf16* sl = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
+      // fragment 4 gq + k of this half = k-step 2 hf2 + (gq >> 1) of the head, tile 4 (gq & 1) + k
+      ENC_HALF(sl, acc2[4 * (gq & 1) + k] = mfma32(fa, ofr[4 * hd + 2 * hf2 + (gq >> 1)], acc2[4 * (gq & 1) + k]);)
     }
-  }
   bf16x8 xf[16];
   {
     const bf16* xp = a.X + row * 256 + 8 * h;
@@ -704,58 +714,37 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   }
   ENC_RESID_LN(sbo)
 
-  // ---- feed-forward block (chunks 16 .. 31): k_ffn_fused's loop on the fragments just produced
+  // ---- feed-forward block (half-chunks 32 .. 63: per 32 hidden features one half of W1 fragments, one of W2 fragments)
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
   for (int sc = 0; sc < FFN_NSUB; ++sc) {
-    const int g = 16 + sc;
-    ENC_CHUNK_TOP(g);
-    const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+    const int hc = 32 + 2 * sc;
+    ENC_TOP(hc);
+    const bf16* sl = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
     f32x16 acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
-    bf16x8 af[2][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      if (gq < 3) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + k) * 512);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc1 = mfma32(af[gq & 1][k], xf[gq * 4 + k], acc1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    bf16x8 hf[2];
+    ENC_HALF(sl, acc1 = mfma32(fa, xf[gq * 4 + k], acc1);)
+    bf16x8 hfr[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + 32 * sc + 8 * q + 4 * h);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) hf[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
+      for (int j = 0; j < 4; ++j) hfr[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
     }
-#pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      if (gq < 3) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + (gq + 1) * 4 + k) * 512);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], hf[gq >> 1], acc2[4 * (gq & 1) + k]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    ENC_TOP(hc + 1);
+    const bf16* sl2 = ring + ((hc + 1) % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
+    ENC_HALF(sl2, acc2[4 * (gq & 1) + k] = mfma32(fa, hfr[gq >> 1], acc2[4 * (gq & 1) + k]);)
   }
   ENC_RESID_LN(sb2)
   bf16* yp = a.Y + row * 256 + 8 * h;
 #pragma unroll
   for (int s = 0; s < 16; ++s) *reinterpret_cast<bf16x8*>(yp + 16 * s) = xf[s];
 #undef ENC_RESID_LN
-#undef ENC_CHUNK_TOP
+#undef ENC_HALF
+#undef ENC_TOP
 }
 
 int launch_enc_layer(const EncLayerArgs& a, hipStream_t st) {

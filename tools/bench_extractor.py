@@ -24,8 +24,9 @@ if __name__ == "__main__":
     for _ in range(reps):
         ex.transcript_windows(xs)
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t) / (reps * nwin)
-    print(f"{dt*1e3:.3f} ms/window  {ex.window_flops/dt/1e12:.1f} TFLOP/s  {8.192/dt:.0f} audio-s/s")
+    dt = (time.perf_counter() - t) / (max(reps, 1) * nwin)
+    if reps > 0:
+        print(f"{dt*1e3:.3f} ms/window  {ex.window_flops/dt/1e12:.1f} TFLOP/s  {8.192/dt:.0f} audio-s/s")
     from etude_amd import _lib
     _lib.prof_reset(); _lib.prof_enable(True)
     ex.transcript_windows(xs)

@@ -70,7 +70,8 @@ def main():
     # the same table under the names bench.py's launch profiler uses (template instances merged, launch-weighted):
     # profiles/traffic.json, read by bench.py for `roofline.traffic`
     groups = {"k_linear": ("k_linear<0>", "k_linear<1>"), "k_linear_ln": ("k_linear<2>",), "k_linear_dec": ("k_linear<10>", "k_linear<11>", "k_linear<12>", "k_linear<14>"),
-              "k_dgemm_s": ("k_dgemm_s<true, 5>", "k_dgemm_s<true, 3>")}
+              "k_dgemm_s": ("k_dgemm_s<true, 5>", "k_dgemm_s<true, 3>"), "k_dstep_attn_down": ("k_dstep_attn_down<4>", "k_dstep_attn_down<8>", "k_dstep_attn_down<16>"),
+              "k_proj256": ("k_proj256<true>", "k_proj256<false>")}
     bench = {}
     for k, v in traffic.items():
         name = next((g for g, members in groups.items() if k in members), k)

@@ -59,6 +59,7 @@ def main():
     rows.sort()
     # decoder kernels only, inside the decode stage of the LAST step of the run (the eager event pass runs engines one at a
     # time, so take the window in which >= 3 queues launch k_dattn: the graph-replayed step)
+    rows = [(a_, b_, (k[:k.index("<")] if k.startswith("k_dstep_attn_down<") else k), q) for a_, b_, k, q in rows]     # k_dstep_attn_down<NW> -> k_dstep_attn_down
     anchor = "k_dstep_attn_down" if any(k == "k_dstep_attn_down" for _, _, k, _ in rows) else "k_dattn"
     datt = [(s, e, q) for s, e, k, q in rows if k == anchor]
     t0, t1 = datt[0][0], datt[-1][1]
