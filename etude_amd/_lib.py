@@ -92,6 +92,8 @@ SIGNATURES = {
     "etd_extractor_window_flops": (C.c_double, [C.c_void_p]),
     "etd_mpe2note": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_float,
                                C.c_float, C.c_int, C.c_int, C.c_int, C.POINTER(Note), C.c_longlong, C.POINTER(C.c_longlong)]),
+    "etd_mpe2note_modes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_float, C.c_float,
+                                     C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Note), C.c_longlong, C.POINTER(C.c_longlong)]),
     "etd_mpe2note_dev_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "etd_mpe2note_dev_destroy": (None, [C.c_void_p]),
     "etd_mpe2note_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_float,

@@ -48,10 +48,11 @@ void find_peaks(const float* x, long long T, int stride, float thr, double hop_s
 }
 }  // namespace
 
-extern "C" int etd_mpe2note(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T,
-                            int n_note, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr,
-                            int note_min, etd_note* out, long long cap, long long* n_out) {
+extern "C" int etd_mpe2note_modes(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T,
+                                  int n_note, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr,
+                                  int note_min, int mode_velocity, int mode_offset, etd_note* out, long long cap, long long* n_out) {
   if (!onset || !offset || !mpe || !velocity || T < 0 || n_note <= 0 || !n_out) ETD_FAIL(ETD_EINVAL, "mpe2note: bad args");
+  if (mode_velocity < 0 || mode_velocity > 1 || mode_offset < 0 || mode_offset > 2) ETD_FAIL(ETD_EINVAL, "mpe2note: unknown mode");
   const double hop_sec = (double)hop_sample / (double)sr;
   std::vector<etd_note> notes;
   std::vector<Peak> on, off;
@@ -80,8 +81,10 @@ extern "C" int etd_mpe2note(const float* onset, const float* offset, const float
       if (!flag_off && !flag_mpe) off_val = t_next;
       else if (flag_off && !flag_mpe) off_val = t_off;
       else if (!flag_off && flag_mpe) off_val = t_mpe;
-      else off_val = (loc_off <= loc_mpe) ? t_off : t_mpe;          // mode_offset = "shorter"
-      if (vel > 0) notes.push_back({on[k].time, off_val, j + note_min, vel});   // mode_velocity = "ignore_zero"
+      else if (mode_offset == ETD_M2N_OFFSET) off_val = t_off;                                  // extractor.py:391-393
+      else if (mode_offset == ETD_M2N_LONGER) off_val = (loc_off >= loc_mpe) ? t_off : t_mpe;    // :394-399
+      else off_val = (loc_off <= loc_mpe) ? t_off : t_mpe;                                       // "shorter" (the default), :400-404
+      if (mode_velocity == ETD_M2N_VEL_ORG || vel > 0) notes.push_back({on[k].time, off_val, j + note_min, vel});   // "ignore_zero" drops velocity 0 (:405-409)
       const size_t n = notes.size();
       if (n > 1 && notes[n - 1].pitch == notes[n - 2].pitch && notes[n - 1].onset < notes[n - 2].offset)
         notes[n - 2].offset = notes[n - 1].onset;
@@ -94,4 +97,12 @@ extern "C" int etd_mpe2note(const float* onset, const float* offset, const float
   if ((long long)notes.size() > cap || (!out && !notes.empty())) ETD_FAIL(ETD_ENOMEM, "mpe2note: need room for %zu notes", notes.size());
   std::copy(notes.begin(), notes.end(), out);
   return ETD_OK;
+}
+
+// the reference's defaults: mode_velocity = "ignore_zero", mode_offset = "shorter" (extractor.py:256)
+extern "C" int etd_mpe2note(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T,
+                            int n_note, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr,
+                            int note_min, etd_note* out, long long cap, long long* n_out) {
+  return etd_mpe2note_modes(onset, offset, mpe, velocity, T, n_note, thred_onset, thred_offset, thred_mpe, hop_sample, sr, note_min,
+                            ETD_M2N_VEL_IGNORE_ZERO, ETD_M2N_SHORTER, out, cap, n_out);
 }

@@ -165,7 +165,11 @@ class AMTAPC_Extractor:
         res = tuple(o.cpu().numpy() for o in out)
         return res if mode == "combination" else res[:4]
 
-    def _mpe2note_array(self, a_onset, a_offset, a_mpe, a_velocity, thred_onset=0.5, thred_offset=0.5, thred_mpe=0.5) -> np.ndarray:
+    _M2N_VEL = {"ignore_zero": 0, "org": 1}
+    _M2N_OFF = {"shorter": 0, "longer": 1, "offset": 2}
+
+    def _mpe2note_array(self, a_onset, a_offset, a_mpe, a_velocity, thred_onset=0.5, thred_offset=0.5, thred_mpe=0.5,
+                        mode_velocity="ignore_zero", mode_offset="shorter") -> np.ndarray:
         """extractor.py:256-418 through the C ABI; returns a structured array (onset f8, offset f8, pitch i4, velocity i4)."""
         on = np.ascontiguousarray(a_onset, np.float32)
         off = np.ascontiguousarray(a_offset, np.float32)
@@ -178,9 +182,10 @@ class AMTAPC_Extractor:
         while True:
             buf = np.empty(cap, dtype=NOTE_DTYPE)
             n = C.c_longlong()
-            rc = lib.etd_mpe2note(on.ctypes.data, off.ctypes.data, mp.ctypes.data, ve.ctypes.data, T, nn, thred_onset,
-                                  thred_offset, thred_mpe, f.hop_sample, f.sr, self.config.midi.note_min,
-                                  C.cast(buf.ctypes.data, C.POINTER(_lib.Note)), cap, C.byref(n))
+            rc = lib.etd_mpe2note_modes(on.ctypes.data, off.ctypes.data, mp.ctypes.data, ve.ctypes.data, T, nn, thred_onset,
+                                        thred_offset, thred_mpe, f.hop_sample, f.sr, self.config.midi.note_min,
+                                        self._M2N_VEL[mode_velocity], self._M2N_OFF[mode_offset],
+                                        C.cast(buf.ctypes.data, C.POINTER(_lib.Note)), cap, C.byref(n))
             if rc == -12 and n.value > cap:
                 cap = int(n.value)
                 continue
@@ -224,9 +229,10 @@ class AMTAPC_Extractor:
     def _mpe2note(self, a_onset=None, a_offset=None, a_mpe=None, a_velocity=None, thred_onset=0.5, thred_offset=0.5,
                   thred_mpe=0.5, mode_velocity="ignore_zero", mode_offset="shorter") -> List[dict]:
         """extractor.py:256-418 (host C++ through the C ABI)."""
-        if mode_velocity != "ignore_zero" or mode_offset != "shorter":
-            raise _lib.EtudeHipError("only the modes the reference uses are implemented (ignore_zero / shorter)")
-        return self._notes_from_array(self._mpe2note_array(a_onset, a_offset, a_mpe, a_velocity, thred_onset, thred_offset, thred_mpe))
+        if mode_velocity not in self._M2N_VEL or mode_offset not in self._M2N_OFF:
+            raise ValueError(f"_mpe2note: unknown mode {mode_velocity!r} / {mode_offset!r}")
+        return self._notes_from_array(self._mpe2note_array(a_onset, a_offset, a_mpe, a_velocity, thred_onset, thred_offset, thred_mpe,
+                                                           mode_velocity, mode_offset))
 
     def _note2json(self, notes, path_output, min_length=0.0):
         """extractor.py:432-446."""

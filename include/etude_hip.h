@@ -128,6 +128,15 @@ typedef struct { double onset, offset; int32_t pitch, velocity; } etd_note;
 int etd_mpe2note(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T,
                  int n_note, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr,
                  int note_min, etd_note* out, long long cap, long long* n_out);
+/* The same with the reference's two mode switches (extractor.py:256-258): mode_velocity "ignore_zero" (default) drops notes whose
+ * velocity argmax is 0, "org" keeps them; mode_offset picks, when both an offset peak and an mpe drop exist, the earlier one
+ * ("shorter", default), the later one ("longer") or always the offset peak ("offset") (:386-404).  Host only: the device path
+ * (etd_mpe2note_dev) implements the defaults, which is all the reference's callers use. */
+enum { ETD_M2N_VEL_IGNORE_ZERO = 0, ETD_M2N_VEL_ORG = 1 };
+enum { ETD_M2N_SHORTER = 0, ETD_M2N_LONGER = 1, ETD_M2N_OFFSET = 2 };
+int etd_mpe2note_modes(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T, int n_note,
+                       float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr, int note_min,
+                       int mode_velocity, int mode_offset, etd_note* out, long long cap, long long* n_out);
 /* The same conversion on the DEVICE: the four frame-wise arrays stay in HBM ([T][n_note], as
  * etd_transcript wrote them), only the notes come back, already in the reference's order.  Bit-identical to etd_mpe2note.
  * The handle owns scratch that grows to the largest T seen; calls on one handle are not re-entrant. */

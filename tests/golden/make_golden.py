@@ -157,6 +157,28 @@ def gen_mpe2note():
     (HERE / "mpe2note.json").write_text(json.dumps(cases))
 
 
+def gen_mpe2note_modes():
+    """the reference's _mpe2note with its non-default mode switches (extractor.py:256-258, 386-409) on random frame arrays"""
+    ex, _ = ref_extractor(TINY_EXT, seed=11)
+    ex.config.midi.num_note = 6
+    rng = np.random.default_rng(41)
+    cases, inputs = [], []
+    for k in range(3):
+        Tn = 160
+        on = np.round(rng.random((Tn, 6)) ** 3, 2).astype(np.float32)
+        off = np.round(rng.random((Tn, 6)) ** 2, 2).astype(np.float32)
+        mpe = rng.random((Tn, 6)).astype(np.float32)
+        vel = (rng.integers(0, 128, (Tn, 6)) * (rng.random((Tn, 6)) > 0.15)).astype(np.int8)
+        inputs.append(dict(thr=[0.6, 0.5, 0.45], onset=on.tolist(), offset=off.tolist(), mpe=np.round(mpe, 4).tolist(), velocity=vel.tolist()))
+        mpe = np.asarray(inputs[-1]["mpe"], np.float32)
+        for mv in ("ignore_zero", "org"):
+            for mo in ("shorter", "longer", "offset"):
+                notes = ex._mpe2note(on, off, mpe, vel, thred_onset=0.6, thred_offset=0.5, thred_mpe=0.45, mode_velocity=mv, mode_offset=mo)
+                cases.append(dict(input=k, mode_velocity=mv, mode_offset=mo, notes=notes))
+    (HERE / "mpe2note_modes.json").write_text(json.dumps(dict(inputs=inputs, cases=cases)))
+    print("  mpe2note_modes:", [len(c["notes"]) for c in cases])
+
+
 def ref_decoder(dims, seed, **kw):
     from etude.models.etude_decoder import EtudeDecoder, EtudeDecoderConfig
     d = synth.decoder_dims(**dims)
@@ -409,7 +431,7 @@ def gen_clip_full():
                         gen_ids=np.asarray(gen_ids, np.int32))
 
 
-ALL = dict(clip_full=gen_clip_full, tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
+ALL = dict(clip_full=gen_clip_full, mpe2note_modes=gen_mpe2note_modes, tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
            decoder_tiny=gen_decoder_tiny, decoder_full=gen_decoder_full)
 
 if __name__ == "__main__":

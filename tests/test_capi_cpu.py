@@ -53,6 +53,30 @@ def test_mpe2note_capi_matches_reference_golden(golden_dir):
         assert notes == c["notes"], c["name"]     # exact, incl. the float32-interpolated onset/offset times
 
 
+def test_mpe2note_modes_capi_matches_reference_golden(golden_dir):
+    """etd_mpe2note_modes against the reference's own output for every (mode_velocity, mode_offset) pair"""
+    g = json.loads((golden_dir / "mpe2note_modes.json").read_text())
+    lib = _lib.lib()
+    seen = set()
+    for c in g["cases"]:
+        i = g["inputs"][c["input"]]
+        on, off, mpe = (np.ascontiguousarray(i[k], np.float32) for k in ("onset", "offset", "mpe"))
+        vel = np.ascontiguousarray(i["velocity"], np.int8)
+        T, nn = on.shape
+        cap = T * nn
+        buf = (_lib.Note * cap)()
+        n = C.c_longlong()
+        mv, mo = {"ignore_zero": 0, "org": 1}[c["mode_velocity"]], {"shorter": 0, "longer": 1, "offset": 2}[c["mode_offset"]]
+        _lib.check(lib.etd_mpe2note_modes(on.ctypes.data, off.ctypes.data, mpe.ctypes.data, vel.ctypes.data, T, nn, *i["thr"], 256, 16000, 21,
+                                          mv, mo, buf, cap, C.byref(n)), "etd_mpe2note_modes")
+        notes = [{"pitch": int(b.pitch), "onset": float(b.onset), "offset": float(b.offset), "velocity": int(b.velocity)} for b in buf[: n.value]]
+        assert notes == c["notes"], (c["input"], c["mode_velocity"], c["mode_offset"])
+        seen.add(json.dumps(notes))
+    assert len(seen) > 6          # the switches do change the result on these inputs
+    assert lib.etd_mpe2note_modes(on.ctypes.data, off.ctypes.data, mpe.ctypes.data, vel.ctypes.data, T, nn, 0.5, 0.5, 0.5, 256, 16000, 21,
+                                  0, 3, buf, cap, C.byref(n)) == -22     # ETD_EINVAL
+
+
 def test_mpe2note_capi_matches_oracle_on_random_frames():
     from oracle import mpe2note as om
     rng = np.random.default_rng(0)

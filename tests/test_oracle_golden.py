@@ -59,6 +59,18 @@ def test_mpe2note_cases(golden_dir):
         assert mpe2note.notes_for_json(notes, c["min_dur"]) == c["json"], c["name"]
 
 
+def test_mpe2note_mode_switches(golden_dir):
+    """the reference's non-default modes (extractor.py:386-409), fixtures made by the reference itself"""
+    g = json.loads((golden_dir / "mpe2note_modes.json").read_text())
+    assert len(g["cases"]) == 18
+    for c in g["cases"]:
+        i = g["inputs"][c["input"]]
+        on, off, mpe = (np.asarray(i[k], np.float32) for k in ("onset", "offset", "mpe"))
+        vel = np.asarray(i["velocity"], np.int8)
+        notes = mpe2note.mpe2note(on, off, mpe, vel, *i["thr"], mode_velocity=c["mode_velocity"], mode_offset=c["mode_offset"])
+        assert notes == c["notes"], (c["input"], c["mode_velocity"], c["mode_offset"])
+
+
 @pytest.mark.parametrize("name,dims,seed,kw", [("decoder_tiny", TINY_DEC, 2, TINY_DEC_KW), ("decoder_full", {}, 1, {})])
 def test_decoder_logits_and_greedy_ids(golden_dir, name, dims, seed, kw):
     g = np.load(golden_dir / f"{name}.npz")
