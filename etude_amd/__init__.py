@@ -10,6 +10,14 @@ Drop-in surfaces (same names/signatures as the reference):
 All arithmetic runs in libetude_hip.so (hand-written HIP, see csrc/); importing the heavy
 modules is lazy so that `import etude_amd` works on a box without a GPU.
 """
+import os as _os
+
+# Four decoder engines (run_engines) want four hardware queues that sit on four different compute pipes.  The HIP runtime's
+# default of four queues puts the fourth engine's stream on a queue it shares with the null stream: with the default, four engines
+# stepping together reach 7.8 engine-steps per ms instead of 10.0 (tools/runs/r2_run15.sh vs r2_run16.sh).  The runtime reads
+# this when it initialises, so it only takes effect if etude_amd is imported before the first HIP call of the process.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 __all__ = ["AMTAPC_Extractor", "EtudeDecoder", "EtudeDecoderConfig", "load_etude_decoder", "Vocab", "Event",
            "ExtractorConfig", "DecoderConfig", "HFT_Transformer", "HFTConfig", "TinyREMITokenizer", "run_engines"]
 

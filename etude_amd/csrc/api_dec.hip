@@ -58,6 +58,7 @@ struct etd_dec {
   unsigned long long* rng_key = nullptr;         // [S] per-stream draw keys
   std::vector<unsigned long long> host_key; bool keys_dirty = true; bool sampling = false;
   float* Pk = nullptr;                           // [5][512][H] split-K partials of the decode-step (down | dense) projection
+  int* row_cnt = nullptr;                        // [L][512] arrival counters of the in-launch row finish (DRowFin); zero between launches
   bf16* Xcat = nullptr;                          // [512][I + H] bf16: GELU(up) | attention output, the K-concatenated input of that GEMM
   std::vector<int> stage;                        // host staging of a prefill batch (fallback when the pinned buffer is absent)
   // pinned host memory (hipHostMalloc): copies to / from it are true async DMAs -- a pageable source or destination costs a
@@ -228,10 +229,24 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       DGemmArgs dn = {};
       dn.Xb = d->Xcat; dn.ldx = d->I + d->H; dn.W = w.cat.W; dn.K = d->I + d->H; dn.M = M; dn.N = d->H; dn.Npad = d->H;
       dn.k_splits = ksd; dn.Y = d->Pk; dn.ldy = d->H;
-      ETD_TRY(launch_dstep_attn_down(at, dn, st));
       const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
-      ETD_TRY(launch_resid_ln_rows(d->Pk, ksd + d->nh, w.cat.b, nullptr, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
-                                   nx ? nx->ln2g : nullptr, nx ? nx->ln2b : nullptr, d->cfg.layer_norm_eps, nx ? d->X1b : nullptr, nx ? d->X2b : nullptr, st));
+      // ETD_ROWFIN=1: the row kernel (split-K sum + bias + residual + next LayerNorms) rides in the attention launch -- the last
+      // contributor of a row finishes it (DRowFin; 17 launches per step instead of 25, bit-identical results).  Measured round 2
+      // (tools/runs/r2_run21/24/27.sh): a step of one engine 0.197 -> 0.185 ms, four engines stepping 9.9 -> 10.1 engine-steps/ms,
+      // but the JOB 569-575 -> 567 audio-s/s (the attention workgroups live 19 instead of 15.5 us and hold 128 registers per
+      // wave while the other engines' prefill GEMMs want the same CUs).  Off by default.
+      static const bool rowfin = getenv("ETD_ROWFIN") && atoi(getenv("ETD_ROWFIN")) > 0;
+      if (rowfin && ksd + d->nh == 12 && M <= 512) {
+        DRowFin fin = {};
+        fin.cnt = d->row_cnt + (size_t)l * 512; fin.target = d->nh + 16 * ksd; fin.P = d->Pk; fin.nslab = 12;
+        fin.bias = w.cat.b; fin.hin = hin; fin.hout = hout; fin.eps = d->cfg.layer_norm_eps;
+        if (nx) { fin.g1 = nx->ln1g; fin.b1 = nx->ln1b; fin.g2 = nx->ln2g; fin.b2 = nx->ln2b; fin.x1 = d->X1b; fin.x2 = d->X2b; }
+        ETD_TRY(launch_dstep_attn_down(at, dn, &fin, st));
+      } else {
+        ETD_TRY(launch_dstep_attn_down(at, dn, nullptr, st));
+        ETD_TRY(launch_resid_ln_rows(d->Pk, ksd + d->nh, w.cat.b, nullptr, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
+                                     nx ? nx->ln2g : nullptr, nx ? nx->ln2b : nullptr, d->cfg.layer_norm_eps, nx ? d->X1b : nullptr, nx ? d->X2b : nullptr, st));
+      }
       float* t = hin; hin = hout; hout = t;
       continue;
     }
@@ -435,6 +450,7 @@ int alloc_workspaces(etd_dec* d) {
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
     rc = rc ? rc : d->alloc(&d->Pk, (size_t)12 * 512 * H);     // split-K slabs of the decode step: 5 (down | dense) or 4 (down) + one per head (dense inside the attention workgroups)
+    rc = rc ? rc : d->alloc(&d->row_cnt, (size_t)d->L * 512, true);
     rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
     rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;

@@ -79,10 +79,21 @@ struct DAttnArgs {
   float* dense_out;              // [heads][M][512] fp32 partial sums = split-K slabs of k_resid_ln_rows
 };
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
+// k_dstep_attn_down with the row kernel folded in: every contributor of a row's split-K slabs (its 8 attention workgroups, the
+// 16 x k_splits down-projection units of its row tile) stores its slab write-through and adds 1 to cnt[row]; the one that
+// brings the count to `target` is the last, reads the row's slabs back and does what k_resid_ln_rows does for that row
+// (same additions in the same order: bit-identical).  cnt is all zero between launches (the last arriver resets its word).
+struct DRowFin {
+  int* cnt; int target;          // [M] arrival counters of this layer; target = n_heads + 16 * k_splits
+  const float* P; int nslab;     // slabs [nslab][M][512]: k_splits of the down projection, then one per head
+  const float* bias; const float* hin; float* hout;
+  const float* g1; const float* b1; const float* g2; const float* b2; float eps;   // next layer's LayerNorms (x1 == null: none)
+  bf16* x1; bf16* x2;
+};
 // decode step, bf16: attention of every (row, head) WITH its share of attention.dense, and -- in the same launch, on other
 // workgroups -- the MLP down projection (which depends on the QKV|up launch only): `down` is a DEPI_PARTIAL request
 // (k_splits slabs of K / k_splits each, over the first K columns of the (down | dense) weight).
-int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& down, hipStream_t st);
+int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& down, const DRowFin* fin, hipStream_t st);
 
 // h fp32 [M,H] -> LayerNorm with (g1,b1) and (g2,b2) -> two bf16 matrices (the two parallel-residual branches read the same h)
 int launch_ln_rows(const float* h, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,

@@ -15,6 +15,35 @@
 
 #include "dec_epilogue.h"
 
+// Diagnostic build (-DETD_STEP_STAMP, tools/step_stamps.py): every workgroup of the three per-layer decode-step kernels records
+// s_memrealtime (100 MHz, one clock for the whole chip) at its phase boundaries into a device buffer handed over with
+// etd_debug_step_stamps.  Record = 8 x int64: [kernel id | role << 8 | blockIdx << 16, t0 .. t5, XCC id].  The shipped build has none.
+#ifdef ETD_STEP_STAMP
+__device__ long long* g_ss_buf;
+__device__ unsigned long long g_ss_cap;
+__device__ unsigned long long g_ss_cnt;
+#define SS_DECL() long long ss_t[6] = {0, 0, 0, 0, 0, 0}
+#define SS(i) do { __builtin_amdgcn_sched_barrier(0); ss_t[i] = (long long)__builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SS_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define SS_FLUSH(kid, role) do { if (threadIdx.x == 0 && g_ss_buf) { const unsigned long long i_ = atomicAdd(&g_ss_cnt, 1ull); if (i_ < g_ss_cap) { long long* o_ = g_ss_buf + i_ * 8;          \
+      o_[0] = (long long)(kid) | ((long long)(role) << 8) | ((long long)blockIdx.x << 16); o_[1] = ss_t[0]; o_[2] = ss_t[1]; o_[3] = ss_t[2]; o_[4] = ss_t[3]; o_[5] = ss_t[4]; o_[6] = ss_t[5];   \
+      o_[7] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)); } } } while (0)      /* HW_REG_XCC_ID bits [3:0] */
+extern "C" int etd_debug_step_stamps(long long* dev_buf, unsigned long long cap_records, unsigned long long* count_out) {
+  HIP_TRY(hipDeviceSynchronize());
+  if (count_out) HIP_TRY(hipMemcpyFromSymbol(count_out, HIP_SYMBOL(g_ss_cnt), 8));
+  const unsigned long long zero = 0;
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ss_cnt), &zero, 8));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ss_buf), &dev_buf, 8));
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ss_cap), &cap_records, 8));
+  return ETD_OK;
+}
+#else
+#define SS_DECL() do { } while (0)
+#define SS(i) do { } while (0)
+#define SS_LANDED() do { } while (0)
+#define SS_FLUSH(kid, role) do { } while (0)
+#endif
+
 // ================================================================================================
 // k_dgemm: Y[M,N] = epi( LN?(X)[M,K] * W[N,K]^T + b ).  Workgroup = 4 waves = 32 tokens x 128
 // features (each wave one 32x32 accumulator, token on the lane).
@@ -285,6 +314,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int M = p_M, K = p_K;
+  SS_DECL(); SS(0);
   // workgroup -> tile as in k_dgemm_s: the row tiles of one weight tile run back to back on one XCD
   const int RT = (M + 31) / 32, bid = blockIdx.x, ft = ((bid >> 3) / RT) * 8 + (bid & 7);
   if (ft >= p_ftiles) return;
@@ -318,7 +348,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
     bf16x8 wf[NS], xf[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
+#ifdef ETD_ABL_QKVW
+      wf[s] = bf16x8{(bf16)(float)(((uintptr_t)(wrow + s)) & 7), 0, 0, 0, 0, 0, 0, 0};
+#else
       wf[s] = *reinterpret_cast<const bf16x8*>(wrow + kb + s * 16 + h * 8);
+#endif
       xf[s] = *reinterpret_cast<const bf16x8*>(xbrow + kb + s * 16 + h * 8);
     }
     if (wave == 0 && rope) {
@@ -327,6 +361,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
       rs = *reinterpret_cast<const f32x4*>(q.rope_sin + (long long)pos * 8 + 4 * h);
     }
     __builtin_amdgcn_sched_barrier(0);
+    SS_LANDED(); SS(1);
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc = mfma32(wf[s], xf[s], acc);
   }
@@ -337,12 +372,17 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
   }
   __syncthreads();
   if (wave != 0) return;
+  SS(2);
 #pragma unroll
   for (int w = 0; w < DS_WAVES - 1; ++w)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
   const int m = m0 + r;
+#ifdef ETD_STEP_STAMP
+  if (m >= M) { SS(3); SS_FLUSH(1, isq ? 0 : 1); return; }
+#else
   if (m >= M) return;
+#endif
   float v[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
@@ -355,6 +395,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
         *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
             pack4(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
     }
+    SS(3); SS_FLUSH(1, 1);
     return;
   }
   if (rope) {
@@ -374,6 +415,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<bf16x4*>(kp + 8 * q4 + 4 * h) = pack4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
   }
+  SS(3); SS_FLUSH(1, 0);
 }
 
 int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st) {
@@ -897,6 +939,101 @@ template <> struct Raw8<bf16> {
   __device__ __forceinline__ float get(int j) const { return bf2f(v[j]); }
 };
 
+// ================================================================================================
+// Row finish (DRowFin): what k_resid_ln_rows<12> does for ONE row, by ONE wave, inside the launch that produced the slabs.
+// The slabs were stored write-through (sc1) by other workgroups, possibly on other XCDs, and every one of them added to the
+// row's counter after its stores had drained; this wave's add came last, so every load of them here is an sc1 load (past
+// this CU's L1, which other CUs' stores never refresh) -- MI355X_MICROARCH.md, inter-workgroup visibility, "all sc1" form.
+// The sums run in slab order like the row kernel's, so the result is bit-identical to it.
+// ================================================================================================
+#ifndef ETD_FIN_ZB
+#define ETD_FIN_ZB 12      // slabs requested per batch by the finishing wave: all of them (96 registers in flight)
+#endif
+typedef __amdgpu_buffer_rsrc_t drsrc_t;
+__device__ __forceinline__ drsrc_t d_rsrc(const void* p, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes), 0x00020000);
+}
+#define D_SC1 16     // cache-policy bit of the raw buffer intrinsics on gfx942 / gfx950: sc1
+__device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, const int M_in, const int lane) {
+  // the row is the same for the whole wave: say so, or hipcc wraps every buffer load in a readfirstlane loop with its own vmcnt(0)
+  // (24 dependent round trips: the first build of this function took 22 us per row)
+  const int row = __builtin_amdgcn_readfirstlane(row_in), M = __builtin_amdgcn_readfirstlane(M_in);
+  const drsrc_t ps = d_rsrc(f.P, (long long)f.nslab * M * 512 * 4);
+  const long long ro = (long long)row * 512;
+  const int k = lane * 8;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  // (parameters and the residual row come from earlier launches: plain loads, requested together with the first batch)
+  const f32x4 ba = *reinterpret_cast<const f32x4*>(f.bias + k), bb = *reinterpret_cast<const f32x4*>(f.bias + k + 4);
+  const f32x4 ha = *reinterpret_cast<const f32x4*>(f.hin + ro + k), hb = *reinterpret_cast<const f32x4*>(f.hin + ro + k + 4);
+  f32x4 pg1[2], pb1[2], pg2[2], pb2[2];
+  if (f.x1) {
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      pg1[hh] = *reinterpret_cast<const f32x4*>(f.g1 + k + 4 * hh); pb1[hh] = *reinterpret_cast<const f32x4*>(f.b1 + k + 4 * hh);
+      pg2[hh] = *reinterpret_cast<const f32x4*>(f.g2 + k + 4 * hh); pb2[hh] = *reinterpret_cast<const f32x4*>(f.b2 + k + 4 * hh);
+    }
+  }
+  constexpr int ZB = ETD_FIN_ZB;   // slabs per batch of loads
+#pragma unroll
+  for (int z0 = 0; z0 < 12; z0 += ZB) {
+    f32x4 pa[ZB], pb[ZB];
+#pragma unroll
+    for (int z = 0; z < ZB; ++z) {
+      const int so = (int)((((long long)(z0 + z) * M + row) * 512) * 4);       // < 2^31: 12 slabs x 512 rows x 2 KiB
+      pa[z] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ps, k * 4, so, D_SC1));
+      pb[z] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ps, k * 4 + 16, so, D_SC1));
+    }
+#pragma unroll
+    for (int z = 0; z < ZB; ++z)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { acc[j] += pa[z][j]; acc[4 + j] += pb[z][j]; }
+  }
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { v[j] = ((acc[j] + ba[j]) + 0.f) + ha[j]; v[4 + j] = ((acc[4 + j] + bb[j]) + 0.f) + hb[j]; }   // (+ 0.f: the row kernel's absent `add` term)
+  {
+    const f32x4 oa = {v[0], v[1], v[2], v[3]}, ob = {v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4*>(f.hout + ro + k) = oa;
+    *reinterpret_cast<f32x4*>(f.hout + ro + k + 4) = ob;
+  }
+  if (!f.x1) return;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += v[j];
+  s = wave_sum(s);
+  const float mean = s / 512.f;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { const float d0 = v[j] - mean; q += d0 * d0; }
+  q = wave_sum(q);
+  const float rstd = rsqrtf(q / 512.f + f.eps);
+  bf16x8 o1, o2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float n = (v[j] - mean) * rstd;
+    o1[j] = (bf16)(n * pg1[j >> 2][j & 3] + pb1[j >> 2][j & 3]);
+    o2[j] = (bf16)(n * pg2[j >> 2][j & 3] + pb2[j >> 2][j & 3]);
+  }
+  *reinterpret_cast<bf16x8*>(f.x1 + ro + k) = o1;
+  *reinterpret_cast<bf16x8*>(f.x2 + ro + k) = o2;
+}
+#define D_ARRIVE(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define D_CNT_RESET(p) __hip_atomic_store((p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// measurement builds (tools/runs/r2_run18.sh): -DETD_ABL_DENSE / -DETD_ABL_GEMMW / -DETD_ABL_QKVW replace a weight stream by a
+// constant (wrong results on purpose) to see what that stream costs the OTHER engines' kernels
+#ifdef ETD_ABL_DENSE
+#define ABL_DENSE_LOAD(p) (bf16x8{(bf16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
+#else
+#define ABL_DENSE_LOAD(p) (*reinterpret_cast<const bf16x8*>(p))
+#endif
+#ifdef ETD_ABL_GEMMW
+#define ABL_GEMMW_LOAD(p) (bf16x8{(bf16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
+#else
+#define ABL_GEMMW_LOAD(p) (*reinterpret_cast<const bf16x8*>(p))
+#endif
 #define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
 // DENSE: instead of storing the head's 64 outputs, multiply them (rounded to bf16, as the projection GEMM would read them)
 // with this head's [512][64] slice of attention.dense and store the 512 partial sums as one more split-K slab for
@@ -906,11 +1043,12 @@ template <> struct Raw8<bf16> {
 // workgroup has 2 x 16 NW keys x 256 B in flight and walks the context in ceil(ctx / (16 NW)) dependent round trips: at the
 // serving shape (54 rows per engine, ctx ~340) NW = 4 is six round trips of ~1-2 us each with ~30 KiB in flight per CU (the
 // 0.29-of-peak kernel of round 1); NW = 16 requests the whole context of a (row, head) at once (2 iterations, both in flight).
-template <typename KVT, bool DENSE, int NW>
+template <typename KVT, bool DENSE, int NW, bool FIN = false>
 __device__ __forceinline__ void dattn_core(const int m, const int head, float (&red)[NW][8][10], float* osh, float* outsh,
                                            const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
-                                           int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a) {
+                                           int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a, const DRowFin* fin = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
+  SS_DECL(); SS(0);
   constexpr int G2 = 8 * NW;         // offset of a wave's second 8-key group inside an iteration
   constexpr int KI = 16 * NW;        // keys per workgroup iteration
   int slot, pos;
@@ -958,6 +1096,9 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   };
   int k0 = wave * 8;
   if (!p_identity && k0 < ctx) issue(k0, kA, kB, wA, wB);
+#ifdef ETD_STEP_STAMP
+  SS_LANDED(); SS(1);             // row metadata, q and the first K/V block have arrived
+#endif
   for (; k0 < ctx; k0 += KI) {
     const bool more = k0 + KI < ctx;
     if (more) issue(k0 + KI, nkA, nkB, nwA, nwB);
@@ -989,13 +1130,14 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
 
   // DENSE: this wave's dense-weight fragments (512 / NW rows = 64 / NW one-KiB fragments; the first 8 of them at most) are
   // requested here -- the key loop's K/V registers are dead, and the merge below (shuffles, LDS, a barrier) covers their round trip
+  SS(2);                           // key loop done
   constexpr int FR = 64 / NW, FP = FR > 8 ? 8 : FR, NPASS = FR / FP;
   bf16x8 dwv[DENSE ? FP : 1];
   const bf16* dwb = nullptr;
   if constexpr (DENSE) {
     dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * (512 / NW) + (lane >> 3)) * 64 + (lane & 7) * 8;
 #pragma unroll
-    for (int it = 0; it < FP; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + it * 8 * 64);
+    for (int it = 0; it < FP; ++it) dwv[it] = ABL_DENSE_LOAD(dwb + it * 8 * 64);
   }
   // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the NW waves through LDS
 #define ETD_MERGE_STAGES()                                                                                                  \
@@ -1073,6 +1215,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     // the merge), the 8-lane sums use DPP exchanges.  The weights of a head are one contiguous 64 KiB block (dense_w).
     // (register budget at NW = 4: the kernel streams K/V at 7 waves per SIMD, so its 16 fragments come in two passes of 8)
     __syncthreads();
+    SS(3);                         // merged across waves, normalised
     const int g8 = lane >> 3, sub = lane & 7;
     float ov[8];
 #pragma unroll
@@ -1081,7 +1224,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     for (int pass = 0; pass < NPASS; ++pass) {
       if (pass == 1) {
 #pragma unroll
-        for (int it = 0; it < FP; ++it) dwv[it] = *reinterpret_cast<const bf16x8*>(dwb + (FP + it) * 8 * 64);
+        for (int it = 0; it < FP; ++it) dwv[it] = ABL_DENSE_LOAD(dwb + (FP + it) * 8 * 64);
       }
 #pragma unroll
       for (int it = 0; it < FP; ++it) {
@@ -1094,10 +1237,49 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    if (tid < 256) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      const f32x2 o2 = {outsh[2 * tid], outsh[2 * tid + 1]};
-      *reinterpret_cast<f32x2*>(a.dense_out + ((long long)head * a.M + m) * 512 + 2 * tid) = o2;
+    SS(4);                         // dense slice applied
+    if constexpr (FIN) {
+      // the head's slab row leaves write-through in 16-byte pieces; every storing wave drains, then ONE lane arrives at the row's counter
+      if (tid < 128) {
+        const drsrc_t os = d_rsrc(a.dense_out, (long long)p_n_heads * a.M * 512 * 4);
+        const f32x4 o4 = {outsh[4 * tid], outsh[4 * tid + 1], outsh[4 * tid + 2], outsh[4 * tid + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), os, tid * 16, (int)((((long long)head * a.M + m) * 512) * 4), D_SC1);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      SS(5); SS_FLUSH(2, 0);
+      if (wave != 0) return;
+#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 1
+      return;
+#endif
+#ifdef ETD_STEP_STAMP
+      ss_t[0] = ss_t[5]; ss_t[3] = ss_t[4] = ss_t[5] = 0;
+#endif
+      int old = 0;
+      if (lane == 0) old = D_ARRIVE(fin->cnt + m);
+      old = __builtin_amdgcn_readfirstlane(old);
+      SS(1);
+#ifdef ETD_STEP_STAMP
+      if (old != fin->target - 1) { SS_FLUSH(4, 0); return; }
+#else
+      if (old != fin->target - 1) return;
+#endif
+#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 2
+      if (lane == 0) D_CNT_RESET(fin->cnt + m);
+      return;
+#endif
+      row_finish(*fin, m, a.M, lane);
+      if (lane == 0) D_CNT_RESET(fin->cnt + m);
+#ifdef ETD_STEP_STAMP
+      SS_LANDED(); SS(2); SS_FLUSH(4, 1);
+#endif
+    } else {
+      if (tid < 256) {
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 o2 = {outsh[2 * tid], outsh[2 * tid + 1]};
+        *reinterpret_cast<f32x2*>(a.dense_out + ((long long)head * a.M + m) * 512 + 2 * tid) = o2;
+      }
+      SS(5); SS_FLUSH(2, 0);
     }
   }
 }
@@ -1121,17 +1303,20 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
 // ================================================================================================
 template <int NW> struct AdOcc { static constexpr int lo = 7, hi = 8; };      // 72 registers; forcing 64 (8 waves per SIMD) spills inside the key loop, and a scratch reload there drains the K/V stream
 template <> struct AdOcc<4> { static constexpr int lo = 7, hi = 8; };      // keeps the MFMA accumulator out of AGPRs: 72 registers, 7 waves per SIMD like k_dattn (5 without the hint)
-template <int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(AdOcc<NW>::lo, AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+#ifndef ETD_FIN_OCC
+#define ETD_FIN_OCC 4      // waves per SIMD the row-finish instantiation is built for (128 registers).  Job-level (bench.py, r2_run27.sh): 4 -> 567, 5 -> 552, 6 -> 515-522 audio-s/s; at 7 (72 registers) the key loop spills
+#endif
+template <int NW, bool FIN>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? ETD_FIN_OCC : AdOcc<NW>::lo, AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                                          int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
-                                                         DAttnArgs a, DGemmArgs g) {
+                                                         DAttnArgs a, DGemmArgs g, DRowFin fin) {
   constexpr int UNITS = NW / 2;
   __shared__ float red[NW][8][10];
   __shared__ float osh[64];
   __shared__ __attribute__((aligned(16))) float sh[UNITS * 16 * 64 > 512 ? UNITS * 16 * 64 : 512];      // attention: 512 staged outputs; GEMM: the units' cross-wave sums
   if ((int)blockIdx.x >= p_gemm_wgs) {
     const int lid = blockIdx.x - p_gemm_wgs;
-    dattn_core<bf16, true, NW>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
+    dattn_core<bf16, true, NW, FIN>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a, &fin);
     return;
   }
   // ---- GEMM role
@@ -1149,6 +1334,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(AdOcc<N
   // (the same 16 MFMAs in the same order as k_dgemm_s, but fed in four passes of 4 k-steps: this role shares the launch -- and
   // so the register allocation -- with the attention role; four short round trips of a few dozen workgroups hide behind the
   // attention workgroups)
+  SS_DECL(); SS(0);
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -1156,11 +1342,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(AdOcc<N
   for (int ps = 0; ps < 4; ++ps) {
     bf16x8 wf[4], xf[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) { wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + (ps * 4 + s4) * 16); xf[s4] = *reinterpret_cast<const bf16x8*>(xrow + (ps * 4 + s4) * 16); }
+    for (int s4 = 0; s4 < 4; ++s4) { wf[s4] = ABL_GEMMW_LOAD(wrow + (ps * 4 + s4) * 16); xf[s4] = *reinterpret_cast<const bf16x8*>(xrow + (ps * 4 + s4) * 16); }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
   }
+  SS(1);
   float* redg = sh + unit * (16 * 64);
   if (wave == 1) {
 #pragma unroll
@@ -1171,10 +1358,47 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(AdOcc<N
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] += redg[i * 64 + lane];
   const int m = m0 + r;
-  if (m >= p_M) return;
-  DGemmArgs b = g;
-  b.Y = g.Y + (long long)bz * p_M * g.ldy;
-  dgemm_epilogue<true, DEPI_PARTIAL>(b, acc, m, n0, h);
+  if constexpr (FIN) {
+    // slab bz, rows of this tile: write-through 16-byte stores, drain, then lane r (h == 0) arrives at its row's counter; a unit that
+    // happens to arrive last for some rows (rare: the attention workgroups outlive the units) finishes them one after the other
+    if (m < p_M) {
+      const drsrc_t ys = d_rsrc(g.Y, (long long)g.k_splits * p_M * 512 * 4);
+      const int vo = ((bz * p_M + m) * 512 + n0 + 4 * h) * 4;       // the row differs per lane: it belongs in the VECTOR offset (a per-lane scalar offset becomes a 32-trip readfirstlane loop); < 2^31
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o4 = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o4), ys, vo + 32 * q, 0, D_SC1);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SS(2); SS_FLUSH(2, 1);
+    // both lane halves of a row have drained their stores before the row's lane adds: the wait above is wave-wide
+#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 1
+    return;
+#endif
+#ifdef ETD_FIN_TEST_SLOWGEMM      /* test build: the units of odd feature tiles arrive ~40 us late, so that THEY are the last arrivers and finish the rows */
+    if ((n0 >> 5) & 1) for (int i = 0; i < 10; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+    int old = -1;
+    if (h == 0 && m < p_M) old = D_ARRIVE(fin.cnt + m);
+    unsigned long long last = __ballot(old == fin.target - 1);
+#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 2
+    if (last) { if (old == fin.target - 1) D_CNT_RESET(fin.cnt + m); }
+    return;
+#endif
+    while (last) {
+      const int rl = __builtin_ctzll(last);
+      last &= last - 1;
+      row_finish(fin, m0 + rl, p_M, lane);
+      if (lane == 0) D_CNT_RESET(fin.cnt + m0 + rl);
+    }
+  } else {
+    if (m >= p_M) return;
+    DGemmArgs b = g;
+    b.Y = g.Y + (long long)bz * p_M * g.ldy;
+    dgemm_epilogue<true, DEPI_PARTIAL>(b, acc, m, n0, h);
+    SS(2); SS_FLUSH(2, 1);
+  }
 }
 
 // waves per attention workgroup: 4, or ETD_AD_WAVES = 8 / 16 (measurement builds).  Measured on MI355X, round 2 (tools/runs/r2_run1.sh):
@@ -1188,7 +1412,10 @@ static int ad_waves(int M) {
   (void)M;
   return (env == 8 || env == 16) ? env : 4;
 }
-int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, hipStream_t st) {
+int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin* fin, hipStream_t st) {
+  if (fin && (!fin->cnt || fin->target != a.n_heads + 16 * g.k_splits || fin->nslab != 12 || g.k_splits + a.n_heads != 12 || fin->P != g.Y ||
+              a.dense_out != g.Y + (size_t)g.k_splits * a.M * 512 || !fin->bias || !fin->hin || !fin->hout || fin->hin == fin->hout || (fin->x1 && (!fin->x2 || !fin->g1 || !fin->b1 || !fin->g2 || !fin->b2))))
+    ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad row-finish arguments");
   if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 256 ||
       g.M != a.M || !g.Xb || !g.W || !g.Y || g.ldy != 512 || g.N != 512 || g.Npad != 512 || g.k_splits < 1 || g.k_splits * 512 > g.K || (g.K % 8) || a.n_heads * 64 != 512)
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad arguments");
@@ -1197,9 +1424,11 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, hipStream_t s
   const int slots = ((FT * g.k_splits + 7) / 8) * RT;               // per XCD
   const int gemm_wgs = ((slots + units - 1) / units) * 8;
   ProfScope ps("k_dstep_attn_down", st, 2.0 * a.M * 512 * (512.0 * g.k_splits + 512.0), a.bytes_hint + 512.0 * (512.0 * g.k_splits + 512.0) * 2);
-#define ETD_AD_LAUNCH(NW_) hipLaunchKernelGGL(k_dstep_attn_down<NW_>, dim3(gemm_wgs + a.M * a.n_heads), dim3(64 * NW_), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, \
-                                              a.identity ? 1 : 0, gemm_wgs, a.M, a, g)
-  if (nw == 16) ETD_AD_LAUNCH(16); else if (nw == 8) ETD_AD_LAUNCH(8); else ETD_AD_LAUNCH(4);
+  const DRowFin f0 = fin ? *fin : DRowFin{};
+#define ETD_AD_LAUNCH(NW_, FIN_) hipLaunchKernelGGL((k_dstep_attn_down<NW_, FIN_>), dim3(gemm_wgs + a.M * a.n_heads), dim3(64 * NW_), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, \
+                                              a.identity ? 1 : 0, gemm_wgs, a.M, a, g, f0)
+  if (fin) { if (nw == 16) ETD_AD_LAUNCH(16, true); else if (nw == 8) ETD_AD_LAUNCH(8, true); else ETD_AD_LAUNCH(4, true); }
+  else if (nw == 16) ETD_AD_LAUNCH(16, false); else if (nw == 8) ETD_AD_LAUNCH(8, false); else ETD_AD_LAUNCH(4, false);
 #undef ETD_AD_LAUNCH
   HIP_TRY(hipGetLastError());
   return ETD_OK;
@@ -1287,6 +1516,7 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
                                                        const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  SS_DECL(); SS(0);
   const long long ro = (long long)row * H;
   float v[4][8];
   float s = 0.f;
@@ -1341,6 +1571,7 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
     }
   }
   if (!x1) return;
+  SS(1);                 // slabs, bias, residual summed (loads landed), row stored
   s = wave_sum(s);
   const float mean = s / (float)H;
   float q = 0.f;
@@ -1352,6 +1583,7 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
     }
   q = wave_sum(q);
   const float rstd = rsqrtf(q / (float)H + eps);
+  SS(2);
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int k = lane * 8 + it * 512;
@@ -1369,6 +1601,7 @@ __global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__
       *reinterpret_cast<bf16x8*>(x2 + ro + k) = o2;
     }
   }
+  SS(3); SS_FLUSH(3, 0);
 }
 int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const float* add, const float* hin, float* hout, int M, int H,
                          const float* g1, const float* b1, const float* g2, const float* b2, float eps, bf16* x1, bf16* x2, hipStream_t st) {

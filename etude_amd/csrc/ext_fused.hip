@@ -510,11 +510,16 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   };
   // top of a half-chunk: it has landed for this wave (counted wait) and, behind the barrier, for everybody; the slot of half-chunk
   // hc - 1 is free (every wave has passed this barrier, so it is done reading it) and takes half-chunk hc + 4
+#ifdef ETD_ENC_SYNCTHREADS      /* A/B build: the round-2 form */
+#define ENC_BARRIER() __syncthreads()
+#else
+#define ENC_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
 #define ENC_TOP(hc)                                                                                                    \
   do {                                                                                                                 \
-    if ((hc) + ENC_AHEAD - 1 < ENC_NHC) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                             \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                              \
-    __syncthreads();                                                                                                   \
+    if ((hc) + ENC_AHEAD - 1 < ENC_NHC) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");                  \
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                   \
+    ENC_BARRIER();                    /* NOT __syncthreads(): its fence waits vmcnt(0) while LDS-DMA is pending and drains the ring */ \
     if ((hc) + ENC_AHEAD < ENC_NHC) issue((hc) + ENC_AHEAD);                                                           \
   } while (0)
   // 16 fragments of a half-chunk against B (or A) operands, four at a time, one group requested ahead of the MFMAs that use it
@@ -605,7 +610,8 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
         }
       }
     }
-    __syncthreads();                                      // K and V images of this head complete
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // K and V images of this head complete (raw: the ring's DMAs stay in flight)
     // ---- attention of the wave's 32 queries against the 256 keys, 64 keys per step
     f32x16 o[2];
 #pragma unroll

@@ -264,3 +264,21 @@ def test_small_geometry_truncation_and_history_knobs_against_oracle(dev):
     wantb = [neox.generate_ids(sd, neox_dims(over), 4, 5, b, a, max_output_tokens=25600, max_bar_token_limit=20, context_overlap_ratio=0.5) for b, a in jobs]
     first_bar = sum(1 for g, w in zip(gotb, wantb) if g[0][:4] == w[0][:4])
     assert first_bar >= 3, (gotb[0][0], wantb[0][0])          # greedy paths diverge after a flip, so only the start of the first bar is comparable
+
+
+def test_row_finish_opt_in_is_bit_identical(dev):
+    """ETD_ROWFIN=1 folds k_resid_ln_rows into the attention launch (the last contributor of a row sums its split-K slabs, adds the
+    residual and normalises it for the next layer -- an in-launch hand-off through write-through stores, an agent-scope counter
+    and sc1 loads).  Same additions in the same order: the greedy token streams of two engines stepping concurrently must be the
+    same bytes as with the separate row kernel.  (The switch is read once per process, hence the child processes.)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    tool = Path(__file__).resolve().parent.parent / "tools" / "ab_tokens.py"
+    outs = []
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, str(tool), "20", "96", "24", "2"], env=dict(os.environ, ETD_ROWFIN=flag), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("rep")])
+    assert len(outs[0]) == 6 and outs[0] == outs[1]

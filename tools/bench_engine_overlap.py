@@ -16,6 +16,8 @@ if __name__ == "__main__":
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 72
     ctx0 = int(sys.argv[2]) if len(sys.argv) > 2 else 320
     steps = int(sys.argv[3]) if len(sys.argv) > 3 else 96
+    import os
+    MAXCTX = int(os.environ.get("ETD_BENCH_MAXCTX", "1024"))       # KV positions per stream: sets the stride between (slot, head) regions of the caches
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
@@ -27,7 +29,7 @@ if __name__ == "__main__":
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     for e in range(4):
-        dec = decs[0].clone() if decs else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=1024)
+        dec = decs[0].clone() if decs else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=MAXCTX)
         if mask_mode != "none":
             bits = [0] * 256
             if mask_mode == "thirds":
@@ -57,7 +59,7 @@ if __name__ == "__main__":
         for dec in decs:
             st = dec._stream()
             for s, (ids, cls, a4) in enumerate(prompts):
-                _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, min(1000, 1024 - ctx0), st), "begin_bar")
+                _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data, -1, min(1000, MAXCTX - ctx0), st), "begin_bar")
             _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, S, 4, st), "step")
         torch.cuda.synchronize(dev)
 
