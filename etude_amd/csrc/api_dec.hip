@@ -7,6 +7,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/etude_hip.h"
@@ -614,10 +615,23 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   return ETD_OK;
 }
 
+// clone / destroy bookkeeping of a weight-sharing family (n_clones, zombie) runs under one process-wide lock: handles of a family
+// may be cloned and destroyed from different threads
+static std::mutex g_family_mu;
+
 extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
   if (!src || !out) ETD_FAIL(ETD_EINVAL, "decoder_clone: null argument");
   etd_dec* own = src->weights_owner ? src->weights_owner : src;
-  if (own->zombie) ETD_FAIL(ETD_EINVAL, "decoder_clone: the source handle was destroyed");
+  {
+    std::lock_guard<std::mutex> lk(g_family_mu);
+    if (own->zombie) ETD_FAIL(ETD_EINVAL, "decoder_clone: the source handle was destroyed");
+    ++own->n_clones;          // taken BEFORE the workspaces are built: the owner cannot free the weights underneath this clone
+  }
+  auto unref = [own]() {
+    bool last;
+    { std::lock_guard<std::mutex> lk(g_family_mu); last = --own->n_clones == 0 && own->zombie; }
+    if (last) { for (void* p : own->allocs) (void)hipFree(p); delete own; }
+  };
   etd_dec* d = new etd_dec();
   d->cfg = own->cfg; d->bf16w = own->bf16w;
   d->H = own->H; d->I = own->I; d->V = own->V; d->L = own->L; d->nh = own->nh; d->S = own->S; d->ctx = own->ctx;
@@ -635,10 +649,9 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
     if (d->pin_stage) (void)hipHostFree(d->pin_stage);
     if (d->pin_rb) (void)hipHostFree(d->pin_rb);
     if (d->pin_stage_evt) (void)hipEventDestroy(d->pin_stage_evt);
-    delete d; return rc;
+    delete d; unref(); return rc;
   }
   HIP_TRY(hipDeviceSynchronize());
-  ++own->n_clones;
   *out = d;
   return ETD_OK;
 }
@@ -655,14 +668,17 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
     etd_dec* own = d->weights_owner;
     for (void* p : d->allocs) (void)hipFree(p);
     delete d;
-    if (--own->n_clones == 0 && own->zombie) { for (void* p : own->allocs) (void)hipFree(p); delete own; }
+    bool last;
+    { std::lock_guard<std::mutex> lk(g_family_mu); last = --own->n_clones == 0 && own->zombie; }
+    if (last) { for (void* p : own->allocs) (void)hipFree(p); delete own; }
     return;
   }
-  if (d->n_clones > 0) {
+  bool keep;
+  { std::lock_guard<std::mutex> lk(g_family_mu); keep = d->n_clones > 0; if (keep) d->zombie = true; }
+  if (keep) {
     // clones still read the weights: release this handle's own workspaces now, the weights with the last clone
     for (size_t i = d->n_weight_allocs; i < d->allocs.size(); ++i) (void)hipFree(d->allocs[i]);
     d->allocs.resize(d->n_weight_allocs);
-    d->zombie = true;
     return;
   }
   for (void* p : d->allocs) (void)hipFree(p);

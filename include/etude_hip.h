@@ -163,9 +163,9 @@ int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const f
 void etd_decoder_destroy(etd_dec*);
 /* A second engine over the SAME weights: own KV cache, workspaces and stream state (same cfg), the weight buffers of `src`
  * (or of the handle `src` was cloned from) are shared, not copied -- concurrent engines then stream one weight set through
- * the caches instead of one copy each.  Handles may be destroyed in any order; the weights go with the last one.  Create,
- * clone and destroy handles of one family from ONE thread (the reference count is not atomic); using them concurrently,
- * one host thread per handle, is what they are for. */
+ * the caches instead of one copy each.  Handles may be destroyed in any order and from any thread (the family's reference count
+ * is kept under a lock); the weights go with the last one.  Using the handles concurrently, one host thread per handle, is what
+ * they are for. */
 int etd_decoder_clone(etd_dec* src, etd_dec** out);
 /* Start one bar on stream `slot` (etude_decoder.py:291-297 + first loop iteration): reset the slot's KV
  * cache and generation state, run the prompt (ids/cls: int32 host [T]; attrs4: int32 host [4][T] in the
