@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 // more CUs streaming weights than the 128-feature tile does when M is a handful of decode rows.
 // ================================================================================================
 #define DS_MAX_ROWS 512   // up to this many rows a GEMM runs on the weight-streaming skinny tile (decode steps of <= 512 streams)
-#define DS_WAVES 2   // K is split over the waves of a workgroup; each wave keeps 512 / DS_WAVES of k (32 fragment loads) in flight per round trip.
+#ifndef DS_WAVES
+#define DS_WAVES 2
+#endif
+// K is split over the waves of a workgroup; each wave keeps 512 / DS_WAVES of k (32 fragment loads) in flight per round trip.
                      // Measured per 128-stream step: 8 waves 0.423 ms, 4 waves 0.404 ms, 2 waves 0.385 ms (fewer wave slots held, shorter LDS reduction)
 template <bool WBF16, int EPI>
 __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, int p_ks, int p_K, const void* p_W, const bf16* p_Xb, int p_ldx, DGemmArgs a) {   // leading scalars: kernarg preload
@@ -1302,7 +1305,10 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
 // k_resid_ln_rows then sums k_splits + n_heads slabs.  A decode-step layer is 3 launches instead of 4.
 // ================================================================================================
 template <int NW> struct AdOcc { static constexpr int lo = 7, hi = 8; };      // 72 registers; forcing 64 (8 waves per SIMD) spills inside the key loop, and a scratch reload there drains the K/V stream
-template <> struct AdOcc<4> { static constexpr int lo = 7, hi = 8; };      // keeps the MFMA accumulator out of AGPRs: 72 registers, 7 waves per SIMD like k_dattn (5 without the hint)
+#ifndef ETD_AD_OCC
+#define ETD_AD_OCC 5      // built for 5 waves per SIMD (96 registers).  Job level (bench.py, tools/runs/r2_run28.sh): 7 -> 581-583, 5 -> 586-588, 4 -> 588, 3 -> 585 audio-s/s
+#endif
+template <> struct AdOcc<4> { static constexpr int lo = ETD_AD_OCC, hi = 8; };
 #ifndef ETD_FIN_OCC
 #define ETD_FIN_OCC 4      // waves per SIMD the row-finish instantiation is built for (128 registers).  Job-level (bench.py, r2_run27.sh): 4 -> 567, 5 -> 552, 6 -> 515-522 audio-s/s; at 7 (72 registers) the key loop spills
 #endif
@@ -1509,12 +1515,15 @@ int launch_ln_rows(const float* hsrc, int M, int H, const float* g1, const float
 }
 
 // hout = ((sum_z P[z] + bias) + add) + hin, then the next layer's two LayerNorms -> bf16.  One wave per row, single pass.
+#ifndef ETD_RL_ROWS
+#define ETD_RL_ROWS 4      // rows (= waves) per workgroup of the row kernel
+#endif
 template <int KS>   // KS > 0: slab count known at compile time -> all slab loads of a row are in flight together (a runtime loop makes them dependent round trips)
-__global__ __launch_bounds__(256) void k_resid_ln_rows(const float* __restrict__ P, int ks_rt, const float* __restrict__ bias, const float* __restrict__ add,
+__global__ __launch_bounds__(64 * ETD_RL_ROWS) void k_resid_ln_rows(const float* __restrict__ P, int ks_rt, const float* __restrict__ bias, const float* __restrict__ add,
                                                        const float* __restrict__ hin, float* __restrict__ hout, int M, int H,
                                                        const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2,
                                                        const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, row = blockIdx.x * ETD_RL_ROWS + (threadIdx.x >> 6);
   if (row >= M) return;
   SS_DECL(); SS(0);
   const long long ro = (long long)row * H;
@@ -1607,9 +1616,9 @@ int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const 
                          const float* g1, const float* b1, const float* g2, const float* b2, float eps, bf16* x1, bf16* x2, hipStream_t st) {
   if (M <= 0 || H % 8 || H > 2048 || k_splits < 1) ETD_FAIL(ETD_EINVAL, "resid_ln_rows: bad shape");
   ProfScope ps("k_resid_ln_rows", st, 0, (double)M * H * 4 * (k_splits + 3));
-  if (k_splits == 5) hipLaunchKernelGGL(k_resid_ln_rows<5>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
-  else if (k_splits == 12) hipLaunchKernelGGL(k_resid_ln_rows<12>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
-  else hipLaunchKernelGGL(k_resid_ln_rows<0>, dim3((M + 3) / 4), dim3(256), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
+  if (k_splits == 5) hipLaunchKernelGGL(k_resid_ln_rows<5>, dim3((M + ETD_RL_ROWS - 1) / ETD_RL_ROWS), dim3(64 * ETD_RL_ROWS), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
+  else if (k_splits == 12) hipLaunchKernelGGL(k_resid_ln_rows<12>, dim3((M + ETD_RL_ROWS - 1) / ETD_RL_ROWS), dim3(64 * ETD_RL_ROWS), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
+  else hipLaunchKernelGGL(k_resid_ln_rows<0>, dim3((M + ETD_RL_ROWS - 1) / ETD_RL_ROWS), dim3(64 * ETD_RL_ROWS), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
