@@ -446,45 +446,75 @@ def decode_jobs_async(decs, jobs, vocab, bar_tokens, ready, one_at_a_time=False)
     return join_tokens
 
 
-def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64):
+def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64, engines: int = 2):
     """BASELINE configs[3]: 128 concurrent streams, each prefilled to ctx0 then `steps` greedy decode steps
-    (EOS suppressed so every stream runs the full length -- throughput does not depend on the token values)."""
-    import ctypes as C
+    (EOS suppressed so every stream runs the full length -- throughput does not depend on the token values).
+    The streams are dealt over `engines` decoder engines (own stream, KV cache and captured graphs, shared weights) that
+    step concurrently from one host thread each, like the headline's decode stage: one step of the figure below = every one
+    of the n_streams streams advanced by one token.  Measured (tools/runs/r2_run31.sh): ctx 512: 0.359 / 0.346 / 0.367 ms
+    with 1 / 2 / 4 engines; ctx 3.5 k: 1.30 / 1.21 / 1.18 ms."""
+    import threading
     from etude_amd import _lib, synth
     from etude_amd.decoder import EtudeDecoder
-    dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=n_streams, max_ctx=4096)
+    engines = max(1, min(engines, n_streams))
+    per = [n_streams // engines + (1 if e < n_streams % engines else 0) for e in range(engines)]
+    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=max(per), max_ctx=4096)]
+    while len(decs) < engines:
+        decs.append(decs[0].clone())
     lib = _lib.lib()
     rng = np.random.default_rng(0)
-    st = dec._stream()
     tg = np.asarray([2, 1, 1, 1], np.int32)
-    for s in range(n_streams):
-        ids = rng.integers(6, 154, ctx0).astype(np.int32)
-        cls = rng.integers(1, 3, ctx0).astype(np.int32)
-        a4 = rng.integers(0, 3, (4, ctx0)).astype(np.int32)
-        _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data,
-                                             -1, min(1000, 4096 - ctx0), st), "begin_bar")
-    slots = np.arange(n_streams, dtype=np.int32)
-    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, 4, st), "step")
+    slots = [np.arange(n, dtype=np.int32) for n in per]
+    for e, dec in enumerate(decs):
+        st = dec._stream()
+        for s in range(per[e]):
+            ids = rng.integers(6, 154, ctx0).astype(np.int32)
+            cls = rng.integers(1, 3, ctx0).astype(np.int32)
+            a4 = rng.integers(0, 3, (4, ctx0)).astype(np.int32)
+            _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data,
+                                                 -1, min(1000, 4096 - ctx0), st), "begin_bar")
+        _lib.check(lib.etd_decoder_step(dec._h, slots[e].ctypes.data, per[e], 4, st), "step")
     torch.cuda.synchronize(dev)
+    errs = []
+
+    gate = threading.Barrier(engines + 1)
+
+    def run(e):
+        try:
+            torch.cuda.set_device(dev)
+            gate.wait()
+            _lib.check(lib.etd_decoder_step(decs[e]._h, slots[e].ctypes.data, per[e], steps, decs[e]._stream()), "step")     # hipGraph replays
+            decs[e]._ts.synchronize()
+        except Exception as ex:      # noqa: BLE001
+            errs.append(ex)
+    th = [threading.Thread(target=run, args=(e,)) for e in range(engines)]
+    for x in th:
+        x.start()
+    gate.wait()                                          # the engine threads exist and are bound to the device: start the clock
     t = time.perf_counter()
-    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, steps, st), "step")     # hipGraph replays
+    for x in th:
+        x.join()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t
+    if errs:
+        raise errs[0]
     _lib.prof_reset(); _lib.prof_enable(True)
     psteps = 8
-    _lib.check(lib.etd_decoder_step(dec._h, slots.ctypes.data, n_streams, psteps, st), "step")    # eager + events: per-kernel breakdown
-    torch.cuda.synchronize(dev)
+    for e, dec in enumerate(decs):                       # eager + events, one engine after the other: per-kernel breakdown
+        _lib.check(lib.etd_decoder_step(dec._h, slots[e].ctypes.data, per[e], psteps, dec._stream()), "step")
+        torch.cuda.synchronize(dev)
     _lib.prof_enable(False)
     prof = _lib.prof_report()
     ctx_mid = ctx0 + 4 + steps // 2
-    bytes_step = dec.step_bytes(n_streams, ctx_mid)
+    bytes_step = sum(decs[0].step_bytes(n, ctx_mid) for n in per)       # every engine streams the weight set once per step
     gbs = bytes_step * steps / dt / 1e9
-    out = {"workload": f"BASELINE configs[3]: {n_streams} streams, bf16 weights+KV, ctx {ctx0}->{ctx0 + 4 + steps}, {steps} greedy steps, EOS suppressed",
-           "tokens_per_s": round(n_streams * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
+    out = {"workload": f"BASELINE configs[3]: {n_streams} streams on {engines} engine(s), bf16 weights+KV, ctx {ctx0}->{ctx0 + 4 + steps}, {steps} greedy steps, EOS suppressed",
+           "engines": engines, "tokens_per_s": round(n_streams * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
            "alg_bytes_per_step": bytes_step,
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
            "kernel_ms_per_step": {k: round(v["ms"] / psteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
-    dec.close()
+    for dec in reversed(decs):
+        dec.close()
     return out
 
 
