@@ -477,7 +477,7 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     torch.cuda.synchronize(dev)
     errs = []
 
-    gate = threading.Barrier(engines + 1)
+    gate = threading.Barrier(engines + 1, timeout=120)
 
     def run(e):
         try:
