@@ -704,6 +704,10 @@ extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, c
     HIP_TRY(hipMemcpyAsync(d->rng_key, d->host_key.data(), (size_t)d->S * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
     d->keys_dirty = false;
   }
+  // the row-finish counters (ETD_ROWFIN=1) are zero between launches by construction (the last arriver resets its word); a launch
+  // that died half way would leave them poisoned for good, so every bar starts from zero anyway (16 KiB, on the stream)
+  static const bool rowfin_on = getenv("ETD_ROWFIN") && atoi(getenv("ETD_ROWFIN")) > 0;
+  if (rowfin_on && d->row_cnt) HIP_TRY(hipMemsetAsync(d->row_cnt, 0, (size_t)d->L * 512 * sizeof(int), st));
   Staged sg; float* hf = nullptr;
   bool compact = false;
   ETD_TRY(stage_and_forward(d, n, slots, T, ids, cls, attrs4, init.data(), &sg, &hf, st, &compact));
