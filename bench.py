@@ -393,7 +393,7 @@ def main():
             extras["single_clip"] = {"error": repr(e)}
         for key, c0 in (("decoder_streams", 512), ("decoder_streams_4k", 3500)):     # reference-faithful context / 4k stress
             try:
-                extras[key] = decoder_stream_bench(dcfg, dev, ctx0=c0)
+                extras[key] = decoder_stream_bench(dcfg, dev, ctx0=c0, streams=[d._ts for d in decs])
             except Exception as e:
                 extras[key] = {"error": repr(e)}
         result["extras"] = extras
@@ -446,13 +446,16 @@ def decode_jobs_async(decs, jobs, vocab, bar_tokens, ready, one_at_a_time=False)
     return join_tokens
 
 
-def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64, engines: int = 2):
+def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64, engines: int = 2, streams=None):
     """BASELINE configs[3]: 128 concurrent streams, each prefilled to ctx0 then `steps` greedy decode steps
     (EOS suppressed so every stream runs the full length -- throughput does not depend on the token values).
     The streams are dealt over `engines` decoder engines (own stream, KV cache and captured graphs, shared weights) that
     step concurrently from one host thread each, like the headline's decode stage: one step of the figure below = every one
     of the n_streams streams advanced by one token.  Measured (tools/runs/r2_run31.sh): ctx 512: 0.359 / 0.346 / 0.367 ms
-    with 1 / 2 / 4 engines; ctx 3.5 k: 1.30 / 1.21 / 1.18 ms."""
+    with 1 / 2 / 4 engines; ctx 3.5 k: 1.30 / 1.21 / 1.18 ms.
+    `streams`: torch streams the engines run on.  Inside bench.py these are the headline engines' own (idle by then): a process
+    that already holds seven streams gets hardware queues for two NEW ones that may share a compute pipe, and two dependent
+    kernel chains on one pipe run one after the other (0.50 instead of 0.34 ms per step at ctx 512, tools/runs/r2_run40/41.sh)."""
     import threading
     from etude_amd import _lib, synth
     from etude_amd.decoder import EtudeDecoder
@@ -461,6 +464,9 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=max(per), max_ctx=4096)]
     while len(decs) < engines:
         decs.append(decs[0].clone())
+    if streams:
+        for dec, ts in zip(decs, streams):
+            dec._ts = ts
     lib = _lib.lib()
     rng = np.random.default_rng(0)
     tg = np.asarray([2, 1, 1, 1], np.int32)
