@@ -437,7 +437,8 @@ def decode_jobs_async(decs, jobs, vocab, bar_tokens, ready, one_at_a_time=False)
     engine).  `ready` = (flags, job -> flag index) gates the admission of each job on its clip's upstream stages.  Returns
     a function that joins and yields (results, n_tokens)."""
     from etude_amd.decoder import run_engines
-    join = run_engines(decs, jobs, vocab, one_at_a_time=one_at_a_time, ready=ready, force_bar_tokens=bar_tokens)
+    join = run_engines(decs, jobs, vocab, one_at_a_time=one_at_a_time, ready=ready, force_bar_tokens=bar_tokens,
+                       stagger_s=float(os.environ.get("ETD_ENGINE_STAGGER_MS", "0")) * 1e-3)
 
     def join_tokens():
         out, stats = join()

@@ -289,7 +289,7 @@ class EtudeDecoder:
             pass
 
 
-def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: bool = False, ready=None, **generate_many_kwargs):
+def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: bool = False, ready=None, stagger_s: float = 0.0, **generate_many_kwargs):
     """`generate_many` over several engines at once: the job list is dealt round-robin over ``engines`` (normally one
     EtudeDecoder and its ``clone()``s, which share the device weights) and each engine runs its share from its own host
     thread -- ctypes releases the GIL inside the library calls.  On MI355X four engines is the useful maximum: a GPU has
@@ -297,8 +297,10 @@ def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: b
 
     ``ready=(flags, job_index_to_flag)`` is split per engine like the jobs.  Returns ``join``: calling it waits for the
     engines and returns ``(results in job order, per-engine stats dicts)``; exceptions of the workers are re-raised there.
-    ``one_at_a_time`` runs the engines one after the other (profiling passes)."""
+    ``one_at_a_time`` runs the engines one after the other (profiling passes).  ``stagger_s``: engine i starts i * stagger_s
+    seconds after engine 0, so that engines whose bars all take the same time do not prefill (and then step) in phase."""
     import threading
+    import time as _time
     n = len(engines)
     seed = generate_many_kwargs.pop("seed", None)
     if seed is None and float(generate_many_kwargs.get("temperature", 0.0) or 0.0) > 0:
@@ -319,6 +321,8 @@ def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: b
             kw["_job_key"] = (i, n)                   # ... and GLOBAL job indices in the draw keys: engine i holds jobs i, i + n, ...
             if ready is not None:
                 kw["ready"] = (ready[0], ready[1][i::n])
+            if stagger_s > 0 and i > 0 and not one_at_a_time:
+                _time.sleep(i * stagger_s)
             outs[i] = engines[i].generate_many(jobs[i::n], vocab, stats=stats[i], **kw)
         except Exception as e:      # noqa: BLE001 -- surfaced by join()
             errs.append(e)
