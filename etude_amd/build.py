@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "csrc" / "_obj"
 LIB = HERE / "libetude_hip.so"
-SOURCES = ["ext_kernels.hip", "ext_fused.hip", "ext_fp32.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp", "midi.cpp"]
+SOURCES = ["ext_kernels.hip", "ext_fused.hip", "ext_fp32.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "dec_fused.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp", "midi.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result",
          "-I", str(HERE.parent / "include")]
 # gfx950 can hand the first kernel arguments to a wave in SGPRs at launch (kernarg preload): kernels whose hot arguments are

@@ -27,7 +27,8 @@ struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0;
              void* Wf = nullptr; };   // bf16 weights: a second copy in MFMA-fragment order for k_linear (the batched prefill); W stays row-major for the step kernels
 struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
                void* dense_hw = nullptr;   // bf16 [heads][H][64]: attention.dense regrouped per head for k_dstep_attn_down
-               Lin cat; };   // decode step: [dense_4h_to_h | attention.dense] along K, so mlp + attn come out of ONE GEMM
+               Lin cat;      // decode step: [dense_4h_to_h | attention.dense] along K, so mlp + attn come out of ONE GEMM
+               void* mlp_frag = nullptr; };   // batched prefill: up | (down | dense) as k_dmlp_fused's weight stream (H 512, I 2048)
 
 }  // namespace
 
@@ -163,13 +164,19 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && M > 1;
   const bool big = bpipe && M > 512 && d->layers[0].qkv.Wf && d->layers[0].up.Wf && d->layers[0].cat.Wf;   // M: must match DS_MAX_ROWS in dec_kernels.hip
+  bool ln_ready = false;            // X1b / X2b already hold this layer's LayerNorm rows (written by the previous layer's k_dmlp_fused)
   for (int l = 0; l < d->L; ++l) {
     const Layer& w = d->layers[l];
     void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * esz;
     void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * esz;
     const bool small = bpipe && !big && (d->I + d->H) % (5 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
     const bool catk = small || big;     // attention.dense folded into the down projection: [W2 | Wd] [gelu(..) ; attn] + (b2 + bd), one GEMM and no fp32 round trip of the dense output
-    if (bpipe && (!small || (l == 0 && !ln0_done))) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
+    // batched prefill on the fused MLP kernel: it also writes the NEXT layer's LayerNorm rows, so only layer 0 needs the row kernel
+    // OPT-IN (ETD_FUSED_PMLP=1 at create time packs the stream; read per call so that the A/B test can toggle it): measured round 2
+    // (tools/runs/r2_run47.sh) at 290 us per launch against 166 + 16 us for the launches it replaces -- see csrc/dec_fused.hip
+    const bool fmlp = big && w.mlp_frag && d->H == 512 && d->I == 2048 && getenv("ETD_FUSED_PMLP") && atoi(getenv("ETD_FUSED_PMLP")) > 0;
+    if (bpipe && (!small || (l == 0 && !ln0_done)) && !ln_ready) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
+    ln_ready = false;
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
     q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
@@ -281,6 +288,18 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
     up.Y = d->M1; up.ldy = d->I;
     if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; if (catk) { up.Yb = d->Xcat; up.ldy = d->I + d->H; } } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
+    if (fmlp) {
+      // up + GELU, (down | dense), residual and the next layer's LayerNorms: one launch, the hidden layer never leaves the CU
+      const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
+      DMlpArgs ma = {};
+      ma.X2 = d->X2b; ma.AO = d->Xcat + d->I; ma.ldao = d->I + d->H; ma.hin = hin; ma.hout = hout; ma.Wm = (const bf16*)w.mlp_frag;
+      ma.b_up = w.up.b; ma.b_cat = w.cat.b; ma.eps = d->cfg.layer_norm_eps; ma.M = M;
+      if (nx) { ma.g1 = nx->ln1g; ma.b1 = nx->ln1b; ma.g2 = nx->ln2g; ma.b2 = nx->ln2b; ma.nx1 = d->X1b; ma.nx2 = d->X2b; }
+      ETD_TRY(launch_dmlp_fused(ma, st));
+      ln_ready = nx != nullptr;
+      float* t = hin; hin = hout; hout = t;
+      continue;
+    }
     if (big) {
       LinArgs a = {};
       a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.Wf; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
@@ -573,6 +592,16 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
         w.cat.Wf = pf;
       }
       if ((rc = up_f32(d, &w.cat.b, bc.data(), H))) return fail(rc);
+      if (H == 512 && d->I == 2048 && getenv("ETD_FUSED_PMLP") && atoi(getenv("ETD_FUSED_PMLP")) > 0) {
+        const float* W1 = Ld.get(p + "mlp.dense_h_to_4h.weight", (int64_t)d->I * H);
+        if (!W1) return fail(ETD_EINVAL);
+        std::vector<uint16_t> w1((size_t)d->I * H), ws((size_t)DMLP_STREAM_ELEMS);
+        for (size_t i = 0; i < w1.size(); ++i) w1[i] = f2bf_h(W1[i]);
+        pack_dmlp_weights(w1.data(), wc.data(), ws.data());
+        uint16_t* pm; if ((rc = d->alloc(&pm, ws.size()))) return fail(rc);
+        HIP_TRY(hipMemcpy(pm, ws.data(), ws.size() * 2, hipMemcpyHostToDevice));
+        w.mlp_frag = pm;
+      }
     }
   }
   if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.weight", H, &d->lnfg))) return fail(rc);

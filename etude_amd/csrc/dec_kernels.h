@@ -104,6 +104,24 @@ int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const 
 // out[i][:] = src[idx[i]][:]  (fp32 rows of H)
 int launch_gather_rows(const float* src, const int* idx, int n, int H, float* out, hipStream_t st);
 
+// batched prefill, bf16 (csrc/dec_fused.hip): MLP branch + attention.dense + parallel residual + the next layer's LayerNorms in
+// one launch, bit-identical to k_linear<GELU> -> k_linear<RESID> -> k_ln_rows.  H = 512, I = 2048 only.
+#define DMLP_NCHUNK 73                               // 64 KiB chunks of the weight stream: 65 of the MLP, 8 of attention.dense
+#define DMLP_STREAM_ELEMS (DMLP_NCHUNK * 32 * 1024)  // bf16 elements per layer
+struct DMlpArgs {
+  const bf16* X2;                // [M][512] post_attention_layernorm(h_in)
+  const bf16* AO; int ldao;      // [M][512] attention output, row stride ldao (it sits behind the hidden block of Xcat)
+  const float* hin; float* hout; // [M][512] fp32 residual stream in / out (different buffers)
+  const bf16* Wm;                // pack_dmlp_weights
+  const float* b_up;             // [2048]
+  const float* b_cat;            // [512] dense_4h_to_h.bias + attention.dense.bias
+  const float* g1; const float* b1; const float* g2; const float* b2; float eps;   // next layer's LayerNorms (nx1 == null: none)
+  bf16* nx1; bf16* nx2;          // [M][512]
+  int M;
+};
+int launch_dmlp_fused(const DMlpArgs& a, hipStream_t st);
+void pack_dmlp_weights(const uint16_t* Wup_bf16 /* [2048][512] */, const uint16_t* Wcat_bf16 /* [512][2560] */, uint16_t* dst /* DMLP_STREAM_ELEMS */);
+
 struct DEmbedArgs {
   const int* ids; const int* cls; const int* attrs;   // [M], [M], [4][M] (explicit mode)  -- or null:
   const int* cur_tok; const int* tgt_attrs;           // decode mode: ids = cur_tok[slot], cls = tgt_cls, attrs = tgt_attrs[slot][4]

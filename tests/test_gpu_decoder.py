@@ -282,3 +282,32 @@ def test_row_finish_opt_in_is_bit_identical(dev):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("rep")])
     assert len(outs[0]) == 6 and outs[0] == outs[1]
+
+
+def test_fused_prefill_mlp_is_bit_identical_to_the_three_launch_path(dev, monkeypatch):
+    """k_dmlp_fused (csrc/dec_fused.hip, opt-in: ETD_FUSED_PMLP=1) replaces up + GELU -> (down | dense) + residual -> LayerNorm
+    rows of a batched-prefill layer by one launch that multiplies the same operands in the same order: logits of a 600-token
+    prompt (every row, all eight layers, the tail rows of a 128-token tile included) and the greedy ids of 48 batched streams
+    (last-positions-only final layer) must be the SAME BYTES with the kernel on and off."""
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    v = _vocab()
+    cfgd = EtudeDecoderConfig(**synth.decoder_dims())
+    sd = synth.decoder_state_dict(1, {})
+    rng = np.random.default_rng(11)
+    T = 600                                    # > 512 rows: the big-tile path; 600 = 4 tiles of 128 + 88
+    ids, cls, a4 = rng.integers(4, 154, T), rng.integers(1, 3, T), rng.integers(0, 3, (4, T))
+    jobs = []
+    for s_ in range(48):
+        bars = synth.song_bars(seed=500 + s_ % 5, n_bars=3)
+        jobs.append((bars, [synth.attrs(s_ % 3, (s_ // 3) % 3, (s_ // 9) % 3, 2)] * len(bars)))
+    res = []
+    for on in (True, False):
+        monkeypatch.setenv("ETD_FUSED_PMLP", "1" if on else "0")
+        dec = EtudeDecoder(cfgd, sd, "cuda", precision="bf16", max_streams=48, max_ctx=1088)
+        lg = dec.prefill_logits(ids, cls, a4)
+        got = dec.generate_many(jobs, v, force_bar_tokens=12)
+        dec.close()
+        res.append((lg, got))
+    assert np.isfinite(res[0][0]).all() and np.abs(res[0][0]).max() > 1e-3
+    assert np.array_equal(res[0][0], res[1][0]), f"logits differ by {np.abs(res[0][0] - res[1][0]).max()}"
+    assert res[0][1] == res[1][1]
