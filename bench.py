@@ -358,41 +358,19 @@ def main():
         extras = {}
         try:
             xs = torch.from_numpy(synth.window_features(5, 16)).to(dev)          # configs[2]: 16 windows
-            # dealt over the extractor instances (own stream + host thread each, like the headline's extract stage): one instance's
-            # small launches and batch tails run beside the other's big ones
-            import threading
-            n_inst = len(exs)
-            parts = [xs[i::n_inst].contiguous() for i in range(n_inst)]
-
-            def pass16():
-                errs = []
-
-                def one(i):
-                    try:
-                        torch.cuda.set_device(dev)
-                        with torch.cuda.stream(ex_streams[i]):
-                            exs[i].transcript_windows(parts[i])
-                        ex_streams[i].synchronize()
-                    except Exception as e_:      # noqa: BLE001
-                        errs.append(e_)
-                th_ = [threading.Thread(target=one, args=(i,)) for i in range(n_inst)]
-                for t_ in th_:
-                    t_.start()
-                for t_ in th_:
-                    t_.join()
-                if errs:
-                    raise errs[0]
-            pass16()
+            # (dealing the windows over both extractor instances, as the headline's extract stage does with clips, measured 1.64 against
+            # 1.60 ms per window here: two 8-window halves are two batches each and gain nothing from each other -- tools/runs/r2_run49.sh)
+            ex.transcript_windows(xs)
             torch.cuda.synchronize(dev)
             t = time.perf_counter()
             reps = 3
             for _ in range(reps):
-                pass16()
+                ex.transcript_windows(xs)
             torch.cuda.synchronize(dev)
             dt = (time.perf_counter() - t) / (reps * 16)
             tf = ex.window_flops / dt / 1e12
-            extras["extractor_only"] = {"workload": f"BASELINE configs[2]: 16 x 512-frame windows (8.192 s each), hFT-Transformer only, dealt over {n_inst} extractor instance(s)",
-                                        "instances": n_inst, "ms_per_window": round(dt * 1e3, 3), "audio_s_per_s": round(8.192 / dt, 1),
+            extras["extractor_only"] = {"workload": "BASELINE configs[2]: 16 x 512-frame windows (8.192 s each), hFT-Transformer only",
+                                        "ms_per_window": round(dt * 1e3, 3), "audio_s_per_s": round(8.192 / dt, 1),
                                         "alg_gflop_per_window": round(ex.window_flops / 1e9, 1),
                                         "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4)}}
         except Exception as e:      # extras must never take the headline down
