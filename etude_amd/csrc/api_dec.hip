@@ -173,7 +173,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     const bool catk = small || big;     // attention.dense folded into the down projection: [W2 | Wd] [gelu(..) ; attn] + (b2 + bd), one GEMM and no fp32 round trip of the dense output
     // batched prefill on the fused MLP kernel: it also writes the NEXT layer's LayerNorm rows, so only layer 0 needs the row kernel
     // OPT-IN (ETD_FUSED_PMLP=1 at create time packs the stream; read per call so that the A/B test can toggle it): measured round 2
-    // (tools/runs/r2_run47.sh) at 290 us per launch against 166 + 16 us for the launches it replaces -- see csrc/dec_fused.hip
+    // (tools/runs/r2_run47.sh) at 195 us per launch against 166 + 16 us for the launches it replaces, +1.3 % in the job -- csrc/dec_fused.hip
     const bool fmlp = big && w.mlp_frag && d->H == 512 && d->I == 2048 && getenv("ETD_FUSED_PMLP") && atoi(getenv("ETD_FUSED_PMLP")) > 0;
     if (bpipe && (!small || (l == 0 && !ln0_done)) && !ln_ready) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
     ln_ready = false;

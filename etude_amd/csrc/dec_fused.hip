@@ -7,13 +7,27 @@
 // token through HBM and run their 128 x 256 tiles at 460-520 TFLOP/s -- bound by L2 -> CU traffic (52 FLOP per byte the tile pulls
 // from L2).  Here the token tile stays in registers for the whole branch, as in the extractor's k_ffn_fused.
 //
-// STATUS: correct and bit-identical, but OPT-IN (ETD_FUSED_PMLP=1) -- measured 290 us per launch (54 prompts x ~340 tokens)
-// against 166 us for the two GEMMs + 16 us for the row kernel it replaces (tools/runs/r2_run47.sh: the job 574 -> 558 audio-s/s).
-// A token's input fragments (128 registers) and its 512 fp32 outputs (256) leave 128 of a wave's 512 registers for everything
-// else: hipcc parks part of the fragments in AGPRs (272 v_accvgpr moves per 64-MFMA chunk) and keeps only two A-fragment buffers
-// in the first GEMM, so with ONE wave per SIMD every MFMA waits out the LDS read issued one MFMA earlier (~24 % MFMA duty).
-// What it would take: the x2 fragments of half the K range in LDS (64 registers back), or MFMAs in inline asm with the B operand
-// read from AGPRs directly.
+// STATUS: correct and bit-identical (logits of a 600-token prompt, token streams of 48 batched jobs), OPT-IN: ETD_FUSED_PMLP=1.
+// Measured on MI355X (54 prompts x ~340 tokens per launch; tools/runs/r2_run47.sh, serial event pass): 195 us per launch against
+// 166 us for the two GEMMs + 16 us for the row kernel it replaces; in the four-engine job 581-589 against 572-586 audio-s/s
+// (+1.3 % over six pairs: it occupies 144 CUs and moves a quarter of the bytes, so it disturbs the other engines' steps less).
+// It stays off by default because its inner loop is hand-placed asm whose MFMAs the compiler's hazard recognizer cannot see.
+// How it got from 290 to 195 us, in order (every step kept the bit-identity test green, and every one is needed):
+//   1. a token's input fragments (128 registers) and 512 fp32 outputs (256) leave 128 of a wave's 512 registers: hipcc put all
+//      256 accumulator registers into AGPRs, the fragments into VGPRs and copied them through ONE AGPR quad (272 v_accvgpr moves
+//      per 64-MFMA chunk); with the fragments loaded straight into AGPRs (global_load ... a[n:n+3]) and read from there as the
+//      MFMA's B operand, and the output tiles split 8 AGPR / 8 VGPR by asm constraints, no copy is left;
+//   2. hipcc read every weight fragment right in front of its MFMA (s_waitcnt lgkmcnt(0) per MFMA: with ONE wave per SIMD nobody
+//      hides that): the fragment reads, counted waits and MFMAs are volatile asm in program order, one 4-fragment group ahead
+//      (two groups ahead spills 19 registers, and a scratch reload's vmcnt(0) drains the LDS-DMA);
+//   3. the bias values of the GELU are read by hand too (a compiler-placed ds_read brings lgkmcnt(0) and drains the prefetch);
+//   4. the next chunk's 16 LDS-DMA pieces per wave are issued one per group instead of as a burst at the chunk top;
+//   5. the GELU halves are pinned BETWEEN the chained MFMAs (empty volatile asms): LLVM otherwise sinks all sixteen behind the up
+//      phase, where they block the in-order issue for ~1100 clocks per chunk.
+// What is left (~40 % MFMA duty): 16 LDS-DMA issues (~60 clocks each) and 16 GELUs (~70) per wave and chunk against 2048 clocks
+// of MFMAs, in one instruction stream; the barrier and first-read latency at every chunk top.  Dead end on the way: the DMA issue
+// BETWEEN the independent MFMAs of a down group gave wrong results (a register the compiler took for free was still the A operand
+// of a queued MFMA) -- the asm form is only safe where the compiler's reuse distance is known.
 //   * a wave owns 32 tokens; x2 enters once as the 32 B-operand fragments of v_mfma_f32_32x32x16_bf16 (128 registers);
 //   * the 2048-wide hidden layer exists 32 features at a time: acc1 = W1[32 rows] . x2 (32 chained MFMAs), bias + erf-GELU +
 //     bf16 rounding in registers; two v_permlane32_swap per k-step turn the accumulator's row order into the natural k order of a
@@ -31,10 +45,191 @@
 #include "dec_kernels.h"
 #include "prof.h"
 
+#include <utility>
 #define PM_SLOT_ELEMS (32 * 1024)          // bf16 elements per ring slot: 64 fragments of 512 elements (64 KiB)
 
 typedef const __attribute__((address_space(1))) void* pm_gptr_t;
 typedef __attribute__((address_space(3))) void* pm_lptr_t;
+
+// ---- hand-placed instruction stream.  One wave per SIMD has nobody to hide an LDS read behind, and hipcc, short of registers,
+// reads each weight fragment right in front of the MFMA that uses it (s_waitcnt lgkmcnt(0) per MFMA: ~24 % MFMA duty).  So the
+// fragment reads, their counted waits and the MFMAs are volatile asm statements in program order: a chunk's 64 fragments are 16
+// groups of 4, group j + 1 is requested before group j is waited for (lgkmcnt(4): the younger group stays in flight; LDS
+// returns in order, and a read the compiler adds of its own only makes the wait stricter), two 4-fragment buffers alternate
+// (a third, two groups ahead, does not fit: 19 registers spilled and every reload drained the LDS-DMA with vmcnt(0)).
+// Register classes are explicit too: the 32 x2 / attention fragments are BORN in AGPRs (a global load may name an AccVGPR
+// destination) and are read from there as the MFMA's B operand; output tiles 0..7 live in AGPRs, 8..15 in VGPRs -- 256 + 241.
+// (Left to itself hipcc puts all 256 accumulator registers into AGPRs and shuttles the fragments through one AGPR quad.)
+template <int F> __device__ __forceinline__ void pm_rd(bf16x8& b, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(F * 1024));
+}
+template <int F0> __device__ __forceinline__ void pm_rd4(bf16x8 (&b)[4], unsigned addr) {
+  pm_rd<F0>(b[0], addr); pm_rd<F0 + 1>(b[1], addr); pm_rd<F0 + 2>(b[2], addr); pm_rd<F0 + 3>(b[3], addr);
+}
+template <int N> __device__ __forceinline__ void pm_wait_lds() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+// acc (VGPR) += A (VGPR) . B (AGPR)
+__device__ __forceinline__ void pm_mfma_v_a(f32x16& acc, const bf16x8& af, const bf16x8& bf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(af), "a"(bf));
+}
+// output tile T (AGPR for T < 8, VGPR above) += A (VGPR) . B (VGPR: the hidden fragment / AGPR: an attention fragment)
+template <int T, bool B_AGPR> __device__ __forceinline__ void pm_mfma_out(f32x16& acc, const bf16x8& af, const bf16x8& bf) {
+  if constexpr (T < 8) {
+    if constexpr (B_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(bf));
+    else                  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(bf));
+  } else {
+    if constexpr (B_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(af), "a"(bf));
+    else                  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(af), "v"(bf));
+  }
+}
+// The NEXT chunk's 16 one-KiB LDS-DMA pieces of this wave are issued one per fragment group (two in the half chunks), behind the
+// group's MFMAs: issued as one burst at the chunk top they cost the wave ~100 clocks each with an idle MFMA pipe.
+struct PmNext { const bf16* src; bf16* dst; bool on; };
+template <int I> __device__ __forceinline__ void pm_dma(const PmNext& n) {
+  if (n.on) __builtin_amdgcn_global_load_lds((pm_gptr_t)(n.src + I * 512), (pm_lptr_t)(n.dst + I * 512), 16, 0, 0);
+}
+// fragments of group J of an MLP chunk [down(k - 1): 0 .. 31 | up(k): 32 .. 63]: groups 0 .. 7 = up, 8 .. 15 = down
+template <int J> struct PmMlpGroup { static constexpr int f0 = J < 8 ? 32 + 4 * J : 4 * (J - 8); };
+template <int J, int JEND> __device__ __forceinline__ void pm_roll(bf16x8 (&buf)[2][4], unsigned addr) {
+  // in front of group J: request group J + 1 (if the chunk has one), then wait until group J has landed
+  if constexpr (J + 1 < JEND) { pm_rd4<PmMlpGroup<J + 1>::f0>(buf[(J + 1) & 1], addr); pm_wait_lds<4>(); }
+  else pm_wait_lds<0>();
+}
+// register 4 q + j of the hidden accumulator is hidden feature 32 kc + 8 q + 4 h + j: bias + erf-GELU of registers 2 J, 2 J + 1
+template <int J> __device__ __forceinline__ void pm_gelu2(f32x16& acc1, const float* sbu, int kc, int h) {
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    constexpr int dummy = 0; (void)dummy;
+    const int i = 2 * J + e;
+    acc1[i] = gelu_fast(acc1[i] + sbu[32 * kc + 8 * (i >> 2) + 4 * h + (i & 3)]);
+  }
+}
+// up group J (0 .. 7) of chunk k into accn, with the GELU of two registers of the previous chunk's accumulator beside it
+template <int J, bool GELU> __device__ __forceinline__ void pm_up_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, f32x16& acc1, const bf16x8 (&xf)[32],
+                                                                        const float* sbu, unsigned bias_addr, int h, const PmNext& nx) {
+  if constexpr (GELU) {
+    // the two bias values of this group's GELU are read by hand as well, AHEAD of group J + 1's fragments: a read the compiler places
+    // comes with s_waitcnt lgkmcnt(0) and drains the fragment reads that are meant to stay in flight.  Outstanding at the first wait:
+    // group J (4), the bias (1), group J + 1 (4) -> lgkmcnt(5) = group J has landed; behind the MFMAs lgkmcnt(4) = the bias has
+    f32x2 bb;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bb) : "v"(bias_addr), "n"((8 * (J >> 1) + 2 * (J & 1)) * 4));
+    pm_rd4<PmMlpGroup<J + 1>::f0>(buf[(J + 1) & 1], addr);
+    pm_wait_lds<5>();
+    // One wave per SIMD issues in order: VALU work that follows four chained MFMAs in program order waits out all four (128 clocks
+    // of blocked issue), so the two GELUs of this group are cut in halves and placed BETWEEN the MFMAs -- ~24 of an MFMA's 32 clocks
+    // are free for other issue.  gelu_fast's operations in gelu_fast's order (dec_epilogue.h), only spread over the statements.
+    pm_mfma_v_a(accn, buf[J & 1][0], xf[4 * J]);
+    // the bias pair has landed (nothing younger than group J + 1's fragments is outstanding).  bb is an operand of the wait: the
+    // compiler takes an asm's output for ready at once and is free to move the (non-asm) GELU arithmetic above a bare s_waitcnt.
+    // PM_PIN: an empty volatile asm with the value as in/out operand -- volatile asms keep their order, so arithmetic whose inputs
+    // come out of one pin and whose results go into the next stays between the two MFMAs it was written between (left alone, LLVM
+    // sinks all sixteen GELUs behind the last MFMA of the up phase, where they block the issue for ~1100 clocks)
+#define PM_PIN(x) asm volatile("" : "+v"(x))
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bb) : : "memory");
+    float x0 = acc1[2 * J] + bb[0];
+    float z0 = fabsf(x0) * 0.70710678118654752440f;
+    float t0 = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z0, 1.f));
+    float e0 = __builtin_amdgcn_exp2f(-1.4426950408889634f * z0 * z0);
+    PM_PIN(x0); PM_PIN(t0); PM_PIN(e0);
+    pm_mfma_v_a(accn, buf[J & 1][1], xf[4 * J + 1]);
+    PM_PIN(x0); PM_PIN(t0); PM_PIN(e0);
+    {
+      float p = fmaf(1.061405429f, t0, -1.453152027f);
+      p = fmaf(p, t0, 1.421413741f); p = fmaf(p, t0, -0.284496736f); p = fmaf(p, t0, 0.254829592f);
+      const float er = fmaf(-p * t0, e0, 1.f);
+      float r0 = 0.5f * x0 * (1.f + copysignf(er, x0));
+      PM_PIN(r0);
+      acc1[2 * J] = r0;
+    }
+    float a1 = acc1[2 * J + 1], b1 = bb[1];
+    pm_mfma_v_a(accn, buf[J & 1][2], xf[4 * J + 2]);
+    PM_PIN(a1); PM_PIN(b1);
+    float x1 = a1 + b1;
+    float z1 = fabsf(x1) * 0.70710678118654752440f;
+    float t1 = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z1, 1.f));
+    float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * z1 * z1);
+    PM_PIN(x1); PM_PIN(t1); PM_PIN(e1);
+    pm_mfma_v_a(accn, buf[J & 1][3], xf[4 * J + 3]);
+    PM_PIN(x1); PM_PIN(t1); PM_PIN(e1);
+    {
+      float p = fmaf(1.061405429f, t1, -1.453152027f);
+      p = fmaf(p, t1, 1.421413741f); p = fmaf(p, t1, -0.284496736f); p = fmaf(p, t1, 0.254829592f);
+      const float er = fmaf(-p * t1, e1, 1.f);
+      float r1 = 0.5f * x1 * (1.f + copysignf(er, x1));
+      PM_PIN(r1);
+      acc1[2 * J + 1] = r1;
+    }
+#undef PM_PIN
+    pm_dma<J>(nx);
+  } else {
+    pm_roll<J, 8>(buf, addr);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pm_mfma_v_a(accn, buf[J & 1][q], xf[4 * J + q]);
+    pm_dma<2 * J>(nx); pm_dma<2 * J + 1>(nx);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+// down group J (8 .. 15): k-step (J - 8) >> 2, tiles 4 ((J - 8) & 3) .. + 4
+template <int J, bool HALF> __device__ __forceinline__ void pm_down_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&hf)[2], const PmNext& nx) {
+  pm_roll<J, 16>(buf, addr);
+  constexpr int g = J - 8, t0 = 4 * (g & 3);
+  pm_mfma_out<t0 + 0, false>(acc2[t0 + 0], buf[J & 1][0], hf[g >> 2]);
+  pm_mfma_out<t0 + 1, false>(acc2[t0 + 1], buf[J & 1][1], hf[g >> 2]);
+  pm_mfma_out<t0 + 2, false>(acc2[t0 + 2], buf[J & 1][2], hf[g >> 2]);
+  pm_mfma_out<t0 + 3, false>(acc2[t0 + 3], buf[J & 1][3], hf[g >> 2]);
+  if constexpr (HALF) { pm_dma<2 * g>(nx); pm_dma<2 * g + 1>(nx); } else pm_dma<J>(nx);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// attention.dense group J (0 .. 15) of dense chunk DC: fragments 4 J .. + 4 = k-step 4 DC + (J >> 2), tiles 4 (J & 3) .. + 4
+template <int DC, int J> __device__ __forceinline__ void pm_dense_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], const PmNext& nx) {
+  if constexpr (J + 1 < 16) { pm_rd4<4 * (J + 1)>(buf[(J + 1) & 1], addr); pm_wait_lds<4>(); }
+  else pm_wait_lds<0>();
+  constexpr int t0 = 4 * (J & 3), s = 4 * DC + (J >> 2);
+  pm_mfma_out<t0 + 0, true>(acc2[t0 + 0], buf[J & 1][0], xf[s]);
+  pm_mfma_out<t0 + 1, true>(acc2[t0 + 1], buf[J & 1][1], xf[s]);
+  pm_mfma_out<t0 + 2, true>(acc2[t0 + 2], buf[J & 1][2], xf[s]);
+  pm_mfma_out<t0 + 3, true>(acc2[t0 + 3], buf[J & 1][3], xf[s]);
+  pm_dma<J>(nx);
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int DC, int... Js> __device__ __forceinline__ void pm_dense_chunk(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], const PmNext& nx,
+                                                                            std::integer_sequence<int, Js...>) {
+  pm_rd4<0>(buf[0], addr);
+  (pm_dense_group<DC, Js>(buf, addr, acc2, xf, nx), ...);
+}
+// the 32 GELU'd hidden features of a chunk as two natural-order B fragments: own rows are q = 2 ks -> hidden 16 ks + 4 h + (0..3)
+// and q = 2 ks + 1 -> 16 ks + 8 + 4 h + (0..3); a B fragment wants 16 ks + 8 h + (0..7): the lower lane half takes its partner's
+// q = 2 ks rows, the upper half its partner's q = 2 ks + 1
+__device__ __forceinline__ void pm_hidden_frags(const f32x16& acc1, bf16x8 (&hf)[2]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x4 p0 = pack4(acc1[8 * ks], acc1[8 * ks + 1], acc1[8 * ks + 2], acc1[8 * ks + 3]);
+    const bf16x4 p1 = pack4(acc1[8 * ks + 4], acc1[8 * ks + 5], acc1[8 * ks + 6], acc1[8 * ks + 7]);
+    const u32x2 v0 = __builtin_bit_cast(u32x2, p0), v1 = __builtin_bit_cast(u32x2, p1);
+    const auto s0 = __builtin_amdgcn_permlane32_swap(v0[0], v1[0], false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(v0[1], v1[1], false, false);
+    const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+    hf[ks] = __builtin_bit_cast(bf16x8, o);
+  }
+  asm volatile("s_nop 4" ::: "memory");      // (VALU -> MFMA source wait states: the compiler does not know the asm below is an MFMA)
+}
+template <int... Js> __device__ __forceinline__ void pm_up_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, f32x16& acc1, const bf16x8 (&xf)[32], const float* sbu, int h,
+                                                                const PmNext& nx, std::integer_sequence<int, Js...>) {
+  pm_rd4<PmMlpGroup<0>::f0>(buf[0], addr);
+  (pm_up_group<Js, false>(buf, addr, accn, acc1, xf, sbu, 0u, h, nx), ...);
+}
+template <int... Js> __device__ __forceinline__ void pm_up_gelu(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, f32x16& acc1, const bf16x8 (&xf)[32], const float* sbu, unsigned bias_addr, int h,
+                                                                const PmNext& nx, std::integer_sequence<int, Js...>) {
+  pm_rd4<PmMlpGroup<0>::f0>(buf[0], addr);
+  (pm_up_group<Js, true>(buf, addr, accn, acc1, xf, sbu, bias_addr, h, nx), ...);
+}
+template <int... Js> __device__ __forceinline__ void pm_down(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&hf)[2], const PmNext& nx, std::integer_sequence<int, Js...>) {
+  (pm_down_group<8 + Js, false>(buf, addr, acc2, hf, nx), ...);
+}
+template <int... Js> __device__ __forceinline__ void pm_down_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&hf)[2], const PmNext& nx, std::integer_sequence<int, Js...>) {
+  // chunk 64: only the down half exists -- groups 8 .. 15 with their own lead
+  pm_rd4<PmMlpGroup<8>::f0>(buf[8 & 1], addr);
+  (pm_down_group<8 + Js, true>(buf, addr, acc2, hf, nx), ...);
+}
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dmlp_fused(DMlpArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PM_SLOT_ELEMS * 2 + 2048 * 4];
@@ -43,6 +238,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int m = blockIdx.x * 128 + wave * 32 + r;
   const int mc = m < a.M ? m : a.M - 1;
+  const unsigned ring_lds = (unsigned)reinterpret_cast<uintptr_t>(ring) + lane * 16;      // LDS byte address of this lane's 16 bytes of fragment 0, slot 0
+  const unsigned sbu_lds = (unsigned)reinterpret_cast<uintptr_t>(sbu) + h * 16;            // ... of b_up[4 h]: register 4 q + j of a hidden accumulator wants b_up[32 kc + 8 q + 4 h + j]
 
   // ring slot (k & 1) <- stream chunk k: 64 one-KiB pieces, 16 per wave
   auto issue = [&](int k) {
@@ -54,18 +251,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   };
 #define PM_TOP(k)                                                                                                     \
   do {                                                                                                                \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   /* this wave's pieces of chunk k have landed ... */              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* this wave's pieces of chunk k have landed ... */   \
     __syncthreads();                                    /* ... and everybody's; every wave is done reading the other slot */ \
-    if ((k) + 1 < DMLP_NCHUNK) issue((k) + 1);                                                                          \
   } while (0)
+  // this wave's 16 pieces of chunk k (source, destination slot); nothing behind the last chunk
+  auto next_of = [&](int k) {
+    return PmNext{a.Wm + (long long)(k + 1) * PM_SLOT_ELEMS + wave * (16 * 512) + lane * 8, ring + ((k + 1) & 1) * PM_SLOT_ELEMS + wave * (16 * 512), k + 1 < DMLP_NCHUNK};
+  };
+#define PM_LOADX(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(dst) : "v"(ptr) : "memory")
 
   issue(0);
-  // the token tile as B fragments: lane (token r, half h) holds x2[token][16 s + 8 h .. + 8], s = 0 .. 31
+  // the token tile as B fragments: lane (token r, half h) holds x2[token][16 s + 8 h .. + 8], s = 0 .. 31 -- loaded straight into
+  // AGPRs; the compiler does not count these loads, PM_TOP(0)'s vmcnt(0) does
   bf16x8 xf[32];
   {
     const bf16* xp = a.X2 + (long long)mc * 512 + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    for (int s = 0; s < 32; ++s) PM_LOADX(xf[s], xp + 16 * s);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   for (int i = tid; i < 2048; i += 256) sbu[i] = a.b_up[i];
 
@@ -75,106 +278,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
   f32x16 acc1;
-
-  // ---- up(k): acc = W1[32 k .. + 32] . x2 -- fragments 32 .. 63 of the slot, 8 groups of 4, one group requested ahead.
-  // GELU_OF: registers 2 g, 2 g + 1 of the PREVIOUS chunk's accumulator get bias + GELU beside group g's MFMAs.
-#define PM_UP(sl, accn, GELU_STMT)                                                                                    \
-  {                                                                                                                   \
-    bf16x8 af[2][4];                                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) af[0][q] = *reinterpret_cast<const bf16x8*>((sl) + (32 + q) * 512);  \
-    _Pragma("unroll") for (int g = 0; g < 8; ++g) {                                                                   \
-      if (g < 7) {                                                                                                    \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) af[(g + 1) & 1][q] = *reinterpret_cast<const bf16x8*>((sl) + (32 + (g + 1) * 4 + q) * 512); \
-      }                                                                                                               \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) accn = mfma32(af[g & 1][q], xf[g * 4 + q], accn);                  \
-      GELU_STMT;                                                                                                      \
-      __builtin_amdgcn_sched_barrier(0);                                                                              \
-    }                                                                                                                 \
-  }
-  // register 4 q + j of the accumulator is hidden feature 32 kc + 8 q + 4 h + j
-#define PM_GELU2(kc, g)                                                                                               \
-  {                                                                                                                   \
-    _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                   \
-      const int i = 2 * (g) + e;                                                                                      \
-      acc1[i] = gelu_fast(acc1[i] + sbu[32 * (kc) + 8 * (i >> 2) + 4 * h + (i & 3)]);                                  \
-    }                                                                                                                 \
-  }
-  // ---- down(kc): the 32 GELU'd hidden features as two natural-order B fragments, then 32 MFMAs into the 16 output tiles
-#define PM_DOWN(sl)                                                                                                   \
-  {                                                                                                                   \
-    bf16x8 hf[2];                                                                                                     \
-    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                \
-      /* own rows: q = 2 ks -> hidden 16 ks + 4 h + (0..3), q = 2 ks + 1 -> 16 ks + 8 + 4 h + (0..3); a B fragment wants  */ \
-      /* 16 ks + 8 h + (0..7): the lower lane half takes its partner's q = 2 ks rows, the upper half its partner's q = 2 ks + 1 */ \
-      const bf16x4 p0 = pack4(acc1[8 * ks], acc1[8 * ks + 1], acc1[8 * ks + 2], acc1[8 * ks + 3]);                       \
-      const bf16x4 p1 = pack4(acc1[8 * ks + 4], acc1[8 * ks + 5], acc1[8 * ks + 6], acc1[8 * ks + 7]);                   \
-      const u32x2 v0 = __builtin_bit_cast(u32x2, p0), v1 = __builtin_bit_cast(u32x2, p1);                              \
-      const auto s0 = __builtin_amdgcn_permlane32_swap(v0[0], v1[0], false, false);                                    \
-      const auto s1 = __builtin_amdgcn_permlane32_swap(v0[1], v1[1], false, false);                                    \
-      const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};                                                                    \
-      hf[ks] = __builtin_bit_cast(bf16x8, o);                                                                          \
-    }                                                                                                                 \
-    bf16x8 af[2][4];                                                                                                  \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) af[0][q] = *reinterpret_cast<const bf16x8*>((sl) + q * 512);         \
-    _Pragma("unroll") for (int g = 0; g < 8; ++g) {     /* group g: k-step g >> 2, tiles 4 (g & 3) .. + 4 */            \
-      if (g < 7) {                                                                                                    \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) af[(g + 1) & 1][q] = *reinterpret_cast<const bf16x8*>((sl) + ((g + 1) * 4 + q) * 512); \
-      }                                                                                                               \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) acc2[4 * (g & 3) + q] = mfma32(af[g & 1][q], hf[g >> 2], acc2[4 * (g & 3) + q]); \
-      __builtin_amdgcn_sched_barrier(0);                                                                              \
-    }                                                                                                                 \
-  }
+  bf16x8 buf[2][4], hf[2];
+  using seq8 = std::make_integer_sequence<int, 8>;
+  using seq16 = std::make_integer_sequence<int, 16>;
 #define PM_ZERO(x) _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) x[i_] = 0.f
 
   // chunk 0: [ -- | up(0)]
   {
     PM_TOP(0);
-    const bf16* sl = ring + lane * 8;
     PM_ZERO(acc1);
-    PM_UP(sl, acc1, (void)0);
+    f32x16 unused = acc1;
+    pm_up_only(buf, ring_lds, acc1, unused, xf, sbu, h, next_of(0), seq8{});
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (MFMA -> VALU wait states: the next chunk's GELU reads acc1)
   }
   // chunks 1 .. 63: [down(k - 1) | up(k)] -- GELU of chunk k - 1 beside the MFMAs of up(k), then down(k - 1)
   for (int k = 1; k < 64; ++k) {
     PM_TOP(k);
-    const bf16* sl = ring + (k & 1) * PM_SLOT_ELEMS + lane * 8;
+    const unsigned sa = ring_lds + (k & 1) * (PM_SLOT_ELEMS * 2);
     f32x16 accn;
     PM_ZERO(accn);
-    PM_UP(sl, accn, PM_GELU2(k - 1, g));
-    PM_DOWN(sl);
+    const PmNext nx = next_of(k);
+    pm_up_gelu(buf, sa, accn, acc1, xf, sbu, sbu_lds + (k - 1) * 128, h, nx, seq8{});
+    pm_hidden_frags(acc1, hf);
+    pm_down(buf, sa, acc2, hf, nx, seq8{});
     acc1 = accn;
   }
-  // chunk 64: [down(63) | -- ]; the attention rows replace x2 in the fragment registers (they land behind the next barrier)
+  // chunk 64: [down(63) | -- ]; the attention rows replace x2 in the fragment registers
   {
     PM_TOP(64);
-    const bf16* sl = ring + lane * 8;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) PM_GELU2(63, g);
+    const unsigned sa = ring_lds;
+    pm_gelu2<0>(acc1, sbu, 63, h); pm_gelu2<1>(acc1, sbu, 63, h); pm_gelu2<2>(acc1, sbu, 63, h); pm_gelu2<3>(acc1, sbu, 63, h);
+    pm_gelu2<4>(acc1, sbu, 63, h); pm_gelu2<5>(acc1, sbu, 63, h); pm_gelu2<6>(acc1, sbu, 63, h); pm_gelu2<7>(acc1, sbu, 63, h);
     {
       const bf16* ap = a.AO + (long long)mc * a.ldao + 8 * h;
 #pragma unroll
-      for (int s = 0; s < 32; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(ap + 16 * s);
+      for (int s = 0; s < 32; ++s) PM_LOADX(xf[s], ap + 16 * s);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    PM_DOWN(sl);
+    pm_hidden_frags(acc1, hf);
+    pm_down_only(buf, sa, acc2, hf, next_of(64), seq8{});
   }
   // chunks 65 .. 72: attention.dense, 4 k-steps x 16 tiles each
-  for (int dc = 0; dc < 8; ++dc) {
-    PM_TOP(65 + dc);
-    const bf16* sl = ring + ((65 + dc) & 1) * PM_SLOT_ELEMS + lane * 8;
-    bf16x8 af[2][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) af[0][q] = *reinterpret_cast<const bf16x8*>(sl + q * 512);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {                              // group g: k-step 4 dc + (g >> 2), tiles 4 (g & 3) .. + 4
-      if (g < 15) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) af[(g + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(sl + ((g + 1) * 4 + q) * 512);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc2[4 * (g & 3) + q] = mfma32(af[g & 1][q], xf[4 * dc + (g >> 2)], acc2[4 * (g & 3) + q]);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
+  { PM_TOP(65); pm_dense_chunk<0>(buf, ring_lds + (65 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(65), seq16{}); }
+  { PM_TOP(66); pm_dense_chunk<1>(buf, ring_lds + (66 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(66), seq16{}); }
+  { PM_TOP(67); pm_dense_chunk<2>(buf, ring_lds + (67 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(67), seq16{}); }
+  { PM_TOP(68); pm_dense_chunk<3>(buf, ring_lds + (68 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(68), seq16{}); }
+  { PM_TOP(69); pm_dense_chunk<4>(buf, ring_lds + (69 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(69), seq16{}); }
+  { PM_TOP(70); pm_dense_chunk<5>(buf, ring_lds + (70 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(70), seq16{}); }
+  { PM_TOP(71); pm_dense_chunk<6>(buf, ring_lds + (71 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(71), seq16{}); }
+  { PM_TOP(72); pm_dense_chunk<7>(buf, ring_lds + (72 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(72), seq16{}); }
 
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // (MFMA -> VALU wait states behind the asm MFMAs)
   // ---- epilogue: h_out = (acc + bias) + h_in (the order of k_linear's residual epilogue), then the next layer's LayerNorms with
   // k_ln_rows's arithmetic: its lane l holds features 8 l .. 8 l + 7 = group (t, u, h) here, l = 4 t + 2 u + h; its butterfly
   // folds lane bits 5 .. 0 = t bits 3 .. 0, u, h in that order
