@@ -210,7 +210,9 @@ __device__ __forceinline__ void pm_hidden_frags(const f32x16& acc1, bf16x8 (&hf)
     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
     hf[ks] = __builtin_bit_cast(bf16x8, o);
   }
-  asm volatile("s_nop 4" ::: "memory");      // (VALU -> MFMA source wait states: the compiler does not know the asm below is an MFMA)
+  // (VALU -> MFMA source wait states: the compiler does not know the asm below is an MFMA.  The fragments are operands of the nop so
+  // that the arithmetic producing them cannot be scheduled behind it.)
+  asm volatile("s_nop 4" : "+v"(hf[0]), "+v"(hf[1]) : : "memory");
 }
 template <int... Js> __device__ __forceinline__ void pm_up_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, f32x16& acc1, const bf16x8 (&xf)[32], const float* sbu, int h,
                                                                 const PmNext& nx, std::integer_sequence<int, Js...>) {
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     PM_ZERO(acc1);
     f32x16 unused = acc1;
     pm_up_only(buf, ring_lds, acc1, unused, xf, sbu, h, next_of(0), seq8{});
-    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // (MFMA -> VALU wait states: the next chunk's GELU reads acc1)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc1) : : "memory");      // (MFMA -> VALU wait states: the next chunk's GELU reads acc1)
   }
   // chunks 1 .. 63: [down(k - 1) | up(k)] -- GELU of chunk k - 1 beside the MFMAs of up(k), then down(k - 1)
   for (int k = 1; k < 64; ++k) {
@@ -301,6 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pm_up_gelu(buf, sa, accn, acc1, xf, sbu, sbu_lds + (k - 1) * 128, h, nx, seq8{});
     pm_hidden_frags(acc1, hf);
     pm_down(buf, sa, acc2, hf, nx, seq8{});
+    asm volatile("" : "+v"(accn));          // accn's asm MFMAs ended a whole down phase ago: no copy of it may be scheduled before this point
     acc1 = accn;
   }
   // chunk 64: [down(63) | -- ]; the attention rows replace x2 in the fragment registers
@@ -328,7 +331,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   { PM_TOP(71); pm_dense_chunk<6>(buf, ring_lds + (71 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(71), seq16{}); }
   { PM_TOP(72); pm_dense_chunk<7>(buf, ring_lds + (72 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(72), seq16{}); }
 
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // (MFMA -> VALU wait states behind the asm MFMAs)
+  // (MFMA -> VALU wait states behind the asm MFMAs; the tiles are operands, so no read of them can be scheduled before the nops)
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc2[0]), "+a"(acc2[1]), "+a"(acc2[2]), "+a"(acc2[3]), "+a"(acc2[4]), "+a"(acc2[5]), "+a"(acc2[6]), "+a"(acc2[7]) : : "memory");
+  asm volatile("" : "+v"(acc2[8]), "+v"(acc2[9]), "+v"(acc2[10]), "+v"(acc2[11]), "+v"(acc2[12]), "+v"(acc2[13]), "+v"(acc2[14]), "+v"(acc2[15]));
   // ---- epilogue: h_out = (acc + bias) + h_in (the order of k_linear's residual epilogue), then the next layer's LayerNorms with
   // k_ln_rows's arithmetic: its lane l holds features 8 l .. 8 l + 7 = group (t, u, h) here, l = 4 t + 2 u + h; its butterfly
   // folds lane bits 5 .. 0 = t bits 3 .. 0, u, h in that order
