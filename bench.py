@@ -269,6 +269,10 @@ def main():
         a, b, c, d, out = step()
         t_ext += a; t_dec += b; n_tok += c; n_notes = d
     gathered_jobs = len(out)
+    # digest of every token this rank generated in the last timed step (job order): two builds / switches whose kernels must be
+    # equivalent print the same value under the real four-engine load
+    import hashlib
+    tok_digest = hashlib.sha256(np.asarray([t for job in out for bar in job for t in bar], np.int32).tobytes()).hexdigest()[:16]
     if use_dist:
         # the path's only exchange: ONE final gather of the small variable-length results (token ids of every job)
         g = parallel.gather_int_arrays([np.asarray([t for bar in job for t in bar], np.int32) for job in out], device=dev, force=True)
@@ -310,7 +314,7 @@ def main():
                    "stage_overlap": "pipelined per clip (jobs of clip c admitted when its extraction is done; extraction of c+1 overlaps)" if args.pipeline else "stages back to back"},
         "extract_audio_s_per_s": round(audio_s / t_ext, 2),
         "decoder_tokens_per_s": round(n_tok_all / t_dec, 2),
-        "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": n_notes, "jobs_gathered": gathered_jobs,
+        "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": n_notes, "jobs_gathered": gathered_jobs, "tokens_sha256_rank0": tok_digest,
     }
 
     # ---- roofline of the dominant kernel (HIP events inside the library, on the stream the kernel runs on)

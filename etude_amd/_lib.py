@@ -73,6 +73,7 @@ SIGNATURES = {
                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "etd_debug_boundary_cost": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "etd_debug_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
+    "etd_debug_kernel_loop": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
     "etd_frontend_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
     "etd_frontend_destroy": (None, [C.c_void_p]),
@@ -130,6 +131,8 @@ SIGNATURES = {
     "etd_decoder_prefill_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p]),
     "etd_decoder_step_bytes": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    "etd_debug_decoder_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),
+    "etd_debug_decoder_kv_rowsums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
 }
 
 _lib = None

@@ -35,6 +35,7 @@ struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
 struct etd_dec {
   etd_dec_cfg cfg;
   std::vector<void*> allocs;
+  std::vector<size_t> alloc_bytes;               // parallel to allocs (etd_debug_decoder_checksum)
   bool bf16w = false;
   int H, I, V, L, nh, S, ctx, Mmax, Mcap, out_cap;
   float *word = nullptr, *cls_emb = nullptr, *attr_tab = nullptr;
@@ -83,6 +84,7 @@ struct etd_dec {
     HIP_TRY(hipMalloc(&q, n * sizeof(T) + 256));
     if (zero) HIP_TRY(hipMemset(q, 0, n * sizeof(T) + 256));
     allocs.push_back(q);
+    alloc_bytes.push_back(n * sizeof(T) + 256);
     *p = (T*)q;
     return ETD_OK;
   }
@@ -956,6 +958,61 @@ extern "C" int etd_decoder_prefill_logits(etd_dec* d, int slot, const int32_t* i
   ETD_TRY(head_logits(d, hf, T, d->logits, st));
   HIP_TRY(hipMemcpyAsync(logits_host, d->logits, (size_t)T * d->V * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
+  return ETD_OK;
+}
+
+// diagnostic: a 64-bit sum over every 32-bit word of everything this handle allocated except its weights (KV cache, workspaces,
+// stream state) -- changes if anybody, this handle or another, writes a single word of it
+__global__ void k_sum_words(const unsigned* __restrict__ p, long long n, unsigned long long* out) {
+  unsigned long long s = 0;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += (unsigned long long)p[i] * (unsigned long long)((i & 1023) + 1);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+}
+// out[0] = the sum over everything; out[1 + i] = allocation i of alloc_workspaces (in its order: K cache, V cache, h, h2, Q, AO, DO, M1,
+// logits, qkv_raw, hlast, X1b, X2b, AOb, M1b, Pk, row_cnt, Xcat, Qb, Kp, VTp, samp, rng_key, row_sp, row_slot, ...) while cap allows
+extern "C" int etd_debug_decoder_checksum(etd_dec* d, unsigned long long* out, int cap, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !out || cap < 1) ETD_FAIL(ETD_EINVAL, "decoder_checksum: bad arguments");
+  const size_t first = d->weights_owner ? 0 : d->n_weight_allocs;
+  const size_t n = d->allocs.size() - first;
+  unsigned long long* acc = nullptr;
+  HIP_TRY(hipMalloc(&acc, 8 * (n + 1)));
+  HIP_TRY(hipMemsetAsync(acc, 0, 8 * (n + 1), st));
+  for (size_t i = 0; i < n; ++i)
+    hipLaunchKernelGGL(k_sum_words, dim3(1024), dim3(256), 0, st, (const unsigned*)d->allocs[first + i], (long long)(d->alloc_bytes[first + i] / 4), acc + 1 + i);
+  std::vector<unsigned long long> h(n + 1);
+  HIP_TRY(hipMemcpyAsync(h.data(), acc, 8 * (n + 1), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  (void)hipFree(acc);
+  for (size_t i = 1; i <= n; ++i) h[0] += h[i];
+  for (int i = 0; i < cap; ++i) out[i] = (size_t)i <= n ? h[i] : 0ull;
+  return ETD_OK;
+}
+
+// diagnostic: out[(layer * S + slot) * ctx + pos] = 32-bit sum over the K and V words of that position (all heads), bf16 caches only
+__global__ void k_kv_rowsums(const unsigned* __restrict__ K, const unsigned* __restrict__ V, int L, int S, int nh, int ctx, unsigned* out) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)L * S * ctx) return;
+  const int pos = (int)(i % ctx), slot = (int)((i / ctx) % S), l = (int)(i / ((long long)ctx * S));
+  unsigned s = 0;
+  for (int hd = 0; hd < nh; ++hd) {
+    const long long w0 = ((((long long)l * S + slot) * nh + hd) * ctx + pos) * 32;      // 64 bf16 = 32 words
+    for (int w = 0; w < 32; ++w) s += K[w0 + w] * (unsigned)(w + 1 + 64 * hd) + V[w0 + w] * (unsigned)(w + 33 + 64 * hd);
+  }
+  out[i] = s;
+}
+extern "C" int etd_debug_decoder_kv_rowsums(etd_dec* d, unsigned* out_host, long long cap, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !out_host || !d->bf16w) ETD_FAIL(ETD_EINVAL, "kv_rowsums: bf16 handles only");
+  const long long n = (long long)d->L * d->S * d->ctx;
+  if (cap < n) ETD_FAIL(ETD_ENOMEM, "kv_rowsums: need room for %lld words", n);
+  unsigned* dev = nullptr;
+  HIP_TRY(hipMalloc(&dev, n * 4));
+  hipLaunchKernelGGL(k_kv_rowsums, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const unsigned*)d->Kc, (const unsigned*)d->Vc, d->L, d->S, d->nh, d->ctx, dev);
+  HIP_TRY(hipMemcpyAsync(out_host, dev, n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  (void)hipFree(dev);
   return ETD_OK;
 }
 

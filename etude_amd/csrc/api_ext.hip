@@ -479,6 +479,9 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
     ea.Wf = e->Wf; ea.bf = e->bfold; ea.pos = e->pos_freq_enc; ea.Y = e->X; ea.w0 = w0; ea.n_win = nw; ea.f0 = f0; ea.fc = fc;
     ea.nf = nf; ea.margin = e->margin; ea.center = -8.0f; ea.pad_value = e->cfg.min_value;
     ETD_TRY(launch_embed(ea, st));
+    // diagnostic (tools/probe_race.py): stop the launch sequence early -- 1: after the embedding, 2: after the encoder layers (outputs are garbage)
+    static const int stop_stage = getenv("ETD_EXT_STOP_STAGE") ? atoi(getenv("ETD_EXT_STOP_STAGE")) : 0;
+    if (stop_stage == 1) continue;
     const bool first = (w0 == 0 && f0 == 0);
     ETD_TRY(tap(e, 0, e->X, (size_t)Mtok * 512, first, st));
     for (int l = 0; l < 3; ++l) {
@@ -491,6 +494,7 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       }
       ETD_TRY(tap(e, 1 + l, e->X, (size_t)Mtok * 512, first, st));
     }
+    if (stop_stage == 2) continue;
     // ---- cross-attention K/V of the encoder output for the 3 decoder layers, one z-batched launch pair
     {
       LinArgs a = {};

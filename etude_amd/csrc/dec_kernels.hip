@@ -41,7 +41,17 @@ extern "C" int etd_debug_step_stamps(long long* dev_buf, unsigned long long cap_
 #define SS_DECL() do { } while (0)
 #define SS(i) do { } while (0)
 #define SS_LANDED() do { } while (0)
+#ifdef ETD_STEP_FENCE       /* measurement build: an agent-scope fence behind the last stores of every per-layer step kernel (1: both, 2: release, 3: acquire) */
+#if ETD_STEP_FENCE == 2
+#define SS_FLUSH(kid, role) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#elif ETD_STEP_FENCE == 3
+#define SS_FLUSH(kid, role) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define SS_FLUSH(kid, role) __threadfence()
+#endif
+#else
 #define SS_FLUSH(kid, role) do { } while (0)
+#endif
 #endif
 
 // ================================================================================================
@@ -768,6 +778,7 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
     }
   }
   HSTAMP(4);
+  SS_FLUSH(0, 0);
 }
 
 #ifdef ETD_HEAD_STAMP
@@ -938,7 +949,14 @@ template <> struct Raw8<bf16> {
   // K/V rows are read once per step and never again before they are overwritten in the caches by the next row's stream: the
   // nontemporal hint keeps them from evicting the weights (shared by all engines) from L2 / the Infinity Cache -- measured
   // -5.5 % per step with one engine and with four (tools/bench_engine_overlap.py)
+#ifndef ETD_KV_NT
+#define ETD_KV_NT 1
+#endif
+#if ETD_KV_NT
   __device__ __forceinline__ void load(const bf16* p) { v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+#else
+  __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+#endif
   __device__ __forceinline__ float get(int j) const { return bf2f(v[j]); }
 };
 
@@ -1066,8 +1084,13 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     const int ka = wave * 8 + j, kbb = ka + G2;                        // < 16 NW <= max_ctx (checked by the launcher)
     kA.load(kb0 + (long long)ka * 64 + c * 8); kB.load(kb0 + (long long)kbb * 64 + c * 8);
     wA.load(vb0 + (long long)ka * 64 + c * 8); wB.load(vb0 + (long long)kbb * 64 + c * 8);
+#if ETD_KV_NT
     slot = m; pos = __builtin_nontemporal_load(p_row_sp + 2 * m + 1);
   } else if (p_row_sp) { const i32x2 sp = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(p_row_sp + 2 * m)); slot = sp[0]; pos = sp[1]; }   // one 8-byte load
+#else
+    slot = m; pos = p_row_sp[2 * m + 1];
+  } else if (p_row_sp) { const i32x2 sp = *reinterpret_cast<const i32x2*>(p_row_sp + 2 * m); slot = sp[0]; pos = sp[1]; }
+#endif
   else { slot = a.rows.slot[m]; pos = a.rows.pos[m]; }
   const int ctx = (pos < p_max_ctx ? pos : p_max_ctx - 1) + 1;
   const int hidden = p_n_heads * 64;

@@ -7,6 +7,7 @@
 
 #include "../../include/etude_hip.h"
 #include "ext_kernels.h"
+#include "dec_kernels.h"
 
 namespace {
 struct Entry { double ms = 0; long long n = 0; double flops = 0, bytes = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; };
@@ -145,5 +146,67 @@ extern "C" int etd_debug_linear(int M, int N, int K, int iters, void* stream, do
   *us = 1e3 * ms / iters;
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   (void)hipFree(X); (void)hipFree(W); (void)hipFree(Y); (void)hipFree(b);
+  return rc;
+}
+
+// Diagnostic aggressors (tools/probe_race.py): `iters` launches of ONE kernel type on private buffers filled with random values.
+//   which 0: k_attn, 2048 sequences x 256 queries x 256 keys, 4 heads (the extractor's shape)
+//         1: k_attn causal, 54 ragged sequences of ~340 rows, 8 heads (the decoder prefill's shape)
+//         2: k_linear<2> (LayerNorm epilogue), M = 131072, K = 256
+//         3: k_ln_rows, 18432 rows x 512
+extern "C" int etd_debug_kernel_loop(int which, int iters, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (which < 0 || which > 3 || iters < 1) ETD_FAIL(ETD_EINVAL, "debug_kernel_loop: bad arguments");
+  std::vector<void*> bufs;
+  auto get = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes + 256) != hipSuccess) return nullptr; bufs.push_back(p); return p; };
+  auto fill = [&](void* p, size_t n_bf16, unsigned seed) { hipLaunchKernelGGL(k_fill_bf16, dim3(1024), dim3(256), 0, st, (bf16*)p, (long long)n_bf16, seed); };
+  int rc = ETD_OK;
+  if (which == 0 || which == 1) {
+    const int nh = which == 0 ? 4 : 8, H = nh * 64;
+    const int n_seq = which == 0 ? 2048 : 54, S = which == 0 ? 256 : 340, Spad = which == 0 ? 256 : 384;
+    const long long M = (long long)n_seq * S;
+    bf16 *Q = (bf16*)get(M * H * 2), *K = (bf16*)get(M * H * 2), *VT = (bf16*)get((size_t)n_seq * nh * 64 * Spad * 2), *O = (bf16*)get(M * H * 2);
+    int* meta = (int*)get(n_seq * 8);
+    if (!Q || !K || !VT || !O || !meta) rc = ETD_ENOMEM;
+    if (rc == ETD_OK) {
+      fill(Q, M * H, 1u); fill(K, M * H, 2u); fill(VT, (size_t)n_seq * nh * 64 * Spad, 3u);
+      std::vector<int> hm(2 * n_seq);
+      for (int i = 0; i < n_seq; ++i) { hm[i] = i * S; hm[n_seq + i] = S; }
+      HIP_TRY(hipMemcpyAsync(meta, hm.data(), hm.size() * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      AttnArgs a = {};
+      a.Q = Q; a.ldq = H; a.q_seq_stride = (long long)S * H; a.K = K; a.ldk = H; a.k_seq_stride = (long long)S * H; a.VT = VT; a.Spad = Spad;
+      a.O = O; a.ldo = H; a.o_seq_stride = (long long)S * H; a.n_seq = n_seq; a.Sq = S; a.Sk = S; a.scale_log2e = 0.125f * 1.4426950408889634f; a.n_heads = nh;
+      if (which == 1) { a.seq_row0 = meta; a.seq_len = meta + n_seq; a.causal = 1; }
+      for (int it = 0; it < iters && rc == ETD_OK; ++it) rc = launch_attn(a, st);
+    }
+  } else if (which == 2) {
+    const int M = 131072, K = 256, N = 256;
+    bf16 *X = (bf16*)get((size_t)M * K * 2), *W = (bf16*)get((size_t)N * K * 2), *R = (bf16*)get((size_t)M * N * 2), *Y = (bf16*)get((size_t)M * N * 2);
+    float* par = (float*)get(3 * N * 4);
+    if (!X || !W || !R || !Y || !par) rc = ETD_ENOMEM;
+    if (rc == ETD_OK) {
+      fill(X, (size_t)M * K, 1u); fill(W, (size_t)N * K, 2u); fill(R, (size_t)M * N, 3u);
+      std::vector<float> hp(3 * N, 0.f);
+      for (int i = 0; i < N; ++i) hp[N + i] = 1.f;
+      HIP_TRY(hipMemcpyAsync(par, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      LinArgs a = {};
+      a.X = X; a.ldx = K; a.W = W; a.bias = par; a.M = M; a.N = N; a.K = K; a.Y = Y; a.ldy = N; a.vt_block = -1; a.R = R; a.ldr = N; a.gamma = par + N; a.beta = par + 2 * N;
+      for (int it = 0; it < iters && rc == ETD_OK; ++it) rc = launch_linear_ln(a, st);
+    }
+  } else {
+    const int M = 18432, H = 512;
+    float* h = (float*)get((size_t)M * H * 4); float* par = (float*)get(4 * H * 4);
+    bf16 *x1 = (bf16*)get((size_t)M * H * 2), *x2 = (bf16*)get((size_t)M * H * 2);
+    if (!h || !par || !x1 || !x2) rc = ETD_ENOMEM;
+    if (rc == ETD_OK) {
+      fill(h, (size_t)M * H * 2, 7u);            // (random bf16 pairs read as floats: finite, any magnitude)
+      HIP_TRY(hipMemsetAsync(par, 0, 4 * H * 4, st));
+      for (int it = 0; it < iters && rc == ETD_OK; ++it) rc = launch_ln_rows(h, M, H, par, par + H, par + 2 * H, par + 3 * H, 1e-5f, x1, x2, st);
+    }
+  }
+  (void)hipStreamSynchronize(st);
+  for (void* p : bufs) (void)hipFree(p);
   return rc;
 }

@@ -60,6 +60,9 @@ int etd_prof_entry(int i, char* name, int name_cap, double* total_ms, long long*
 int etd_debug_boundary_cost(int n_nodes, int iters, int big_args, void* stream, double* eager_us, double* graph_us);
 /* measurement hook: average time (us) of the token-major bf16 GEMM kernel on a synthetic [M,K] x [N,K]^T problem (N % 256 == 0, K % 128 == 0) */
 int etd_debug_linear(int M, int N, int K, int iters, void* stream, double* us);
+/* Diagnostic aggressors (tools/probe_race.py): `iters` launches of one kernel type on private random buffers:
+   which 0 = k_attn (extractor shape), 1 = k_attn causal ragged (prefill shape), 2 = k_linear with the LayerNorm epilogue, 3 = k_ln_rows. */
+int etd_debug_kernel_loop(int which, int iters, void* stream);
 
 /* ------------------------------------------------------------------ audio front end */
 typedef struct etd_frontend etd_frontend;
@@ -231,6 +234,11 @@ int etd_decoder_prefill_logits(etd_dec*, int slot, const int32_t* ids, const int
                                float* logits_host, void* stream);
 /* algorithmic HBM bytes of one decode step for n_streams at context `ctx` (SURVEY.md 8d formula) */
 double etd_decoder_step_bytes(const etd_dec*, int n_streams, int ctx);
+/* Diagnostic (tools/probe_race.py): weighted 64-bit sums over the words of the handle's KV cache, workspaces and stream state:
+   out[0] = everything, out[1 + i] = its i-th allocation (as many as `cap` allows). */
+int etd_debug_decoder_checksum(etd_dec*, unsigned long long* out, int cap, void* stream);
+/* Diagnostic: out[(layer * max_streams + slot) * max_ctx + pos] = 32-bit sum over the K and V rows of that position (bf16 handles). */
+int etd_debug_decoder_kv_rowsums(etd_dec*, unsigned* out_host, long long cap, void* stream);
 
 /* ---- TinyREMITokenizer glue on either side of the decoder (host code, no GPU) ----
  * etd_tok_create      TinyREMITokenizer.__init__ / _create_measures      etude/data/tokenizer.py:24-41,166-229

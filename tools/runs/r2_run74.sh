@@ -1,0 +1,6 @@
+#!/bin/bash
+export GPU_MAX_HW_QUEUES=8
+export TMPDIR=/tmp
+O=gpurun_out/r74; mkdir -p $O
+for i in 1 2 3; do timeout -k 10 200 python3 tools/probe_race.py 12 600 hog 2>&1 | grep "^(m" | sed "s/^/hog run $i /" | tee -a $O/race.txt; done
+for i in 1 2 3; do timeout -k 10 200 python3 tools/probe_race.py 12 600 hogw 2>&1 | grep "^(m" | sed "s/^/hogw run $i /" | tee -a $O/race.txt; done
