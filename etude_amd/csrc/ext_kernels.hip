@@ -806,6 +806,9 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
   float* bsm = reinterpret_cast<float*>(smem + 256 * LDE * 2 + (EFB + 80) * ELDX * 4 + 32 * ELDP * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+#if defined(ETD_EMBED_ABL) && ETD_EMBED_ABL == 4      /* diagnostic builds (tools/probe_race.py): 4 = return at once, 5 = return behind the LDS fill */
+  if (a.n_win > 0) { if (tid == 9999) bsm[0] = 1.f; return; }
+#endif
   const int b0 = blockIdx.x * 32;
   const int fl0 = blockIdx.y * EFB;              // first frame of this block inside the chunk
   const int wl = blockIdx.z, w = a.w0 + wl;
@@ -839,6 +842,9 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
     Xsm[tr * ELDX + bin] = v;
   }
   __syncthreads();
+#if defined(ETD_EMBED_ABL) && ETD_EMBED_ABL == 5
+  if (a.n_win > 0) return;
+#endif
 
   for (int fi = 0; fi < EFB / 4; ++fi) {
     const int fl = wave * (EFB / 4) + fi;          // frame inside the block

@@ -147,19 +147,28 @@ if __name__ == "__main__":
 
     def extractor_loop():
         torch.cuda.set_device(0)
+        t_c0 = __import__("time").perf_counter()
         from etude_amd.config import ExtractorConfig
         from etude_amd.extractor import AMTAPC_Extractor
         ex = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(7), "cuda", max_windows=4)
         xs = torch.from_numpy(synth.window_features(5, 4)).to(dev)
         est = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(est):
+            ex.transcript_windows(xs)
+            est.synchronize()
+            print("(x) extractor engine ready after %.1f s" % (__import__("time").perf_counter() - t_c0), flush=True)
+            ext_ready.set()                      # the engine exists, its first pass is done: only the steady-state loop runs beside the steppers
             while not stop[0]:
                 ex.transcript_windows(xs)
                 est.synchronize()
 
+    ext_ready = threading.Event()
     if extr:
         ht = threading.Thread(target=extractor_loop); ht.start()
-        time_mod = __import__("time"); time_mod.sleep(3.0)
+        if os.environ.get("PROBE_EXT_EARLY"):       # (the first version of this probe: steppers start 3 s after the extractor's creation BEGAN)
+            __import__("time").sleep(3.0)
+        else:
+            ext_ready.wait()
         ths = [threading.Thread(target=stepper, args=(e,)) for e in (1, 2, 3)]
         for x in ths:
             x.start()
@@ -236,6 +245,46 @@ if __name__ == "__main__":
                         dbuf2.copy_(dbuf, non_blocking=True)
                 hst.synchronize()
 
+    evt = len(sys.argv) > 3 and sys.argv[3] in ("events", "alloc", "emptykernel")    # ... or only event records / only allocator traffic / only empty launches
+
+    def eventer():
+        torch.cuda.set_device(0)
+        hst = torch.cuda.Stream(device=dev)
+        mode = sys.argv[3]
+        nl = C.CDLL(str(Path(__file__).resolve().parent / "ubench" / "liblds_noise.so"))
+        nl.noise_launch2.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
+        sink = torch.zeros(16, dtype=torch.int32, device=dev)
+        with torch.cuda.stream(hst):
+            while not stop[0]:
+                if mode == "events":
+                    for _ in range(64):
+                        e_ = torch.cuda.Event(); e_.record(hst)
+                    hst.synchronize()
+                elif mode == "alloc":
+                    for _ in range(16):
+                        ts = [torch.empty((2048, 88), dtype=torch.float32, device=dev) for _ in range(4)]
+                        del ts
+                    hst.synchronize()
+                elif os.environ.get("PROBE_EMPTY"):      # "which,gx,gy,gz": an empty kernel (0 plain, 1 82 KiB static LDS, 2 296 registers) on that grid
+                    w_, gx_, gy_, gz_ = [int(x) for x in os.environ["PROBE_EMPTY"].split(",")]
+                    nl.empty_launch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+                    nl.empty_launch(w_, gx_, gy_, gz_, sink.data_ptr(), hst.cuda_stream)
+                    hst.synchronize()
+                else:                       # one small launch, then a stream synchronize -- the cadence of the k_embed-only aggressor
+                    nl.noise_launch2(256, 82 * 1024, 0x3f800000, sink.data_ptr(), hst.cuda_stream)
+                    hst.synchronize()
+
+    if evt:
+        ht = threading.Thread(target=eventer); ht.start()
+        ths = [threading.Thread(target=stepper, args=(e,)) for e in (1, 2, 3)]
+        for x in ths:
+            x.start()
+        for x in ths:
+            x.join()
+        stop[0] = True; ht.join()
+        torch.cuda.synchronize(dev)
+        print("(a) stepping engines' tokens:", " ".join(tokens(decs[e]) for e in (1, 2, 3)))
+        sys.exit(0)
     if mset:
         ht = threading.Thread(target=copier); ht.start()
         ths = [threading.Thread(target=stepper, args=(e,)) for e in (1, 2, 3)]

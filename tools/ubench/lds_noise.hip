@@ -106,3 +106,29 @@ extern "C" int scatter8_launch(int n_wg, unsigned long long* dst, long long n_ro
   hipLaunchKernelGGL(k_scatter8, dim3(n_wg), dim3(256), 0, (hipStream_t)stream, dst, n_rows, frames, val);
   return (int)hipGetLastError();
 }
+
+// Empty kernels that differ in ONE launch property each (the k_embed-only aggressor still disturbs other queues' kernels when its body
+// returns at once): which property of a launch does it?
+__global__ __launch_bounds__(256) void k_empty_static82(int* sink, int never) {
+  __shared__ int big[81728 / 4];
+  if (never) { for (int i = threadIdx.x; i < 81728 / 4; i += 256) big[i] = i; __syncthreads(); sink[threadIdx.x] = big[(threadIdx.x * 7) % (81728 / 4)]; }
+}
+// both at once: k_embed's footprint (82 KiB of LDS, 296 registers per wave, 4 waves) and nothing else
+__global__ __launch_bounds__(256) void k_empty_both(int* sink, int never) {
+  __shared__ int big[81728 / 4];
+  asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a39, v255" ::: "v255", "a39");
+  if (never) { for (int i = threadIdx.x; i < 81728 / 4; i += 256) big[i] = i; __syncthreads(); sink[threadIdx.x] = big[(threadIdx.x * 7) % (81728 / 4)]; }
+}
+__global__ __launch_bounds__(256) void k_empty_plain(int* sink) { if (threadIdx.x == 9999) sink[0] = 1; }
+__global__ __launch_bounds__(256) void k_empty_regs(int* sink) {
+  asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a39, v255" ::: "v255", "a39");      // forces a 296-register allocation (one wave per SIMD)
+  if (threadIdx.x == 9999) sink[0] = 1;
+}
+extern "C" int empty_launch(int which, int gx, int gy, int gz, int* sink, void* stream) {
+  const dim3 g(gx, gy, gz);
+  if (which == 0) hipLaunchKernelGGL(k_empty_plain, g, dim3(256), 0, (hipStream_t)stream, sink);
+  else if (which == 1) hipLaunchKernelGGL(k_empty_static82, g, dim3(256), 0, (hipStream_t)stream, sink, 0);
+  else if (which == 3) hipLaunchKernelGGL(k_empty_both, g, dim3(256), 0, (hipStream_t)stream, sink, 0);
+  else hipLaunchKernelGGL(k_empty_regs, g, dim3(256), 0, (hipStream_t)stream, sink);
+  return (int)hipGetLastError();
+}
