@@ -15,7 +15,7 @@ from pathlib import Path
 
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
-LIB_PATH = Path(__file__).resolve().parent / "libetude_hip.so"
+LIB_PATH = Path(os.environ["ETD_LIB_PATH"]) if os.environ.get("ETD_LIB_PATH") else Path(__file__).resolve().parent / "libetude_hip.so"     # (ETD_LIB_PATH: measurement builds side by side, tools/runs)
 
 c_int_p = C.POINTER(C.c_int)
 c_i32_p = C.POINTER(C.c_int32)
@@ -74,6 +74,7 @@ SIGNATURES = {
     "etd_debug_boundary_cost": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "etd_debug_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
     "etd_debug_kernel_loop": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
+    "etd_debug_empty_launch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "etd_frontend_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.POINTER(C.c_void_p)]),
     "etd_frontend_destroy": (None, [C.c_void_p]),
@@ -133,6 +134,12 @@ SIGNATURES = {
     "etd_decoder_step_bytes": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
     "etd_debug_decoder_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),
     "etd_debug_decoder_kv_rowsums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
+    "etd_debug_decoder_trace_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "etd_debug_decoder_trace_slabs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "etd_debug_decoder_trace_lanes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "etd_debug_decoder_trace_q": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]),
+    "etd_debug_decoder_peek_kv": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "etd_debug_decoder_trace_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
 }
 
 _lib = None

@@ -61,6 +61,8 @@ struct etd_dec {
   unsigned long long* rng_key = nullptr;         // [S] per-stream draw keys
   std::vector<unsigned long long> host_key; bool keys_dirty = true; bool sampling = false;
   float* Pk = nullptr;                           // [5][512][H] split-K partials of the decode-step (down | dense) projection
+  // diagnostic (etd_debug_decoder_trace_*): per-row hashes of every decode-step kernel's outputs, one record per step
+  unsigned* trace = nullptr; int* trace_step = nullptr; int trace_cap = 0; float* trace_pk = nullptr; float* trace_q = nullptr; float* trace_dbg = nullptr;   // trace_pk: layer 0's slabs of the LAST traced step
   int* row_cnt = nullptr;                        // [L][512] arrival counters of the in-launch row finish (DRowFin); zero between launches
   bf16* Xcat = nullptr;                          // [512][I + H] bf16: GELU(up) | attention output, the K-concatenated input of that GEMM
   std::vector<int> stage;                        // host staging of a prefill batch (fallback when the pinned buffer is absent)
@@ -157,6 +159,44 @@ int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst)
 struct PrefillInfo { int n; const int* seq_row0; const int* seq_len; int max_len; double attn_flops; };
 // "Only each prompt's last position is needed" (begin_bars): the last layer then runs its attention, MLP and residual for
 // those n rows only -- on the decode-step kernels -- after the big QKV GEMM has put every position's K/V into the cache.
+// ---- step trace (diagnostic): hash of every row of a buffer -> trace[step % cap][off + slab * M + row]
+__global__ __launch_bounds__(64) void k_trace_rows(const unsigned* buf, long long row_stride, int words, long long slab_stride, int M,
+                                                   unsigned* trace, const int* step, int cap, long long wps, int off) {
+  const int row = blockIdx.x, slab = blockIdx.y, lane = threadIdx.x;
+  const unsigned* p = buf + (long long)slab * slab_stride + (long long)row * row_stride;
+  unsigned acc = 0;
+  for (int i = lane; i < words; i += 64) acc += p[i] * (2654435761u * (unsigned)(i + 1) | 1u);
+  for (int o = 32; o; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) trace[(long long)(*step % cap) * wps + off + slab * M + row] = acc;
+}
+// K / V cache of (row, head) as the step's attention will read it: hash of the row appended by this step, and of rows 0 .. pos
+__global__ __launch_bounds__(64) void k_trace_kv(const unsigned* Kc, const unsigned* Vc, long long slot_stride_w, int max_ctx, const int* row_slot, const int* row_pos, int M,
+                                                 unsigned* trace, const int* step, int cap, long long wps, int off) {
+  const int row = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
+  const int slot = row_slot[row], pos = row_pos[row] < max_ctx ? row_pos[row] : max_ctx - 1;
+  unsigned* out = trace + (long long)(*step % cap) * wps + off;
+  for (int which = 0; which < 2; ++which) {
+    const unsigned* base = (which ? Vc : Kc) + (long long)slot * slot_stride_w + (long long)head * max_ctx * 32;      // 64 bf16 = 32 words per position
+    unsigned a_new = 0, a_all = 0;
+    for (long long i = lane; i < (long long)(pos + 1) * 32; i += 64) {
+      const unsigned w = base[i] * (2654435761u * (unsigned)(i + 1) | 1u);
+      a_all += w;
+      if (i >= (long long)pos * 32) a_new += w;
+    }
+    for (int o = 32; o; o >>= 1) { a_new += __shfl_xor(a_new, o); a_all += __shfl_xor(a_all, o); }
+    if (lane == 0) { out[(which * 8 + head) * M + row] = a_new; out[(16 + which * 8 + head) * M + row] = a_all; }
+  }
+}
+__global__ void k_trace_next(int* step) { *step += 1; }
+#define ETD_TRACE_LAYER 49     // records per row and layer: Q, gelu(up), 12 slabs, h_out, ln1, ln2, then per head K[pos], V[pos], K[0..pos], V[0..pos]
+static inline long long trace_wps(const etd_dec* d, int M) { return (long long)(ETD_TRACE_LAYER * d->L + 2) * M; }
+static int trace_rows(etd_dec* d, const void* buf, long long row_stride, int words, int nslab, long long slab_stride, int M, int off, hipStream_t st) {
+  hipLaunchKernelGGL(k_trace_rows, dim3(M, nslab), dim3(64), 0, st, (const unsigned*)buf, row_stride, words, slab_stride, M, d->trace, d->trace_step,
+                     d->trace_cap, trace_wps(d, M), off);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
 struct LastOnly { int n; const int* idx; DecRows rows; };
 
 int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false,
@@ -223,6 +263,16 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
       up.Y = d->M1; up.Xb = d->X2b; up.Yb = d->Xcat; up.ldy = d->I + d->H;
       ETD_TRY(launch_dstep_qkv_up(q, up, st));
+      if (d->trace) {
+        ETD_TRY(trace_rows(d, d->Q, d->H, d->H, 1, 0, M, l * ETD_TRACE_LAYER * M, st));
+        if (l == 0) HIP_TRY(hipMemcpyAsync(d->trace_q, d->Q, (size_t)M * d->H * 4, hipMemcpyDeviceToDevice, st));
+        ETD_TRY(trace_rows(d, d->Xcat, (d->I + d->H) / 2, d->I / 2, 1, 0, M, l * ETD_TRACE_LAYER * M + M, st));
+        if (d->nh == 8) {
+          hipLaunchKernelGGL(k_trace_kv, dim3(M, 8), dim3(64), 0, st, (const unsigned*)Kl, (const unsigned*)Vl, d->slot_stride / 2, d->ctx, d->row_slot, d->row_pos, M,
+                             d->trace, d->trace_step, d->trace_cap, trace_wps(d, M), l * ETD_TRACE_LAYER * M + 17 * M);
+          HIP_TRY(hipGetLastError());
+        }
+      }
     } else {
       ETD_TRY(launch_dgemm(q, DEPI_QKV, d->bf16w, st));
     }
@@ -236,6 +286,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0;
       const int ksd = d->I / 512;
       at.dense_w = (const bf16*)w.dense_hw; at.dense_out = d->Pk + (size_t)ksd * M * d->H;
+      at.dbg = (d->trace && l == 0) ? d->trace_dbg : nullptr;
       DGemmArgs dn = {};
       dn.Xb = d->Xcat; dn.ldx = d->I + d->H; dn.W = w.cat.W; dn.K = d->I + d->H; dn.M = M; dn.N = d->H; dn.Npad = d->H;
       dn.k_splits = ksd; dn.Y = d->Pk; dn.ldy = d->H;
@@ -254,8 +305,17 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
         ETD_TRY(launch_dstep_attn_down(at, dn, &fin, st));
       } else {
         ETD_TRY(launch_dstep_attn_down(at, dn, nullptr, st));
+        if (d->trace && ksd + d->nh == 12) ETD_TRY(trace_rows(d, d->Pk, d->H, d->H, 12, (long long)M * d->H, M, l * ETD_TRACE_LAYER * M + 2 * M, st));
+        if (d->trace && l == 0 && ksd + d->nh == 12) HIP_TRY(hipMemcpyAsync(d->trace_pk, d->Pk, (size_t)12 * M * d->H * 4, hipMemcpyDeviceToDevice, st));
         ETD_TRY(launch_resid_ln_rows(d->Pk, ksd + d->nh, w.cat.b, nullptr, hin, hout, M, d->H, nx ? nx->ln1g : nullptr, nx ? nx->ln1b : nullptr,
                                      nx ? nx->ln2g : nullptr, nx ? nx->ln2b : nullptr, d->cfg.layer_norm_eps, nx ? d->X1b : nullptr, nx ? d->X2b : nullptr, st));
+        if (d->trace) {
+          ETD_TRY(trace_rows(d, hout, d->H, d->H, 1, 0, M, l * ETD_TRACE_LAYER * M + 14 * M, st));
+          if (nx) {
+            ETD_TRY(trace_rows(d, d->X1b, d->H / 2, d->H / 2, 1, 0, M, l * ETD_TRACE_LAYER * M + 15 * M, st));
+            ETD_TRY(trace_rows(d, d->X2b, d->H / 2, d->H / 2, 1, 0, M, l * ETD_TRACE_LAYER * M + 16 * M, st));
+          }
+        }
       }
       float* t = hin; hin = hout; hout = t;
       continue;
@@ -692,6 +752,7 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
   (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
   d->graphs.clear();
+  if (d->trace) { (void)hipFree(d->trace); (void)hipFree(d->trace_step); (void)hipFree(d->trace_pk); (void)hipFree(d->trace_q); d->trace = nullptr; d->trace_step = nullptr; d->trace_pk = nullptr; d->trace_q = nullptr; }
   if (d->pin_stage) { (void)hipHostFree(d->pin_stage); d->pin_stage = nullptr; }
   if (d->pin_rb) { (void)hipHostFree(d->pin_rb); d->pin_rb = nullptr; }
   if (d->pin_stage_evt) { (void)hipEventDestroy(d->pin_stage_evt); d->pin_stage_evt = nullptr; }
@@ -827,6 +888,11 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
       hd.h = d->h; hd.x1 = d->X1b; hd.x2 = d->X2b;
       hd.samp = d->samp_dev; hd.rng_key = d->rng_key;             // the device-side config selects greedy / sampling
       ETD_TRY(launch_dstep_head(hd, s_));
+      if (d->trace) {
+        ETD_TRY(trace_rows(d, d->h, d->H, d->H, 1, 0, n_active, ETD_TRACE_LAYER * d->L * n_active, s_));
+        ETD_TRY(trace_rows(d, d->cur_tok, 1, 1, 1, 0, n_active, ETD_TRACE_LAYER * d->L * n_active + n_active, s_));
+        hipLaunchKernelGGL(k_trace_next, dim3(1), dim3(1), 0, s_, d->trace_step);
+      }
       return ETD_OK;
     }
     ETD_TRY(head_logits(d, hf, n_active, d->logits, s_));
@@ -1013,6 +1079,75 @@ extern "C" int etd_debug_decoder_kv_rowsums(etd_dec* d, unsigned* out_host, long
   HIP_TRY(hipMemcpyAsync(out_host, dev, n * 4, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   (void)hipFree(dev);
+  return ETD_OK;
+}
+
+// Step trace (tools/probe_trace.py): after trace_begin every decode step of the bf16 fused path records a hash of each row of each
+// kernel's outputs -- per layer Q, gelu(up), the 12 split-K slabs, the residual stream and the next LayerNorm rows; then the next
+// step's embeddings and tokens -- into a ring of cap_steps records.  words_per_step = (49 * layers + 2) * n_active.
+extern "C" int etd_debug_decoder_trace_begin(etd_dec* d, int cap_steps, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || cap_steps < 1 || !d->bf16w) ETD_FAIL(ETD_EINVAL, "trace_begin: bad args");
+  HIP_TRY(hipStreamSynchronize(st));
+  for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);       // the captured steps do not hold the trace launches
+  d->graphs.clear();
+  if (d->trace) { (void)hipFree(d->trace); (void)hipFree(d->trace_step); (void)hipFree(d->trace_pk); (void)hipFree(d->trace_q); d->trace = nullptr; d->trace_step = nullptr; d->trace_pk = nullptr; d->trace_q = nullptr; }
+  HIP_TRY(hipMalloc(&d->trace_pk, (size_t)12 * d->S * d->H * 4));
+  HIP_TRY(hipMalloc(&d->trace_q, (size_t)d->S * d->H * 4));
+  if (!d->trace_dbg) HIP_TRY(hipMalloc(&d->trace_dbg, (size_t)d->nh * d->S * 256 * 8 * 4));
+  const size_t bytes = (size_t)cap_steps * trace_wps(d, d->S) * 4;
+  HIP_TRY(hipMalloc(&d->trace, bytes));
+  HIP_TRY(hipMalloc(&d->trace_step, 4));
+  HIP_TRY(hipMemsetAsync(d->trace, 0, bytes, st));
+  HIP_TRY(hipMemsetAsync(d->trace_step, 0, 4, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  d->trace_cap = cap_steps;
+  return ETD_OK;
+}
+extern "C" int etd_debug_decoder_trace_slabs(etd_dec* d, float* out_host, long long cap_floats, int n_active, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !d->trace_pk || !out_host || n_active < 1 || n_active > d->S) ETD_FAIL(ETD_EINVAL, "trace_slabs: bad args");
+  const long long n = 12LL * n_active * d->H;
+  if (cap_floats < n) ETD_FAIL(ETD_ENOMEM, "trace_slabs: need room for %lld floats", n);
+  HIP_TRY(hipMemcpyAsync(out_host, d->trace_pk, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return ETD_OK;
+}
+// layer 0's queries [n_active][hidden] of the last traced step, and one (layer, slot, head)'s K and V cache rows [n_pos][64] (bf16 bit patterns)
+// the attention workgroups' per-lane softmax state of layer 0 in the last traced step: [heads][n_active][256][8]
+extern "C" int etd_debug_decoder_trace_lanes(etd_dec* d, float* out_host, long long cap_floats, int n_active, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)(d ? d->nh : 0) * n_active * 256 * 8;
+  if (!d || !d->trace_dbg || !out_host || n_active < 1 || n_active > d->S || cap_floats < n) ETD_FAIL(ETD_EINVAL, "trace_lanes: bad args");
+  HIP_TRY(hipMemcpyAsync(out_host, d->trace_dbg, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return ETD_OK;
+}
+extern "C" int etd_debug_decoder_trace_q(etd_dec* d, float* out_host, long long cap_floats, int n_active, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !d->trace_q || !out_host || n_active < 1 || n_active > d->S || cap_floats < (long long)n_active * d->H) ETD_FAIL(ETD_EINVAL, "trace_q: bad args");
+  HIP_TRY(hipMemcpyAsync(out_host, d->trace_q, (size_t)n_active * d->H * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return ETD_OK;
+}
+extern "C" int etd_debug_decoder_peek_kv(etd_dec* d, int layer, int slot, int head, int n_pos, unsigned short* k_out, unsigned short* v_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !d->bf16w || layer < 0 || layer >= d->L || slot < 0 || slot >= d->S || head < 0 || head >= d->nh || n_pos < 1 || n_pos > d->ctx || !k_out || !v_out)
+    ETD_FAIL(ETD_EINVAL, "peek_kv: bad args");
+  const size_t off = ((size_t)layer * d->layer_stride + (size_t)slot * d->slot_stride + (size_t)head * d->ctx * 64) * 2;
+  HIP_TRY(hipMemcpyAsync(k_out, (const char*)d->Kc + off, (size_t)n_pos * 128, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(v_out, (const char*)d->Vc + off, (size_t)n_pos * 128, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return ETD_OK;
+}
+extern "C" int etd_debug_decoder_trace_read(etd_dec* d, unsigned* out_host, long long cap_words, int n_active, int* steps_done, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || !d->trace || !out_host || !steps_done || n_active < 1 || n_active > d->S) ETD_FAIL(ETD_EINVAL, "trace_read: bad args");
+  const long long n = (long long)d->trace_cap * trace_wps(d, n_active);
+  if (cap_words < n) ETD_FAIL(ETD_ENOMEM, "trace_read: need room for %lld words", n);
+  HIP_TRY(hipMemcpyAsync(out_host, d->trace, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(steps_done, d->trace_step, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
   return ETD_OK;
 }
 

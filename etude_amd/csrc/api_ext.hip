@@ -481,7 +481,7 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
     ETD_TRY(launch_embed(ea, st));
     // diagnostic (tools/probe_race.py): stop the launch sequence early -- 1: after the embedding, 2: after the encoder layers (outputs are garbage)
     static const int stop_stage = getenv("ETD_EXT_STOP_STAGE") ? atoi(getenv("ETD_EXT_STOP_STAGE")) : 0;
-    if (stop_stage == 1) continue;
+    if (stop_stage == 1) return ETD_OK;
     const bool first = (w0 == 0 && f0 == 0);
     ETD_TRY(tap(e, 0, e->X, (size_t)Mtok * 512, first, st));
     for (int l = 0; l < 3; ++l) {
@@ -494,7 +494,7 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
       }
       ETD_TRY(tap(e, 1 + l, e->X, (size_t)Mtok * 512, first, st));
     }
-    if (stop_stage == 2) continue;
+    if (stop_stage == 2) return ETD_OK;
     // ---- cross-attention K/V of the encoder output for the 3 decoder layers, one z-batched launch pair
     {
       LinArgs a = {};

@@ -77,6 +77,7 @@ struct DAttnArgs {
   // k_dstep_attn_down only: attention.dense applied inside the attention workgroup
   const bf16* dense_w;           // [heads][512][64]: per head, the [out][64] slice of attention.dense (contiguous 64 KiB)
   float* dense_out;              // [heads][M][512] fp32 partial sums = split-K slabs of k_resid_ln_rows
+  float* dbg;                    // diagnostic (step trace): [heads][M][256 lanes][8] = lr, mr, o[0] after the key loop, lr after merge stages 8 / 16 / 32
 };
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
 // k_dstep_attn_down with the row kernel folded in: every contributor of a row's split-K slabs (its 8 attention workgroups, the

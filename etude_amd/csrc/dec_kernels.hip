@@ -802,6 +802,12 @@ int launch_dstep_head(const DHeadArgs& a, hipStream_t st) {
 // k_dgemv (M == 1, the reference's batch-1 token loop): each wave owns 4 output features, the 64 lanes
 // split K in 16-byte pieces (one fully coalesced 1 KiB / 2 KiB row segment per load instruction).
 // ================================================================================================
+// fmaf as a v_fma_f32 of its own: the SLP vectoriser otherwise pairs the four feature accumulators into v_pk_fma_f32 ... op_sel:[0,1,0]
+// (low result reads a high register) -- the packed form kept out of this library, see merge_sum below / tests/test_isa_guard.py
+__device__ __forceinline__ float fma_scalar(float a, float b, float c) {
+  asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+}
 template <bool WBF16, int EPI>
 __global__ __launch_bounds__(256) void k_dgemv(DGemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -845,7 +851,7 @@ __global__ __launch_bounds__(256) void k_dgemv(DGemmArgs a) {
         const float* wp = reinterpret_cast<const float*>(a.W) + (long long)(nb + f) * a.K + k;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[f] = fmaf(w0[j], x0[j], acc[f]); acc[f] = fmaf(w1[j], x1[j], acc[f]); }
+        for (int j = 0; j < 4; ++j) { acc[f] = fma_scalar(w0[j], x0[j], acc[f]); acc[f] = fma_scalar(w1[j], x1[j], acc[f]); }
       }
     }
   }
@@ -1055,6 +1061,29 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 #else
 #define ABL_GEMMW_LOAD(p) (*reinterpret_cast<const bf16x8*>(p))
 #endif
+// cross-lane exchanges of the attention core: 0 = __shfl_xor (ds_bpermute_b32, LDS crossbar), 1 = lane_xor (DPP / permlane swaps)
+#ifndef ETD_AD_XCHG
+#define ETD_AD_XCHG 0
+#endif
+#if ETD_AD_XCHG
+#define ETD_XCH(v, O) lane_xor<O>(v)
+#else
+#define ETD_XCH(v, O) __shfl_xor(v, O, 64)
+#endif
+// measurement builds: ETD_AD_TRANS_NOP=1 puts 16 wait states between the merge's v_exp_f32 results and their first use, = 2 also in the key loop
+#ifndef ETD_AD_TRANS_NOP
+#define ETD_AD_TRANS_NOP 0
+#endif
+#if ETD_AD_TRANS_NOP
+#define ETD_TRANS_SETTLE(a_, b_) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a_), "+v"(b_))
+#else
+#define ETD_TRANS_SETTLE(a_, b_) ((void)0)
+#endif
+#if ETD_AD_TRANS_NOP > 1
+#define ETD_TRANS_SETTLE_LOOP(a_, b_) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a_), "+v"(b_))
+#else
+#define ETD_TRANS_SETTLE_LOOP(a_, b_) ((void)0)
+#endif
 #define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
 // DENSE: instead of storing the head's 64 outputs, multiply them (rounded to bf16, as the projection GEMM would read them)
 // with this head's [512][64] slice of attention.dense and store the 512 partial sums as one more split-K slab for
@@ -1064,11 +1093,29 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 // workgroup has 2 x 16 NW keys x 256 B in flight and walks the context in ceil(ctx / (16 NW)) dependent round trips: at the
 // serving shape (54 rows per engine, ctx ~340) NW = 4 is six round trips of ~1-2 us each with ~30 KiB in flight per CU (the
 // 0.29-of-peak kernel of round 1); NW = 16 requests the whole context of a (row, head) at once (2 iterations, both in flight).
+// a * b + c * d of the softmax merge as three VALU instructions of its own (mul, mul, add: the roundings hipcc's code has under
+// -ffp-contract=off).  Left to the SLP vectoriser these sums are paired crosswise -- v_pk_mul_f32 x2 + v_pk_add_f32 / v_pk_fma_f32
+// with op_sel:[0,0,1] op_sel_hi:[1,1,0]: the LOW result takes an operand's HIGH register and vice versa -- and on MI355X such an
+// instruction's low result came out as if that operand were 0 in lanes 48-55 whenever the SIMD was shared with another queue's
+// MFMA waves (batched prefill, Extract stage): a (wave, j = 6) slot's softmax denominator vanished, the head's output grew by
+// ~3 %, tokens changed from run to run.  DESIGN.md section 8, "packed FP32 with crossed op_sel"; tools/probe_trace.py;
+// tests/test_isa_guard.py keeps the form out of the library.
+__device__ __forceinline__ float merge_sum(float a, float b, float c, float d) {
+  float t, u, r;
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
+  asm volatile("v_mul_f32 %0, %1, %2" : "=v"(u) : "v"(c), "v"(d));
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(u));
+  return r;
+}
 template <typename KVT, bool DENSE, int NW, bool FIN = false>
 __device__ __forceinline__ void dattn_core(const int m, const int head, float (&red)[NW][8][10], float* osh, float* outsh,
                                            const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                            int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a, const DRowFin* fin = nullptr) {
+#if defined(ETD_AD_UNIFORM) && ETD_AD_UNIFORM
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane >> 3, c = lane & 7;      // (measurement build: the key loop's trip count is then provably wave-uniform)
+#else
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
+#endif
   SS_DECL(); SS(0);
   constexpr int G2 = 8 * NW;         // offset of a wave's second 8-key group inside an iteration
   constexpr int KI = 16 * NW;        // keys per workgroup iteration
@@ -1132,12 +1179,13 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     float sA = 0.f, sB = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sA = fmaf(q[e], kA.get(e), sA); sB = fmaf(q[e], kB.get(e), sB); }
-    sA += __shfl_xor(sA, 1, 64); sB += __shfl_xor(sB, 1, 64);      // ds_bpermute on purpose: the LDS pipe is idle here and the VALU is not (DPP measured 6 % slower)
-    sA += __shfl_xor(sA, 2, 64); sB += __shfl_xor(sB, 2, 64);
-    sA += __shfl_xor(sA, 4, 64); sB += __shfl_xor(sB, 4, 64);
+    sA += ETD_XCH(sA, 1); sB += ETD_XCH(sB, 1);      // ds_bpermute on purpose: the LDS pipe is idle here and the VALU is not (DPP measured 6 % slower)
+    sA += ETD_XCH(sA, 2); sB += ETD_XCH(sB, 2);
+    sA += ETD_XCH(sA, 4); sB += ETD_XCH(sB, 4);
     if (vA) {
       const float mn = fmaxf(mr, sA);
-      const float al = EXPF(mr - mn), p = EXPF(sA - mn);
+      float al = EXPF(mr - mn), p = EXPF(sA - mn);
+      ETD_TRANS_SETTLE_LOOP(al, p);
       lr = lr * al + p;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wA.get(e);
@@ -1145,7 +1193,8 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     }
     if (vB) {
       const float mn = fmaxf(mr, sB);
-      const float al = EXPF(mr - mn), p = EXPF(sB - mn);
+      float al = EXPF(mr - mn), p = EXPF(sB - mn);
+      ETD_TRANS_SETTLE_LOOP(al, p);
       lr = lr * al + p;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = o[e] * al + p * wB.get(e);
@@ -1160,22 +1209,44 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   constexpr int FR = 64 / NW, FP = FR > 8 ? 8 : FR, NPASS = FR / FP;
   bf16x8 dwv[DENSE ? FP : 1];
   const bf16* dwb = nullptr;
+  // measurement builds: ETD_AD_DENSE_LATE=1 requests the fragments AFTER the intra-wave merge, =2 requests them here but drains them before the merge
+#ifndef ETD_AD_DENSE_LATE
+#define ETD_AD_DENSE_LATE 0
+#endif
   if constexpr (DENSE) {
     dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * (512 / NW) + (lane >> 3)) * 64 + (lane & 7) * 8;
+#if ETD_AD_DENSE_LATE != 1
+#pragma unroll
+    for (int it = 0; it < FP; ++it) dwv[it] = ABL_DENSE_LOAD(dwb + it * 8 * 64);
+#endif
+#if ETD_AD_DENSE_LATE == 2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+  // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the NW waves through LDS
+#define ETD_MERGE_STAGE(off)                                                                                                \
+  {                                                                                                                         \
+    const float m2 = ETD_XCH(mr, off), l2 = ETD_XCH(lr, off);                                                               \
+    const float mn = fmaxf(mr, m2);                                                                                         \
+    float f1 = (mr == -INFINITY) ? 0.f : EXPF(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : EXPF(m2 - mn);                       \
+    ETD_TRANS_SETTLE(f1, f2);                                                                                               \
+    lr = merge_sum(lr, f1, l2, f2);                                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float o2 = ETD_XCH(o[e], off); o[e] = merge_sum(o[e], f1, o2, f2); } \
+    mr = mn;                                                                                                                \
+  }
+#define ETD_MERGE_STAGES() ETD_MERGE_STAGE(8) ETD_MERGE_STAGE(16) ETD_MERGE_STAGE(32)
+  float* dp = a.dbg ? a.dbg + ((long long)(head * a.M + m) * 256 + tid) * 8 : nullptr;
+  if (dp) { dp[0] = lr; dp[1] = mr; dp[2] = o[0]; }
+  ETD_MERGE_STAGES()
+  if (dp) { dp[5] = lr; dp[7] = o[0]; }
+#if ETD_AD_DENSE_LATE == 1
+  if constexpr (DENSE) {
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int it = 0; it < FP; ++it) dwv[it] = ABL_DENSE_LOAD(dwb + it * 8 * 64);
   }
-  // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the NW waves through LDS
-#define ETD_MERGE_STAGES()                                                                                                  \
-  _Pragma("unroll") for (int off = 8; off < 64; off <<= 1) {                                                                \
-    const float m2 = __shfl_xor(mr, off, 64), l2 = __shfl_xor(lr, off, 64);                                                 \
-    const float mn = fmaxf(mr, m2);                                                                                         \
-    const float f1 = (mr == -INFINITY) ? 0.f : EXPF(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : EXPF(m2 - mn);                 \
-    lr = lr * f1 + l2 * f2;                                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 8; ++e) { const float o2 = __shfl_xor(o[e], off, 64); o[e] = o[e] * f1 + o2 * f2; } \
-    mr = mn;                                                                                                                \
-  }
-  ETD_MERGE_STAGES()
+#endif
   if (j == 0) {
     red[wave][c][0] = mr; red[wave][c][1] = lr;
 #pragma unroll
@@ -1210,9 +1281,9 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
         const float m2 = red[w][c][0], l2 = red[w][c][1];
         const float mn = fmaxf(mr, m2);
         const float f1 = (mr == -INFINITY) ? 0.f : EXPF(mr - mn), f2 = (m2 == -INFINITY) ? 0.f : EXPF(m2 - mn);
-        lr = lr * f1 + l2 * f2;
+        lr = merge_sum(lr, f1, l2, f2);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = o[e] * f1 + red[w][c][2 + e] * f2;
+        for (int e = 0; e < 8; ++e) o[e] = merge_sum(o[e], f1, red[w][c][2 + e], f2);
         mr = mn;
       }
       ETD_MERGE_STAGES()
@@ -1235,6 +1306,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     }
   }
 #undef ETD_MERGE_STAGES
+#undef ETD_MERGE_STAGE
   if constexpr (DENSE) {
     // out[n] = sum_d Wd[n][64 head + d] * o[d] for the 512 outputs: 8 lanes share a weight row (128 contiguous bytes), a wave
     // instruction covers 8 consecutive rows = 1 KiB; the wave's fragments are in flight together (requested above, before

@@ -155,6 +155,7 @@ __global__ __launch_bounds__(256, 2) void k_ffn_fused(FfnArgs a) {
 int launch_ffn_fused(const FfnArgs& a, hipStream_t st) {
   if (a.M <= 0 || !a.X || !a.Wf || !a.b1 || !a.b2 || !a.gamma || !a.beta || !a.Y || (((uintptr_t)a.X | (uintptr_t)a.Y | (uintptr_t)a.Wf) & 15))
     ETD_FAIL(ETD_EINVAL, "ffn_fused: bad arguments");
+  ETD_LAUNCH_FILTER("k_ffn_fused");
   ProfScope ps("k_ffn_fused", st, 2.0 * a.M * 256.0 * 512.0 * 2.0, (double)a.M * 256 * 2 * 2 + 512.0 * 256 * 2 * 2);
   hipLaunchKernelGGL(k_ffn_fused, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -437,6 +438,7 @@ int launch_proj256(const ProjArgs& a, hipStream_t st) {
     if (p.kind == PROJ_LN && (!a.R || !a.gamma || !a.beta || a.nblk != 1)) ETD_FAIL(ETD_EINVAL, "proj256: an LN block needs residual + LayerNorm parameters and a launch of its own");
   }
   const char* pname = a.blk[0].kind == PROJ_LN ? "k_proj256_ln" : (a.nblk == 6 ? "k_proj256_kv6" : (a.nblk == 3 ? "k_proj256_qkv" : "k_proj256_row"));
+  ETD_LAUNCH_FILTER(pname);
   ProfScope ps(pname, st, 2.0 * a.M * 256.0 * 256.0 * a.nblk, ((double)a.M * 256 * (1 + a.nblk) + 65536.0 * a.nblk) * 2);
   if (a.blk[0].kind == PROJ_LN) hipLaunchKernelGGL(k_proj256<true>, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
   else hipLaunchKernelGGL(k_proj256<false>, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
@@ -757,6 +759,7 @@ int launch_enc_layer(const EncLayerArgs& a, hipStream_t st) {
   if (a.n_seq <= 0 || !a.X || !a.Wl || !a.bqkv || !a.bo || !a.gamma || !a.beta || !a.b1 || !a.b2 || !a.Y || (((uintptr_t)a.X | (uintptr_t)a.Y | (uintptr_t)a.Wl) & 15))
     ETD_FAIL(ETD_EINVAL, "enc_layer: bad arguments");
   const double tok = (double)a.n_seq * 256;
+  ETD_LAUNCH_FILTER("k_enc_layer");
   ProfScope ps("k_enc_layer", st, 2.0 * tok * 256 * (768 + 256 + 1024) + 4.0 * a.n_seq * 256.0 * 256 * 256, tok * 256 * 2 * 2 + 1048576.0);
   hipLaunchKernelGGL(k_enc_layer, dim3(a.n_seq), dim3(512), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -940,6 +943,7 @@ int launch_post_attn(const PostAttnArgs& a, hipStream_t st) {
   if (a.M <= 0 || !a.AO || !a.R || !a.Wo || !a.bo || !a.gamma || !a.beta || !a.Y || (a.Wffn && (!a.b1 || !a.b2)) ||
       (((uintptr_t)a.AO | (uintptr_t)a.R | (uintptr_t)a.Y | (uintptr_t)a.Wo | (uintptr_t)a.Wffn) & 15))
     ETD_FAIL(ETD_EINVAL, "post_attn: bad arguments");
+  ETD_LAUNCH_FILTER(a.Wffn ? "k_post_attn_ffn" : "k_post_attn");
   ProfScope ps(a.Wffn ? "k_post_attn_ffn" : "k_post_attn", st, 2.0 * a.M * 256.0 * (256.0 + (a.Wffn ? 1024.0 : 0.0)), (double)a.M * 256 * 2 * 3 + 655360.0);
   hipLaunchKernelGGL(k_post_attn, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -1046,6 +1050,7 @@ __global__ __launch_bounds__(256) void k_attn_frag(AttnFragArgs a) {
 int launch_attn_frag(const AttnFragArgs& a, hipStream_t st) {
   if (a.Sq <= 0 || a.Sk <= 0 || a.Sk % 64 || a.n_seq <= 0 || !a.Q || !a.KV || !a.O || (((uintptr_t)a.Q | (uintptr_t)a.KV) & 15) || a.ldq % 8 || a.ldo % 4)
     ETD_FAIL(ETD_EINVAL, "attn_frag: bad arguments (Sk must be a multiple of 64)");
+  ETD_LAUNCH_FILTER("k_attn_frag");
   ProfScope ps("k_attn_frag", st, 1024.0 * a.n_seq * a.Sq * a.Sk, ((double)a.n_seq * (2.0 * a.Sq + 2.0 * a.Sk) * 256) * 2);
   hipLaunchKernelGGL(k_attn_frag, dim3((a.Sq + 127) / 128, a.n_seq * 4), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());

@@ -61,6 +61,7 @@ struct AttnArgs {
   double flops_hint;                                 // algorithmic FLOPs of this launch (profiler only; 0 = derive from Sq/Sk)
 };
 int launch_attn(const AttnArgs& a, hipStream_t st);
+struct EmbedArgs;
 
 // ---- front-end embedding: unfold(65) + conv(1x5) + Linear(244,256) folded to one 65->256 map ----
 struct EmbedArgs {

@@ -552,6 +552,7 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   if (a.Y && (a.ldy % 8 || a.yz % 8 || ((uintptr_t)a.Y & 15))) ETD_FAIL(ETD_EINVAL, "linear: Y rows must be 16-byte aligned (ldy=%d)", a.ldy);
   // row-major blocks [0, vt_block) (or all), then the V^T block as its own launch (orientation is a
   // compile-time property of the MFMA loop)
+  ETD_LAUNCH_FILTER("k_linear");
   ProfScope ps("k_linear", st, 2.0 * a.M * a.N * a.K * nz, ((double)a.M * a.K + (double)a.N * a.K * nz + (double)a.M * a.N * nz) * 2);
   const int nblk = a.N / 256;
   const int n_plain = a.vt_block >= 0 ? a.vt_block : nblk;
@@ -598,6 +599,7 @@ int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
   if (dec_epi == DEPI_GELU && (!a.dec.Yb || a.dec.ldy % 8 || ((uintptr_t)a.dec.Yb & 15))) ETD_FAIL(ETD_EINVAL, "linear_dec: GELU needs 16-byte aligned bf16 rows");
   if (dec_epi == DEPI_RESID && (!a.dec.hin || !a.dec.hout || a.dec.N % 4)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad residual arguments");
   if (dec_epi == DEPI_QKV && a.dec.Qb && (!a.dec.Kp || !a.dec.VTp || a.dec.rot_half != 8 || a.N % 192 || !a.dec.rows.seq)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad QKV arguments");
+  ETD_LAUNCH_FILTER("k_linear_dec");
   ProfScope ps("k_linear_dec", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K) * 2);
   dim3 g(lin_grid_x(a.M, a.N / 256), 1, 1);
   LinArgs b = a; b.nb0 = 0; b.dbg = lin_dbg(); b.nby = a.N / 256;
@@ -615,6 +617,7 @@ int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
 int launch_linear_ln(const LinArgs& a, hipStream_t st) {
   if (a.K % 128 || a.N != 256 || a.M <= 0 || !a.R || !a.gamma || !a.beta || a.ldr % 8 || a.ldy % 8 || (((uintptr_t)a.R | (uintptr_t)a.Y) & 15))
     ETD_FAIL(ETD_EINVAL, "linear_ln: bad args");
+  ETD_LAUNCH_FILTER("k_linear_ln");
   ProfScope ps("k_linear_ln", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K + 2.0 * a.M * a.N) * 2);
   dim3 g(lin_grid_x(a.M, 1), 1, 1);
   LinArgs b = a; b.nb0 = 0; b.dbg = lin_dbg(); b.nby = 1;
@@ -780,6 +783,7 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
   if (a.Sq <= 0 || a.Sk <= 0 || a.n_seq <= 0 || a.Spad % 64 || a.Spad < ((a.Sk + 63) / 64) * 64)
     ETD_FAIL(ETD_EINVAL, "attn: bad shape Sq=%d Sk=%d Spad=%d", a.Sq, a.Sk, a.Spad);
   const int nh = a.n_heads > 0 ? a.n_heads : 4;
+  ETD_LAUNCH_FILTER(a.causal ? "k_attn_causal" : "k_attn");
   ProfScope ps(a.causal ? "k_attn_causal" : "k_attn", st, a.flops_hint > 0 ? a.flops_hint : (a.causal ? 0.5 : 1.0) * 256.0 * nh * a.n_seq * a.Sq * a.Sk, ((double)a.n_seq * (2.0 * a.Sq + 2.0 * a.Sk) * 64 * nh) * 2);
   dim3 g((a.Sq + 127) / 128, a.n_seq * nh);
   hipLaunchKernelGGL(k_attn, g, dim3(256), 0, st, a);
@@ -806,9 +810,6 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
   float* bsm = reinterpret_cast<float*>(smem + 256 * LDE * 2 + (EFB + 80) * ELDX * 4 + 32 * ELDP * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-#if defined(ETD_EMBED_ABL) && ETD_EMBED_ABL == 4      /* diagnostic builds (tools/probe_race.py): 4 = return at once, 5 = return behind the LDS fill */
-  if (a.n_win > 0) { if (tid == 9999) bsm[0] = 1.f; return; }
-#endif
   const int b0 = blockIdx.x * 32;
   const int fl0 = blockIdx.y * EFB;              // first frame of this block inside the chunk
   const int wl = blockIdx.z, w = a.w0 + wl;
@@ -842,9 +843,6 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
     Xsm[tr * ELDX + bin] = v;
   }
   __syncthreads();
-#if defined(ETD_EMBED_ABL) && ETD_EMBED_ABL == 5
-  if (a.n_win > 0) return;
-#endif
 
   for (int fi = 0; fi < EFB / 4; ++fi) {
     const int fl = wave * (EFB / 4) + fi;          // frame inside the block
@@ -881,6 +879,7 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
 
 int launch_embed(const EmbedArgs& a, hipStream_t st) {
   if (a.fc <= 0 || a.n_win <= 0 || a.margin != 32) ETD_FAIL(ETD_EINVAL, "embed: bad args");
+  ETD_LAUNCH_FILTER("k_embed");
   ProfScope ps("k_embed", st, 2.0 * a.n_win * a.fc * 256.0 * 256 * 65, (double)a.n_win * a.fc * 256 * 256 * 2);
   dim3 g(8, (a.fc + EFB - 1) / EFB, a.n_win);
   hipLaunchKernelGGL(k_embed, g, dim3(256), 0, st, a);
@@ -974,6 +973,7 @@ __global__ __launch_bounds__(256) void k_heads(HeadsArgs a) {
 
 int launch_heads(const HeadsArgs& a, hipStream_t st) {
   if (a.M <= 0) ETD_FAIL(ETD_EINVAL, "heads: bad M");
+  ETD_LAUNCH_FILTER("k_heads");
   ProfScope ps("k_heads", st, 2.0 * a.M * 256 * 131, (double)a.M * 256 * 2);
   hipLaunchKernelGGL(k_heads, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -1004,6 +1004,7 @@ __global__ void k_freq2time(const bf16* __restrict__ src, bf16* __restrict__ dst
 }
 int launch_freq2time(const bf16* src, bf16* dst, const float* pos, int nw, int fc, int f0, int nf, int nn, hipStream_t st) {
   const long long total = (long long)nw * fc * nn * 32;
+  ETD_LAUNCH_FILTER("k_freq2time");
   ProfScope ps("k_freq2time", st, 0, (double)total * 32);
   long long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_freq2time, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, pos, nw, fc, f0, nf, nn);

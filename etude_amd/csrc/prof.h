@@ -12,3 +12,8 @@ struct ProfScope {   // the start event lives in the scope object, so concurrent
   ProfScope(const char* n, hipStream_t s, double f = 0, double b = 0) : name(n), st(s), flops(f), bytes(b), start(prof_begin(s)) {}
   ~ProfScope() { if (start) prof_end(name, start, st, flops, bytes); }
 };
+
+// Diagnostic (tools/probe_race.py): ETD_EXT_ONLY=name[,name...] makes every OTHER Extract-stage launcher return without launching
+// (outputs are then garbage; buffer shapes do not change, so what does run stays in bounds).  Unset: nothing is skipped.
+bool launch_skipped(const char* name);
+#define ETD_LAUNCH_FILTER(name) do { if (launch_skipped(name)) return ETD_OK; } while (0)

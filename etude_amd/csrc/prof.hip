@@ -25,6 +25,20 @@ hipEvent_t get_event() {
 }  // namespace
 
 bool prof_enabled() { return g_on; }
+bool launch_skipped(const char* name) {
+  static const char* only = getenv("ETD_EXT_ONLY");
+  if (!only || !*only) return false;
+  if (!strcmp(name, "k_linear_dec") || !strcmp(name, "k_attn_causal")) return false;     // the decoder's batched prefill, never the Extract stage
+  const size_t n = strlen(name);
+  for (const char* p = only; *p;) {
+    const char* q = strchr(p, ',');
+    const size_t len = q ? (size_t)(q - p) : strlen(p);
+    if (len == n && !strncmp(p, name, n)) return false;
+    p += len + (q ? 1 : 0);
+  }
+  return true;
+}
+
 hipEvent_t prof_begin(hipStream_t st) {
   if (!g_on) return nullptr;
   hipEvent_t e;
@@ -209,4 +223,17 @@ extern "C" int etd_debug_kernel_loop(int which, int iters, void* stream) {
   (void)hipStreamSynchronize(st);
   for (void* p : bufs) (void)hipFree(p);
   return rc;
+}
+
+// Diagnostic: an empty kernel with k_embed's footprint (82 KiB of static LDS, 296 registers) launched from INSIDE this library
+__global__ __launch_bounds__(256) void k_dbg_empty(int* sink, int never) {
+  __shared__ int big[81728 / 4];
+  asm volatile("v_mov_b32 v255, 0\n\tv_accvgpr_write_b32 a39, v255" ::: "v255", "a39");
+  if (never) { for (int i = threadIdx.x; i < 81728 / 4; i += 256) big[i] = i; __syncthreads(); sink[threadIdx.x] = big[(threadIdx.x * 7) % (81728 / 4)]; }
+}
+extern "C" int etd_debug_empty_launch(int gx, int gy, int gz, int* sink, void* stream) {
+  if (gx < 1 || gy < 1 || gz < 1) ETD_FAIL(ETD_EINVAL, "empty_launch: bad grid");
+  hipLaunchKernelGGL(k_dbg_empty, dim3(gx, gy, gz), dim3(256), 0, (hipStream_t)stream, sink, 0);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
 }

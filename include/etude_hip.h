@@ -63,6 +63,8 @@ int etd_debug_linear(int M, int N, int K, int iters, void* stream, double* us);
 /* Diagnostic aggressors (tools/probe_race.py): `iters` launches of one kernel type on private random buffers:
    which 0 = k_attn (extractor shape), 1 = k_attn causal ragged (prefill shape), 2 = k_linear with the LayerNorm epilogue, 3 = k_ln_rows. */
 int etd_debug_kernel_loop(int which, int iters, void* stream);
+/* Diagnostic: one launch of an empty kernel with k_embed's footprint (82 KiB static LDS, 296 registers) on the given grid. */
+int etd_debug_empty_launch(int gx, int gy, int gz, int* sink_dev, void* stream);
 
 /* ------------------------------------------------------------------ audio front end */
 typedef struct etd_frontend etd_frontend;
@@ -239,6 +241,18 @@ double etd_decoder_step_bytes(const etd_dec*, int n_streams, int ctx);
 int etd_debug_decoder_checksum(etd_dec*, unsigned long long* out, int cap, void* stream);
 /* Diagnostic: out[(layer * max_streams + slot) * max_ctx + pos] = 32-bit sum over the K and V rows of that position (bf16 handles). */
 int etd_debug_decoder_kv_rowsums(etd_dec*, unsigned* out_host, long long cap, void* stream);
+/* Diagnostic step trace (tools/probe_trace.py): after trace_begin every bf16 decode step records a hash of each row of each kernel's
+ * outputs into a ring of cap_steps records of (49 * layers + 2) * n_active words; trace_read copies the ring and the step count. */
+int etd_debug_decoder_trace_begin(etd_dec*, int cap_steps, void* stream);
+/* layer 0's 12 split-K slabs [12][n_active][512] of the last traced step */
+int etd_debug_decoder_trace_slabs(etd_dec*, float* out_host, long long cap_floats, int n_active, void* stream);
+/* layer 0's queries [n_active][hidden] of the last traced step; one (layer, slot, head)'s K / V cache rows [n_pos][64] as bf16 bit patterns */
+/* per-lane softmax state of layer 0's attention workgroups in the last traced step: [heads][n_active][256][8] =
+ * lr, mr, o[0] after the key loop; lr after merge stages 8, 16, 32; o[0] after stages 8 and 32 */
+int etd_debug_decoder_trace_lanes(etd_dec*, float* out_host, long long cap_floats, int n_active, void* stream);
+int etd_debug_decoder_trace_q(etd_dec*, float* out_host, long long cap_floats, int n_active, void* stream);
+int etd_debug_decoder_peek_kv(etd_dec*, int layer, int slot, int head, int n_pos, unsigned short* k_out, unsigned short* v_out, void* stream);
+int etd_debug_decoder_trace_read(etd_dec*, unsigned* out_host, long long cap_words, int n_active, int* steps_done, void* stream);
 
 /* ---- TinyREMITokenizer glue on either side of the decoder (host code, no GPU) ----
  * etd_tok_create      TinyREMITokenizer.__init__ / _create_measures      etude/data/tokenizer.py:24-41,166-229

@@ -158,6 +158,28 @@ if __name__ == "__main__":
             est.synchronize()
             print("(x) extractor engine ready after %.1f s" % (__import__("time").perf_counter() - t_c0), flush=True)
             ext_ready.set()                      # the engine exists, its first pass is done: only the steady-state loop runs beside the steppers
+            if os.environ.get("PROBE_EXT_IDLE") == "2":     # the extractor exists; what is launched is the prof.hip empty kernel (harmless on its own)
+                sink2 = torch.zeros(1024, dtype=torch.int32, device=dev)
+                nl_ = 0
+                while not stop[0]:
+                    _lib.check(lib.etd_debug_empty_launch(*[int(v) for v in os.environ.get("PROBE_EXT_IDLE_GRID", "8,8,4").split(",")], sink2.data_ptr(), C.c_void_p(est.cuda_stream)), "empty_launch")
+                    est.synchronize(); nl_ += 1
+                print("(x) aggressor: %d empty launches through etd_debug_empty_launch" % nl_, flush=True)
+            if os.environ.get("PROBE_EXT_IDLE"):    # the extractor exists and has run once; nothing is launched while the steppers run
+                while not stop[0]:
+                    __import__("time").sleep(0.01)
+            if os.environ.get("PROBE_EXT_CAPI"):    # the C entry point directly, outputs allocated once: no Python wrapper, no torch allocator
+                outs = ex._alloc(4 * ex.n_frame)
+                argp = [t.data_ptr() for t in outs]
+                stv = C.c_void_p(est.cuda_stream)
+                nl_ = 0
+                while not stop[0]:
+                    _lib.check(lib.etd_transcript_windows(ex._h, xs.data_ptr(), 4, *argp, None, None, None, None, stv), "etd_transcript_windows")
+                    if not os.environ.get("PROBE_EXT_NOSYNC"):
+                        est.synchronize()
+                    nl_ += 1
+                est.synchronize()
+                print("(x) aggressor: %d calls of etd_transcript_windows" % nl_, flush=True)
             while not stop[0]:
                 ex.transcript_windows(xs)
                 est.synchronize()
@@ -264,6 +286,10 @@ if __name__ == "__main__":
                     for _ in range(16):
                         ts = [torch.empty((2048, 88), dtype=torch.float32, device=dev) for _ in range(4)]
                         del ts
+                    hst.synchronize()
+                elif os.environ.get("PROBE_EMPTY_INLIB"):    # the same empty kernel, but compiled into and launched from libetude_hip.so
+                    gx_, gy_, gz_ = [int(x) for x in os.environ["PROBE_EMPTY_INLIB"].split(",")]
+                    _lib.check(lib.etd_debug_empty_launch(gx_, gy_, gz_, sink.data_ptr(), C.c_void_p(hst.cuda_stream)), "empty_launch")
                     hst.synchronize()
                 elif os.environ.get("PROBE_EMPTY"):      # "which,gx,gy,gz": an empty kernel (0 plain, 1 82 KiB static LDS, 2 296 registers) on that grid
                     w_, gx_, gy_, gz_ = [int(x) for x in os.environ["PROBE_EMPTY"].split(",")]
