@@ -197,6 +197,7 @@ static int trace_rows(etd_dec* d, const void* buf, long long row_stride, int wor
   return ETD_OK;
 }
 
+static inline bool fused_pmlp_on() { const char* e = getenv("ETD_FUSED_PMLP"); return !e || atoi(e) > 0; }
 struct LastOnly { int n; const int* idx; DecRows rows; };
 
 int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false,
@@ -214,9 +215,9 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     const bool small = bpipe && !big && (d->I + d->H) % (5 * 64 * 8) == 0;            // decode step: split-K down projection + fused (partial-sum, residual, next LayerNorm) kernel
     const bool catk = small || big;     // attention.dense folded into the down projection: [W2 | Wd] [gelu(..) ; attn] + (b2 + bd), one GEMM and no fp32 round trip of the dense output
     // batched prefill on the fused MLP kernel: it also writes the NEXT layer's LayerNorm rows, so only layer 0 needs the row kernel
-    // OPT-IN (ETD_FUSED_PMLP=1 at create time packs the stream; read per call so that the A/B test can toggle it): measured round 2
+    // ON by default, ETD_FUSED_PMLP=0 turns it off (read at create time for the packed stream, and per call so that the A/B test can toggle it): measured round 2
     // (tools/runs/r2_run47.sh) at 195 us per launch against 166 + 16 us for the launches it replaces, +1.3 % in the job -- csrc/dec_fused.hip
-    const bool fmlp = big && w.mlp_frag && d->H == 512 && d->I == 2048 && getenv("ETD_FUSED_PMLP") && atoi(getenv("ETD_FUSED_PMLP")) > 0;
+    const bool fmlp = big && w.mlp_frag && d->H == 512 && d->I == 2048 && fused_pmlp_on();
     if (bpipe && (!small || (l == 0 && !ln0_done)) && !ln_ready) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
     ln_ready = false;
     // ---- fused QKV + RoPE + KV append
@@ -654,7 +655,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
         w.cat.Wf = pf;
       }
       if ((rc = up_f32(d, &w.cat.b, bc.data(), H))) return fail(rc);
-      if (H == 512 && d->I == 2048 && getenv("ETD_FUSED_PMLP") && atoi(getenv("ETD_FUSED_PMLP")) > 0) {
+      if (H == 512 && d->I == 2048 && fused_pmlp_on()) {
         const float* W1 = Ld.get(p + "mlp.dense_h_to_4h.weight", (int64_t)d->I * H);
         if (!W1) return fail(ETD_EINVAL);
         std::vector<uint16_t> w1((size_t)d->I * H), ws((size_t)DMLP_STREAM_ELEMS);

@@ -285,7 +285,7 @@ def test_row_finish_opt_in_is_bit_identical(dev):
 
 
 def test_fused_prefill_mlp_is_bit_identical_to_the_three_launch_path(dev, monkeypatch):
-    """k_dmlp_fused (csrc/dec_fused.hip, opt-in: ETD_FUSED_PMLP=1) replaces up + GELU -> (down | dense) + residual -> LayerNorm
+    """k_dmlp_fused (csrc/dec_fused.hip, on by default; ETD_FUSED_PMLP=0 turns it off) replaces up + GELU -> (down | dense) + residual -> LayerNorm
     rows of a batched-prefill layer by one launch that multiplies the same operands in the same order: logits of a 600-token
     prompt (every row, all eight layers, the tail rows of a 128-token tile included) and the greedy ids of 48 batched streams
     (last-positions-only final layer) must be the SAME BYTES with the kernel on and off."""
