@@ -145,3 +145,14 @@ def test_decoder_kv_window_requirement_formula():
 def test_library_build_id_matches_the_tree():
     from etude_amd import _lib, build
     assert _lib.lib().etd_build_id().decode() == build.src_hash()
+
+
+def test_traffic_table_is_keyed_by_the_names_the_bench_profiler_uses():
+    """bench.py fills roofline.traffic from profiles/traffic.json[<dominant kernel>]: the committed table must be the aggregated one
+    (tools/summarize_profile.py's traffic_bench.json: template instances merged), not the raw per-instantiation table"""
+    import json
+    from pathlib import Path
+    t = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "traffic.json").read_text())
+    for name in ("k_dstep_attn_down", "k_dstep_qkv_up", "k_enc_layer"):
+        assert isinstance(t.get(name), (int, float)) and t[name] > 0, name
+    assert not any("<" in k for k in t)
