@@ -1100,7 +1100,11 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 // MFMA waves (batched prefill, Extract stage): a (wave, j = 6) slot's softmax denominator vanished, the head's output grew by
 // ~3 %, tokens changed from run to run.  DESIGN.md section 8, "packed FP32 with crossed op_sel"; tools/probe_trace.py;
 // tests/test_isa_guard.py keeps the form out of the library.
+// (-DETD_AD_CROSSED_PK=1 rebuilds the failing form: tools/probe_trace.py and tests/test_gpu_reproducibility.py then fail again)
 __device__ __forceinline__ float merge_sum(float a, float b, float c, float d) {
+#if defined(ETD_AD_CROSSED_PK) && ETD_AD_CROSSED_PK
+  return a * b + c * d;
+#endif
   float t, u, r;
   asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
   asm volatile("v_mul_f32 %0, %1, %2" : "=v"(u) : "v"(c), "v"(d));

@@ -34,7 +34,7 @@ def _jobs(n_jobs, n_bars):
     return jobs
 
 
-def _run(precision, n_engines, n_jobs, n_bars, reps, bar_tokens=24):
+def _run(precision, n_engines, n_jobs, n_bars, reps, bar_tokens=24, stagger_s=0.0):
     from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig, run_engines
     assert torch.cuda.is_available()
     cfg = EtudeDecoderConfig(**synth.decoder_dims())
@@ -44,7 +44,7 @@ def _run(precision, n_engines, n_jobs, n_bars, reps, bar_tokens=24):
     jobs, v = _jobs(n_jobs, n_bars), _vocab()
     outs = []
     for _ in range(reps):
-        out, _stats = run_engines(decs, jobs, v, force_bar_tokens=bar_tokens)()
+        out, _stats = run_engines(decs, jobs, v, force_bar_tokens=bar_tokens, stagger_s=stagger_s)()
         torch.cuda.synchronize()
         outs.append(out)
     for d in reversed(decs):
@@ -65,9 +65,10 @@ def test_concurrent_fp32_engines_are_reproducible():
 
 
 def test_concurrent_bf16_engines_are_reproducible():
-    """4 engines x 27 jobs x 6 bars, three times: every engine's batched prefills overlap the other engines' decode steps (the
-    configuration in which 15-40 of the headline's 216 jobs used to differ between identical runs)."""
-    outs = _run("bf16", 4, 108, 6, 3)
+    """4 engines x 54 jobs x 10 bars of 32 tokens, three times, the engines started 4 ms apart so that every engine's batched prefills
+    (54 prompts, the big-tile path) fall into the other engines' decode steps -- the configuration in which 15-40 of the headline's 216
+    jobs used to differ between identical runs (a build with -DETD_AD_CROSSED_PK=1 fails this test)."""
+    outs = _run("bf16", 4, 216, 10, 3, bar_tokens=32, stagger_s=0.004)
     for k in (1, 2):
         differ = sum(1 for a, b in zip(outs[0], outs[k]) if a != b)
         assert differ == 0, f"concurrent bf16 engines: {differ} of {len(outs[0])} jobs differ between identical runs"
@@ -106,3 +107,13 @@ def test_decode_steps_beside_the_extract_stage_are_reproducible():
         th.join()
     dec.close()
     assert beside[0] == alone and beside[1] == alone
+
+
+def test_tokens_do_not_depend_on_the_number_of_engines():
+    """the same 54 jobs on 1, 2 and 4 engines (different batch compositions, different overlap of prefills and steps): every job's
+    greedy tokens are the same -- a row's arithmetic does not depend on which rows share its launch"""
+    ref = _run("bf16", 1, 54, 4, 1)[0]
+    for n in (2, 4):
+        out = _run("bf16", n, 54, 4, 1)[0]
+        differ = sum(1 for a, b in zip(ref, out) if a != b)
+        assert differ == 0, f"{differ} of {len(ref)} jobs differ between 1 and {n} engines"
