@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Does packed-FP32 arithmetic stay correct beside another stream's MFMA kernels?  A self-checking kernel
 (tools/ubench/pk_check.hip; build: hipcc -O3 --offload-arch=gfx950 -shared -fPIC pk_check.hip -o libpk_check.so) runs
-alone, then beside the Extract stage restricted to ETD_EXT_ONLY's launchers.  usage: probe_pk.py [seconds=3] [n_wg=432] [iters=40]"""
+alone, then beside the Extract stage restricted to ETD_EXT_ONLY's launchers.  usage: probe_pk.py [seconds=3] [n_wg=432] [iters=40]; PROBE_PK_ASYNC=1|2|3 runs ubench/pk_async_check.hip instead
+(crossed packed ops while ds_bpermute (1) / global_load (2) / both (3) results of the same wave are in flight)"""
 import ctypes as C
 import os
 import sys
@@ -22,12 +23,21 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     lib = _lib.lib()
-    xl = C.CDLL(str(Path(__file__).resolve().parent / "ubench" / "libpk_check.so"))
-    xl.pk_check.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    amode = int(os.environ.get("PROBE_PK_ASYNC", "0"))
+    xl = C.CDLL(str(Path(__file__).resolve().parent / "ubench" / ("libpk_async_check.so" if amode else "libpk_check.so")))
+    if not amode:
+        xl.pk_check.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    if amode:
+        xl.pk_async_fill.argtypes = [C.c_void_p, C.c_longlong, C.c_void_p]
+        xl.pk_async_check.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        gsrc = torch.empty(64 << 20, dtype=torch.int32, device=dev)
     errs = torch.zeros(8, dtype=torch.int64, device=dev)
     lanes = torch.zeros(64, dtype=torch.int64, device=dev)
     first = torch.zeros(8, dtype=torch.int32, device=dev)
     vst = torch.cuda.Stream(device=dev)
+    if amode:
+        assert xl.pk_async_fill(gsrc.data_ptr(), gsrc.numel(), vst.cuda_stream) == 0
+        vst.synchronize()
     stop = [False]
     ready = threading.Event()
 
@@ -54,11 +64,18 @@ if __name__ == "__main__":
         t0 = time.perf_counter(); n = 0
         while time.perf_counter() - t0 < secs:
             for _ in range(20):
-                assert xl.pk_check(n_wg, iters, errs.data_ptr(), lanes.data_ptr(), first.data_ptr(), vst.cuda_stream) == 0
+                if amode:
+                    assert xl.pk_async_check(n_wg, iters, amode, gsrc.data_ptr(), gsrc.numel() // 4, errs.data_ptr(), lanes.data_ptr(), first.data_ptr(), vst.cuda_stream) == 0
+                else:
+                    assert xl.pk_check(n_wg, iters, errs.data_ptr(), lanes.data_ptr(), first.data_ptr(), vst.cuda_stream) == 0
             vst.synchronize(); n += 20
         e = errs.cpu().numpy(); f = first.cpu().numpy().astype(np.uint32); ln = lanes.cpu().numpy()
-        print("%s: %d launches of %d workgroups x %d iterations x 8; wrong results: v_pk_mul_f32 %d, v_pk_fma_f32 %d, v_pk_fma_f32 with crossed op_sel %d"
-              % (label, n, n_wg, iters, e[0], e[1], e[2]), flush=True)
+        if amode:
+            print("%s: %d launches of %d workgroups x %d iterations (async mode %d); wrong results: crossed packed sum %d, exchanged values %d, loaded values %d"
+                  % (label, n, n_wg, iters, amode, e[0], e[1], e[2]), flush=True)
+        else:
+            print("%s: %d launches of %d workgroups x %d iterations x 8; wrong results: v_pk_mul_f32 %d, v_pk_fma_f32 %d, v_pk_fma_f32 with crossed op_sel %d"
+                  % (label, n, n_wg, iters, e[0], e[1], e[2]), flush=True)
         if ln.sum():
             print("   wrong results by lane group of 8: %s" % [int(ln[8 * g:8 * g + 8].sum()) for g in range(8)], flush=True)
         if f[7]:
