@@ -25,30 +25,41 @@ __device__ __forceinline__ unsigned mixu(unsigned a, unsigned b, unsigned c, uns
 }
 __device__ __forceinline__ float unitf(unsigned h) { return __uint_as_float(0x3f800000u | (h >> 9)); }
 
-// errs[0]: crossed add wrong, errs[1]: uncrossed add wrong; lanes[64]: crossed errors per lane
+// errs[k]: wrong results of form k (see FORMS in main); lanes[64]: errors of form 0 per lane
+#define PK2(name, text, lo, hi) { f32x2_t r_; asm volatile(text : "=v"(r_) : "v"(a), "v"(b)); float e0_, e1_; lo; hi; \
+                                  if (__float_as_uint(r_[0]) != __float_as_uint(e0_) || __float_as_uint(r_[1]) != __float_as_uint(e1_)) ++name; }
+#define PK3(name, text, lo, hi) { f32x2_t r_; asm volatile(text : "=v"(r_) : "v"(a), "v"(b), "v"(c)); float e0_, e1_; lo; hi; \
+                                  if (__float_as_uint(r_[0]) != __float_as_uint(e0_) || __float_as_uint(r_[1]) != __float_as_uint(e1_)) ++name; }
+#define ADD(d, x, y) asm volatile("v_add_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
+#define MUL(d, x, y) asm volatile("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(x), "v"(y))
+#define FMA(d, x, y, z) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(x), "v"(y), "v"(z))
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_victim(int iters, unsigned long long* errs, unsigned long long* lanes) {
   __shared__ unsigned pad[2432];
   const int tid = threadIdx.x, lane = tid & 63;
   pad[(tid * 9 + iters) & 2047] = tid;
-  unsigned e0 = 0, e1 = 0;
+  unsigned e0 = 0, e1 = 0, e2 = 0, e3 = 0, e4 = 0, e5 = 0, e6 = 0, e7 = 0;
   for (int it = 0; it < iters; ++it) {
     const unsigned h = mixu(blockIdx.x, tid, it, 0);
-    const f32x2_t a = {unitf(h), unitf(h * 3u + 1u)}, b = {unitf(h * 5u + 2u), unitf(h * 7u + 3u)};
-    f32x2_t x, y;
-    asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(x) : "v"(a), "v"(b));
-    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(y) : "v"(a), "v"(b));
-    float x0, x1, y0, y1;
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(x0) : "v"(a[0]), "v"(b[1]));
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(x1) : "v"(a[1]), "v"(b[0]));
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(y0) : "v"(a[0]), "v"(b[0]));
-    asm volatile("v_add_f32 %0, %1, %2" : "=v"(y1) : "v"(a[1]), "v"(b[1]));
-    if (__float_as_uint(x[0]) != __float_as_uint(x0) || __float_as_uint(x[1]) != __float_as_uint(x1)) ++e0;
-    if (__float_as_uint(y[0]) != __float_as_uint(y0) || __float_as_uint(y[1]) != __float_as_uint(y1)) ++e1;
+    const f32x2_t a = {unitf(h), unitf(h * 3u + 1u)}, b = {unitf(h * 5u + 2u), unitf(h * 7u + 3u)}, c = {unitf(h * 11u + 4u), unitf(h * 13u + 5u)};
+    PK2(e0, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]", ADD(e0_, a[0], b[1]), ADD(e1_, a[1], b[0]))
+    PK2(e1, "v_pk_add_f32 %0, %1, %2", ADD(e0_, a[0], b[0]), ADD(e1_, a[1], b[1]))
+    PK2(e2, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1]", ADD(e0_, a[1], b[0]), ADD(e1_, a[0], b[1]))
+    PK2(e3, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]", MUL(e0_, a[0], b[1]), MUL(e1_, a[1], b[0]))
+    PK3(e4, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]", FMA(e0_, a[0], b[0], c[1]), FMA(e1_, a[1], b[1], c[0]))
+    PK3(e5, "v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0]", FMA(e0_, a[0], b[1], c[0]), FMA(e1_, a[1], b[1], c[1]))
+    PK2(e6, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1]", ADD(e0_, a[0], b[1]), ADD(e1_, a[1], b[1]))
+    PK2(e7, "v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]", MUL(e0_, a[0], b[0]), MUL(e1_, a[1], b[0]))
   }
   if (e0) { atomicAdd(errs + 0, (unsigned long long)e0); atomicAdd(lanes + lane, (unsigned long long)e0); }
   if (e1) atomicAdd(errs + 1, (unsigned long long)e1);
+  if (e2) atomicAdd(errs + 2, (unsigned long long)e2);
+  if (e3) atomicAdd(errs + 3, (unsigned long long)e3);
+  if (e4) atomicAdd(errs + 4, (unsigned long long)e4);
+  if (e5) atomicAdd(errs + 5, (unsigned long long)e5);
+  if (e6) atomicAdd(errs + 6, (unsigned long long)e6);
+  if (e7) atomicAdd(errs + 7, (unsigned long long)e7);
   __syncthreads();
-  if (pad[(tid * 5) & 2047] == 0x1234567u) errs[7] = 1;
+  if (pad[(tid * 5) & 2047] == 0x1234567u) errs[8] = 1;
 }
 
 template <int KIND>
@@ -116,12 +127,14 @@ __global__ __launch_bounds__(256, 2) void k_aggr_proj(int iters, const bf16x8_t*
 int main(int argc, char** argv) {
   const double secs = argc > 1 ? atof(argv[1]) : 2.0;
   unsigned long long *errs, *lanes; float* sink; bf16x8_t* gsrc;
-  CK(hipMalloc(&errs, 64)); CK(hipMalloc(&lanes, 512)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&gsrc, (size_t)(1 << 20) * 16));
+  CK(hipMalloc(&errs, 128)); CK(hipMalloc(&lanes, 512)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&gsrc, (size_t)(1 << 20) * 16));
   CK(hipMemset(gsrc, 0x3c, (size_t)(1 << 20) * 16));
   hipStream_t sv, sa; CK(hipStreamCreate(&sv)); CK(hipStreamCreate(&sa));
   const char* names[9] = {"no aggressor", "register-only MFMA loop", "MFMA fed by ds_read_b128 from a 64 KiB LDS ring", "the same + global_load_lds refills", "register-only MFMA, ~250 live registers", "register-only MFMA, 15 accumulators", "MFMA with 14 accumulators fed by ds_read_b128 from a 64 KiB LDS ring",
                           "projection shape: 16 resident token fragments as B, weights from LDS as A, 8 accumulators", "projection shape with the token fragments as the A operand"};
+  const bool all = argc > 2;
   for (int kind = 0; kind < 9; ++kind) {
+    if (!all && kind != 0 && kind != 1 && kind != 7 && kind != 8) continue;
     std::atomic<bool> stop{false};
     std::thread th([&] {
       if (kind == 0) return;
@@ -140,7 +153,7 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(sa));
       }
     });
-    CK(hipMemsetAsync(errs, 0, 64, sv)); CK(hipMemsetAsync(lanes, 0, 512, sv)); CK(hipStreamSynchronize(sv));
+    CK(hipMemsetAsync(errs, 0, 128, sv)); CK(hipMemsetAsync(lanes, 0, 512, sv)); CK(hipStreamSynchronize(sv));
     const auto t0 = std::chrono::steady_clock::now();
     long long n = 0;
     while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
@@ -148,12 +161,16 @@ int main(int argc, char** argv) {
       CK(hipStreamSynchronize(sv)); n += 20;
     }
     stop.store(true); th.join(); CK(hipDeviceSynchronize());
-    unsigned long long he[8], hl[64];
-    CK(hipMemcpy(he, errs, 64, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl, lanes, 512, hipMemcpyDeviceToHost));
+    unsigned long long he[16], hl[64];
+    CK(hipMemcpy(he, errs, 128, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl, lanes, 512, hipMemcpyDeviceToHost));
     unsigned long long g[8] = {0};
     for (int i = 0; i < 64; ++i) g[i >> 3] += hl[i];
-    printf("aggressor %d (%s): %lld victim launches x 432 workgroups x 256 lanes x 40 adds; crossed v_pk_add_f32 wrong %llu, uncrossed wrong %llu; crossed errors by lanes 0-7, 8-15, ...: %llu %llu %llu %llu %llu %llu %llu %llu\n",
-           kind, names[kind], n, he[0], he[1], g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
+    static const char* FORMS[8] = {"add op_sel:[0,1] op_sel_hi:[1,0] (src1 halves swapped)", "add (plain)", "add op_sel:[1,0] op_sel_hi:[0,1] (src0 halves swapped)",
+                                   "mul op_sel:[0,1] op_sel_hi:[1,0]", "fma op_sel:[0,0,1] op_sel_hi:[1,1,0] (src2 halves swapped)", "fma op_sel:[0,1,0] (src1 high broadcast)",
+                                   "add op_sel:[0,1] (src1 high broadcast)", "mul op_sel_hi:[1,0] (src1 low broadcast)"};
+    printf("aggressor %d (%s): %lld victim launches x 432 workgroups x 256 lanes x 40 iterations\n", kind, names[kind], n);
+    for (int k = 0; k < 8; ++k) printf("    v_pk_%-62s wrong %llu\n", FORMS[k], he[k]);
+    printf("    form 0 errors by lanes 0-7, 8-15, ...: %llu %llu %llu %llu %llu %llu %llu %llu\n", g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[7]);
     fflush(stdout);
   }
   return 0;
