@@ -111,7 +111,8 @@ def test_decode_steps_beside_the_extract_stage_are_reproducible():
 
 def test_tokens_do_not_depend_on_the_number_of_engines():
     """the same 54 jobs on 1, 2 and 4 engines (different batch compositions, different overlap of prefills and steps): every job's
-    greedy tokens are the same -- a row's arithmetic does not depend on which rows share its launch"""
+    greedy tokens are the same -- on the big-tile / fused-step paths (batches of 16 jobs and more) a row's arithmetic does not depend on
+    which rows share its launch; smaller batches take other kernel paths with other bf16 roundings (tools/probe_batch_dependence.py)"""
     ref = _run("bf16", 1, 54, 4, 1)[0]
     for n in (2, 4):
         out = _run("bf16", n, 54, 4, 1)[0]
