@@ -1111,14 +1111,20 @@ __device__ __forceinline__ float merge_sum(float a, float b, float c, float d) {
   asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(u));
   return r;
 }
-template <typename KVT, bool DENSE, int NW, bool FIN = false>
+// PAIR (DENSE only; the default of the decode step, ETD_AD_PAIR=0 turns it off): the workgroup holds TWO rows of the same head, NW waves each (threads 0 .. 64 NW - 1
+// row `m`, the rest row `m + 1`, given by the caller with its own `red` / `osh` / `outsh`); every one of the 2 NW waves then applies 512 / (2 NW)
+// rows of the head's dense slice to BOTH rows' outputs, so the slice is read once per pair (half the L2 traffic of the dense phase, one
+// pass of 8 fragments instead of two) -- per row the same operations in the same order: bit-identical.  `dup`: the second row repeats
+// the first (odd M) and stores nothing.
+template <typename KVT, bool DENSE, int NW, bool FIN = false, bool PAIR = false>
 __device__ __forceinline__ void dattn_core(const int m, const int head, float (&red)[NW][8][10], float* osh, float* outsh,
                                            const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
-                                           int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a, const DRowFin* fin = nullptr) {
+                                           int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a, const DRowFin* fin = nullptr,
+                                           const float* osh_other = nullptr, float* outsh_other = nullptr, bool dup = false) {
 #if defined(ETD_AD_UNIFORM) && ETD_AD_UNIFORM
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane >> 3, c = lane & 7;      // (measurement build: the key loop's trip count is then provably wave-uniform)
 #else
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
+  const int tid = PAIR ? (int)(threadIdx.x & (64 * NW - 1)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
 #endif
   SS_DECL(); SS(0);
   constexpr int G2 = 8 * NW;         // offset of a wave's second 8-key group inside an iteration
@@ -1210,7 +1216,9 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   // DENSE: this wave's dense-weight fragments (512 / NW rows = 64 / NW one-KiB fragments; the first 8 of them at most) are
   // requested here -- the key loop's K/V registers are dead, and the merge below (shuffles, LDS, a barrier) covers their round trip
   SS(2);                           // key loop done
-  constexpr int FR = 64 / NW, FP = FR > 8 ? 8 : FR, NPASS = FR / FP;
+  constexpr int FR = PAIR ? 64 / (2 * NW) : 64 / NW, FP = FR > 8 ? 8 : FR, NPASS = FR / FP;
+  const int dwave = PAIR ? (int)(threadIdx.x >> 6) : wave;             // wave index among the waves that share the dense slice
+  constexpr int DROWS = PAIR ? 512 / (2 * NW) : 512 / NW;              // dense rows (output features) per wave
   bf16x8 dwv[DENSE ? FP : 1];
   const bf16* dwb = nullptr;
   // measurement builds: ETD_AD_DENSE_LATE=1 requests the fragments AFTER the intra-wave merge, =2 requests them here but drains them before the merge
@@ -1218,7 +1226,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
 #define ETD_AD_DENSE_LATE 0
 #endif
   if constexpr (DENSE) {
-    dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(wave * (512 / NW) + (lane >> 3)) * 64 + (lane & 7) * 8;
+    dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(dwave * DROWS + (lane >> 3)) * 64 + (lane & 7) * 8;
 #if ETD_AD_DENSE_LATE != 1
 #pragma unroll
     for (int it = 0; it < FP; ++it) dwv[it] = ABL_DENSE_LOAD(dwb + it * 8 * 64);
@@ -1322,6 +1330,21 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     float ov[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) ov[e] = osh[sub * 8 + e];
+    if constexpr (PAIR) {
+      // this wave's 8 fragments (64 output features) against this half's row AND the other half's
+      float ov2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ov2[e] = osh_other[sub * 8 + e];
+#pragma unroll
+      for (int it = 0; it < FP; ++it) {
+        float sacc = 0.f, sacc2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sacc = fmaf(bf2f(dwv[it][e]), ov[e], sacc); sacc2 = fmaf(bf2f(dwv[it][e]), ov2[e], sacc2); }
+        sacc += lane_xor<1>(sacc); sacc += lane_xor<2>(sacc); sacc += lane_xor<4>(sacc);
+        sacc2 += lane_xor<1>(sacc2); sacc2 += lane_xor<2>(sacc2); sacc2 += lane_xor<4>(sacc2);
+        if (sub == 0) { outsh[dwave * DROWS + it * 8 + g8] = sacc; outsh_other[dwave * DROWS + it * 8 + g8] = sacc2; }
+      }
+    } else
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
       if (pass == 1) {
@@ -1376,7 +1399,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
       SS_LANDED(); SS(2); SS_FLUSH(4, 1);
 #endif
     } else {
-      if (tid < 256) {
+      if (tid < 256 && !dup) {
         typedef float f32x2 __attribute__((ext_vector_type(2)));
         const f32x2 o2 = {outsh[2 * tid], outsh[2 * tid + 1]};
         *reinterpret_cast<f32x2*>(a.dense_out + ((long long)head * a.M + m) * 512 + 2 * tid) = o2;
@@ -1411,14 +1434,27 @@ template <> struct AdOcc<4> { static constexpr int lo = ETD_AD_OCC, hi = 8; };
 #ifndef ETD_FIN_OCC
 #define ETD_FIN_OCC 4      // waves per SIMD the row-finish instantiation is built for (128 registers).  Job-level (bench.py, r2_run27.sh): 4 -> 567, 5 -> 552, 6 -> 515-522 audio-s/s; at 7 (72 registers) the key loop spills
 #endif
-template <int NW, bool FIN>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? ETD_FIN_OCC : AdOcc<NW>::lo, AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+template <int NW, bool FIN, bool PAIR = false>      // PAIR (NW = 8 threads-wise): attention workgroups hold two rows of a head, 4 waves each (dattn_core<PAIR>)
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? ETD_FIN_OCC : (PAIR ? ETD_AD_OCC : AdOcc<NW>::lo), AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                                          int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
                                                          DAttnArgs a, DGemmArgs g, DRowFin fin) {
   constexpr int UNITS = NW / 2;
   __shared__ float red[NW][8][10];
-  __shared__ float osh[64];
-  __shared__ __attribute__((aligned(16))) float sh[UNITS * 16 * 64 > 512 ? UNITS * 16 * 64 : 512];      // attention: 512 staged outputs; GEMM: the units' cross-wave sums
+  __shared__ float osh[PAIR ? 128 : 64];
+  __shared__ __attribute__((aligned(16))) float sh[UNITS * 16 * 64 > 512 ? UNITS * 16 * 64 : 512];      // attention: 512 staged outputs (per row); GEMM: the units' cross-wave sums
+  if constexpr (PAIR) {
+    static_assert(!PAIR || (NW == 8 && !FIN), "paired rows: 8 waves, no in-launch row finish");
+    if ((int)blockIdx.x >= p_gemm_wgs) {
+      const int lid = blockIdx.x - p_gemm_wgs, P = (p_M + 1) >> 1, pr = lid % P, half = threadIdx.x >> 8;
+      int m = 2 * pr + half;
+      const bool dup = m >= p_M;
+      m = dup ? 2 * pr : m;
+      float (&redh)[4][8][10] = *reinterpret_cast<float (*)[4][8][10]>(&red[4 * half][0][0]);
+      dattn_core<bf16, true, 4, false, true>(m, lid / P, redh, osh + 64 * half, sh + 512 * half, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a,
+                                             nullptr, osh + 64 * (half ^ 1), sh + 512 * (half ^ 1), dup);
+      return;
+    }
+  }
   if ((int)blockIdx.x >= p_gemm_wgs) {
     const int lid = blockIdx.x - p_gemm_wgs;
     dattn_core<bf16, true, NW, FIN>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a, &fin);
@@ -1524,7 +1560,12 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
   if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 256 ||
       g.M != a.M || !g.Xb || !g.W || !g.Y || g.ldy != 512 || g.N != 512 || g.Npad != 512 || g.k_splits < 1 || g.k_splits * 512 > g.K || (g.K % 8) || a.n_heads * 64 != 512)
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad arguments");
-  const int nw = ad_waves(a.M), units = nw / 2;
+  // two rows of a head per 8-wave attention workgroup, the head's dense slice read once per pair (ETD_AD_PAIR=0: one row per 4-wave workgroup).
+  // Bit-identical results; measured at the end of round 2 (tools/runs/r2_run132.sh, r2_run133.sh): the launch 14.8 -> 13.9 us, one engine's step
+  // 0.1985 -> 0.1894 ms, four engines 9.78 -> 10.03 engine-steps / ms, the job +0.3 % (within its spread)
+  static const bool pair_env = !getenv("ETD_AD_PAIR") || atoi(getenv("ETD_AD_PAIR")) > 0;
+  const bool pair = pair_env && !fin && ad_waves(a.M) == 4;
+  const int nw = pair ? 8 : ad_waves(a.M), units = nw / 2;
   const int RT = (a.M + 31) / 32, FT = g.Npad / 32;
   const int slots = ((FT * g.k_splits + 7) / 8) * RT;               // per XCD
   const int gemm_wgs = ((slots + units - 1) / units) * 8;
@@ -1532,6 +1573,10 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
   const DRowFin f0 = fin ? *fin : DRowFin{};
 #define ETD_AD_LAUNCH(NW_, FIN_) hipLaunchKernelGGL((k_dstep_attn_down<NW_, FIN_>), dim3(gemm_wgs + a.M * a.n_heads), dim3(64 * NW_), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, \
                                               a.identity ? 1 : 0, gemm_wgs, a.M, a, g, f0)
+  if (pair) {
+    hipLaunchKernelGGL((k_dstep_attn_down<8, false, true>), dim3(gemm_wgs + ((a.M + 1) / 2) * a.n_heads), dim3(512), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale,
+                       a.identity ? 1 : 0, gemm_wgs, a.M, a, g, f0);
+  } else
   if (fin) { if (nw == 16) ETD_AD_LAUNCH(16, true); else if (nw == 8) ETD_AD_LAUNCH(8, true); else ETD_AD_LAUNCH(4, true); }
   else if (nw == 16) ETD_AD_LAUNCH(16, false); else if (nw == 8) ETD_AD_LAUNCH(8, false); else ETD_AD_LAUNCH(4, false);
 #undef ETD_AD_LAUNCH
