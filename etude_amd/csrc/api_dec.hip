@@ -71,10 +71,11 @@ struct etd_dec {
   int* pin_stage = nullptr; size_t pin_stage_ints = 0; hipEvent_t pin_stage_evt = nullptr;   // prefill upload; the event = "the last upload has left the buffer"
   int* pin_rb = nullptr;                         // read-back: [done S][n_out S][tokens S * out_cap]
   std::vector<int> host_n_out; bool host_n_out_valid = false;   // n_out as of the last poll; valid until the next step / begin_bars
-  std::map<int, hipGraphExec_t> graphs;          // captured decode step per (n_active, rows_identity): key 2 * n_active + identity
+  std::map<int, hipGraphExec_t> graphs;          // captured decode step per (n_active, paired rows, rows_identity): key 4 * n_active + 2 * pair + identity
   bool rows_identity = false;                    // the step's slot list is 0, 1, ..., n_active - 1
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
   double attn_bytes_hint = 0;
+  bool step_pair = false;                        // this call's decode steps pair the rows of a head in the attention launch (mean context <= 448)
   // weight sharing (etd_decoder_clone): a clone reads the owner's weight buffers and has its own KV cache, workspaces and
   // stream state.  `allocs` of an owner = weights first (n_weight_allocs of them), then its workspaces; a clone's = workspaces only.
   etd_dec* weights_owner = nullptr;              // null: this handle owns its weights
@@ -284,6 +285,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       DAttnArgs at = {};
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = rows; at.M = M; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+      at.pair = d->step_pair ? 1 : 0;
       at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0;
       const int ksd = d->I / 512;
       at.dense_w = (const bf16*)w.dense_hw; at.dense_out = d->Pk + (size_t)ksd * M * d->H;
@@ -852,6 +854,13 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     HIP_TRY(hipMemcpyAsync(d->slots_dev, d->last_slots.data(), (size_t)n_active * 4, hipMemcpyHostToDevice, st));
   }
   d->host_n_out_valid = false;
+  {
+    // two rows of a head per attention workgroup pay at short contexts only (dec_kernels.hip, launch_dstep_attn_down): decided per call from the
+    // contexts the host knows, and part of the captured graph's key
+    double ctx_sum = 0;
+    for (int i = 0; i < n_active; ++i) ctx_sum += d->host_len[slots[i]] + 1;
+    d->step_pair = ctx_sum <= 448.0 * n_active;
+  }
   d->rows_identity = true;
   for (int i = 0; i < n_active; ++i) if (slots[i] != i) { d->rows_identity = false; break; }
   // bf16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
@@ -917,7 +926,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   // a non-default stream and must not contain the profiler's event records.
   const bool use_graph = st != nullptr && !prof_enabled() && !getenv("ETD_NO_GRAPH");
   if (use_graph) {
-    const int gkey = 2 * n_active + (d->rows_identity ? 1 : 0);
+    const int gkey = 4 * n_active + (d->step_pair ? 2 : 0) + (d->rows_identity ? 1 : 0);
     auto it = d->graphs.find(gkey);
     if (it == d->graphs.end()) {
       hipGraph_t g = nullptr;

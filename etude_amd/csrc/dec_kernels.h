@@ -70,6 +70,7 @@ struct DAttnArgs {
   DecRows rows; int M;
   const int* row_sp;             // optional [M][2] = (slot, position) pairs: one scalar load instead of two dependent ones
   int identity;                  // row i uses slot i (host knowledge): the first K/V block is requested before the row metadata arrives
+  int pair;                      // k_dstep_attn_down: two rows of a head per 8-wave workgroup (host decision by mean context, api_dec.hip)
   float* O;                      // [M][hidden]
   bf16* Ob; int ldob;            // optional bf16 copy of O (input of the dense GEMM in the bf16 pipeline), row stride ldob (0 = hidden)
   float scale;

@@ -1560,11 +1560,13 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
   if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 256 ||
       g.M != a.M || !g.Xb || !g.W || !g.Y || g.ldy != 512 || g.N != 512 || g.Npad != 512 || g.k_splits < 1 || g.k_splits * 512 > g.K || (g.K % 8) || a.n_heads * 64 != 512)
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad arguments");
-  // two rows of a head per 8-wave attention workgroup, the head's dense slice read once per pair (ETD_AD_PAIR=0: one row per 4-wave workgroup).
+  // two rows of a head per 8-wave attention workgroup, the head's dense slice read once per pair (ETD_AD_PAIR=0: always one row per 4-wave workgroup).
   // Bit-identical results; measured at the end of round 2 (tools/runs/r2_run132.sh, r2_run133.sh): the launch 14.8 -> 13.9 us, one engine's step
   // 0.1985 -> 0.1894 ms, four engines 9.78 -> 10.03 engine-steps / ms, the job +0.3 % (within its spread)
-  static const bool pair_env = !getenv("ETD_AD_PAIR") || atoi(getenv("ETD_AD_PAIR")) > 0;
-  const bool pair = pair_env && !fin && ad_waves(a.M) == 4;
+  // -- at the contexts of the headline (54 rows x ~340 keys).  At 64 rows x ctx 512-580 and 3.5 k it is 1.5 % SLOWER per step (half as many, longer
+  // workgroups; the dense phase is a small part of a long key loop), so the host asks for it by mean context (DAttnArgs::pair; ETD_AD_PAIR=1 forces it)
+  static const int pair_env = getenv("ETD_AD_PAIR") ? atoi(getenv("ETD_AD_PAIR")) : -1;
+  const bool pair = (pair_env < 0 ? a.pair != 0 : pair_env > 0) && !fin && ad_waves(a.M) == 4;
   const int nw = pair ? 8 : ad_waves(a.M), units = nw / 2;
   const int RT = (a.M + 31) / 32, FT = g.Npad / 32;
   const int slots = ((FT * g.k_splits + 7) / 8) * RT;               // per XCD
