@@ -280,6 +280,17 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
     // acc[t][i]: token (i & 3) + 8 (i >> 2) + 4 h of the wave's 32, feature 32 t + r
     const int seq = m0w / a.S, pos0 = m0w - seq * a.S;
     const bool vec = (a.S % 32 == 0) && (a.Spad % 8 == 0) && (m0w + 32 <= a.M);
+    // sequence length a multiple of 4 but not of 32 (the 88-note self-attention of the frequency decoder): a lane's four tokens 8 q + 4 h + j of a
+    // group q are consecutive positions of ONE sequence, so they leave as one 8-byte store; (sequence, position) of the four groups once per block
+    const bool quad = !vec && (a.S % 4 == 0) && (a.Spad % 4 == 0) && (m0w + 32 <= a.M);
+    long long qoff[4];
+    if (quad) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int mt = m0w + 8 * q + 4 * h, sq = mt / a.S;
+        qoff[q] = (long long)sq * 4 * 64 * a.Spad + (mt - sq * a.S);
+      }
+    }
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
       const int f = 32 * t + r;
@@ -297,8 +308,13 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
           const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
           *reinterpret_cast<u32x4*>(row + pos0 + 16 * p + 8 * h) = o;
         }
+      } else if (quad) {
+        bf16* base = pb.dst + ((long long)(f >> 6) * 64 + (f & 63)) * a.Spad;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<bf16x4*>(base + qoff[q]) = pack4(acc[t][4 * q] + bv, acc[t][4 * q + 1] + bv, acc[t][4 * q + 2] + bv, acc[t][4 * q + 3] + bv);
       } else {
-        // (sequence length not a multiple of 32 -- the 88-note self-attention of the frequency decoder -- or the ragged last tile)
+        // (any other sequence length, or the ragged last tile)
         float vals[16];
 #pragma unroll
         for (int i = 0; i < 16; ++i) vals[i] = acc[t][i] + bv;
