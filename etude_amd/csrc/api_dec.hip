@@ -2,6 +2,8 @@
 // generation state kept on the device, prefill / decode-step launch sequences.
 // Reference: etude/models/etude_decoder.py:148-206 (forward), :291-343 (token loop);
 // etude/utils/model_loader.py:12-60 (checkpoint contract).
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -75,11 +77,14 @@ struct etd_dec {
   bool rows_identity = false;                    // the step's slot list is 0, 1, ..., n_active - 1
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
   double attn_bytes_hint = 0;
-  bool step_pair = false;                        // this call's decode steps pair the rows of a head in the attention launch (mean context <= 448)
+  bool step_pair = false;                        // this call's decode steps pair the rows of a head in the attention launch (etd_decoder_step decides)
   // weight sharing (etd_decoder_clone): a clone reads the owner's weight buffers and has its own KV cache, workspaces and
   // stream state.  `allocs` of an owner = weights first (n_weight_allocs of them), then its workspaces; a clone's = workspaces only.
   etd_dec* weights_owner = nullptr;              // null: this handle owns its weights
   size_t n_weight_allocs = 0;
+  // activity board of the family (lives in the owner): steady-clock time of each engine's last etd_decoder_step call, slot = family_index
+  std::atomic<long long> last_step_ns[16];
+  int family_index = 0, next_family_index = 1;    // owner: 0; clones: 1, 2, ... in creation order (beyond 15: not on the board)
   int n_clones = 0; bool zombie = false;         // owner destroyed while clones are alive: weights freed with the last clone
 
   template <typename T> int alloc(T** p, size_t n, bool zero = false) {
@@ -721,6 +726,8 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
     if (own->zombie) ETD_FAIL(ETD_EINVAL, "decoder_clone: the source handle was destroyed");
     ++own->n_clones;          // taken BEFORE the workspaces are built: the owner cannot free the weights underneath this clone
   }
+  int fam_idx;
+  { std::lock_guard<std::mutex> lk(g_family_mu); fam_idx = own->next_family_index++; }
   auto unref = [own]() {
     bool last;
     { std::lock_guard<std::mutex> lk(g_family_mu); last = --own->n_clones == 0 && own->zombie; }
@@ -737,6 +744,7 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
   d->host_key.resize(d->S);
   for (int i = 0; i < d->S; ++i) d->host_key[i] = (unsigned long long)i;
   d->weights_owner = own;
+  d->family_index = fam_idx;
   const int rc = alloc_workspaces(d);
   if (rc) {
     for (void* p : d->allocs) (void)hipFree(p);
@@ -857,9 +865,31 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   {
     // two rows of a head per attention workgroup pay at short contexts only (dec_kernels.hip, launch_dstep_attn_down): decided per call from the
     // contexts the host knows, and part of the captured graph's key
+    // Measured on MI355X (tools/runs/r2_run137.sh .. r2_run139.sh, tools/bench_engine_overlap.py): with three or more engines sharing the chip
+    // the pair form is 1-4 % faster per step-round from 32 rows up (mean context 256 .. 900), slower below; one or two engines depend on how the
+    // launch's workgroups quantise over the 256 CUs (64 + 8 M one-row workgroups of 1 unit against 32 + 4 M pair workgroups of 2 units: the
+    // busiest CU decides) -- pair at 32-54 and 96 rows (-3 .. -6 % per step), one-row at 60-72 and 128 rows (pair +2 .. +11 %).
     double ctx_sum = 0;
     for (int i = 0; i < n_active; ++i) ctx_sum += d->host_len[slots[i]] + 1;
-    d->step_pair = ctx_sum <= 448.0 * n_active;
+    const double mean_ctx = ctx_sum / n_active;
+    bool pair = n_active >= 32 && mean_ctx >= 192.0 && mean_ctx <= 1024.0;
+    // engines of this weight family that stepped within the last 100 ms (this one included): the proxy for how many chains share the chip
+    int family = 1;
+    {
+      etd_dec* own = d->weights_owner ? d->weights_owner : d;
+      const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+      if (d->family_index < 16) own->last_step_ns[d->family_index].store(now, std::memory_order_relaxed);
+      for (int i = 0; i < 16; ++i) {
+        if (i == d->family_index) continue;
+        const long long t = own->last_step_ns[i].load(std::memory_order_relaxed);
+        if (t != 0 && now - t < 100000000LL) ++family;
+      }
+    }
+    if (pair && family < 3) {
+      const int u1 = (64 + 8 * n_active + 255) / 256, u2 = 2 * ((32 + 4 * n_active + 255) / 256);
+      pair = u2 <= u1;
+    }
+    d->step_pair = pair;
   }
   d->rows_identity = true;
   for (int i = 0; i < n_active; ++i) if (slots[i] != i) { d->rows_identity = false; break; }

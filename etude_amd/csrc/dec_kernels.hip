@@ -1563,8 +1563,8 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
   // two rows of a head per 8-wave attention workgroup, the head's dense slice read once per pair (ETD_AD_PAIR=0: always one row per 4-wave workgroup).
   // Bit-identical results; measured at the end of round 2 (tools/runs/r2_run132.sh, r2_run133.sh): the launch 14.8 -> 13.9 us, one engine's step
   // 0.1985 -> 0.1894 ms, four engines 9.78 -> 10.03 engine-steps / ms, the job +0.3 % (within its spread)
-  // -- at the contexts of the headline (54 rows x ~340 keys).  At 64 rows x ctx 512-580 and 3.5 k it is 1.5 % SLOWER per step (half as many, longer
-  // workgroups; the dense phase is a small part of a long key loop), so the host asks for it by mean context (DAttnArgs::pair; ETD_AD_PAIR=1 forces it)
+  // -- at the headline's shape (54 rows x ~340 keys).  Whether it pays depends on rows, context and on how many engines share the chip: the host decides
+  // per call (DAttnArgs::pair, api_dec.hip etd_decoder_step); ETD_AD_PAIR=0 / 1 force either form
   static const int pair_env = getenv("ETD_AD_PAIR") ? atoi(getenv("ETD_AD_PAIR")) : -1;
   const bool pair = (pair_env < 0 ? a.pair != 0 : pair_env > 0) && !fin && ad_waves(a.M) == 4;
   const int nw = pair ? 8 : ad_waves(a.M), units = nw / 2;
