@@ -764,6 +764,7 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
   d->graphs.clear();
   if (d->trace) { (void)hipFree(d->trace); (void)hipFree(d->trace_step); (void)hipFree(d->trace_pk); (void)hipFree(d->trace_q); d->trace = nullptr; d->trace_step = nullptr; d->trace_pk = nullptr; d->trace_q = nullptr; }
+  if (d->trace_dbg) { (void)hipFree(d->trace_dbg); d->trace_dbg = nullptr; }
   if (d->pin_stage) { (void)hipHostFree(d->pin_stage); d->pin_stage = nullptr; }
   if (d->pin_rb) { (void)hipHostFree(d->pin_rb); d->pin_rb = nullptr; }
   if (d->pin_stage_evt) { (void)hipEventDestroy(d->pin_stage_evt); d->pin_stage_evt = nullptr; }
