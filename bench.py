@@ -4,28 +4,37 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One STEP = each rank's share of BASELINE.json configs[4] (the configuration the metric is quoted on: "3-min clip
-batch", 64 clips sharded 8 per GPU, attribute grid {0,1,2}^3).  Per rank: --clips (8) 3-minute 44.1 kHz stereo
-clips, already resident in HBM, go through the whole Extract hot path (channel mean, resample, STFT/log-mel,
-hFT-Transformer over 22 windows, D2H of the frame outputs, note picking -> the note list extract() writes); then
-the Decode hot path generates a cover for each (clip, attribute tuple) job -- --attr-grid (27) tuples per clip,
-~92 condition bars each -- as concurrent device streams (continuous batching on four decoder engines), greedy.
-Ranks work on different clips (seed 1234 + clip index) with no data-path collective: weak scaling; at N=8 the
-job is exactly configs[4].  `--clips 1 --attr-grid 1` is configs[1] (one clip, attributes 1/1/1).
+One STEP = ONE PASS OVER THE BATCH north_star NAMES: 64 x 3-minute 44.1 kHz stereo clips (BASELINE.json configs[4]), sharded 64 / N
+per rank -- at N = 8 exactly configs[4], at N = 1 the whole batch on one MI355X ("strong" scaling: the batch is fixed).  Per rank the
+step is infer.py's stage sequence for its clips (etude_amd/pipeline.py):
 
-value = audio seconds taken through BOTH stages per wall second, whole job (all ranks).  The per-stage
-numbers the metric names are reported next to it (extract_audio_s_per_s, decoder_tokens_per_s), plus
-  roofline      the dominant kernel of the timed region (HIP-event timed inside the library)
-  cpu_baseline  the CPU oracle timed on this node's host cores on a bounded sample (rank 0, N=1 only)
-  extras        extractor-only (configs[2]) and 128-stream decoder (configs[3]) measurements taken OUTSIDE the
-                timed region, each with its own roofline fraction.
-Weights are seeded synthetic tensors of the reference's architecture (no checkpoints / network); the
-condition bars are the synthetic ~8-notes/bar song of SURVEY.md 8(d) config 1 because the Structuralize
-stage and the tokenizer are outside the hot path.
+    per clip   wav (already resident in HBM) -> channel mean, resample, STFT / log-mel, hFT-Transformer over 22 windows, device note
+               picking -> the note list extract() writes; volume contour (analyze_volume); TinyREMITokenizer on the synthetic
+               tempo.json (stage 2, beat detection, is out of scope) -> vocab ids -> condition bars
+    per job    (clip, attribute tuple) for the 27 tuples {0,1,2}^3, overlap bin 2: greedy generate() over the clip's OWN ~92 condition
+               bars -- all jobs as concurrent device streams, continuous batching on four decoder engines -- then decode_to_notes with
+               the clip's volume map (MIDI file writing is left out: file I/O)
+    ranks work on different clips with no data-path collective; ONE final gather of the token ids (RCCL).
+
+--bar-tokens (48) tokens are generated per bar and Bar_EOS does not end a bar: seeded synthetic weights carry no musical EOS statistics,
+so bar lengths would otherwise be an artefact of the seed (the reference's own chain ends in degenerate 400-token bars on these
+weights).  Everything else -- prompt assembly, 4-pair history, truncation to the last 512 prompt tokens, KV reset per bar -- is
+generate()'s.  value = audio seconds taken through the WHOLE chain per wall second, all ranks.  Next to it:
+  extract_audio_s_per_s / decoder_tokens_per_s   the per-stage rates the metric names
+  roofline      the dominant kernel (k_dstep_attn_down) in the TIMED configuration: device-side span of every launch of one extra
+                decode stage with all engines running (etd_decoder_stamp), algorithmic bytes from the library's exact counters;
+                decode_stage = all decode-step bytes of the timed steps / the decode stage's wall time
+  cpu_baseline  the CPU oracle on this node's host cores, bounded sample (rank 0, N = 1 only)
+  extras        configs[2] (extractor only), configs[1] (one clip), configs[3] (128 streams at ctx 512 and 3.5 k), outside the timed region
+Harness budget: the driver runs `--steps 20 --warmup 5` under a wall-clock limit.  The first warm-up step is always a full step; if W + K
+full steps do not fit ETD_BENCH_BUDGET_S (default 480 s) the remaining warm-up steps run 4 bars per job (same launches, same widths:
+everything is allocated, captured and cached by then), and if K full steps alone do not fit, the batch shrinks to 8 clips per rank --
+both are written into config.workload / config.warmup_step.  The K timed steps are always full steps of the stated batch.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -39,19 +48,62 @@ from pathlib import Path
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
+T_START = time.perf_counter()
 
 
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
-        print(*a, file=sys.stderr, flush=True)
+        print(f"[bench {time.perf_counter() - T_START:7.1f}s]", *a, file=sys.stderr, flush=True)
+
+
+def count_gpus_without_hip() -> int:
+    """GPUs of this node as the kernel driver lists them (KFD topology: nodes with SIMDs), WITHOUT initialising HIP: the launcher
+    process must never touch the GPU (a process that has cannot start other programs on this pool, and its children inherit nothing
+    useful from it).  Honours ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when they list indices."""
+    n = 0
+    base = Path("/sys/class/kfd/kfd/topology/nodes")
+    if base.is_dir():
+        for nd in base.iterdir():
+            try:
+                props = dict(l.split(None, 1) for l in (nd / "properties").read_text().splitlines() if " " in l)
+                if int(props.get("simd_count", "0")) > 0:
+                    n += 1
+            except Exception:
+                pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""])) if n else len([x for x in v.split(",") if x.strip() != ""])
+    return n
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: run N ranks of this script under torch.distributed.run, one per GPU, over
+    RCCL on 127.0.0.1.  The parent never touches the GPU (GPUs are counted from the KFD topology in sysfs); the ranks are FRESH child
+    processes, rank 0's ONE JSON line is relayed and their exit status becomes ours.  Fails loudly -- exit 3, no JSON line -- when the
+    node has fewer than N GPUs."""
+    import socket
+    import subprocess
+    have = count_gpus_without_hip()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible on this node; not reporting a {n}-GPU number", file=sys.stderr)
+        return 3
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("ETD_FORCE_SPAWN", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    print("bench.py: starting " + " ".join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
 
 
 def make_vocab():
@@ -65,9 +117,12 @@ def make_vocab():
     return v
 
 
-def cpu_baseline(seconds_budget: float = 25.0, clip_seconds: float = 180.0, windows_per_clip: int = 22, attr_tuples: int = 27, bars_per_job: int = 92,
+def cpu_baseline(bars, seconds_budget: float = 25.0, clip_seconds: float = 180.0, windows_per_clip: int = 22, attr_tuples: int = 27, bars_per_job: int = 92,
                  bar_tokens: int = 48):
-    """The CPU oracle (a restatement of the reference, pinned by golden vectors) on this node's host cores."""
+    """The CPU oracle (a restatement of the reference, pinned by golden vectors) on this node's host cores, on a bounded sample of
+    the SAME workload: 2 extractor windows; the first bars of one clip's own condition bars through the oracle's generate loop
+    (prompt pass + `bar_tokens` forced tokens per bar).  `bars`: that clip's condition bars (lists of ids)."""
+    import torch
     from etude_amd import synth
     from oracle import hft, neox
     avail = os.cpu_count() or 1
@@ -89,53 +144,68 @@ def cpu_baseline(seconds_budget: float = 25.0, clip_seconds: float = 180.0, wind
     tsd = {k: torch.from_numpy(v) for k, v in synth.decoder_state_dict(1, {}).items()}
     dthreads = min(avail, 8)        # batch-1 token loop: small ops, more threads only add sync cost
     torch.set_num_threads(dthreads)
-    bars = synth.song_bars(seed=1234, n_bars=2)
+    # bars 0..5 of the clip: bar 5 is the first with a full 4-pair history (a steady-state prompt, truncated to 512 + Bar_BOS like
+    # every later bar); the sample's LAST bar is timed on its own and stands for the steady state
+    nb = min(6, len(bars))
     t0 = time.time()
-    # synthetic weights reach Bar_EOS after ~7 tokens; id 5 (Bar_EOS) is pushed out of reach so that both bars run the full 24
-    # tokens, like the GPU workload (Bar_EOS suppressed)
-    tsd = dict(tsd); tsd["lm_head.weight"] = tsd["lm_head.weight"].clone(); tsd["lm_head.weight"][5] = 0
-    out = neox.generate_ids(tsd, neox.NeoxDims(), 4, 5, bars, [synth.attrs()] * 2, max_bar_token_limit=24)
-    t_dec = time.time() - t0
-    ntok = sum(len(b) - 1 for b in out)
-    # the headline's unit: audio seconds taken through BOTH stages (extract once, decode for every attribute tuple) per wall second.
-    # Extrapolated from the bounded sample: extract = windows_per_clip x (time per window); decode = tuples x bars x (time per bar of
-    # bar_tokens tokens, prompt pass included).
+    out = neox.generate_ids(tsd, neox.NeoxDims(), 4, 5, bars[: nb - 1], [synth.attrs()] * (nb - 1), max_bar_token_limit=512, force_bar_tokens=bar_tokens)
+    t_ramp = time.time() - t0
+    # the steady-state bar: history = the four bars just generated
+    hist_x, hist_y = bars[nb - 5: nb - 1], out[nb - 5: nb - 1]
+    user_keys = sorted(synth.attrs().keys())
+    history = [(xb, yb, synth.attrs()) for xb, yb in zip(hist_x, hist_y)]
+    toks, cls, al = neox.build_bar_prompt(history, bars[nb - 1], synth.attrs(), user_keys, 4, 5, neox.NeoxDims(), 512, 0.5)
+    t0 = time.time()
+    ids_t, cls_t = torch.tensor([toks]), torch.tensor([cls])
+    at_t = {neox.ATTR_KEY_MAP[k]: torch.tensor([al[k]]) for k in user_keys}
+    kv = None
+    ntok = 0
+    with torch.no_grad():
+        for _ in range(bar_tokens):
+            logits, kv = neox.forward_logits(tsd, neox.NeoxDims(), ids_t, cls_t, at_t, kv)
+            nxt = int(torch.argmax(logits[:, -1, :], dim=-1).item())
+            ntok += 1
+            ids_t, cls_t = torch.tensor([[nxt]]), torch.tensor([[2]])
+            at_t = {neox.ATTR_KEY_MAP[k]: torch.tensor([[synth.attrs()[k]]]) for k in user_keys}
+    t_bar = time.time() - t0
+    assert ntok == bar_tokens and all(len(b) == bar_tokens + 1 for b in out), "cpu_baseline: the sample bars must run the full forced length"
+    # the headline's unit: audio seconds taken through BOTH stages (extract once, decode for every attribute tuple) per wall second,
+    # extrapolated from the bounded sample: extract = windows_per_clip x (time per window); decode = tuples x bars x (time of a steady-state bar)
     ext_s_per_clip = (t_ext / nwin) * windows_per_clip
-    dec_s_per_clip = attr_tuples * bars_per_job * (t_dec / 2.0) * (bar_tokens / 24.0)
+    dec_s_per_clip = attr_tuples * bars_per_job * t_bar
     return {"value": round(clip_seconds / (ext_s_per_clip + dec_s_per_clip), 4),
             "unit": "audio-s/s (each clip extracted and decoded for every attribute tuple; extrapolated from the sample)", "cores": cores, "kind": "port",
             "sample": f"oracle hFT forward on {nwin} window(s) of 512 frames (8.192 s audio each) in {t_ext:.1f}s on {cores} threads; "
-                      f"oracle greedy generate on 2 bars of 24 tokens ({ntok} tokens) in {t_dec:.1f}s on {dthreads} threads",
+                      f"oracle generate on one clip's own condition bars: {nb - 1} ramp-up bars in {t_ramp:.1f}s, then ONE steady-state bar "
+                      f"(prompt of {len(toks)} tokens + {bar_tokens} forced tokens) in {t_bar:.1f}s on {dthreads} threads",
             "extract_audio_s_per_s": round(nwin * 8.192 / t_ext, 4),
-            "decoder_tokens_per_s": round(ntok / t_dec, 2), "decoder_cores": dthreads}
+            "decoder_tokens_per_s": round(bar_tokens / t_bar, 2), "decoder_cores": dthreads}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=180.0, help="clip length")
-    ap.add_argument("--clips", type=int, default=8, help="clips per rank")
+    ap.add_argument("--batch-clips", type=int, default=64, help="clips in the batch (all ranks together); each rank takes batch / N")
+    ap.add_argument("--clips", type=int, default=0, help="clips per rank (overrides --batch-clips / N)")
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
-    ap.add_argument("--streams", type=int, default=256, help="concurrent decoder streams (capped at the number of jobs)")
     ap.add_argument("--ext-engines", type=int, default=int(os.environ.get("ETD_EXT_ENGINES", "2")),
                     help="extractor instances that transcribe different clips at the same time (own stream + host thread each)")
     ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "4")),
-                    help="independent decoder engines (own HIP stream + KV cache each) driven from host threads: the short dependent kernels of one engine's decode step overlap the other's")
-    ap.add_argument("--bars", type=int, default=92)
-    ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS suppressed)")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="overlap the stages across clips (jobs of clip c are admitted when its extraction is done) instead of running them back to back; "
-                         "measured 4 %% slower on one GPU: both stages are GPU-bound, the overlap only adds contention and a ragged ramp-up")
+                    help="independent decoder engines (own HIP stream + KV cache each) driven from host threads")
+    ap.add_argument("--max-streams", type=int, default=512, help="streams per engine (the fused decode step takes up to 512 rows)")
+    ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS does not end a bar)")
+    ap.add_argument("--synthetic-bars", action="store_true", help="rounds 1-2 workload: ~8-notes/bar synthetic condition bars instead of the clip's own (A/B only)")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "480")))
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stamp", action="store_true", help="skip the stamped decode stage (roofline then comes from the serial event pass)")
     args = ap.parse_args()
 
-    # ---- N > 1 without a launcher: start the N ranks ourselves.  Nothing in this process has touched the GPU yet
-    # (torch.cuda.device_count() does not initialise HIP), the ranks are fresh child processes of torch.distributed.run, their
-    # stdout (rank 0's ONE JSON line) is relayed and their exit status becomes ours.
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # ---- N > 1 without a launcher: start the N ranks ourselves, before anything in this process touches the GPU
+    if (args.gpus > 1 or os.environ.get("ETD_FORCE_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,6 +213,9 @@ def main():
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to report a mislabelled number", file=sys.stderr)
         sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
     if torch.cuda.device_count() < max(1, min(world, local + 1)):
         print(f"bench.py: rank {rank} needs GPU {local} but only {torch.cuda.device_count()} device(s) are visible", file=sys.stderr)
         sys.exit(3)
@@ -154,7 +227,8 @@ def main():
     os.dup2(2, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("ETD_FORCE_DIST") == "1"      # ETD_FORCE_DIST: exercise the RCCL path on one GPU
+    launched = "WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ
+    use_dist = world > 1 or launched or os.environ.get("ETD_FORCE_DIST") == "1"      # a launcher-started single rank exercises the RCCL path too
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
@@ -164,206 +238,251 @@ def main():
 
     from etude_amd import _lib, parallel, synth
     from etude_amd.config import ExtractorConfig
-    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig, PackedBars
     from etude_amd.extractor import AMTAPC_Extractor
+    from etude_amd.pipeline import ClipBatchPipeline, ClipConditions, attr_grid, synthetic_tempo
 
-    cfg = ExtractorConfig()
-    ex = AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=int(os.environ.get("ETD_WB", "4")))
-    exs = [ex] + [AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=int(os.environ.get("ETD_WB", "4"))) for _ in range(max(1, args.ext_engines) - 1)]
-    ex_streams = [torch.cuda.Stream(device=dev) for _ in exs]
-    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
-    n_jobs = args.clips * args.attr_grid
-    n_eng = max(1, min(args.engines, n_jobs))
-    per_eng = (min(args.streams, n_jobs) + n_eng - 1) // n_eng
-    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng)]
-    decs += [decs[0].clone() for _ in range(n_eng - 1)]            # engines share one weight set (own KV caches and state)
-    vocab = make_vocab()
-    clip_ids = [rank * args.clips + c for c in range(args.clips)]                      # global clip index = rank-major shard
-    base = synth.clip_audio(seed=1234, seconds=args.seconds)
-    wavs = []
-    for ci in clip_ids:                                                                 # distinct clips, resident in HBM
-        rng = np.random.default_rng(1234 + ci)
-        w = np.roll(base, int(rng.integers(0, base.shape[1])), axis=1) * np.float32(rng.uniform(0.6, 1.0))
-        wavs.append(torch.from_numpy(np.ascontiguousarray(w)).to(dev))
-    if args.attr_grid == 1:
-        grid = [(1, 1, 1)]
+    if args.clips > 0:
+        clips = args.clips
     else:
-        grid = [(p, r, s_) for p in range(3) for r in range(3) for s_ in range(3)][: args.attr_grid]
-    jobs = []
-    for ci in clip_ids:
-        bars = synth.song_bars(seed=1234 + ci, n_bars=args.bars)
-        for (p, r, s_) in grid:
-            jobs.append((bars, [synth.attrs(p, r, s_, 2)] * len(bars)))
-    inf = cfg.infer
+        if args.batch_clips % world:
+            print(f"bench.py: a batch of {args.batch_clips} clips does not split evenly over {world} ranks", file=sys.stderr)
+            sys.exit(2)
+        clips = args.batch_clips // world
+    cfg = ExtractorConfig()
+    wb = int(os.environ.get("ETD_WB", "4"))
+    exs = [AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=wb) for _ in range(max(1, args.ext_engines))]
+    dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+    grid = attr_grid(args.attr_grid)
+    vocab = make_vocab()
 
-    # the extractor stays on torch's default stream: engines + default must fit the runtime's hardware queues (4 unless
-    # GPU_MAX_HW_QUEUES says otherwise) or streams start sharing a queue and serialise against each other
-    ext_stream = torch.cuda.Stream(device=dev) if os.environ.get("ETD_EXT_STREAM") == "1" else torch.cuda.default_stream(dev)
-    job_clip = [k // len(grid) for k in range(n_jobs)]              # job -> local clip whose stages must have finished
+    def build_engines(n_clips):
+        n_jobs = n_clips * len(grid)
+        n_eng = max(1, min(args.engines, n_jobs))
+        per_eng = min(args.max_streams, (n_jobs + n_eng - 1) // n_eng)
+        decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng)]
+        decs += [decs[0].clone() for _ in range(n_eng - 1)]            # engines share one weight set (own KV caches and state)
+        return decs, n_jobs, per_eng
 
-    def step(profiling=False):
-        """One pass over this rank's clips: extract every clip (wav -> notes on the host), then decode all (clip, attribute
-        tuple) jobs on the engines.  With --pipeline the stages overlap across clips instead (infer.py:82-198 order kept per
-        clip: the engines admit the jobs of clip c once the extractor, on the main thread, has delivered clip c)."""
+    def make_wavs(n_clips):
+        base = synth.clip_audio(seed=1234, seconds=args.seconds)
+        wavs = []
+        for ci in [rank * n_clips + c for c in range(n_clips)]:          # global clip index = rank-major shard; distinct clips, resident in HBM
+            rng = np.random.default_rng(1234 + ci)
+            w = np.roll(base, int(rng.integers(0, base.shape[1])), axis=1) * np.float32(rng.uniform(0.6, 1.0))
+            wavs.append(torch.from_numpy(np.ascontiguousarray(w)).to(dev))
+        return wavs
+
+    decs, n_jobs, per_eng = build_engines(clips)
+    wavs = make_wavs(clips)
+    pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+    log(f"setup done: {clips} clip(s) on this rank, {n_jobs} decode jobs on {len(decs)} engine(s) x {per_eng} streams")
+
+    def synthetic_conditions(conds):
+        """rounds 1-2 workload (A/B): replace each clip's own bars by the synthetic ~8-notes/bar song"""
+        out = []
+        for c, cd in enumerate(conds):
+            out.append(ClipConditions(cd.notes, cd.volume, PackedBars.from_lists(synth.song_bars(seed=1234 + rank * clips + c, n_bars=92)), cd.tokenizer))
+        return out
+
+    state = {}
+
+    def step(max_bars=0):
+        """One pass over this rank's clips.  Returns (t_extract, t_decode, t_notes, tokens)."""
         t0 = time.perf_counter()
-        ready = np.zeros(len(wavs), np.int32)
-        serial = (not args.pipeline) or profiling
-        if serial:
-            ready[:] = 1
-        n_notes = 0
-        bg = None if serial else decode_jobs_async(decs, jobs, vocab, args.bar_tokens, (ready, job_clip))
-        try:
-            if len(exs) > 1 and not profiling:
-                # several extractor instances, one host thread and stream each, clips dealt round-robin
-                import threading
-                cnt = [0] * len(exs); errs = []
-
-                def run_ex(i):
-                    try:
-                        torch.cuda.set_device(dev)
-                        with torch.cuda.stream(ex_streams[i]):
-                            for c in range(i, len(wavs), len(exs)):
-                                cnt[i] += len(exs[i].extract_notes(wavs[c], 44100, inf.min_duration))
-                                ready[c] = 1
-                        ex_streams[i].synchronize()
-                    except Exception as e:      # noqa: BLE001
-                        errs.append(e)
-                th = [threading.Thread(target=run_ex, args=(i,)) for i in range(len(exs))]
-                for t in th:
-                    t.start()
-                for t in th:
-                    t.join()
-                if errs:
-                    raise errs[0]
-                n_notes += sum(cnt)
-            else:
-                with torch.cuda.stream(ext_stream):
-                    for c, wav in enumerate(wavs):
-                        notes = ex.extract_notes(wav, 44100, inf.min_duration)      # device wav -> the note list extract() writes (host)
-                        n_notes += len(notes)
-                        ready[c] = 1
-                ext_stream.synchronize()
-        finally:
-            ready[:] = 1                                                         # never leave a scheduler waiting
+        conds = pipe.extract_stage(wavs)
+        if args.synthetic_bars:
+            conds = synthetic_conditions(conds)
         t1 = time.perf_counter()
-        if bg is None:
-            bg = decode_jobs_async(decs, jobs, vocab, args.bar_tokens, (ready, job_clip), one_at_a_time=profiling)
-        out, ntok = bg()
+        results, stats = pipe.decode_stage(conds, max_bars=max_bars)
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
-        return t1 - t0, (t2 - t1) if serial else (t2 - t0), ntok, n_notes / len(wavs), out
+        notes = pipe.notes_stage(conds, results)
+        t3 = time.perf_counter()
+        state.update(conds=conds, results=results, notes=notes)
+        return t1 - t0, t2 - t1, t3 - t2, sum(s["tokens"] for s in stats)
 
-    for _ in range(args.warmup):
-        step()
+    def agree(*vals):
+        """the same decision on every rank: MAX over ranks"""
+        if not use_dist:
+            return list(vals)
+        t = torch.tensor(list(vals), dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
+    # ---- warm-up, with the harness budget in view (module docstring)
+    warm_mode = "full step"
+    shrunk_from = None
+    batch64 = None
+    OVERHEAD_S = 75.0            # stamped decode stage + short event pass + extras + CPU baseline + teardown, measured ~60 s
+    if args.warmup > 0:
+        tw = time.perf_counter()
+        a, b, c_, ntok1 = step()
+        t_first, since = agree(time.perf_counter() - tw, time.perf_counter() - T_START)
+        log(f"first warm-up step: {t_first:.2f}s (extract {a:.2f} decode {b:.2f} notes {c_:.2f})")
+        rest = args.warmup - 1
+        if since + (rest + args.steps) * t_first + OVERHEAD_S > args.budget_s:
+            if since + args.steps * t_first + rest * (0.06 * t_first + 0.5) + OVERHEAD_S <= args.budget_s:
+                warm_mode = "first warm-up step full, the others 4 bars per job (W + K full steps exceed the harness budget)"
+                for _ in range(rest):
+                    step(max_bars=4)
+                rest = 0
+            elif clips > 8 and args.clips == 0:
+                # K full steps of this batch do not fit: keep the measured full step as extras.batch64 and time an 8-clip share per rank
+                batch64 = {"workload": f"the {clips}-clip share of the 64-clip batch on this rank, ONE full step (the first warm-up step)", "s_per_step": round(t_first, 3),
+                           "audio_s_per_s": round(args.seconds * clips * world / t_first, 2), "decode_s": round(b, 3), "extract_s": round(a, 3),
+                           "decoder_tokens_per_s": round(ntok1 / b, 1)}
+                shrunk_from = clips
+                log(f"{args.steps} steps of {t_first:.1f}s do not fit the {args.budget_s:.0f}s budget: timing 8 clips per rank instead")
+                for d in reversed(decs):
+                    d.close()
+                pipe.close()
+                del wavs[8:]
+                clips = 8
+                decs, n_jobs, per_eng = build_engines(clips)
+                pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+                step()
+                rest = max(0, rest - 1)
+        for _ in range(rest):
+            step()
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    for d in decs:
+        d.stats_reset()
     barrier()
     t0 = time.perf_counter()
-    t_ext = t_dec = 0.0
-    n_tok = n_notes = 0
-    for _ in range(args.steps):
-        a, b, c, d, out = step()
-        t_ext += a; t_dec += b; n_tok += c; n_notes = d
-    gathered_jobs = len(out)
+    t_ext = t_dec = t_notes = 0.0
+    n_tok = 0
+    for i in range(args.steps):
+        a, b, c_, d_ = step()
+        t_ext += a; t_dec += b; t_notes += c_; n_tok += d_
+        if i == 0:
+            log(f"timed step 1: {a + b + c_:.2f}s (extract {a:.2f} decode {b:.2f} notes {c_:.2f})")
+    results = state["results"]
+    gathered_jobs = len(results)
     # digest of every token this rank generated in the last timed step (job order): two builds / switches whose kernels must be
     # equivalent print the same value under the real four-engine load
-    import hashlib
-    tok_digest = hashlib.sha256(np.asarray([t for job in out for bar in job for t in bar], np.int32).tobytes()).hexdigest()[:16]
+    tok_digest = hashlib.sha256(np.concatenate([r[0] for r in results]).astype(np.int32).tobytes()).hexdigest()[:16]
     if use_dist:
         # the path's only exchange: ONE final gather of the small variable-length results (token ids of every job)
-        g = parallel.gather_int_arrays([np.asarray([t for bar in job for t in bar], np.int32) for job in out], device=dev, force=True)
+        g = parallel.gather_int_arrays([np.asarray(r[0], np.int32) for r in results], device=dev, force=True)
         gathered_jobs = sum(len(x) for x in g)
     barrier()
     elapsed = time.perf_counter() - t0
-    # per-kernel HIP-event timing: one extra step over the same inputs with an event pair around every launch.  It sits
-    # outside the K timed steps because event records cannot be placed inside the hipGraph replays that the
-    # production decode loop uses (with the profiler on the library launches the same kernels eagerly), and it runs the
-    # stages and the decoder engines one after another: an event pair on one stream also counts the time its kernel
-    # queues behind the other engines' kernels, which is not that kernel's duration.
-    _lib.prof_reset()
-    _lib.prof_enable(True)
-    step(profiling=True)
-    _lib.prof_enable(False)
-    prof = _lib.prof_report()
-    prof_steps = 1
+    timed_stats = [d.stats() for d in decs]
 
-    tmax = torch.tensor([elapsed, t_ext, t_dec], dtype=torch.float64, device=dev)
-    tsum = torch.tensor([float(n_tok)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed, t_ext, t_dec, t_notes], dtype=torch.float64, device=dev)
+    tsum = torch.tensor([float(n_tok), sum(s["kv_bytes"] + s["steps"] * s["weight_bytes_per_step"] for s in timed_stats)], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-    elapsed, t_ext, t_dec = [float(x) for x in tmax.tolist()]
-    n_tok_all = float(tsum.item())
+    elapsed, t_ext, t_dec, t_notes = [float(x) for x in tmax.tolist()]
+    n_tok_all, dec_bytes_all = [float(x) for x in tsum.tolist()]
 
-    audio_s = args.seconds * args.clips * args.steps * world
+    conds = state["conds"]
+    nbars = [len(cd.bars) for cd in conds]
+    xlen = float(np.mean([cd.bars.ids.size / max(1, len(cd.bars)) for cd in conds]))
+    audio_s = args.seconds * clips * args.steps * world
     result = {
         "metric": "audio-sec/s transcribed + decoder tokens/s, 3-min clip batch",
-        "value": round(audio_s / elapsed, 3), "unit": "audio-s/s (each clip extracted and decoded for every attribute tuple)",
+        "value": round(audio_s / elapsed, 3), "unit": "audio-s/s (each clip extracted, tokenized and decoded for every attribute tuple)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[4] share per rank: {args.clips} x 3-min 44.1 kHz stereo clips, full extract (wav->notes) each, + greedy decode of "
-                               f"{args.clips}x{args.attr_grid} (clip, attribute tuple) jobs, {args.bars} synthetic condition bars x {args.bar_tokens} generated tokens each "
-                               "(Bar_EOS suppressed: synthetic weights carry no musical EOS statistics), overlap bin 2, bf16 compute / fp32 accumulate; synthetic seeded weights",
-                   "clips_per_gpu": args.clips, "attr_tuples_per_clip": args.attr_grid, "decode_jobs_per_gpu": n_jobs, "decoder_streams": per_eng * n_eng, "decoder_engines": n_eng, "extractor_engines": len(exs),
-                   "clip_seconds": args.seconds, "windows_per_clip": int(np.ceil((1 + int(np.ceil(160 * wavs[0].shape[1] / 441)) // 256) / 512)),
-                   "bars": args.bars, "bar_tokens": args.bar_tokens, "parallelism": f"clip-sharded x{world}",
-                   "stage_overlap": "pipelined per clip (jobs of clip c admitted when its extraction is done; extraction of c+1 overlaps)" if args.pipeline else "stages back to back"},
+        "higher_is_better": True, "scaling": "strong" if args.clips == 0 and shrunk_from is None else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": (f"BASELINE configs[4], the batch north_star names: {clips * world} x 3-min 44.1 kHz stereo clips ({clips} per rank), per clip the chain of infer.py "
+                                f"(extract wav->notes, volume contour, tokenizer on the synthetic tempo.json -> the clip's OWN condition bars: {int(np.mean(nbars))} bars of ~{xlen:.0f} ids), "
+                                f"greedy generate() for {clips}x{args.attr_grid} (clip, attribute tuple) jobs per rank with {args.bar_tokens} generated tokens per bar (Bar_EOS does not end a bar: "
+                                "synthetic weights carry no musical EOS statistics), overlap bin 2, decode_to_notes with the clip's volume map; bf16 compute / fp32 accumulate; seeded synthetic weights"
+                                + (" -- CONDITION BARS REPLACED by the synthetic ~8-notes/bar song (--synthetic-bars, A/B)" if args.synthetic_bars else "")
+                                + (f" -- BATCH SHRUNK from {shrunk_from} to 8 clips per rank to fit the harness budget of {args.budget_s:.0f}s (the full batch: extras.batch64)" if shrunk_from else "")),
+                   "batch_clips": clips * world, "clips_per_gpu": clips, "attr_tuples_per_clip": args.attr_grid, "decode_jobs_per_gpu": n_jobs, "decoder_streams_per_engine": per_eng,
+                   "decoder_engines": len(decs), "extractor_engines": len(exs), "clip_seconds": args.seconds,
+                   "windows_per_clip": int(np.ceil((1 + int(np.ceil(160 * wavs[0].shape[1] / 441)) // 256) / 512)),
+                   "bars": int(np.mean(nbars)), "condition_ids_per_bar": round(xlen, 1), "bar_tokens": args.bar_tokens, "parallelism": f"clip-sharded x{world}",
+                   "stage_order": "extract stage for all clips, then decode stage for all jobs, then notes", "warmup_step": warm_mode},
         "extract_audio_s_per_s": round(audio_s / t_ext, 2),
         "decoder_tokens_per_s": round(n_tok_all / t_dec, 2),
-        "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": n_notes, "jobs_gathered": gathered_jobs, "tokens_sha256_rank0": tok_digest,
+        "notes_stage_s_per_step": round(t_notes / args.steps, 4),
+        "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": float(np.mean([cd.notes.size for cd in conds])),
+        "cover_notes_per_job": float(np.mean([n.size for n in state["notes"]])), "jobs_gathered": gathered_jobs, "tokens_sha256_rank0": tok_digest,
     }
 
-    # ---- roofline of the dominant kernel (HIP events inside the library, on the stream the kernel runs on)
-    MFMA_BOUND = {"k_linear", "k_linear_ln", "k_attn", "k_embed", "k_heads", "k_dgemm"}   # dense contractions; the rest stream weights / KV / audio
-    if prof:
-        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        name, p = dom
-        avg_ms = p["ms"] / max(1, p["launches"])
-        if name in MFMA_BOUND:
-            ach = p["flops"] / (p["ms"] * 1e-3) / 1e12
-            result["roofline"] = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                  "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": p["launches"],
-                                  "avg_launch_ms": round(avg_ms, 5), "alg_flops_per_launch": p["flops"] / max(1, p["launches"])}
-        else:
-            ach = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
-            result["roofline"] = {"kernel": name, "bound": "hbm", "achieved": round(ach, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches": p["launches"], "avg_launch_ms": round(avg_ms, 5),
-                                  "alg_bytes_per_launch": p["bytes"] / max(1, p["launches"])}
-        tp = ROOT / "profiles" / "traffic.json"
-        if tp.exists():
-            try:
-                result["roofline"]["traffic"] = json.loads(tp.read_text()).get(name)
-                result["roofline"]["traffic_source"] = ("static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch from separate "
-                                                        "profiling passes of this same command, committed with the tree; NOT measured in this run")
-            except Exception:
-                pass
-        result["roofline"]["frac_source"] = ("serial event pass: HIP events around every launch of the library during ONE extra step over the same inputs right after "
-                                             "the timed region, stages and engines one at a time (event records cannot sit inside the hipGraph replays of the timed "
-                                             "steps; with four engines running, an event pair also counts queueing behind the other engines' kernels).  The rocprofv3 "
-                                             "kernel-trace average of the timed configuration is in profiles/ (tools/profile.sh).")
-        result["kernel_ms_per_step"] = {k: round(v["ms"] / prof_steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-        # the whole decode stage as ONE figure that needs no per-kernel timing: algorithmic bytes of every decode-step launch of the
-        # step (host-side counts: K/V of every (row, head) + the weights each launch streams) over the stage's wall time in the TIMED steps
-        step_k = ("k_dstep_attn_down", "k_dstep_qkv_up", "k_resid_ln_rows", "k_dstep_head", "k_dattn", "k_dgemm_s", "k_ln_rows")
-        dec_bytes = sum(prof[k]["bytes"] for k in step_k if k in prof) / prof_steps
-        t_dec_step = t_dec / args.steps
-        if t_dec_step > 0:
-            result["roofline"]["decode_stage"] = {"alg_bytes_per_step": dec_bytes, "stage_s_per_step": round(t_dec_step, 4),
-                                                  "achieved": round(dec_bytes / t_dec_step / 1e9, 1), "unit": "GB/s",
-                                                  "frac": round(dec_bytes / t_dec_step / 1e9 / PEAK_HBM_GBS, 4),
-                                                  "note": "sum of algorithmic decode-step bytes / wall time of the decode stage in the timed steps (prefill passes included in the time, not in the bytes)"}
+    # ---- roofline of the dominant kernel, in the timed configuration: one more decode stage over the same conditions with every
+    # engine stamping its k_dstep_attn_down launches on the device (first workgroup's start .. last workgroup's end)
+    roof = {"kernel": "k_dstep_attn_down", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
+    if not args.no_stamp:
+        for d in decs:
+            d.stamp(True)
+            d.stats_reset()
+        pipe.decode_stage(conds)
+        torch.cuda.synchronize(dev)
+        st = [d.stats() for d in decs]
+        for d in decs:
+            d.stamp(False)
+        launches = sum(s["stamped_launches"] for s in st)
+        secs = sum(s["stamped_seconds"] for s in st)
+        byts = sum(s["stamped_alg_bytes"] for s in st)
+        if launches > 0 and secs > 0:
+            ach = byts / secs / 1e9
+            roof.update(achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBS, 4), launches=int(launches), avg_launch_ms=round(1e3 * secs / launches, 5),
+                        alg_bytes_per_launch=byts / launches,
+                        frac_source=("device stamps (etd_decoder_stamp): s_memrealtime of the first workgroup's start and the last workgroup's end of EVERY k_dstep_attn_down launch "
+                                     f"of one extra decode stage over the same jobs with all {len(decs)} engines running, i.e. the kernel's own span in the timed configuration; "
+                                     "algorithmic bytes = K+V rows of every (row, head) context + the down / dense weights a launch streams, counted exactly by the library"))
+    result["roofline"] = roof
+    tp = ROOT / "profiles" / "traffic.json"
+    if tp.exists():
+        try:
+            roof["traffic"] = json.loads(tp.read_text()).get("k_dstep_attn_down")
+            roof["traffic_source"] = ("static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch from separate profiling passes of "
+                                      "this command, committed with the tree; NOT measured in this run")
+        except Exception:
+            pass
+    # the whole decode stage as ONE figure that needs no per-kernel timing: SURVEY 8(d)'s step bytes (weights once per engine-step + K/V of
+    # every row's context over all layers), exact counts of the TIMED steps, over the decode stage's wall time in those steps
+    if t_dec > 0:
+        roof["decode_stage"] = {"alg_bytes_per_step": dec_bytes_all / args.steps, "stage_s_per_step": round(t_dec / args.steps, 4),
+                                "achieved": round(dec_bytes_all / t_dec / 1e9, 1), "unit": "GB/s", "frac": round(dec_bytes_all / t_dec / 1e9 / PEAK_HBM_GBS, 4),
+                                "note": "algorithmic decode-step bytes (SURVEY 8d: W per engine-step + 16 KiB x ctx per row-step) of the timed steps / wall time of their decode stage "
+                                        "(the batched prefill of every bar is in the time, not in the bytes)"}
+
+    # ---- per-kernel HIP-event breakdown: a SHORT serial pass (4 bars per job, stages and engines one at a time, launches eager with an
+    # event pair each -- event records cannot sit inside hipGraph replays).  Indicative: serial durations, not the timed configuration's.
+    try:
+        _lib.prof_reset()
+        _lib.prof_enable(True)
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(pipe.ex_streams[0]):
+            pipe.conditions_of(wavs[0], 0, 0)
+        pipe.ex_streams[0].synchronize()
+        pipe.decode_stage(conds, max_bars=4, one_at_a_time=True)
+        torch.cuda.synchronize(dev)
+        _lib.prof_enable(False)
+        prof = _lib.prof_report()
+        result["kernel_ms_serial_pass"] = {"what": "one clip's extract + 4 bars of every decode job, engines one after the other, HIP events around every launch",
+                                           "ms": {k: round(v["ms"], 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                                           "launches": {k: v["launches"] for k, v in prof.items()}}
+        p = prof.get("k_dstep_attn_down")
+        if p and p["ms"] > 0:
+            roof["frac_serial"] = round(p["bytes"] / (p["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+            if "frac" not in roof:
+                roof.update(achieved=round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1), frac=roof["frac_serial"], launches=p["launches"], avg_launch_ms=round(p["ms"] / p["launches"], 5),
+                            alg_bytes_per_launch=p["bytes"] / p["launches"], frac_source="serial event pass (no device stamps in this run)")
+    except Exception as e:      # a diagnostics failure must not take the headline down
+        _lib.prof_enable(False)
+        result["kernel_ms_serial_pass"] = {"error": repr(e)}
+    if batch64:
+        result.setdefault("extras", {})["batch64"] = batch64
 
     # ---- extras outside the timed region
     if not args.no_extras and rank == 0:
-        extras = {}
+        extras = result.setdefault("extras", {})
+        ex = exs[0]
         try:
             xs = torch.from_numpy(synth.window_features(5, 16)).to(dev)          # configs[2]: 16 windows
-            # (dealing the windows over both extractor instances, as the headline's extract stage does with clips, measured 1.64 against
-            # 1.60 ms per window here: two 8-window halves are two batches each and gain nothing from each other -- tools/runs/r2_run49.sh)
             ex.transcript_windows(xs)
             torch.cuda.synchronize(dev)
             t = time.perf_counter()
@@ -380,21 +499,17 @@ def main():
         except Exception as e:      # extras must never take the headline down
             extras["extractor_only"] = {"error": repr(e)}
         try:
-            # configs[1]: ONE 3-min clip, full extract + greedy decode with the default attributes (1/1/1, overlap 2) on one engine
+            # configs[1]: ONE 3-min clip, the whole chain with the default attributes (1/1/1, overlap 2) on one engine
+            one = ClipBatchPipeline(exs[:1], decs[:1], vocab, synthetic_tempo(), attr_grid(1), 44100, force_bar_tokens=args.bar_tokens)
             torch.cuda.synchronize(dev)
-            t = time.perf_counter()
-            with torch.cuda.stream(ext_stream):
-                n1 = len(ex.extract_notes(wavs[0], 44100, inf.min_duration))
-            ext_stream.synchronize()
-            t_e = time.perf_counter() - t
-            t = time.perf_counter()
-            st1 = {}
-            decs[0].generate_many([(jobs[0][0], [synth.attrs(1, 1, 1, 2)] * len(jobs[0][0]))], vocab, stats=st1, force_bar_tokens=args.bar_tokens)
-            torch.cuda.synchronize(dev)
-            t_d = time.perf_counter() - t
-            extras["single_clip"] = {"workload": f"BASELINE configs[1]: one 3-min 44.1 kHz clip, extract (wav -> {n1} notes) + greedy decode of {len(jobs[0][0])} bars x {args.bar_tokens} tokens, attributes 1/1/1, bf16",
-                                     "extract_s": round(t_e, 4), "decode_s": round(t_d, 4), "wall_s": round(t_e + t_d, 4),
-                                     "audio_s_per_s": round(args.seconds / (t_e + t_d), 1), "decoder_tokens_per_s": round(st1.get("tokens", 0) / t_d, 1)}
+            r1 = one.run(wavs[:1])
+            extras["single_clip"] = {"workload": f"BASELINE configs[1]: one 3-min 44.1 kHz clip, extract (wav -> {r1['conditions'][0].notes.size} notes) + tokenize + greedy decode of "
+                                                 f"{len(r1['conditions'][0].bars)} bars x {args.bar_tokens} tokens + notes, attributes 1/1/1, bf16",
+                                     "extract_s": round(r1["t_extract"], 4), "decode_s": round(r1["t_decode"], 4), "notes_s": round(r1["t_notes"], 4),
+                                     "wall_s": round(r1["t_extract"] + r1["t_decode"] + r1["t_notes"], 4),
+                                     "audio_s_per_s": round(args.seconds / (r1["t_extract"] + r1["t_decode"] + r1["t_notes"]), 1),
+                                     "decoder_tokens_per_s": round(r1["tokens"] / r1["t_decode"], 1)}
+            one.close()
         except Exception as e:
             extras["single_clip"] = {"error": repr(e)}
         for key, c0 in (("decoder_streams", 512), ("decoder_streams_4k", 3500)):     # reference-faithful context / 4k stress
@@ -402,55 +517,24 @@ def main():
                 extras[key] = decoder_stream_bench(dcfg, dev, ctx0=c0, streams=[d._ts for d in decs])
             except Exception as e:
                 extras[key] = {"error": repr(e)}
-        result["extras"] = extras
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(clip_seconds=args.seconds, windows_per_clip=result["config"]["windows_per_clip"], attr_tuples=args.attr_grid,
-                                                  bars_per_job=args.bars, bar_tokens=args.bar_tokens)
+            cd0 = conds[0]
+            bars0 = [cd0.bars.bar(i) for i in range(min(6, len(cd0.bars)))]
+            if args.synthetic_bars:
+                bars0 = synth.song_bars(seed=1234, n_bars=6)
+            result["cpu_baseline"] = cpu_baseline(bars0, clip_seconds=args.seconds, windows_per_clip=result["config"]["windows_per_clip"], attr_tuples=args.attr_grid,
+                                                  bars_per_job=int(np.mean(nbars)), bar_tokens=args.bar_tokens)
         except Exception as e:
             result["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
+    log("done")
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def spawn_ranks(n: int) -> int:
-    """`python bench.py --gpus N` (no launcher): run N ranks of this script under torch.distributed.run, one per GPU, over
-    RCCL on 127.0.0.1.  Fails loudly -- non-zero exit, no JSON line -- when the node has fewer than N GPUs."""
-    import socket
-    import subprocess
-    have = torch.cuda.device_count()
-    if have < n:
-        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible on this node; not reporting a {n}-GPU number", file=sys.stderr)
-        return 3
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
-    log("bench.py: starting", " ".join(cmd))
-    return subprocess.call(cmd, env=env)
-
-
-def decode_jobs_async(decs, jobs, vocab, bar_tokens, ready, one_at_a_time=False):
-    """Greedy-decode all jobs on the engines (etude_amd.decoder.run_engines: jobs dealt round-robin, one host thread per
-    engine).  `ready` = (flags, job -> flag index) gates the admission of each job on its clip's upstream stages.  Returns
-    a function that joins and yields (results, n_tokens)."""
-    from etude_amd.decoder import run_engines
-    join = run_engines(decs, jobs, vocab, one_at_a_time=one_at_a_time, ready=ready, force_bar_tokens=bar_tokens,
-                       stagger_s=float(os.environ.get("ETD_ENGINE_STAGGER_MS", "0")) * 1e-3)
-
-    def join_tokens():
-        out, stats = join()
-        return out, sum(s["tokens"] for s in stats)
-
-    return join_tokens
 
 
 def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64, engines: int = 2, streams=None):
@@ -458,12 +542,12 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     (EOS suppressed so every stream runs the full length -- throughput does not depend on the token values).
     The streams are dealt over `engines` decoder engines (own stream, KV cache and captured graphs, shared weights) that
     step concurrently from one host thread each, like the headline's decode stage: one step of the figure below = every one
-    of the n_streams streams advanced by one token.  Measured (tools/runs/r2_run31.sh): ctx 512: 0.359 / 0.346 / 0.367 ms
-    with 1 / 2 / 4 engines; ctx 3.5 k: 1.30 / 1.21 / 1.18 ms.
+    of the n_streams streams advanced by one token.
     `streams`: torch streams the engines run on.  Inside bench.py these are the headline engines' own (idle by then): a process
     that already holds seven streams gets hardware queues for two NEW ones that may share a compute pipe, and two dependent
-    kernel chains on one pipe run one after the other (0.50 instead of 0.34 ms per step at ctx 512, tools/runs/r2_run40/41.sh)."""
+    kernel chains on one pipe run one after the other (0.50 instead of 0.34 ms per step at ctx 512, LABNOTES.md)."""
     import threading
+    import torch
     from etude_amd import _lib, synth
     from etude_amd.decoder import EtudeDecoder
     engines = max(1, min(engines, n_streams))
@@ -489,6 +573,8 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
         _lib.check(lib.etd_decoder_step(dec._h, slots[e].ctypes.data, per[e], 4, st), "step")
     torch.cuda.synchronize(dev)
     errs = []
+    for dec in decs:
+        dec.stats_reset()
 
     gate = threading.Barrier(engines + 1, timeout=120)
 
@@ -511,21 +597,13 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     dt = time.perf_counter() - t
     if errs:
         raise errs[0]
-    _lib.prof_reset(); _lib.prof_enable(True)
-    psteps = 8
-    for e, dec in enumerate(decs):                       # eager + events, one engine after the other: per-kernel breakdown
-        _lib.check(lib.etd_decoder_step(dec._h, slots[e].ctypes.data, per[e], psteps, dec._stream()), "step")
-        torch.cuda.synchronize(dev)
-    _lib.prof_enable(False)
-    prof = _lib.prof_report()
-    ctx_mid = ctx0 + 4 + steps // 2
-    bytes_step = sum(decs[0].step_bytes(n, ctx_mid) for n in per)       # every engine streams the weight set once per step
-    gbs = bytes_step * steps / dt / 1e9
-    out = {"workload": f"BASELINE configs[3]: {n_streams} streams on {engines} engine(s), bf16 weights+KV, ctx {ctx0}->{ctx0 + 4 + steps}, {steps} greedy steps, EOS suppressed",
+    st = [dec.stats() for dec in decs]
+    bytes_all = sum(s["kv_bytes"] + s["steps"] * s["weight_bytes_per_step"] for s in st)     # exact: every engine streams the weight set once per step
+    gbs = bytes_all / dt / 1e9
+    out = {"workload": f"BASELINE configs[3]: {n_streams} streams on {engines} engine(s), bf16 weights+KV, ctx {ctx0 + 4}->{ctx0 + 4 + steps}, {steps} greedy steps, EOS suppressed",
            "engines": engines, "tokens_per_s": round(n_streams * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
-           "alg_bytes_per_step": bytes_step,
-           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)},
-           "kernel_ms_per_step": {k: round(v["ms"] / psteps, 4) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}}
+           "alg_bytes_per_step": bytes_all / steps,
+           "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}}
     for dec in reversed(decs):
         dec.close()
     return out

@@ -23,14 +23,22 @@ c_i64_p = C.POINTER(C.c_int64)
 c_f32_p = C.POINTER(C.c_float)
 
 
-class ExtCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("n_margin", "n_frame", "n_bin", "cnn_channel", "cnn_kernel", "hid_dim", "pf_dim",
+class _SizedCfg(C.Structure):
+    """Config structs of ABI version 2 lead with `struct_bytes` = sizeof of the caller's layout; the library refuses any other."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_bytes = C.sizeof(type(self))
+
+
+class ExtCfg(_SizedCfg):
+    _fields_ = [("struct_bytes", C.c_int)] + [(n, C.c_int) for n in ("n_margin", "n_frame", "n_bin", "cnn_channel", "cnn_kernel", "hid_dim", "pf_dim",
                                        "n_heads", "n_layers_enc", "n_layers_dec", "n_note", "n_velocity")] + \
                [("min_value", C.c_float), ("max_windows", C.c_int), ("chunk_frames", C.c_int), ("precision", C.c_int)]
 
 
-class DecCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads",
+class DecCfg(_SizedCfg):
+    _fields_ = [("struct_bytes", C.c_int)] + [(n, C.c_int) for n in ("vocab_size", "hidden_size", "num_hidden_layers", "num_attention_heads",
                                        "intermediate_size", "max_position_embeddings", "num_classes",
                                        "num_attribute_bins", "attribute_emb_dim")] + \
                [("rotary_pct", C.c_float), ("rope_theta", C.c_float), ("layer_norm_eps", C.c_float),
@@ -41,8 +49,8 @@ class Job(C.Structure):
     _fields_ = [("x_ids", C.c_void_p), ("x_offsets", C.c_void_p), ("n_bars", C.c_int), ("attrs4", C.c_void_p), ("ready", C.c_void_p)]
 
 
-class SchedCfg(C.Structure):
-    _fields_ = [(n, C.c_int) for n in ("bar_bos_id", "bar_eos_id", "n_ctx_pairs", "max_position_embeddings", "max_output_tokens",
+class SchedCfg(_SizedCfg):
+    _fields_ = [("struct_bytes", C.c_int)] + [(n, C.c_int) for n in ("bar_bos_id", "bar_eos_id", "n_ctx_pairs", "max_position_embeddings", "max_output_tokens",
                                        "max_bar_token_limit")] + [("context_overlap_ratio", C.c_float)] + \
                [(n, C.c_int) for n in ("force_bar_tokens", "max_streams", "max_prefill_rows", "steps_per_poll")] + \
                [("temperature", C.c_float), ("top_p", C.c_float), ("seed", C.c_ulonglong), ("job_key_offset", C.c_int), ("job_key_stride", C.c_int)]
@@ -60,7 +68,9 @@ class Note(C.Structure):
     _fields_ = [("onset", C.c_double), ("offset", C.c_double), ("pitch", C.c_int32), ("velocity", C.c_int32)]
 
 
-# name -> (restype, argtypes); mirrors include/etude_hip.h one to one
+ABI_VERSION = 2          # == ETD_ABI_VERSION of include/etude_hip.h; lib() refuses any other
+
+# name -> (restype, argtypes); mirrors include/etude_hip.h (the boundary) and include/etude_hip_debug.h (test / measurement hooks) one to one
 SIGNATURES = {
     "etd_version": (C.c_int, []),
     "etd_last_error": (C.c_char_p, []),
@@ -132,6 +142,11 @@ SIGNATURES = {
     "etd_decoder_prefill_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
                                              C.c_void_p]),
     "etd_decoder_step_bytes": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    "etd_decoder_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p]),
+    "etd_decoder_stats_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "etd_decoder_stamp": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "etd_debug_decoder_force_pair": (C.c_int, [C.c_void_p, C.c_int]),
+    "etd_debug_decoder_step_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "etd_debug_decoder_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),
     "etd_debug_decoder_kv_rowsums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p]),
     "etd_debug_decoder_trace_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
@@ -163,6 +178,8 @@ def lib() -> C.CDLL:
             fn = getattr(l, name)          # AttributeError if the .so does not export it: fail loudly
             fn.restype = res
             fn.argtypes = args
+        if l.etd_version() != ABI_VERSION:
+            raise EtudeHipError(f"{LIB_PATH} speaks ABI version {l.etd_version()}, this binding {ABI_VERSION}; rebuild with `python -m etude_amd.build`")
         # provenance: the binary must have been built from the sources it sits next to (diagnostic builds opt out explicitly)
         if not os.environ.get("ETD_PARTIAL") and not os.environ.get("ETD_ALLOW_STALE_LIB"):
             from .build import src_hash

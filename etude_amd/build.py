@@ -25,16 +25,30 @@ FLAGS += os.environ.get("ETD_EXTRA_FLAGS", "").split()      # diagnostic builds 
 # -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
 
 
+def file_flags(src_name: str) -> list:
+    """Effective compile flags of one source: the common FLAGS (incl. ETD_EXTRA_FLAGS) + its ETD_FLAGS_<FILE> experiment flags."""
+    return FLAGS + os.environ.get("ETD_FLAGS_" + src_name.split(".")[0].upper(), "").split()
+
+
+def _flags_tag(src_name: str) -> str:
+    import hashlib
+    return hashlib.sha256("\0".join(file_flags(src_name)).encode()).hexdigest()[:10]
+
+
 def src_hash() -> str:
-    """sha256 over every source and header the library is built from.  build() bakes it into the .so (`etd_build_id`) and
-    `_lib.lib()` compares it with the tree it is loaded from: a stale binary next to newer sources fails loudly instead of
-    passing the GPU tests with yesterday's kernels."""
+    """sha256 over every source and header the library is built from AND the effective compile flags of every file.  build() bakes
+    it into the .so (`etd_build_id`) and `_lib.lib()` compares it with the tree (and environment) it is loaded from: a stale binary
+    next to newer sources -- or a diagnostic build made with ETD_EXTRA_FLAGS / ETD_FLAGS_* (some of which compute wrong results on
+    purpose) loaded by a process that does not ask for those flags -- fails loudly instead of standing in for the shipped kernels."""
     import hashlib
     h = hashlib.sha256()
-    files = sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + [HERE.parent / "include" / "etude_hip.h"], key=lambda p: p.name)
+    inc = HERE.parent / "include"
+    files = sorted([CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + [inc / "etude_hip.h", inc / "etude_hip_debug.h"], key=lambda p: p.name)
     for f in files:
         if f.exists():
             h.update(f.name.encode()); h.update(b"\0"); h.update(f.read_bytes()); h.update(b"\0")
+    for s in SOURCES:
+        h.update(s.encode()); h.update(b"\0"); h.update("\0".join(x for x in file_flags(s) if x != str(inc)).encode()); h.update(b"\0")
     return h.hexdigest()[:32]
 
 
@@ -48,7 +62,7 @@ def _hipcc() -> str:
 def build(force: bool = False, verbose: bool = False) -> Path:
     OBJ.mkdir(exist_ok=True)
     hipcc = _hipcc()
-    headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "etude_hip.h"]
+    headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "etude_hip.h", HERE.parent / "include" / "etude_hip_debug.h"]
     newest_h = max(h.stat().st_mtime for h in headers)
     objs = []
     rebuilt = False
@@ -57,10 +71,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         src = CSRC / s
         if not src.exists():
             continue
-        o = OBJ / (s + ".o")
+        o = OBJ / f"{s}.{_flags_tag(s)}.o"          # one object per (source, flag set): builds with different flags never reuse each other's objects
         objs.append(o)
         if force or not o.exists() or o.stat().st_mtime < max(src.stat().st_mtime, newest_h):
-            cmd = [hipcc, *FLAGS, *os.environ.get("ETD_FLAGS_" + s.split(".")[0].upper(), "").split(), "-c", str(src), "-o", str(o)]   # per-file experiment flags, e.g. ETD_FLAGS_EXT_FUSED
+            cmd = [hipcc, *file_flags(s), "-c", str(src), "-o", str(o)]   # incl. per-file experiment flags, e.g. ETD_FLAGS_EXT_FUSED
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -2,6 +2,7 @@
 // generation state kept on the device, prefill / decode-step launch sequences.
 // Reference: etude/models/etude_decoder.py:148-206 (forward), :291-343 (token loop);
 // etude/utils/model_loader.py:12-60 (checkpoint contract).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -12,7 +13,7 @@
 #include <mutex>
 #include <vector>
 
-#include "../../include/etude_hip.h"
+#include "../../include/etude_hip_debug.h"
 #include "dec_kernels.h"
 #include "ext_kernels.h"
 #include "prof.h"
@@ -34,6 +35,7 @@ struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
 
 }  // namespace
 
+#define ETD_STAMP_WORDS (8 + 2 * 64)      // u64 words of the device-side span accumulator of k_dstep_attn_down (layout: dec_kernels.hip)
 struct etd_dec {
   etd_dec_cfg cfg;
   std::vector<void*> allocs;
@@ -78,13 +80,16 @@ struct etd_dec {
   std::vector<int> host_len;                     // host-side estimate of each slot's KV length (profiler byte counts only)
   double attn_bytes_hint = 0;
   bool step_pair = false;                        // this call's decode steps pair the rows of a head in the attention launch (etd_decoder_step decides)
+  // counters of the decode steps issued on this handle since the last etd_decoder_stats_reset (host-side, exact: etd_decoder_stats)
+  double stat_steps = 0, stat_row_steps = 0, stat_kv_bytes = 0, stat_attn_launches = 0, stat_stamp_bytes = 0;
+  int force_pair = -1;                           // test hook (etd_debug_decoder_force_pair): -1 = the rule above, 0 / 1 = one-row / paired-rows attention form
+  unsigned long long* stamp_dev = nullptr;       // device-side span accumulator of k_dstep_attn_down (etd_decoder_stamp); its own allocation
+  bool stamp_on = false;
+  float* logits_dbg = nullptr; bool logits_dbg_on = false, last_step_fused = false;   // test hook: the fused step's logits [S][V] (etd_debug_decoder_step_logits)
   // weight sharing (etd_decoder_clone): a clone reads the owner's weight buffers and has its own KV cache, workspaces and
   // stream state.  `allocs` of an owner = weights first (n_weight_allocs of them), then its workspaces; a clone's = workspaces only.
   etd_dec* weights_owner = nullptr;              // null: this handle owns its weights
   size_t n_weight_allocs = 0;
-  // activity board of the family (lives in the owner): steady-clock time of each engine's last etd_decoder_step call, slot = family_index
-  std::atomic<long long> last_step_ns[16];
-  int family_index = 0, next_family_index = 1;    // owner: 0; clones: 1, 2, ... in creation order (beyond 15: not on the board)
   int n_clones = 0; bool zombie = false;         // owner destroyed while clones are alive: weights freed with the last clone
 
   template <typename T> int alloc(T** p, size_t n, bool zero = false) {
@@ -207,12 +212,13 @@ static inline bool fused_pmlp_on() { const char* e = getenv("ETD_FUSED_PMLP"); r
 struct LastOnly { int n; const int* idx; DecRows rows; };
 
 int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false,
-                 const LastOnly* lo = nullptr, bool* compact = nullptr) {
+                 const LastOnly* lo = nullptr, bool* compact = nullptr, bool is_step = false) {
   if (compact) *compact = false;
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && M > 1;
-  const bool big = bpipe && M > 512 && d->layers[0].qkv.Wf && d->layers[0].up.Wf && d->layers[0].cat.Wf;   // M: must match DS_MAX_ROWS in dec_kernels.hip
+  // a decode step (is_step: one row per stream, M <= DS_STEP_MAX_ROWS) stays on the fused step kernels whatever its row count
+  const bool big = bpipe && !is_step && M > DS_MAX_ROWS && d->layers[0].qkv.Wf && d->layers[0].up.Wf && d->layers[0].cat.Wf;
   bool ln_ready = false;            // X1b / X2b already hold this layer's LayerNorm rows (written by the previous layer's k_dmlp_fused)
   for (int l = 0; l < d->L; ++l) {
     const Layer& w = d->layers[l];
@@ -239,7 +245,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       LinArgs a = {};
       a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.Wf; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
       ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
-      if (l == d->L - 1 && lo && mfma_attn && lo->n > 1 && lo->n <= 512 && d->H == 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && !getenv("ETD_NO_LAST_ONLY")) {
+      if (l == d->L - 1 && lo && mfma_attn && lo->n > 1 && lo->n <= DS_STEP_MAX_ROWS && d->H == 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && !getenv("ETD_NO_LAST_ONLY")) {
         // last layer, last positions only: every position's K/V is in the cache now; what remains of the layer is needed for
         // n rows, not M (attention, MLP up, (down | dense), residual = 9 % of the prefill's FLOPs at 8 layers)
         const int n = lo->n;
@@ -291,6 +297,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = rows; at.M = M; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
       at.pair = d->step_pair ? 1 : 0;
+      at.stamp = d->stamp_on ? d->stamp_dev : nullptr; at.stamp_par = l & 1;
       at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0;
       const int ksd = d->I / 512;
       at.dense_w = (const bf16*)w.dense_hw; at.dense_out = d->Pk + (size_t)ksd * M * d->H;
@@ -305,9 +312,9 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       // but the JOB 569-575 -> 567 audio-s/s (the attention workgroups live 19 instead of 15.5 us and hold 128 registers per
       // wave while the other engines' prefill GEMMs want the same CUs).  Off by default.
       static const bool rowfin = getenv("ETD_ROWFIN") && atoi(getenv("ETD_ROWFIN")) > 0;
-      if (rowfin && ksd + d->nh == 12 && M <= 512) {
+      if (rowfin && ksd + d->nh == 12 && M <= DS_STEP_MAX_ROWS) {
         DRowFin fin = {};
-        fin.cnt = d->row_cnt + (size_t)l * 512; fin.target = d->nh + 16 * ksd; fin.P = d->Pk; fin.nslab = 12;
+        fin.cnt = d->row_cnt + (size_t)l * DS_STEP_MAX_ROWS; fin.target = d->nh + 16 * ksd; fin.P = d->Pk; fin.nslab = 12;
         fin.bias = w.cat.b; fin.hin = hin; fin.hout = hout; fin.eps = d->cfg.layer_norm_eps;
         if (nx) { fin.g1 = nx->ln1g; fin.b1 = nx->ln1b; fin.g2 = nx->ln2g; fin.b2 = nx->ln2b; fin.x1 = d->X1b; fin.x2 = d->X2b; }
         ETD_TRY(launch_dstep_attn_down(at, dn, &fin, st));
@@ -539,8 +546,8 @@ int alloc_workspaces(etd_dec* d) {
   if (d->bf16w) {
     rc = rc ? rc : d->alloc(&d->X1b, M * H); rc = rc ? rc : d->alloc(&d->X2b, M * H); rc = rc ? rc : d->alloc(&d->AOb, M * H);
     rc = rc ? rc : d->alloc(&d->M1b, M * d->I);
-    rc = rc ? rc : d->alloc(&d->Pk, (size_t)12 * 512 * H);     // split-K slabs of the decode step: 5 (down | dense) or 4 (down) + one per head (dense inside the attention workgroups)
-    rc = rc ? rc : d->alloc(&d->row_cnt, (size_t)d->L * 512, true);
+    rc = rc ? rc : d->alloc(&d->Pk, (size_t)12 * DS_STEP_MAX_ROWS * H);     // split-K slabs of the decode step: 5 (down | dense) or 4 (down) + one per head (dense inside the attention workgroups)
+    rc = rc ? rc : d->alloc(&d->row_cnt, (size_t)d->L * DS_STEP_MAX_ROWS, true);
     rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
     rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
     d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
@@ -570,6 +577,7 @@ int alloc_workspaces(etd_dec* d) {
 extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                                   const int64_t* numels, int n, etd_dec** out) {
   if (!cfg || !names || !host_ptrs || !numels || !out) ETD_FAIL(ETD_EINVAL, "decoder_create: null argument");
+  if (cfg->struct_bytes != (int)sizeof(etd_dec_cfg)) ETD_FAIL(ETD_EINVAL, "decoder_create: etd_dec_cfg of %d bytes, this library (ABI %d) expects %d -- caller built against another etude_hip.h", cfg->struct_bytes, ETD_ABI_VERSION, (int)sizeof(etd_dec_cfg));
   const etd_dec_cfg& c = *cfg;
   if (c.hidden_size % 256 || c.num_attention_heads <= 0 || c.hidden_size / c.num_attention_heads != 64 || c.intermediate_size % 128 ||
       (int)(64 * c.rotary_pct) != 16 || c.num_hidden_layers < 1 || c.vocab_size < 2 || c.max_streams < 1 || c.max_ctx < 16 ||
@@ -709,7 +717,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   d->n_weight_allocs = d->allocs.size();
   rc = alloc_workspaces(d);
   if (rc) return fail(rc);
-  HIP_TRY(hipDeviceSynchronize());
+  if (hipDeviceSynchronize() != hipSuccess) { g_etd_err = "decoder_create: device synchronisation failed"; return fail(ETD_EHIP); }
   *out = d;
   return ETD_OK;
 }
@@ -726,8 +734,6 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
     if (own->zombie) ETD_FAIL(ETD_EINVAL, "decoder_clone: the source handle was destroyed");
     ++own->n_clones;          // taken BEFORE the workspaces are built: the owner cannot free the weights underneath this clone
   }
-  int fam_idx;
-  { std::lock_guard<std::mutex> lk(g_family_mu); fam_idx = own->next_family_index++; }
   auto unref = [own]() {
     bool last;
     { std::lock_guard<std::mutex> lk(g_family_mu); last = --own->n_clones == 0 && own->zombie; }
@@ -744,8 +750,8 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
   d->host_key.resize(d->S);
   for (int i = 0; i < d->S; ++i) d->host_key[i] = (unsigned long long)i;
   d->weights_owner = own;
-  d->family_index = fam_idx;
-  const int rc = alloc_workspaces(d);
+  int rc = alloc_workspaces(d);
+  if (!rc && hipDeviceSynchronize() != hipSuccess) { g_etd_err = "decoder_clone: device synchronisation failed"; rc = ETD_EHIP; }
   if (rc) {
     for (void* p : d->allocs) (void)hipFree(p);
     if (d->pin_stage) (void)hipHostFree(d->pin_stage);
@@ -753,7 +759,6 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
     if (d->pin_stage_evt) (void)hipEventDestroy(d->pin_stage_evt);
     delete d; unref(); return rc;
   }
-  HIP_TRY(hipDeviceSynchronize());
   *out = d;
   return ETD_OK;
 }
@@ -763,8 +768,13 @@ extern "C" void etd_decoder_destroy(etd_dec* d) {
   (void)hipDeviceSynchronize();   // kernels of this handle may still be in flight
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);
   d->graphs.clear();
-  if (d->trace) { (void)hipFree(d->trace); (void)hipFree(d->trace_step); (void)hipFree(d->trace_pk); (void)hipFree(d->trace_q); d->trace = nullptr; d->trace_step = nullptr; d->trace_pk = nullptr; d->trace_q = nullptr; }
+  if (d->trace) { (void)hipFree(d->trace); d->trace = nullptr; }
+  if (d->trace_step) { (void)hipFree(d->trace_step); d->trace_step = nullptr; }
+  if (d->trace_pk) { (void)hipFree(d->trace_pk); d->trace_pk = nullptr; }
+  if (d->trace_q) { (void)hipFree(d->trace_q); d->trace_q = nullptr; }
   if (d->trace_dbg) { (void)hipFree(d->trace_dbg); d->trace_dbg = nullptr; }
+  if (d->stamp_dev) { (void)hipFree(d->stamp_dev); d->stamp_dev = nullptr; }
+  if (d->logits_dbg) { (void)hipFree(d->logits_dbg); d->logits_dbg = nullptr; }
   if (d->pin_stage) { (void)hipHostFree(d->pin_stage); d->pin_stage = nullptr; }
   if (d->pin_rb) { (void)hipHostFree(d->pin_rb); d->pin_rb = nullptr; }
   if (d->pin_stage_evt) { (void)hipEventDestroy(d->pin_stage_evt); d->pin_stage_evt = nullptr; }
@@ -811,7 +821,7 @@ extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, c
   // the row-finish counters (ETD_ROWFIN=1) are zero between launches by construction (the last arriver resets its word); a launch
   // that died half way would leave them poisoned for good, so every bar starts from zero anyway (16 KiB, on the stream)
   static const bool rowfin_on = getenv("ETD_ROWFIN") && atoi(getenv("ETD_ROWFIN")) > 0;
-  if (rowfin_on && d->row_cnt) HIP_TRY(hipMemsetAsync(d->row_cnt, 0, (size_t)d->L * 512 * sizeof(int), st));
+  if (rowfin_on && d->row_cnt) HIP_TRY(hipMemsetAsync(d->row_cnt, 0, (size_t)d->L * DS_STEP_MAX_ROWS * sizeof(int), st));
   Staged sg; float* hf = nullptr;
   bool compact = false;
   ETD_TRY(stage_and_forward(d, n, slots, T, ids, cls, attrs4, init.data(), &sg, &hf, st, &compact));
@@ -864,41 +874,30 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   }
   d->host_n_out_valid = false;
   {
-    // two rows of a head per attention workgroup pay at short contexts only (dec_kernels.hip, launch_dstep_attn_down): decided per call from the
-    // contexts the host knows, and part of the captured graph's key
-    // Measured on MI355X (tools/runs/r2_run137.sh .. r2_run139.sh, tools/bench_engine_overlap.py): with three or more engines sharing the chip
-    // the pair form is 1-4 % faster per step-round from 32 rows up (mean context 256 .. 900), slower below; one or two engines depend on how the
-    // launch's workgroups quantise over the 256 CUs (64 + 8 M one-row workgroups of 1 unit against 32 + 4 M pair workgroups of 2 units: the
-    // busiest CU decides) -- pair at 32-54 and 96 rows (-3 .. -6 % per step), one-row at 60-72 and 128 rows (pair +2 .. +11 %).
+    // Two rows of a head per attention workgroup (dec_kernels.hip, launch_dstep_attn_down) or one: BIT-IDENTICAL results
+    // (tests/test_gpu_decoder.py::test_paired_rows_form_is_bit_identical), so the choice is a pure performance matter -- and it is a
+    // deterministic function of (rows, mean context) alone, part of the captured graph's key.  Measured on MI355X (round 2: tools/README.md "pair
+    // sweeps"; round 3 at 432 rows: profiles/r03_*): the pair form pays from 32 rows up at mean contexts 192 .. 1024 unless the launch's
+    // workgroups quantise badly over the 256 CUs (64 + 8 M one-row workgroups of 1 unit against 32 + 4 M pair workgroups of 2 units: the
+    // busiest CU decides), which matters up to ~128 rows only.
     double ctx_sum = 0;
     for (int i = 0; i < n_active; ++i) ctx_sum += d->host_len[slots[i]] + 1;
     const double mean_ctx = ctx_sum / n_active;
     bool pair = n_active >= 32 && mean_ctx >= 192.0 && mean_ctx <= 1024.0;
-    // engines of this weight family that stepped within the last 100 ms (this one included): the proxy for how many chains share the chip
-    int family = 1;
-    {
-      etd_dec* own = d->weights_owner ? d->weights_owner : d;
-      const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
-      if (d->family_index < 16) own->last_step_ns[d->family_index].store(now, std::memory_order_relaxed);
-      for (int i = 0; i < 16; ++i) {
-        if (i == d->family_index) continue;
-        const long long t = own->last_step_ns[i].load(std::memory_order_relaxed);
-        if (t != 0 && now - t < 100000000LL) ++family;
-      }
-    }
-    if (pair && family < 3) {
+    if (pair && n_active <= 128) {
       const int u1 = (64 + 8 * n_active + 255) / 256, u2 = 2 * ((32 + 4 * n_active + 255) / 256);
       pair = u2 <= u1;
     }
-    d->step_pair = pair;
+    d->step_pair = d->force_pair < 0 ? pair : (d->force_pair > 0 && n_active >= 2);
   }
   d->rows_identity = true;
   for (int i = 0; i < n_active; ++i) if (slots[i] != i) { d->rows_identity = false; break; }
   // bf16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
   // (QKV|up, attention, down|dense, residual + LayerNorm) and one head launch that also prepares the next step's rows
   const int vpad = (d->V + 31) / 32 * 32;
-  const bool fused = d->bf16w && n_active > 1 && n_active <= 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
+  const bool fused = d->bf16w && n_active > 1 && n_active <= DS_STEP_MAX_ROWS && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
                      vpad <= d->head.Npad && d->head_frag && !getenv("ETD_NO_FUSED_STEP");
+  d->last_step_fused = fused;
   auto embed = [&](hipStream_t s_) -> int {
     DEmbedArgs e = {};
     e.slots = d->slots_dev; e.len = d->len; e.done = d->done; e.row_slot_out = d->row_slot; e.row_pos_out = d->row_pos; e.row_active_out = d->row_active; e.row_sp_out = d->row_sp;
@@ -908,14 +907,21 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     e.rows = DecRows{d->row_slot, d->row_pos, d->row_active};
     return launch_dembed(e, s_);
   };
+  // K and V rows one layer's attention launch reads at step `s` of this call: every row's context so far (+ the row it appends)
+  const double kv_row_bytes = (double)d->nh * 64 * 2 * (d->bf16w ? 2 : 4);
+  auto step_kv_bytes = [&](int s) {
+    double b = 0;
+    for (int i = 0; i < n_active; ++i) { const int c = d->host_len[slots[i]] + 1 + s; b += (double)(c < d->ctx ? c : d->ctx) * kv_row_bytes; }
+    return b;
+  };
+  int eager_step = 0;
   auto one_step = [&](hipStream_t s_) -> int {
-    double kvb = 0;
-    for (int i = 0; i < n_active; ++i) { int& hl = d->host_len[slots[i]]; kvb += (double)(hl + 1) * d->nh * 64 * 2 * (d->bf16w ? 2 : 4); if (hl < d->ctx - 1) ++hl; }
-    d->attn_bytes_hint = kvb;
+    d->attn_bytes_hint = step_kv_bytes(eager_step);     // K/V bytes ONE layer's attention launch of this step reads (profiler byte counts)
+    ++eager_step;
     const DecRows rows{d->row_slot, d->row_pos, d->row_active};
     if (!fused) ETD_TRY(embed(s_));
     float* hf = nullptr;
-    ETD_TRY(forward_body(d, n_active, rows, &hf, s_, nullptr, fused));
+    ETD_TRY(forward_body(d, n_active, rows, &hf, s_, nullptr, fused, nullptr, nullptr, fused));
     if (fused) {
       const Layer& w0 = d->layers[0];
       DHeadArgs hd = {};
@@ -928,6 +934,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
       hd.g1 = w0.ln1g; hd.b1 = w0.ln1b; hd.g2 = w0.ln2g; hd.b2 = w0.ln2b;
       hd.h = d->h; hd.x1 = d->X1b; hd.x2 = d->X2b;
       hd.samp = d->samp_dev; hd.rng_key = d->rng_key;             // the device-side config selects greedy / sampling
+      hd.logits_dbg = d->logits_dbg_on ? d->logits_dbg : nullptr;
       ETD_TRY(launch_dstep_head(hd, s_));
       if (d->trace) {
         ETD_TRY(trace_rows(d, d->h, d->H, d->H, 1, 0, n_active, ETD_TRACE_LAYER * d->L * n_active, s_));
@@ -957,13 +964,14 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   // a non-default stream and must not contain the profiler's event records.
   const bool use_graph = st != nullptr && !prof_enabled() && !getenv("ETD_NO_GRAPH");
   if (use_graph) {
-    const int gkey = 4 * n_active + (d->step_pair ? 2 : 0) + (d->rows_identity ? 1 : 0);
+    const int gkey = 16 * n_active + (d->logits_dbg_on ? 8 : 0) + (d->stamp_on ? 4 : 0) + (d->step_pair ? 2 : 0) + (d->rows_identity ? 1 : 0);
     auto it = d->graphs.find(gkey);
     if (it == d->graphs.end()) {
       hipGraph_t g = nullptr;
       HIP_TRY(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       const int rc = one_step(st);
       const hipError_t ce = hipStreamEndCapture(st, &g);
+      eager_step = 0;                                   // (the capture ran one_step once without executing it)
       if (rc != ETD_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
       if (ce != hipSuccess || !g) ETD_FAIL(ETD_EHIP, "decoder_step: stream capture failed: %s", hipGetErrorString(ce));
       hipGraphExec_t ge = nullptr;
@@ -976,6 +984,81 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   } else {
     for (int s = 0; s < n_steps; ++s) ETD_TRY(one_step(st));
   }
+  // exact host-side accounting of what was just issued (graph replays included), then the contexts move on
+  {
+    double kv = 0;
+    for (int s2 = 0; s2 < n_steps; ++s2) kv += step_kv_bytes(s2);
+    kv *= d->L;
+    d->stat_steps += n_steps; d->stat_row_steps += (double)n_steps * n_active; d->stat_kv_bytes += kv; d->stat_attn_launches += (double)n_steps * d->L;
+    if (d->stamp_on) d->stat_stamp_bytes += kv + (double)n_steps * d->L * ((double)d->I + d->H) * d->H * 2.0;     // + the down and dense weights each launch streams
+    for (int i = 0; i < n_active; ++i) { int& hl = d->host_len[slots[i]]; hl = hl + n_steps < d->ctx - 1 ? hl + n_steps : d->ctx - 1; }
+  }
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_stats(etd_dec* d, double* out, int n, void* stream) {
+  if (!d || !out || n < 1) ETD_FAIL(ETD_EINVAL, "decoder_stats: bad arguments");
+  unsigned long long sum_ticks = 0, n_stamped = 0;
+  if (d->stamp_dev) {
+    std::vector<unsigned long long> sp(ETD_STAMP_WORDS);
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemcpy(sp.data(), d->stamp_dev, ETD_STAMP_WORDS * 8, hipMemcpyDeviceToHost));
+    sum_ticks = sp[0]; n_stamped = sp[1];
+    for (int bank = 0; bank < 2; ++bank) {              // the launch(es) no later launch has folded in yet
+      unsigned long long e = 0;
+      for (int i = 0; i < 64; ++i) e = std::max(e, sp[8 + 64 * bank + i]);
+      if (sp[2 + bank] != 0 && e > sp[2 + bank]) { sum_ticks += e - sp[2 + bank]; ++n_stamped; }
+    }
+  }
+  double w = 0;
+  for (const Layer& l : d->layers) w += ((double)l.qkv.N * l.qkv.K + (double)l.dense.N * l.dense.K + (double)l.up.N * l.up.K + (double)l.down.N * l.down.K) * (d->bf16w ? 2.0 : 4.0);
+  w += (double)d->V * d->H * (d->bf16w ? 2.0 : 4.0);
+  const double v[8] = {d->stat_steps, d->stat_row_steps, d->stat_kv_bytes, d->stat_attn_launches, (double)n_stamped, (double)sum_ticks * 1e-8 /* 100 MHz ticks -> s */, d->stat_stamp_bytes, w};
+  for (int i = 0; i < n; ++i) out[i] = i < 8 ? v[i] : 0.0;
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_stats_reset(etd_dec* d, void* stream) {
+  if (!d) ETD_FAIL(ETD_EINVAL, "decoder_stats_reset: null handle");
+  d->stat_steps = d->stat_row_steps = d->stat_kv_bytes = d->stat_attn_launches = d->stat_stamp_bytes = 0;
+  if (d->stamp_dev) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(hipMemset(d->stamp_dev, 0, ETD_STAMP_WORDS * 8));
+  }
+  return ETD_OK;
+}
+
+extern "C" int etd_decoder_stamp(etd_dec* d, int on, void* stream) {
+  if (!d) ETD_FAIL(ETD_EINVAL, "decoder_stamp: null handle");
+  if (on && !d->stamp_dev) {
+    HIP_TRY(hipMalloc((void**)&d->stamp_dev, ETD_STAMP_WORDS * 8));
+    HIP_TRY(hipMemset(d->stamp_dev, 0, ETD_STAMP_WORDS * 8));
+  }
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  d->stamp_on = on != 0;
+  return ETD_OK;
+}
+
+// test hook: pin the attention form of the fused decode step (-1: the host rule; 0: one row per workgroup; 1: two rows of a head per workgroup)
+extern "C" int etd_debug_decoder_force_pair(etd_dec* d, int mode) {
+  if (!d || mode < -1 || mode > 1) ETD_FAIL(ETD_EINVAL, "force_pair: bad arguments");
+  d->force_pair = mode;
+  return ETD_OK;
+}
+
+// test hook: after etd_debug_decoder_step_logits(d, 1, ...) every decode step stores its logits; out_host (may be null when switching)
+// receives the LAST step's [n_active][V] rows, fused bf16 step and unfused steps alike
+extern "C" int etd_debug_decoder_step_logits(etd_dec* d, int on, float* out_host, int n_active, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (!d || n_active < 0 || n_active > d->S) ETD_FAIL(ETD_EINVAL, "step_logits: bad arguments");
+  HIP_TRY(hipStreamSynchronize(st));
+  if (out_host && n_active > 0) {
+    if (d->last_step_fused && !(d->logits_dbg_on && d->logits_dbg)) ETD_FAIL(ETD_EINVAL, "step_logits: the fused step stores its logits only while the hook is on");
+    const float* src = d->last_step_fused ? d->logits_dbg : d->logits;       // (unfused steps leave [n][V] logits in the workspace anyway)
+    HIP_TRY(hipMemcpy(out_host, src, (size_t)n_active * d->V * 4, hipMemcpyDeviceToHost));
+  }
+  if (on && !d->logits_dbg) HIP_TRY(hipMalloc((void**)&d->logits_dbg, (size_t)d->S * d->V * 4));
+  d->logits_dbg_on = on != 0;
   return ETD_OK;
 }
 
@@ -1132,7 +1215,10 @@ extern "C" int etd_debug_decoder_trace_begin(etd_dec* d, int cap_steps, void* st
   HIP_TRY(hipStreamSynchronize(st));
   for (auto& kv : d->graphs) (void)hipGraphExecDestroy(kv.second);       // the captured steps do not hold the trace launches
   d->graphs.clear();
-  if (d->trace) { (void)hipFree(d->trace); (void)hipFree(d->trace_step); (void)hipFree(d->trace_pk); (void)hipFree(d->trace_q); d->trace = nullptr; d->trace_step = nullptr; d->trace_pk = nullptr; d->trace_q = nullptr; }
+  if (d->trace) { (void)hipFree(d->trace); d->trace = nullptr; }
+  if (d->trace_step) { (void)hipFree(d->trace_step); d->trace_step = nullptr; }
+  if (d->trace_pk) { (void)hipFree(d->trace_pk); d->trace_pk = nullptr; }
+  if (d->trace_q) { (void)hipFree(d->trace_q); d->trace_q = nullptr; }
   HIP_TRY(hipMalloc(&d->trace_pk, (size_t)12 * d->S * d->H * 4));
   HIP_TRY(hipMalloc(&d->trace_q, (size_t)d->S * d->H * 4));
   if (!d->trace_dbg) HIP_TRY(hipMalloc(&d->trace_dbg, (size_t)d->nh * d->S * 256 * 8 * 4));

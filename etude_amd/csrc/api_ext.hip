@@ -8,7 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "../../include/etude_hip.h"
+#include "../../include/etude_hip_debug.h"
 #include "ext_kernels.h"
 #include "ext_fp32.h"
 
@@ -198,6 +198,7 @@ int load_heads(DevPool& pool, Loader& L, const std::string& sfx, LinW* w) {
 extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                                     const int64_t* numels, int n, etd_ext** out) {
   if (!cfg || !names || !host_ptrs || !numels || !out) ETD_FAIL(ETD_EINVAL, "extractor_create: null argument");
+  if (cfg->struct_bytes != (int)sizeof(etd_ext_cfg)) ETD_FAIL(ETD_EINVAL, "extractor_create: etd_ext_cfg of %d bytes, this library (ABI %d) expects %d -- caller built against another etude_hip.h", cfg->struct_bytes, ETD_ABI_VERSION, (int)sizeof(etd_ext_cfg));
   const etd_ext_cfg& c = *cfg;
   // The kernels are specialised for the reference's default architecture (schema.py:103-112).
   if (c.hid_dim != 256 || c.n_heads != 4 || c.pf_dim != 512 || c.n_bin != 256 || c.n_margin != 32 || c.cnn_channel != 4 ||
@@ -219,7 +220,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
   if (c.precision == 1) {
     const int rc = ext32_create(c, L.t, &e->f32);
     if (rc) return fail(rc);
-    HIP_TRY(hipDeviceSynchronize());
+    if (hipDeviceSynchronize() != hipSuccess) { g_etd_err = "extractor_create: device synchronisation failed"; if (e->f32) ext32_destroy(e->f32); return fail(ETD_EHIP); }
     *out = e;
     return ETD_OK;
   }
@@ -337,7 +338,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
   rc = rc ? rc : P.alloc(&e->KVimg, MT * 512);
   rc = rc ? rc : P.alloc(&e->KVcimg, 3 * MTe * 512);
   if (rc) return fail(rc);
-  HIP_TRY(hipDeviceSynchronize());
+  if (hipDeviceSynchronize() != hipSuccess) { g_etd_err = "extractor_create: device synchronisation failed"; return fail(ETD_EHIP); }
   *out = e;
   return ETD_OK;
 }

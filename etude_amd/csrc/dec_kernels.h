@@ -2,6 +2,12 @@
 #pragma once
 #include "common.h"
 
+// Row counts: a batched PREFILL of more than DS_MAX_ROWS rows runs on the big-tile MFMA GEMMs, anything smaller on the weight-streaming
+// skinny tile; a decode STEP stays on the fused step kernels (skinny tiles, split-K slabs) up to DS_STEP_MAX_ROWS rows -- 1 728 streams is
+// BASELINE configs[4]'s whole 64-clip x 27-tuple grid in one launch per kernel.
+#define DS_MAX_ROWS 512
+#define DS_STEP_MAX_ROWS 2048
+
 // per-row metadata of a forward pass over M rows (prefill: one stream, T rows; decode: one row per stream)
 struct DecRows {
   const int* slot;     // [M] KV slot of the row
@@ -61,6 +67,7 @@ struct DHeadArgs {
   const float* g1; const float* b1; const float* g2; const float* b2;   // layer 0 LayerNorms
   float* h; bf16* x1; bf16* x2;                // next step's embeddings [M][H] and their LayerNorms
   const DSampleCfg* samp; const unsigned long long* rng_key;   // [slots]; samp == null -> greedy
+  float* logits_dbg;                           // test hook (etd_debug_decoder_step_logits): [M][V] logits of this step, null in production graphs
 };
 int launch_dstep_head(const DHeadArgs& a, hipStream_t st);
 
@@ -79,6 +86,8 @@ struct DAttnArgs {
   const bf16* dense_w;           // [heads][512][64]: per head, the [out][64] slice of attention.dense (contiguous 64 KiB)
   float* dense_out;              // [heads][M][512] fp32 partial sums = split-K slabs of k_resid_ln_rows
   float* dbg;                    // diagnostic (step trace): [heads][M][256 lanes][8] = lr, mr, o[0] after the key loop, lr after merge stages 8 / 16 / 32
+  unsigned long long* stamp;     // k_dstep_attn_down, measurement (null in production graphs): device-side span accumulator, layout at the kernel
+  int stamp_par;                 // bank of this launch (layer & 1)
 };
 int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st);
 // k_dstep_attn_down with the row kernel folded in: every contributor of a row's split-K slabs (its 8 attention workgroups, the

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 // tiles reduced through LDS in a fixed order (bit-reproducible).  (N/32) x (M/32) workgroups keep many
 // more CUs streaming weights than the 128-feature tile does when M is a handful of decode rows.
 // ================================================================================================
-#define DS_MAX_ROWS 512   // up to this many rows a GEMM runs on the weight-streaming skinny tile (decode steps of <= 512 streams)
+// (DS_MAX_ROWS / DS_STEP_MAX_ROWS: dec_kernels.h)
 #ifndef DS_WAVES
 #define DS_WAVES 2
 #endif
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
 }
 
 int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st) {
-  if (q.M != up.M || q.K != up.K || q.M < 1 || q.M > DS_MAX_ROWS || !q.Xb || !up.Xb || !up.Yb || q.K != 512 || q.Npad % 32 || up.Npad % 32 ||
+  if (q.M != up.M || q.K != up.K || q.M < 1 || q.M > DS_STEP_MAX_ROWS || !q.Xb || !up.Xb || !up.Yb || q.K != 512 || q.Npad % 32 || up.Npad % 32 ||
       q.rot_half != 8 || q.N % 192 || q.Qb || !q.Q || !q.bias || !up.bias || up.N % 4)
     ETD_FAIL(ETD_EINVAL, "dstep_qkv_up: bad arguments");
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
@@ -678,6 +678,12 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
   }
   __syncthreads();
   HSTAMP(2);
+  if (a.logits_dbg) {                      // test hook: this step's logits, row-major [M][V]
+    for (int i = tid; i < 32 * a.V; i += 512) {
+      const int rr = i / a.V, f = i - rr * a.V;
+      if (m0 + rr < a.M) a.logits_dbg[(long long)(m0 + rr) * a.V + f] = Ls[rr * DH_LDL + f];
+    }
+  }
   // ---- per row: token choice and state update (registers + LDS only), then ONE round trip for the four word-embedding rows
   // ---- token choice, then the state update with ONE LANE PER ROW (lanes 0..3): the fields are gathered from the two
   // load registers by cross-lane reads, and the stores go out per lane.  (Four scalar copies of this ran the kernel out of SGPRs.)
@@ -922,7 +928,8 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
   if (a.M <= 0 || a.Npad % 128 || a.K % 256 || a.N > a.Npad) ETD_FAIL(ETD_EINVAL, "dgemm: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
   if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "dgemm: QKV epilogue needs head_dim 64 and rotary_ndims 16");
   if (epi == DEPI_RESID && (a.N % 4)) ETD_FAIL(ETD_EINVAL, "dgemm: resid needs N %% 4 == 0");
-  const int path = a.M == 1 ? 2 : (a.M <= DS_MAX_ROWS ? 1 : 0);
+  // (a split-K request is a decode-step / last-rows GEMM: skinny tile up to DS_STEP_MAX_ROWS rows)
+  const int path = a.M == 1 ? 2 : (a.M <= DS_MAX_ROWS || (epi == DEPI_PARTIAL && a.M <= DS_STEP_MAX_ROWS) ? 1 : 0);
   if (epi == DEPI_PARTIAL && (path != 1 || a.k_splits < 1 || (a.K / a.k_splits) % (64 * DS_WAVES) || !a.Y)) ETD_FAIL(ETD_EINVAL, "dgemm: bad split-K request");
   if (epi != DEPI_PARTIAL && a.k_splits > 1) ETD_FAIL(ETD_EINVAL, "dgemm: k_splits needs DEPI_PARTIAL");
   ProfScope ps(path == 2 ? "k_dgemv" : (path == 1 ? "k_dgemm_s" : "k_dgemm"), st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * (w_bf16 ? 2 : 4));
@@ -1435,9 +1442,9 @@ template <> struct AdOcc<4> { static constexpr int lo = ETD_AD_OCC, hi = 8; };
 #define ETD_FIN_OCC 4      // waves per SIMD the row-finish instantiation is built for (128 registers).  Job-level (bench.py, r2_run27.sh): 4 -> 567, 5 -> 552, 6 -> 515-522 audio-s/s; at 7 (72 registers) the key loop spills
 #endif
 template <int NW, bool FIN, bool PAIR = false>      // PAIR (NW = 8 threads-wise): attention workgroups hold two rows of a head, 4 waves each (dattn_core<PAIR>)
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? ETD_FIN_OCC : (PAIR ? ETD_AD_OCC : AdOcc<NW>::lo), AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
-                                                         int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
-                                                         DAttnArgs a, DGemmArgs g, DRowFin fin) {
+__device__ __forceinline__ void dstep_attn_down_body(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+                                                     int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
+                                                     const DAttnArgs& a, const DGemmArgs& g, const DRowFin& fin) {
   constexpr int UNITS = NW / 2;
   __shared__ float red[NW][8][10];
   __shared__ float osh[PAIR ? 128 : 64];
@@ -1542,6 +1549,37 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? E
   }
 }
 
+// The launch itself.  `a.stamp` (null in every production graph): device-side span of THIS launch -- first workgroup's start to last
+// workgroup's end on s_memrealtime (100 MHz, one clock for the whole chip) -- which is what a rocprofv3 kernel trace reports and what HIP
+// events cannot give inside a hipGraph replay.  Cheap by construction (a 1 800-workgroup launch must not queue 5 000 atomics on one
+// address): block 0 stores the start; every workgroup folds its end into ONE of 64 slots with a fire-and-forget atomicMax; the slots
+// alternate between two banks by launch parity (a.stamp_par = layer & 1: consecutive launches of an engine differ), and wave 0 of block 0
+// of the NEXT stamped launch -- the previous one is complete by stream order -- takes the maximum of the other bank, adds end - start to
+// the running sum and re-arms the bank.  The host folds the last launch in (etd_decoder_stats).
+// Layout (u64): [0] sum of spans, [1] launches, [2 + bank] start, [8 + 64 bank + i] end slots.
+template <int NW, bool FIN, bool PAIR = false>
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? ETD_FIN_OCC : (PAIR ? ETD_AD_OCC : AdOcc<NW>::lo), AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
+                                                         int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
+                                                         DAttnArgs a, DGemmArgs g, DRowFin fin) {
+  unsigned long long* const stp = a.stamp;
+  if (stp && blockIdx.x == 0 && threadIdx.x < 64) {
+    const int bank = a.stamp_par & 1, prev = bank ^ 1, lane = threadIdx.x;
+    const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    unsigned long long e = atomicExch(stp + 8 + 64 * prev + lane, 0ull);          // read-and-clear at L2, 64 slots in one round trip
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(e, o, 64); e = x > e ? x : e; }
+    if (lane == 0) {
+      const unsigned long long s0 = atomicExch(stp + 2 + prev, 0ull);
+      if (s0 != 0 && e > s0) { atomicAdd(stp, e - s0); atomicAdd(stp + 1, 1ull); }
+      atomicExch(stp + 2 + bank, now);
+    }
+  }
+  dstep_attn_down_body<NW, FIN, PAIR>(p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, p_gemm_wgs, p_M, a, g, fin);
+  if (stp) {
+    __syncthreads();                     // every wave of the workgroup is back from the body (its early exits return here)
+    if (threadIdx.x == 0) atomicMax(stp + 8 + 64 * (a.stamp_par & 1) + (blockIdx.x & 63), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+}
+
 // waves per attention workgroup: 4, or ETD_AD_WAVES = 8 / 16 (measurement builds).  Measured on MI355X, round 2 (tools/runs/r2_run1.sh):
 // 54 rows x ctx 320, one engine: 0.197 / 0.230 / 0.238 ms per step at 4 / 8 / 16 waves, four engines 9.98 / 9.17 / 8.21
 // engine-steps per ms; 128 rows x ctx 512: 0.356 / 0.349 / 0.419 ms; 128 rows x ctx 3.5 k: 1.290 / 1.343 / 1.362 ms.  Requesting a
@@ -1557,7 +1595,7 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
   if (fin && (!fin->cnt || fin->target != a.n_heads + 16 * g.k_splits || fin->nslab != 12 || g.k_splits + a.n_heads != 12 || fin->P != g.Y ||
               a.dense_out != g.Y + (size_t)g.k_splits * a.M * 512 || !fin->bias || !fin->hin || !fin->hout || fin->hin == fin->hout || (fin->x1 && (!fin->x2 || !fin->g1 || !fin->b1 || !fin->g2 || !fin->b2))))
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad row-finish arguments");
-  if (a.M < 1 || a.M > DS_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 256 ||
+  if (a.M < 1 || a.M > DS_STEP_MAX_ROWS || a.n_heads < 1 || !a.row_sp || !a.dense_w || !a.dense_out || a.max_ctx < 256 ||
       g.M != a.M || !g.Xb || !g.W || !g.Y || g.ldy != 512 || g.N != 512 || g.Npad != 512 || g.k_splits < 1 || g.k_splits * 512 > g.K || (g.K % 8) || a.n_heads * 64 != 512)
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad arguments");
   // two rows of a head per 8-wave attention workgroup, the head's dense slice read once per pair (ETD_AD_PAIR=0: always one row per 4-wave workgroup).

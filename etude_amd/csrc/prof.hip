@@ -5,7 +5,7 @@
 #include <mutex>
 #include <vector>
 
-#include "../../include/etude_hip.h"
+#include "../../include/etude_hip_debug.h"
 #include "ext_kernels.h"
 #include "dec_kernels.h"
 

@@ -10,7 +10,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/etude_hip.h"
+#include "../../include/etude_hip_debug.h"
 #include "common.h"
 
 namespace {
@@ -67,6 +67,7 @@ extern "C" int etd_debug_assemble_prompt(const etd_sched_cfg* cfg, int n_hist, c
                                          const int32_t* const* hy, const int32_t* hyn, const int32_t* hattrs4, const int32_t* x, int xn,
                                          const int32_t* y_attrs4, int32_t* ids_out, int32_t* cls_out, int32_t* attrs4_out, int cap, int* T_out) {
   if (!cfg || n_hist < 0 || !x || !y_attrs4 || !ids_out || !cls_out || !attrs4_out || !T_out) ETD_FAIL(ETD_EINVAL, "assemble_prompt: bad arguments");
+  if (cfg->struct_bytes != (int)sizeof(etd_sched_cfg)) ETD_FAIL(ETD_EINVAL, "assemble_prompt: etd_sched_cfg of %d bytes, expected %d", cfg->struct_bytes, (int)sizeof(etd_sched_cfg));
   const int32_t offs[2] = {0, xn};
   etd_job j{x, offs, 1, y_attrs4, nullptr};
   Job jb; jb.j = &j; jb.bar = 0;
@@ -87,6 +88,7 @@ extern "C" int etd_debug_assemble_prompt(const etd_sched_cfg* cfg, int n_hist, c
 extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const etd_job* jobs, int n_jobs, int32_t* out, long long out_cap,
                                     long long* job_offsets, long long* n_steps_out, void* stream) {
   if (!d || !cfg || !jobs || n_jobs < 1 || !out || !job_offsets) ETD_FAIL(ETD_EINVAL, "run_jobs: bad arguments");
+  if (cfg->struct_bytes != (int)sizeof(etd_sched_cfg)) ETD_FAIL(ETD_EINVAL, "run_jobs: etd_sched_cfg of %d bytes, this library (ABI %d) expects %d -- caller built against another etude_hip.h", cfg->struct_bytes, ETD_ABI_VERSION, (int)sizeof(etd_sched_cfg));
   const etd_sched_cfg& c = *cfg;
   if (c.max_streams < 1 || c.n_ctx_pairs < 0 || c.max_bar_token_limit < 1 || c.max_prefill_rows < 1 || c.steps_per_poll < 1)
     ETD_FAIL(ETD_EINVAL, "run_jobs: bad scheduler config");

@@ -58,6 +58,31 @@ class EtudeDecoderConfig:
             return cls(**json.load(f))
 
 
+class PackedBars:
+    """Condition bars of one song as arrays: ``ids`` int32 (all bars back to back) + ``offsets`` int32 [n_bars + 1].  Shared by every
+    attribute-tuple job of the song, so a 27-tuple grid converts its bars once."""
+
+    def __init__(self, ids: np.ndarray, offsets: np.ndarray):
+        self.ids = np.ascontiguousarray(ids, np.int32)
+        self.offsets = np.ascontiguousarray(offsets, np.int32)
+        if self.offsets.ndim != 1 or self.offsets.size < 1 or int(self.offsets[0]) != 0 or int(self.offsets[-1]) != self.ids.size or (np.diff(self.offsets) < 0).any():
+            raise ValueError("PackedBars: offsets must rise from 0 to len(ids)")
+        self.checked_for = None
+
+    @classmethod
+    def from_lists(cls, bars: Sequence[Sequence[int]]) -> "PackedBars":
+        lens = np.asarray([len(b) for b in bars], np.int64)
+        offs = np.zeros(len(bars) + 1, np.int32)
+        offs[1:] = np.cumsum(lens)
+        return cls(np.concatenate([np.asarray(b, np.int32) for b in bars]) if len(bars) else np.zeros(0, np.int32), offs)
+
+    def __len__(self) -> int:
+        return int(self.offsets.size) - 1
+
+    def bar(self, i: int) -> List[int]:
+        return self.ids[self.offsets[i]: self.offsets[i + 1]].tolist()
+
+
 class EtudeDecoder:
     """GPU-resident EtudeDecoder.  ``state`` maps the reference's state-dict keys to fp32 arrays."""
 
@@ -133,9 +158,13 @@ class EtudeDecoder:
         except Exception as e:  # etude_decoder.py:225-232
             print(f"[etude_amd] ERROR Accessing vocab/config: {e}")
             return None
-        if not all_x_bars or len(all_x_bars) != len(target_attributes_per_bar):
+        if all_x_bars is None or len(all_x_bars) == 0 or target_attributes_per_bar is None or len(all_x_bars) != len(target_attributes_per_bar):
             print("[etude_amd] ERROR Condition bars mismatch with target attributes.")
             return None
+        if isinstance(target_attributes_per_bar, np.ndarray):
+            if target_attributes_per_bar.ndim != 2 or target_attributes_per_bar.shape[1] != 4:
+                raise TypeError("attribute array must be [n_bars, 4] in ABI_ATTR_KEYS order")
+            return bos, eos
         missing = [k for k in ABI_ATTR_KEYS if k not in target_attributes_per_bar[0]]
         if missing:   # the reference's forward() would raise TypeError for the missing positional tensors
             raise TypeError(f"generate() missing attribute keys {missing}")
@@ -169,7 +198,7 @@ class EtudeDecoder:
                       max_bar_token_limit: int = 512, context_overlap_ratio: float = 0.5, steps_per_poll: int = 8,
                       _validate: bool = True, stats: Optional[dict] = None, force_bar_tokens: int = 0,
                       ready: Optional[Tuple[np.ndarray, Sequence[int]]] = None, temperature: float = 0.0, top_p: float = 0.9,
-                      seed: Optional[int] = None, _job_key: Tuple[int, int] = (0, 1)) -> List[List[List[int]]]:
+                      seed: Optional[int] = None, _job_key: Tuple[int, int] = (0, 1), as_arrays: bool = False) -> List[List[List[int]]]:
         """Greedy-decode many independent jobs on up to ``max_streams`` concurrent device streams.
 
         The bar loop (prompt assembly, history, truncation, token budget, EOS stop) runs in the library's native
@@ -178,14 +207,19 @@ class EtudeDecoder:
         throughput does not depend on where synthetic weights happen to emit EOS.
         ``ready=(flags, index)`` gates admission on upstream pipeline stages: ``flags`` is an int32 array another thread sets
         non-zero (e.g. one entry per song, set when its extract..tokenize stages are done) and job i waits for
-        ``flags[index[i]]``; jobs are admitted in list order."""
+        ``flags[index[i]]``; jobs are admitted in list order.
+
+        Batch fast paths (no per-bar Python objects; what bench.py's 1 728-job batches use): a job's condition bars may be a
+        ``PackedBars`` (one int32 id array + bar offsets, shared by all attribute tuples of a song) and its attributes an
+        ``int32 [n_bars, 4]`` array in ``ABI_ATTR_KEYS`` order; ``as_arrays=True`` returns each job as ``(flat_ids, bar_lens)``
+        instead of a list of lists."""
         lib = _lib.lib()
         if not temperature >= 0:
             raise ValueError("temperature must be >= 0")
         lim = int(force_bar_tokens or max_bar_token_limit)
-        need = self.ctx_needed(lim, context_overlap_ratio)
+        need = self.ctx_needed(max_bar_token_limit, context_overlap_ratio, gen_limit=lim)
         if need > self.max_ctx:
-            raise _lib.EtudeHipError(f"generate: max_bar_token_limit={lim} with context_overlap_ratio={context_overlap_ratio} needs {need} KV positions "
+            raise _lib.EtudeHipError(f"generate: max_bar_token_limit={max_bar_token_limit} (bars of up to {lim} generated tokens) with context_overlap_ratio={context_overlap_ratio} needs {need} KV positions "
                                      f"per stream, this decoder was created with max_ctx={self.max_ctx}; pass max_ctx>={need} to EtudeDecoder / load_etude_decoder")
         if seed is None:
             self._draw_calls = getattr(self, "_draw_calls", 0) + 1
@@ -201,7 +235,7 @@ class EtudeDecoder:
         for ji, (x_bars, attrs) in enumerate(jobs):
             v = self._validate(vocab, x_bars, attrs)
             if v is None:
-                results[ji] = []
+                results[ji] = (np.zeros(0, np.int32), np.zeros(0, np.int64)) if as_arrays else []
                 continue
             bos, eos = v
             live.append(ji)
@@ -211,13 +245,23 @@ class EtudeDecoder:
             cap = 0
             for k, ji in enumerate(live):
                 x_bars, attrs = jobs[ji]
-                lens = np.asarray([len(b) for b in x_bars], np.int64)
-                offs = np.zeros(len(x_bars) + 1, np.int32)
-                offs[1:] = np.cumsum(lens)
-                xi = np.ascontiguousarray(np.concatenate([np.asarray(b, np.int32) for b in x_bars]) if len(x_bars) else np.zeros(0, np.int32))
-                a4 = np.ascontiguousarray(np.asarray([[a[key] for key in ABI_ATTR_KEYS] for a in attrs], np.int32).reshape(-1, 4))
-                if xi.size and (xi.min() < 0 or xi.max() >= cfg.vocab_size):
-                    raise IndexError("token id out of range in all_x_bars")
+                if isinstance(x_bars, PackedBars):
+                    xi, offs = x_bars.ids, x_bars.offsets
+                    if not x_bars.checked_for == cfg.vocab_size:
+                        if xi.size and (xi.min() < 0 or xi.max() >= cfg.vocab_size):
+                            raise IndexError("token id out of range in all_x_bars")
+                        x_bars.checked_for = cfg.vocab_size
+                else:
+                    lens = np.asarray([len(b) for b in x_bars], np.int64)
+                    offs = np.zeros(len(x_bars) + 1, np.int32)
+                    offs[1:] = np.cumsum(lens)
+                    xi = np.ascontiguousarray(np.concatenate([np.asarray(b, np.int32) for b in x_bars]) if len(x_bars) else np.zeros(0, np.int32))
+                    if xi.size and (xi.min() < 0 or xi.max() >= cfg.vocab_size):
+                        raise IndexError("token id out of range in all_x_bars")
+                if isinstance(attrs, np.ndarray):
+                    a4 = np.ascontiguousarray(attrs, np.int32).reshape(-1, 4)
+                else:
+                    a4 = np.ascontiguousarray(np.asarray([[a[key] for key in ABI_ATTR_KEYS] for a in attrs], np.int32).reshape(-1, 4))
                 keep += [offs, xi, a4]
                 gate = None
                 if ready is not None:
@@ -247,7 +291,7 @@ class EtudeDecoder:
                 lens = rec[1:1 + nb].astype(np.int64)
                 flat = rec[1 + nb:]
                 ends = np.cumsum(lens)
-                results[ji] = [flat[e - l: e].tolist() for l, e in zip(lens.tolist(), ends.tolist())]
+                results[ji] = (flat.copy(), lens) if as_arrays else [flat[e - l: e].tolist() for l, e in zip(lens.tolist(), ends.tolist())]
                 n_tokens += int(lens.sum()) - nb
             if stats is not None:
                 stats["steps"] = int(nsteps.value)
@@ -256,11 +300,13 @@ class EtudeDecoder:
             stats["steps"] = stats["tokens"] = 0
         return results  # type: ignore[return-value]
 
-    def ctx_needed(self, max_bar_token_limit: int, context_overlap_ratio: float) -> int:
-        """KV positions a bar can touch under generate()'s truncation rule (etude_decoder.py:285-300)."""
+    def ctx_needed(self, max_bar_token_limit: int, context_overlap_ratio: float, gen_limit: Optional[int] = None) -> int:
+        """KV positions a bar can touch under generate()'s truncation rule (etude_decoder.py:285-300): the prompt bound follows
+        ``max_bar_token_limit`` (what the scheduler truncates with), the generated length ``gen_limit`` (= the limit unless a benchmark
+        forces longer / shorter bars)."""
         mp = int(self.config.max_position_embeddings)
         prompt = max(mp - int(max_bar_token_limit), int(mp * float(context_overlap_ratio))) + 1
-        return prompt + int(max_bar_token_limit) - 1
+        return prompt + int(gen_limit if gen_limit is not None else max_bar_token_limit) - 1
 
     # ------------------------------------------------------------------ test / bench hooks
     def prefill_logits(self, ids, cls, attrs4, slot: int = 0) -> np.ndarray:
@@ -276,6 +322,33 @@ class EtudeDecoder:
 
     def step_bytes(self, n_streams: int, ctx: int) -> float:
         return float(_lib.lib().etd_decoder_step_bytes(self._h, n_streams, ctx))
+
+    STAT_KEYS = ("steps", "row_steps", "kv_bytes", "attn_launches", "stamped_launches", "stamped_seconds", "stamped_alg_bytes", "weight_bytes_per_step")
+
+    def stats(self) -> Dict[str, float]:
+        """Exact accounting of the decode steps issued since `stats_reset` (etd_decoder_stats): steps, rows x steps, algorithmic
+        K/V bytes, attention launches, and -- when `stamp(True)` was on -- the device-measured duration of those launches."""
+        out = (C.c_double * 8)()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().etd_decoder_stats(self._h, out, 8, self._stream()), "etd_decoder_stats")
+        return dict(zip(self.STAT_KEYS, [float(x) for x in out]))
+
+    def stats_reset(self) -> None:
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().etd_decoder_stats_reset(self._h, self._stream()), "etd_decoder_stats_reset")
+
+    def stamp(self, on: bool) -> None:
+        """Device-side span measurement of every k_dstep_attn_down launch (measurement runs only; own captured graphs)."""
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().etd_decoder_stamp(self._h, 1 if on else 0, self._stream()), "etd_decoder_stamp")
+
+    def debug_step_logits(self, on: bool, n_active: int = 0) -> Optional[np.ndarray]:
+        """Test hook: switch the per-step logit store on / off; with n_active > 0 also return the LAST step's logits [n_active, V]."""
+        out = np.zeros((n_active, self.config.vocab_size), np.float32) if n_active > 0 else None
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().etd_debug_decoder_step_logits(self._h, 1 if on else 0, out.ctypes.data if out is not None else None, n_active, self._stream()),
+                       "etd_debug_decoder_step_logits")
+        return out
 
     def close(self):
         if getattr(self, "_h", None):

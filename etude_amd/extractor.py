@@ -309,16 +309,20 @@ class AMTAPC_Extractor:
     def debug_tap(self, stage: int, buf: Optional[torch.Tensor]):
         _lib.check(_lib.lib().etd_extractor_debug_tap(self._h, stage, buf.data_ptr() if buf is not None else None), "debug_tap")
 
-    def extract_notes(self, wave: Union[np.ndarray, torch.Tensor], sr: int, min_duration: Optional[float] = None) -> List[dict]:
-        """wav -> note dicts (everything extract() does except the file I/O).  With ``min_duration`` the
-        ``_note2json`` filter (extractor.py:435-437) is applied before the Python objects are built."""
+    def extract_note_array(self, wave: Union[np.ndarray, torch.Tensor], sr: int, min_duration: Optional[float] = None) -> np.ndarray:
+        """wav -> NOTE_DTYPE array: everything extract() does except the file I/O, no per-note Python objects.  With
+        ``min_duration`` the ``_note2json`` filter (extractor.py:435-437) is applied: the array is then what extract.json lists."""
         feat = self.wav2feature_tensor(wave, sr)
         on, off, mpe, vel = self.transcript(feat)
         inf = self.config.infer
         arr = self.mpe2note_device(on, off, mpe, vel, inf.onset_threshold, inf.offset_threshold, inf.frame_threshold)
         if min_duration is not None:
             arr = arr[~((arr["offset"] - arr["onset"]) < min_duration)]
-        return self._notes_from_array(arr)
+        return arr
+
+    def extract_notes(self, wave: Union[np.ndarray, torch.Tensor], sr: int, min_duration: Optional[float] = None) -> List[dict]:
+        """`extract_note_array` as the note dicts the reference handles."""
+        return self._notes_from_array(self.extract_note_array(wave, sr, min_duration))
 
     def extract_many(self, audio_paths: Sequence[str], output_json_paths: Sequence[str]) -> None:
         for a, o in zip(audio_paths, output_json_paths):

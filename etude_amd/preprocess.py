@@ -23,6 +23,37 @@ from .extractor import read_wav
 from .frontend import FrontEnd
 
 
+class VolumeAnalyzer:
+    """`volume_contour_tensor` for many clips of one sample rate: the resampler tables are built once (batch serving)."""
+
+    def __init__(self, sr_in: int, sr: int = 22050, resolution: int = 20, device="cuda"):
+        self.dev = torch.device(device)
+        self.sr, self.resolution = int(sr), int(resolution)
+        with torch.cuda.device(self.dev):
+            self.fe = FrontEnd(int(sr_in), sr_out=int(sr), pad_mode="constant")
+
+    def __call__(self, wave: Union[np.ndarray, torch.Tensor]) -> np.ndarray:
+        w = torch.as_tensor(wave, dtype=torch.float32)
+        if w.dim() == 1:
+            w = w[None]
+        w = w.to(self.dev).contiguous()
+        with torch.cuda.device(self.dev):
+            self.fe(w)                                      # mono mean + resample (the mel output of this call is not used)
+            y = self.fe.last_resampled
+            hop = self.sr // self.resolution
+            T = 1 + y.numel() // hop
+            out = torch.empty(T, dtype=torch.float32, device=self.dev)
+            st = torch.cuda.current_stream(self.dev).cuda_stream
+            _lib.check(_lib.lib().etd_rms_frames(y.data_ptr(), y.numel(), 2 * hop, hop, out.data_ptr(), T, C.c_void_p(st)), "etd_rms_frames")
+            rms = out.cpu().numpy()
+        if rms.size and rms.max() > rms.min():
+            return (rms - rms.min()) / (rms.max() - rms.min())
+        return np.zeros_like(rms)
+
+    def close(self):
+        self.fe.close()
+
+
 def volume_contour_tensor(wave: Union[np.ndarray, torch.Tensor], sr_in: int, sr: int = 22050, resolution: int = 20, device="cuda") -> np.ndarray:
     """[C, L] (or [L]) float32 audio -> normalised RMS contour, float32 [1 + L_resampled // hop]."""
     dev = torch.device(device)

@@ -193,6 +193,48 @@ def decoder_state_dict(seed: int = 0, dims: Dict[str, int] | None = None, gain: 
     return sd
 
 
+def decoder_state_dict_ctx(seed: int = 0, dims: Dict[str, int] | None = None, follow: float = 1.0, p_eos: float = 0.08, qk_gain: float = 6.0,
+                           v_gain: float = 2.0, out_gain: float = 2.0, emb_gain: float = 2.0) -> Dict[str, np.ndarray]:
+    """Seeded weights whose GREEDY PATH DEPENDS ON THE CONTEXT (the parity goldens `decoder_ctx` / `clip_ctx`).
+
+    `decoder_state_dict`'s successor map is a random function, whose walks fall into a cycle of ~8 tokens, and its deflections always
+    land on the same few tokens (the common-mode part of the final hidden state): the greedy ids of the round-1/2 goldens are 94 % two
+    alternating tokens, which a fault in the long-range part of the computation would rarely flip.  Here
+      * the successor map is ONE long cycle over the non-special tokens (a random permutation), with a fraction `p_eos` of the tokens
+        sent to Bar_EOS instead, so an undisturbed walk visits the whole vocabulary and bars end;
+      * query / key projections are scaled by `qk_gain` (sharp, content-addressed attention: which past token a head locks onto changes
+        from step to step and with every change of the context), values and the two output projections by `v_gain` / `out_gain`, so
+        what attention retrieves is as large in the residual stream as the current token's embedding.
+    Measured on the configs[1] condition bars (tests/golden/README): ~44-55 % of the ids are predictable from the previous one, 60+ distinct
+    ids per 16 bars, most bars end in Bar_EOS; dropping a key block, a wrong RoPE position or a wrong row changes the ids within a few tokens."""
+    d = decoder_dims(**(dims or {}))
+    sd = decoder_state_dict(seed, dims, gain=1.0, emb_gain=emb_gain, follow=0.0)
+    H, V, nh = d["hidden_size"], d["vocab_size"], d["num_attention_heads"]
+    hd = H // nh
+    for i in range(d["num_hidden_layers"]):
+        p = f"transformer.layers.{i}."
+        w = sd[p + "attention.query_key_value.weight"].reshape(nh, 3, hd, H)          # HF layout: per head [q | k | v]
+        b = sd[p + "attention.query_key_value.bias"].reshape(nh, 3, hd)
+        w[:, :2] *= qk_gain; b[:, :2] *= qk_gain
+        w[:, 2] *= v_gain; b[:, 2] *= v_gain
+        sd[p + "attention.dense.weight"] *= out_gain
+        sd[p + "mlp.dense_4h_to_h.weight"] *= out_gain
+    rng = np.random.default_rng(seed + 2000)
+    perm = rng.permutation(np.arange(6, V))
+    f = np.zeros(V, np.int64)
+    f[perm] = np.roll(perm, -1)
+    f[:6] = perm[:6]
+    f[rng.random(V) < p_eos] = 5                        # id of Bar_EOS in vocab_tokens()
+    W = sd["lm_head.weight"].copy()
+    E = sd["word_embeddings.weight"]
+    En = E / (np.linalg.norm(E, axis=1, keepdims=True) + 1e-6)
+    sc = follow * float(np.linalg.norm(W, axis=1).mean())
+    for i in range(V):
+        W[f[i]] += sc * En[i]
+    sd["lm_head.weight"] = W.astype(np.float32)
+    return sd
+
+
 def vocab_tokens(n_pos: int = 48) -> Tuple[List[str], List[str]]:
     """A REMI-like vocabulary shaped like the reference tokenizer's events (etude/data/tokenizer.py:253-297):
     specials, Bar_BOS/EOS, Pos_k, Note_21..108, Duration_{allowed 16ths}, Grace_{1,-1}.  154 tokens at n_pos=48."""

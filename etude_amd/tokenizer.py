@@ -43,11 +43,27 @@ class TinyREMITokenizer:
         self.all_events: List[Event] = []
         if tempo_path and Path(tempo_path).exists():
             with open(tempo_path, "r") as f:
-                self.tempo_data = json.load(f)
+                tempo_data = json.load(f)
         else:
-            self.tempo_data = []
+            tempo_data = []
         self.time_resolution_for_map = 20
+        self._h = None
+        self.set_tempo(tempo_data)
+
+    @classmethod
+    def from_tempo_data(cls, tempo_data: Sequence[dict]) -> "TinyREMITokenizer":
+        """The tokenizer of an in-memory tempo.json (list of regions) -- batch pipelines hand it over without a file."""
+        tk = cls(None)
+        tk.set_tempo(tempo_data)
+        return tk
+
+    def set_tempo(self, tempo_data: Sequence[dict]) -> None:
+        """(Re)build the measure grid from tempo.json content (tokenizer.py:24-41, 166-229)."""
         lib = _lib.lib()
+        if getattr(self, "_h", None):
+            lib.etd_tok_destroy(self._h)
+            self._h = None
+        self.tempo_data = list(tempo_data) if tempo_data else []
         self._keep = []
         regs = (_lib.TempoRegion * max(1, len(self.tempo_data)))()
         for i, r in enumerate(self.tempo_data):
@@ -138,6 +154,50 @@ class TinyREMITokenizer:
         tab = np.empty(n, dtype=_EVENT_DTYPE)
         tab[:] = _events_to_array([vocab.decode_to_event(i) for i in range(n)])
         return tab
+
+    @staticmethod
+    def id_lookup(vocab) -> np.ndarray:
+        """Inverse of `event_table` for `encode`'s output: int32 [5, 4096] with ``lut[type, value + 2048]`` = what
+        ``vocab.encode(Event(type, value))`` returns (the UNK id for events the vocabulary does not hold, vocab.py:51-56)."""
+        unk = vocab.token_to_id.get("<UNK>")
+        lut = np.full((5, 4096), -1 if unk is None else int(unk), np.int32)
+        for tok, i in vocab.token_to_id.items():
+            t, _, v = tok.rpartition("_")
+            if t == "Bar" and v in ("BOS", "EOS"):
+                lut[0, 2048 + (1 if v == "BOS" else 0)] = i
+            elif t in _EV_TYPES[1:]:
+                try:
+                    iv = int(v)
+                except ValueError:
+                    continue
+                if -2048 <= iv < 2048 and str(iv) == v:
+                    lut[_EV_TYPES.index(t), 2048 + iv] = i
+        return lut
+
+    @staticmethod
+    def events_to_ids(ev: np.ndarray, lut: np.ndarray) -> np.ndarray:
+        """`vocab.encode_sequence(events)` (infer.py:182) on an event array from `encode_note_array_to_events`."""
+        t, v = ev["type"].astype(np.int64), ev["value"].astype(np.int64)
+        if ev.size and (t.min() < 0 or t.max() > 4 or v.min() < -2048 or v.max() >= 2048):
+            raise ValueError("events_to_ids: event outside the tokenizer's types / value range")
+        ids = lut[t, v + 2048]
+        if ev.size and ids.min() < 0:
+            raise ValueError("Token is not in the vocabulary, and no '<UNK>' is defined")
+        return ids
+
+    @staticmethod
+    def split_ids_into_packed_bars(ids: np.ndarray, bar_bos_id: int, bar_eos_id: int):
+        """`split_sequence_into_bars` (tokenizer.py:43-76) returning (ids int32, offsets int32 [n_bars + 1]) -- the arrays a
+        `decoder.PackedBars` holds."""
+        ids = np.ascontiguousarray(ids, np.int32)
+        n = int(ids.size)
+        out = np.empty(n + 1, np.int32)
+        offs = np.empty(n + 2, np.int64)
+        nb = C.c_longlong()
+        _lib.check(_lib.lib().etd_tok_split_bars(ids.ctypes.data, n, int(bar_bos_id), int(bar_eos_id), out.ctypes.data, n + 1, offs.ctypes.data, n + 2,
+                                                 C.byref(nb)), "etd_tok_split_bars")
+        k = int(nb.value)
+        return out[: int(offs[k])].copy(), offs[: k + 1].astype(np.int32)
 
     def decode_ids_to_note_array(self, ids: Sequence[int], table: np.ndarray, volume: Optional[np.ndarray] = None, pad_id: int = 0) -> np.ndarray:
         """`decode_to_notes(vocab.decode_sequence_to_events(ids))` as arrays: token ids -> NOTE_DTYPE array (same notes, same order)."""

@@ -34,7 +34,10 @@
 extern "C" {
 #endif
 
-#define ETD_ABI_VERSION 1
+/* ABI history: 1 = rounds 1-2 (etd_ext_cfg without `precision` / etd_sched_cfg without the job keys in its first builds);
+ * 2 = round 3: struct_bytes leads every config struct, so a caller compiled against another layout is refused instead of misread;
+ * etd_decoder_stats / _stats_reset / _stamp added; the diagnostic hooks moved to etude_hip_debug.h. */
+#define ETD_ABI_VERSION 2
 #define ETD_OK 0
 #define ETD_EINVAL (-22)
 #define ETD_ENOMEM (-12)
@@ -55,16 +58,6 @@ int etd_prof_reset(void);
 int etd_prof_collect(void);
 int etd_prof_count(void);
 int etd_prof_entry(int i, char* name, int name_cap, double* total_ms, long long* launches, double* flops, double* bytes);
-
-/* measurement hook: device time per dependent (empty) kernel, launched eagerly vs replayed from a hipGraph */
-int etd_debug_boundary_cost(int n_nodes, int iters, int big_args, void* stream, double* eager_us, double* graph_us);
-/* measurement hook: average time (us) of the token-major bf16 GEMM kernel on a synthetic [M,K] x [N,K]^T problem (N % 256 == 0, K % 128 == 0) */
-int etd_debug_linear(int M, int N, int K, int iters, void* stream, double* us);
-/* Diagnostic aggressors (tools/probe_race.py): `iters` launches of one kernel type on private random buffers:
-   which 0 = k_attn (extractor shape), 1 = k_attn causal ragged (prefill shape), 2 = k_linear with the LayerNorm epilogue, 3 = k_ln_rows. */
-int etd_debug_kernel_loop(int which, int iters, void* stream);
-/* Diagnostic: one launch of an empty kernel with k_embed's footprint (82 KiB static LDS, 296 registers) on the given grid. */
-int etd_debug_empty_launch(int gx, int gy, int gz, int* sink_dev, void* stream);
 
 /* ------------------------------------------------------------------ audio front end */
 typedef struct etd_frontend etd_frontend;
@@ -93,6 +86,7 @@ int etd_frontend_run(etd_frontend*, const float* wav_dev, int channels, long lon
 /* ------------------------------------------------------------------ extractor (hFT-Transformer) */
 typedef struct etd_ext etd_ext;
 typedef struct {
+  int struct_bytes;       /* sizeof(etd_ext_cfg) of the caller: a mismatch is ETD_EINVAL */
   int n_margin, n_frame, n_bin, cnn_channel, cnn_kernel, hid_dim, pf_dim, n_heads;
   int n_layers_enc, n_layers_dec, n_note, n_velocity;
   float min_value;        /* -18.0: padding value of _transcript */
@@ -117,11 +111,6 @@ int etd_transcript(etd_ext*, const float* feat_dev, long long T,
 int etd_transcript_windows(etd_ext*, const float* spec_dev, int B,
                            float* onset_B, float* offset_B, float* mpe_B, int8_t* vel_B,
                            float* onset_A, float* offset_A, float* mpe_A, int8_t* vel_A, void* stream);
-/* test hook: fp32 velocity logits of the time heads [rows][n_note][128] for the NEXT transcript call (NULL = off) */
-int etd_extractor_debug_vel_logits(etd_ext*, float* vel_logits_dev);
-/* test hook: after stage s of the FIRST chunk copy the bf16 activation buffer to dst_dev (NULL = off).
- * 0 embed, 1-3 encoder layers, 4-6 freq-decoder layers [frames*n_note][256], 7 time input, 8-10 time layers. */
-int etd_extractor_debug_tap(etd_ext*, int stage, void* dst_dev);
 /* algorithmic FLOPs of one n_frame window (SURVEY.md 8d formula) */
 double etd_extractor_window_flops(const etd_ext*);
 
@@ -155,6 +144,7 @@ int etd_mpe2note_dev(etd_m2n*, const float* onset_dev, const float* offset_dev, 
 /* ------------------------------------------------------------------ decoder (EtudeDecoder / GPT-NeoX) */
 typedef struct etd_dec etd_dec;
 typedef struct {
+  int struct_bytes;       /* sizeof(etd_dec_cfg) of the caller */
   int vocab_size, hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
   int max_position_embeddings, num_classes, num_attribute_bins, attribute_emb_dim;
   float rotary_pct, rope_theta, layer_norm_eps;
@@ -213,6 +203,7 @@ int etd_decoder_read_many(etd_dec*, int n, const int32_t* slots, int32_t* out, i
  * admits jobs in list order and never reads x_ids/x_offsets/attrs4 of a job before its flag is set. */
 typedef struct { const int32_t* x_ids; const int32_t* x_offsets; int n_bars; const int32_t* attrs4; const int32_t* ready; } etd_job;
 typedef struct {
+  int struct_bytes;       /* sizeof(etd_sched_cfg) of the caller */
   int bar_bos_id, bar_eos_id, n_ctx_pairs, max_position_embeddings, max_output_tokens, max_bar_token_limit;
   float context_overlap_ratio;
   int force_bar_tokens;   /* >0 (benchmarks): suppress Bar_EOS, every bar is exactly this many tokens */
@@ -224,10 +215,6 @@ typedef struct {
 } etd_sched_cfg;
 int etd_decoder_run_jobs(etd_dec*, const etd_sched_cfg* cfg, const etd_job* jobs, int n_jobs, int32_t* out, long long out_cap,
                          long long* job_offsets, long long* n_steps_out, void* stream);
-/* test hook (host only): the prompt etd_decoder_run_jobs builds for a bar given n_hist past (X, Y, attrs4) pairs; attrs4_out is [4][cap] */
-int etd_debug_assemble_prompt(const etd_sched_cfg* cfg, int n_hist, const int32_t* const* hx, const int32_t* hxn, const int32_t* const* hy,
-                              const int32_t* hyn, const int32_t* hattrs4, const int32_t* x, int xn, const int32_t* y_attrs4,
-                              int32_t* ids_out, int32_t* cls_out, int32_t* attrs4_out, int cap, int* T_out);
 /* begin_bar + steps until done + read_tokens for one stream.  Synchronous. */
 int etd_decoder_generate_bar(etd_dec*, int slot, const int32_t* ids, const int32_t* cls, const int32_t* attrs4, int T,
                              const int32_t* tgt_attrs4, int eos_id, int limit, int32_t* out, int* n_out, void* stream);
@@ -236,24 +223,17 @@ int etd_decoder_prefill_logits(etd_dec*, int slot, const int32_t* ids, const int
                                float* logits_host, void* stream);
 /* algorithmic HBM bytes of one decode step for n_streams at context `ctx` (SURVEY.md 8d formula) */
 double etd_decoder_step_bytes(const etd_dec*, int n_streams, int ctx);
-/* Diagnostic (tools/probe_race.py): weighted 64-bit sums over the words of the handle's KV cache, workspaces and stream state:
-   out[0] = everything, out[1 + i] = its i-th allocation (as many as `cap` allows). */
-int etd_debug_decoder_checksum(etd_dec*, unsigned long long* out, int cap, void* stream);
-/* Diagnostic: out[(layer * max_streams + slot) * max_ctx + pos] = 32-bit sum over the K and V rows of that position (bf16 handles). */
-int etd_debug_decoder_kv_rowsums(etd_dec*, unsigned* out_host, long long cap, void* stream);
-/* Diagnostic step trace (tools/probe_trace.py): after trace_begin every bf16 decode step records a hash of each row of each kernel's
- * outputs into a ring of cap_steps records of (49 * layers + 2) * n_active words; trace_read copies the ring and the step count. */
-int etd_debug_decoder_trace_begin(etd_dec*, int cap_steps, void* stream);
-/* layer 0's 12 split-K slabs [12][n_active][512] of the last traced step */
-int etd_debug_decoder_trace_slabs(etd_dec*, float* out_host, long long cap_floats, int n_active, void* stream);
-/* layer 0's queries [n_active][hidden] of the last traced step; one (layer, slot, head)'s K / V cache rows [n_pos][64] as bf16 bit patterns */
-/* per-lane softmax state of layer 0's attention workgroups in the last traced step: [heads][n_active][256][8] =
- * lr, mr, o[0] after the key loop; lr after merge stages 8, 16, 32; o[0] after stages 8 and 32 */
-int etd_debug_decoder_trace_lanes(etd_dec*, float* out_host, long long cap_floats, int n_active, void* stream);
-int etd_debug_decoder_trace_q(etd_dec*, float* out_host, long long cap_floats, int n_active, void* stream);
-int etd_debug_decoder_peek_kv(etd_dec*, int layer, int slot, int head, int n_pos, unsigned short* k_out, unsigned short* v_out, void* stream);
-int etd_debug_decoder_trace_read(etd_dec*, unsigned* out_host, long long cap_words, int n_active, int* steps_done, void* stream);
-
+/* Exact host-side accounting of the decode steps issued on this handle since the last reset (graph replays included):
+ *   out[0] steps, out[1] rows x steps (= tokens generated by steps), out[2] algorithmic K/V bytes the steps' attention read (all layers),
+ *   out[3] attention launches, out[4] launches measured by the device stamps, out[5] their summed duration in seconds,
+ *   out[6] algorithmic bytes (K/V + streamed weights) of the stamped launches, out[7] weight bytes one step streams (SURVEY 8d "W").
+ * etd_decoder_stamp(on): while on, every k_dstep_attn_down launch of this handle records its own span on the device
+ * (s_memrealtime of its first workgroup's start and last workgroup's end) -- the kernel's duration in the configuration it
+ * actually runs in, other engines included, which HIP events cannot give inside hipGraph replays.  Stamped steps use their own
+ * captured graphs; production graphs carry no stamp code path.  Both synchronise `stream`. */
+int etd_decoder_stats(etd_dec*, double* out, int n, void* stream);
+int etd_decoder_stats_reset(etd_dec*, void* stream);
+int etd_decoder_stamp(etd_dec*, int on, void* stream);
 /* ---- TinyREMITokenizer glue on either side of the decoder (host code, no GPU) ----
  * etd_tok_create      TinyREMITokenizer.__init__ / _create_measures      etude/data/tokenizer.py:24-41,166-229
  * etd_tok_encode      encode (+ _assign_notes, grace-note linking)        :231-252, :78-116, :265-297

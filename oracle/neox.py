@@ -162,11 +162,15 @@ def build_bar_prompt(history, x_bar, y_attrs, user_keys, bar_bos_id, bar_eos_id,
 
 @torch.no_grad()
 def generate_ids(sd, d: NeoxDims, bar_bos_id: int, bar_eos_id: int, all_x_bars, target_attributes_per_bar,
-                 max_output_tokens=25600, max_bar_token_limit=512, context_overlap_ratio=0.5) -> List[List[int]]:
+                 max_output_tokens=25600, max_bar_token_limit=512, context_overlap_ratio=0.5, force_bar_tokens: int = 0) -> List[List[int]]:
     """Greedy (temperature==0) branch of generate(); returns per-bar id lists ``[Bar_BOS]+tokens``.
 
     The reference returns ``vocab.decode_sequence_to_events`` of exactly these ids
     (etude_decoder.py:350), so id equality <=> event equality.
+
+    ``force_bar_tokens=n`` is NOT reference behaviour: it mirrors the library's benchmark switch of the same name (Bar_EOS does
+    not end a bar, every bar is exactly n tokens long, truncation still by ``max_bar_token_limit``) so that the CPU baseline and
+    the parity tests of the benchmark workload run the same thing as the GPU.
     """
     if not all_x_bars or len(all_x_bars) != len(target_attributes_per_bar):
         return []
@@ -183,14 +187,14 @@ def generate_ids(sd, d: NeoxDims, bar_bos_id: int, bar_eos_id: int, all_x_bars, 
         at_t = {ATTR_KEY_MAP[k]: torch.tensor([al[k]]) for k in user_keys}
         kv = None
         bar: List[int] = []
-        for _ in range(max_bar_token_limit):
+        for _ in range(force_bar_tokens if force_bar_tokens > 0 else max_bar_token_limit):
             if total >= max_output_tokens:
                 break
             logits, kv = forward_logits(sd, d, ids_t, cls_t, at_t, kv)
             nxt = int(torch.argmax(logits[:, -1, :], dim=-1).item())
             bar.append(nxt)
             total += 1
-            if nxt == bar_eos_id:
+            if nxt == bar_eos_id and force_bar_tokens <= 0:
                 break
             ids_t = torch.tensor([[nxt]])
             cls_t = torch.tensor([[TGT_CLASS_ID]])

@@ -431,7 +431,88 @@ def gen_clip_full():
                         gen_ids=np.asarray(gen_ids, np.int32))
 
 
-ALL = dict(clip_full=gen_clip_full, mpe2note_modes=gen_mpe2note_modes, tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
+def _clip_full_bars():
+    """the condition bars of configs[1] as the reference chain produced them (data of clip_full.npz)"""
+    g = np.load(HERE / "clip_full.npz")
+    flat, lens = g["bar_ids"].tolist(), g["bar_lens"].tolist()
+    bars, p = [], 0
+    for l in lens:
+        bars.append(flat[p:p + l]); p += l
+    return bars
+
+
+def _ref_logits(model, ids, cls, at):
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids), class_ids=torch.from_numpy(cls),
+                    polyphony_bin_ids=torch.from_numpy(at["polyphony"]), rhythm_intensity_bin_ids=torch.from_numpy(at["rhythm"]),
+                    note_sustain_bin_ids=torch.from_numpy(at["sustain"]), pitch_overlap_bin_ids=torch.from_numpy(at["overlap"]), use_cache=False)
+    return out.logits[0].numpy()
+
+
+def gen_decoder_ctx():
+    """Decoder goldens whose greedy path DEPENDS ON THE CONTEXT (synth.decoder_state_dict_ctx) and logits at LONG contexts:
+      * reference logits of a 1 024-token and a 3 500-token prompt at sampled positions, for the context weights and for the
+        benchmark's weights (decoder_state_dict(1)) -- pins the oracle's RoPE / attention far beyond the 64 tokens of decoder_full;
+      * greedy ids of the reference's generate() on the first 20 condition bars of configs[1] (clip_full.npz's bars, ~84 ids each:
+        prompts reach the 512-token truncation from bar 4 on) for two attribute tuples, max_bar_token_limit 128."""
+    vocab = _Vocab().v
+    bars = _clip_full_bars()[:20]
+    save = {}
+    rng = np.random.default_rng(2024)
+    for T in (1024, 3500):
+        ids = rng.integers(4, 154, (1, T)); cls = rng.integers(1, 3, (1, T))
+        at = {k: rng.integers(0, 3, (1, T)) for k in ("polyphony", "rhythm", "sustain", "overlap")}
+        pos = np.asarray([0, 1, T // 2 - 1, T // 2, T - 2, T - 1] + sorted(rng.integers(2, T - 2, 10).tolist()), np.int64)
+        save.update({f"p{T}_ids": ids, f"p{T}_cls": cls, f"p{T}_pos": pos, **{f"p{T}_{k}": v for k, v in at.items()}})
+        for tag, (seed, kw, ctxw) in (("ctx", (1, {}, True)), ("bench", (1, {}, False))):
+            if ctxw:
+                from etude.models.etude_decoder import EtudeDecoder, EtudeDecoderConfig
+                model = EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()))
+                model.load_state_dict(_t(synth.decoder_state_dict_ctx(seed)), strict=True)
+                model.eval()
+            else:
+                model, _ = ref_decoder({}, seed, **kw)
+            lg = _ref_logits(model, ids, cls, at)
+            save[f"p{T}_logits_{tag}"] = lg[pos]
+            print(f"  decoder_ctx: T={T} {tag}: logits range {lg.min():.2f} .. {lg.max():.2f}")
+    from etude.models.etude_decoder import EtudeDecoder, EtudeDecoderConfig
+    model = EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()))
+    model.load_state_dict(_t(synth.decoder_state_dict_ctx(1)), strict=True)
+    model.eval()
+    save["n_bars"] = np.int64(len(bars))
+    for j, a in enumerate([(1, 1, 1, 2), (0, 2, 1, 2)]):
+        ev = model.generate(vocab, bars, [synth.attrs(*a)] * len(bars), temperature=0.0, top_p=0.9, max_bar_token_limit=128)
+        gen_ids = [vocab.encode(e) if e.type_ not in vocab.special_tokens else vocab.token_to_id[e.type_] for e in ev]
+        save[f"gen_ids_{j}"] = np.asarray(gen_ids, np.int32); save[f"gen_attrs_{j}"] = np.asarray(a, np.int64)
+        arr = np.asarray(gen_ids)
+        from collections import Counter, defaultdict
+        m = defaultdict(Counter)
+        for x, y in zip(arr[:-1], arr[1:]):
+            m[int(x)][int(y)] += 1
+        pred = sum(c.most_common(1)[0][1] for c in m.values()) / max(1, len(arr) - 1)
+        print(f"  decoder_ctx attrs={a}: {len(gen_ids)} ids, {int((arr == vocab.get_bar_eos_id()).sum())} Bar_EOS in {len(bars)} bars, {len(set(gen_ids))} distinct, "
+              f"{100 * pred:.1f} % predictable from the previous id")
+    np.savez_compressed(HERE / "decoder_ctx.npz", **save)
+
+
+def gen_clip_ctx():
+    """configs[1]'s decode stage with the context weights: the reference's generate() over ALL 92 condition bars of clip_full.npz,
+    default limits (max_bar_token_limit 512, max_output_tokens 25 600), attributes 1/1/1 + overlap 2."""
+    from etude.models.etude_decoder import EtudeDecoder, EtudeDecoderConfig
+    vocab = _Vocab().v
+    bars = _clip_full_bars()
+    model = EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()))
+    model.load_state_dict(_t(synth.decoder_state_dict_ctx(1)), strict=True)
+    model.eval()
+    torch.set_num_threads(8)
+    ev = model.generate(vocab, bars, [synth.attrs(1, 1, 1, 2)] * len(bars), temperature=0.0, top_p=0.9)
+    gen_ids = [vocab.encode(e) if e.type_ not in vocab.special_tokens else vocab.token_to_id[e.type_] for e in ev]
+    arr = np.asarray(gen_ids)
+    print(f"  clip_ctx: {len(gen_ids)} ids, {int((arr == vocab.get_bar_bos_id()).sum())} bars, {int((arr == vocab.get_bar_eos_id()).sum())} Bar_EOS, {len(set(gen_ids))} distinct")
+    np.savez_compressed(HERE / "clip_ctx.npz", gen_ids=np.asarray(gen_ids, np.int32))
+
+
+ALL = dict(decoder_ctx=gen_decoder_ctx, clip_ctx=gen_clip_ctx, clip_full=gen_clip_full, mpe2note_modes=gen_mpe2note_modes, tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
            decoder_tiny=gen_decoder_tiny, decoder_full=gen_decoder_full)
 
 if __name__ == "__main__":

@@ -156,3 +156,46 @@ def test_traffic_table_is_keyed_by_the_names_the_bench_profiler_uses():
     for name in ("k_dstep_attn_down", "k_dstep_qkv_up", "k_enc_layer"):
         assert isinstance(t.get(name), (int, float)) and t[name] > 0, name
     assert not any("<" in k for k in t)
+
+
+def _bench(args, env_extra):
+    import os, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ); env.update(env_extra)
+    for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, str(root / "bench.py")] + args, capture_output=True, text=True, timeout=300, env=env, cwd=str(root))
+
+
+def test_bench_refuses_more_gpus_than_the_node_has():
+    """`bench.py --gpus N` on a node with fewer GPUs: exit 3, NO JSON line -- and the parent decides it without initialising HIP
+    (GPUs are counted from the KFD topology in sysfs; here: none)"""
+    import bench
+    have = bench.count_gpus_without_hip()
+    p = _bench(["--gpus", str(have + 2)], {})
+    assert p.returncode == 3 and p.stdout.strip() == "" and "not reporting" in p.stderr
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    p = _bench(["--gpus", "2"], {"WORLD_SIZE": "1"})
+    assert p.returncode == 2 and p.stdout.strip() == "" and "mislabelled" in p.stderr
+    p = _bench(["--gpus", "1"], {"WORLD_SIZE": "4"})
+    assert p.returncode == 2 and p.stdout.strip() == ""
+
+
+def test_config_structs_carry_their_size():
+    """ABI version 2: every config struct leads with struct_bytes and the library refuses another layout (host-only entry point)"""
+    import ctypes as C
+    import numpy as np
+    from etude_amd import _lib
+    lib = _lib.lib()
+    sc = _lib.SchedCfg(bar_bos_id=4, bar_eos_id=5, n_ctx_pairs=4, max_position_embeddings=1024, max_output_tokens=25600, max_bar_token_limit=512,
+                       context_overlap_ratio=0.5, max_streams=1, max_prefill_rows=1024, steps_per_poll=8)
+    assert sc.struct_bytes == C.sizeof(_lib.SchedCfg)
+    x = np.asarray([4, 10, 5], np.int32); ya = np.asarray([1, 1, 1, 1], np.int32)
+    ids = np.zeros(64, np.int32); cls = np.zeros(64, np.int32); a4 = np.zeros((4, 64), np.int32); T = C.c_int()
+    args = (0, None, None, None, None, None, x.ctypes.data, 3, ya.ctypes.data, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, 64, C.byref(T))
+    assert lib.etd_debug_assemble_prompt(C.byref(sc), *args) == 0 and T.value == 2 * 4 * 2 + 3 + 1
+    sc.struct_bytes -= 8
+    assert lib.etd_debug_assemble_prompt(C.byref(sc), *args) == -22 and b"etd_sched_cfg" in lib.etd_last_error()
