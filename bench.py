@@ -12,7 +12,7 @@ step is infer.py's stage sequence for its clips (etude_amd/pipeline.py):
                picking -> the note list extract() writes; volume contour (analyze_volume); TinyREMITokenizer on the synthetic
                tempo.json (stage 2, beat detection, is out of scope) -> vocab ids -> condition bars
     per job    (clip, attribute tuple) for the 27 tuples {0,1,2}^3, overlap bin 2: greedy generate() over the clip's OWN ~92 condition
-               bars -- all jobs as concurrent device streams, continuous batching on four decoder engines -- then decode_to_notes with
+               bars -- all jobs as concurrent device streams of one decoder engine (1728 rows per decode-step launch) -- then decode_to_notes with
                the clip's volume map (MIDI file writing is left out: file I/O)
     ranks work on different clips with no data-path collective; ONE final gather of the token ids (RCCL).
 
@@ -27,7 +27,7 @@ generate()'s.  value = audio seconds taken through the WHOLE chain per wall seco
   cpu_baseline  the CPU oracle on this node's host cores, bounded sample (rank 0, N = 1 only)
   extras        configs[2] (extractor only), configs[1] (one clip), configs[3] (128 streams at ctx 512 and 3.5 k), outside the timed region
 Harness budget: the driver runs `--steps 20 --warmup 5` under a wall-clock limit.  The first warm-up step is always a full step; if W + K
-full steps do not fit ETD_BENCH_BUDGET_S (default 480 s) the remaining warm-up steps run 4 bars per job (same launches, same widths:
+full steps do not fit ETD_BENCH_BUDGET_S (default 540 s) the remaining warm-up steps run 4 bars per job (same launches, same widths:
 everything is allocated, captured and cached by then), and if K full steps alone do not fit, the batch shrinks to 8 clips per rank --
 both are written into config.workload / config.warmup_step.  The K timed steps are always full steps of the stated batch.
 """
@@ -55,6 +55,15 @@ sys.path.insert(0, str(ROOT))
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 T_START = time.perf_counter()
+
+
+def since_process_start() -> float:
+    """wall seconds since this PROCESS started (interpreter start-up and `import torch` included: the harness's clock runs from there)"""
+    try:
+        import psutil
+        return time.time() - psutil.Process().create_time()
+    except Exception:
+        return time.perf_counter() - T_START + 15.0
 
 
 def log(*a):
@@ -144,9 +153,9 @@ def cpu_baseline(bars, seconds_budget: float = 25.0, clip_seconds: float = 180.0
     tsd = {k: torch.from_numpy(v) for k, v in synth.decoder_state_dict(1, {}).items()}
     dthreads = min(avail, 8)        # batch-1 token loop: small ops, more threads only add sync cost
     torch.set_num_threads(dthreads)
-    # bars 0..5 of the clip: bar 5 is the first with a full 4-pair history (a steady-state prompt, truncated to 512 + Bar_BOS like
+    # bars 0..4 of the clip: bar 4 is the first with a full 4-pair history (a steady-state prompt, truncated to 512 + Bar_BOS like
     # every later bar); the sample's LAST bar is timed on its own and stands for the steady state
-    nb = min(6, len(bars))
+    nb = min(5, len(bars))
     t0 = time.time()
     out = neox.generate_ids(tsd, neox.NeoxDims(), 4, 5, bars[: nb - 1], [synth.attrs()] * (nb - 1), max_bar_token_limit=512, force_bar_tokens=bar_tokens)
     t_ramp = time.time() - t0
@@ -193,12 +202,16 @@ def main():
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
     ap.add_argument("--ext-engines", type=int, default=int(os.environ.get("ETD_EXT_ENGINES", "2")),
                     help="extractor instances that transcribe different clips at the same time (own stream + host thread each)")
-    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "4")),
-                    help="independent decoder engines (own HIP stream + KV cache each) driven from host threads")
-    ap.add_argument("--max-streams", type=int, default=512, help="streams per engine (the fused decode step takes up to 512 rows)")
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "1")),
+                    help="decoder engines (own HIP stream + KV cache each, driven from host threads).  Default ONE engine holding every job of the rank as a stream "
+                         "(1728 rows per decode-step launch at N = 1): the HBM-bound attention launches then never overlap each other and each runs at its own ~0.7 of the "
+                         "HBM peak; four engines x 432 streams overlap the small kernels and the prefill better (+7 %% audio-s/s, measured) but each attention launch then "
+                         "shares the HBM with three others (0.21 of the peak per launch, 0.6 in aggregate) -- DESIGN.md section 5")
+    ap.add_argument("--max-streams", type=int, default=2048, help="streams per engine (the fused decode step takes up to 2048 rows per launch)")
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS does not end a bar)")
     ap.add_argument("--synthetic-bars", action="store_true", help="rounds 1-2 workload: ~8-notes/bar synthetic condition bars instead of the clip's own (A/B only)")
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "480")))
+    ap.add_argument("--max-bars", type=int, default=0, help="diagnostics / profiling passes only: decode just the first N bars of every job (stated in config.workload)")
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "540")))
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stamp", action="store_true", help="skip the stamped decode stage (roofline then comes from the serial event pass)")
@@ -294,7 +307,7 @@ def main():
         if args.synthetic_bars:
             conds = synthetic_conditions(conds)
         t1 = time.perf_counter()
-        results, stats = pipe.decode_stage(conds, max_bars=max_bars)
+        results, stats = pipe.decode_stage(conds, max_bars=max_bars or args.max_bars)
         torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
         notes = pipe.notes_stage(conds, results)
@@ -314,35 +327,44 @@ def main():
     warm_mode = "full step"
     shrunk_from = None
     batch64 = None
-    OVERHEAD_S = 75.0            # stamped decode stage + short event pass + extras + CPU baseline + teardown, measured ~60 s
+    OVERHEAD_S = 55.0            # stamped decode stage (24 bars) + short event pass + extras + CPU baseline + teardown
     if args.warmup > 0:
         tw = time.perf_counter()
         a, b, c_, ntok1 = step()
-        t_first, since = agree(time.perf_counter() - tw, time.perf_counter() - T_START)
-        log(f"first warm-up step: {t_first:.2f}s (extract {a:.2f} decode {b:.2f} notes {c_:.2f})")
+        t_first, since = agree(time.perf_counter() - tw, since_process_start())
+        log(f"first warm-up step: {t_first:.2f}s (extract {a:.2f} decode {b:.2f} notes {c_:.2f}); {since:.0f}s since the process started")
         rest = args.warmup - 1
+        short = lambda t: 0.12 * t + 0.5                      # noqa: E731  (a 4-bar step: the whole extract stage + 4 of 92 bars)
         if since + (rest + args.steps) * t_first + OVERHEAD_S > args.budget_s:
-            if since + args.steps * t_first + rest * (0.06 * t_first + 0.5) + OVERHEAD_S <= args.budget_s:
+            if since + args.steps * t_first + rest * short(t_first) + OVERHEAD_S <= args.budget_s:
                 warm_mode = "first warm-up step full, the others 4 bars per job (W + K full steps exceed the harness budget)"
                 for _ in range(rest):
                     step(max_bars=4)
                 rest = 0
             elif clips > 8 and args.clips == 0:
-                # K full steps of this batch do not fit: keep the measured full step as extras.batch64 and time an 8-clip share per rank
+                # K full steps of this batch do not fit: keep the measured full step as extras.batch64 and time the largest share that does
                 batch64 = {"workload": f"the {clips}-clip share of the 64-clip batch on this rank, ONE full step (the first warm-up step)", "s_per_step": round(t_first, 3),
                            "audio_s_per_s": round(args.seconds * clips * world / t_first, 2), "decode_s": round(b, 3), "extract_s": round(a, 3),
                            "decoder_tokens_per_s": round(ntok1 / b, 1)}
                 shrunk_from = clips
-                log(f"{args.steps} steps of {t_first:.1f}s do not fit the {args.budget_s:.0f}s budget: timing 8 clips per rank instead")
+                new_clips = 8
+                for cand in (32, 16, 8):
+                    if cand < clips and since + (args.steps + 1) * t_first * cand / clips * 1.1 + rest * short(t_first * cand / clips) + OVERHEAD_S <= args.budget_s:
+                        new_clips = cand
+                        break
+                log(f"{args.steps} steps of {t_first:.1f}s do not fit the {args.budget_s:.0f}s budget: timing {new_clips} clips per rank instead")
                 for d in reversed(decs):
                     d.close()
                 pipe.close()
-                del wavs[8:]
-                clips = 8
+                del wavs[new_clips:]
+                clips = new_clips
                 decs, n_jobs, per_eng = build_engines(clips)
                 pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
                 step()
-                rest = max(0, rest - 1)
+                warm_mode = "one full step of the shrunk batch, the others 4 bars per job"
+                for _ in range(max(0, rest - 1)):
+                    step(max_bars=4)
+                rest = 0
         for _ in range(rest):
             step()
 
@@ -391,13 +413,14 @@ def main():
         "metric": "audio-sec/s transcribed + decoder tokens/s, 3-min clip batch",
         "value": round(audio_s / elapsed, 3), "unit": "audio-s/s (each clip extracted, tokenized and decoded for every attribute tuple)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "strong" if args.clips == 0 and shrunk_from is None else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.clips == 0 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[4], the batch north_star names: {clips * world} x 3-min 44.1 kHz stereo clips ({clips} per rank), per clip the chain of infer.py "
                                 f"(extract wav->notes, volume contour, tokenizer on the synthetic tempo.json -> the clip's OWN condition bars: {int(np.mean(nbars))} bars of ~{xlen:.0f} ids), "
                                 f"greedy generate() for {clips}x{args.attr_grid} (clip, attribute tuple) jobs per rank with {args.bar_tokens} generated tokens per bar (Bar_EOS does not end a bar: "
                                 "synthetic weights carry no musical EOS statistics), overlap bin 2, decode_to_notes with the clip's volume map; bf16 compute / fp32 accumulate; seeded synthetic weights"
+                                + (f" -- ONLY THE FIRST {args.max_bars} BARS of every job are decoded (--max-bars: a profiling pass, not a throughput figure)" if args.max_bars else "")
                                 + (" -- CONDITION BARS REPLACED by the synthetic ~8-notes/bar song (--synthetic-bars, A/B)" if args.synthetic_bars else "")
-                                + (f" -- BATCH SHRUNK from {shrunk_from} to 8 clips per rank to fit the harness budget of {args.budget_s:.0f}s (the full batch: extras.batch64)" if shrunk_from else "")),
+                                + (f" -- BATCH SHRUNK from {shrunk_from} to {clips} clips per rank to fit the harness budget of {args.budget_s:.0f}s (the full batch, one step: extras.batch64)" if shrunk_from else "")),
                    "batch_clips": clips * world, "clips_per_gpu": clips, "attr_tuples_per_clip": args.attr_grid, "decode_jobs_per_gpu": n_jobs, "decoder_streams_per_engine": per_eng,
                    "decoder_engines": len(decs), "extractor_engines": len(exs), "clip_seconds": args.seconds,
                    "windows_per_clip": int(np.ceil((1 + int(np.ceil(160 * wavs[0].shape[1] / 441)) // 256) / 512)),
@@ -417,7 +440,8 @@ def main():
         for d in decs:
             d.stamp(True)
             d.stats_reset()
-        pipe.decode_stage(conds)
+        stamp_bars = args.max_bars or 24
+        pipe.decode_stage(conds, max_bars=stamp_bars)
         torch.cuda.synchronize(dev)
         st = [d.stats() for d in decs]
         for d in decs:
@@ -430,7 +454,8 @@ def main():
             roof.update(achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBS, 4), launches=int(launches), avg_launch_ms=round(1e3 * secs / launches, 5),
                         alg_bytes_per_launch=byts / launches,
                         frac_source=("device stamps (etd_decoder_stamp): s_memrealtime of the first workgroup's start and the last workgroup's end of EVERY k_dstep_attn_down launch "
-                                     f"of one extra decode stage over the same jobs with all {len(decs)} engines running, i.e. the kernel's own span in the timed configuration; "
+                                     f"of one extra decode stage over the same jobs (their first {stamp_bars} bars: 20 of them at the steady-state prompt size) with all {len(decs)} "
+                                     "engine(s) running, i.e. the kernel's own span in the timed configuration -- what a rocprofv3 kernel trace of this command averages; "
                                      "algorithmic bytes = K+V rows of every (row, head) context + the down / dense weights a launch streams, counted exactly by the library"))
     result["roofline"] = roof
     tp = ROOT / "profiles" / "traffic.json"
@@ -521,9 +546,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cd0 = conds[0]
-            bars0 = [cd0.bars.bar(i) for i in range(min(6, len(cd0.bars)))]
+            bars0 = [cd0.bars.bar(i) for i in range(min(5, len(cd0.bars)))]
             if args.synthetic_bars:
-                bars0 = synth.song_bars(seed=1234, n_bars=6)
+                bars0 = synth.song_bars(seed=1234, n_bars=5)
             result["cpu_baseline"] = cpu_baseline(bars0, clip_seconds=args.seconds, windows_per_clip=result["config"]["windows_per_clip"], attr_tuples=args.attr_grid,
                                                   bars_per_job=int(np.mean(nbars)), bar_tokens=args.bar_tokens)
         except Exception as e:
@@ -564,12 +589,16 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     slots = [np.arange(n, dtype=np.int32) for n in per]
     for e, dec in enumerate(decs):
         st = dec._stream()
-        for s in range(per[e]):
-            ids = rng.integers(6, 154, ctx0).astype(np.int32)
-            cls = rng.integers(1, 3, ctx0).astype(np.int32)
-            a4 = rng.integers(0, 3, (4, ctx0)).astype(np.int32)
-            _lib.check(lib.etd_decoder_begin_bar(dec._h, s, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, ctx0, tg.ctypes.data,
-                                                 -1, min(1000, 4096 - ctx0), st), "begin_bar")
+        grp = max(1, dec.max_prefill_rows // ctx0)                # prompts per batched prefill pass
+        for s0 in range(0, per[e], grp):
+            n = min(grp, per[e] - s0)
+            ids = rng.integers(6, 154, n * ctx0).astype(np.int32)
+            cls = rng.integers(1, 3, n * ctx0).astype(np.int32)
+            a4 = rng.integers(0, 3, (4, n * ctx0)).astype(np.int32)
+            T = np.full(n, ctx0, np.int32); tgt = np.ascontiguousarray(np.tile(tg, (n, 1))); eos = np.full(n, -1, np.int32)
+            lim = np.full(n, min(1000, 4096 - ctx0), np.int32); sl = np.ascontiguousarray(slots[e][s0: s0 + n])
+            _lib.check(lib.etd_decoder_begin_bars(dec._h, n, sl.ctypes.data, T.ctypes.data, ids.ctypes.data, cls.ctypes.data, a4.ctypes.data, tgt.ctypes.data,
+                                                  eos.ctypes.data, lim.ctypes.data, st), "begin_bars")
         _lib.check(lib.etd_decoder_step(dec._h, slots[e].ctypes.data, per[e], 4, st), "step")
     torch.cuda.synchronize(dev)
     errs = []

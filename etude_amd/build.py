@@ -13,7 +13,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "csrc" / "_obj"
-LIB = HERE / "libetude_hip.so"
+LIB = Path(os.environ["ETD_LIB_OUT"]).resolve() if os.environ.get("ETD_LIB_OUT") else HERE / "libetude_hip.so"      # (ETD_LIB_OUT: measurement builds side by side; load them with ETD_LIB_PATH)
 SOURCES = ["ext_kernels.hip", "ext_fused.hip", "ext_fp32.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "dec_fused.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp", "midi.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result",
          "-I", str(HERE.parent / "include")]

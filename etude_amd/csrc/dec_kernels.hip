@@ -323,17 +323,19 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, 
 // (bf16 inputs, K = hidden).  One dependent kernel boundary less per layer of a latency-bound chain.
 // ================================================================================================
 __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K, int split, int p_ftiles, const void* p_Wq, const void* p_Wu, const bf16* p_Xq,
-                                                               const bf16* p_Xu, int p_ldxq, int p_ldxu, DGemmArgs q, DGemmArgs up) {   // leading scalars: kernarg preload
+                                                               const bf16* p_Xu, int p_ldxq, int p_ldxu, int p_rpt, DGemmArgs q, DGemmArgs up) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int M = p_M, K = p_K;
   SS_DECL(); SS(0);
-  // workgroup -> tile as in k_dgemm_s: the row tiles of one weight tile run back to back on one XCD
-  const int RT = (M + 31) / 32, bid = blockIdx.x, ft = ((bid >> 3) / RT) * 8 + (bid & 7);
+  // workgroup -> (feature tile, group of p_rpt consecutive row tiles) as in k_dgemm_s: the row tiles of one weight tile run back to back on one XCD.
+  // p_rpt = 1 (up to 512 rows: the latency-bound regime wants every tile on its own workgroup) or 4 (above: a workgroup keeps its weight
+  // fragments in registers for four row tiles -- a quarter of the weight traffic from L2 and of the workgroups; round 3: 50 -> ~20 us at 1728 rows).
+  // Per row tile the same loads, MFMAs and epilogue in the same order: bit-identical to p_rpt = 1.
+  const int RT = (M + 31) / 32, RG = (RT + p_rpt - 1) / p_rpt, bid = blockIdx.x, ft = ((bid >> 3) / RG) * 8 + (bid & 7);
   if (ft >= p_ftiles) return;
   const bool isq = ft < split;
-  const int m0 = ((bid >> 3) % RT) * 32, n0 = (isq ? ft : ft - split) * 32;
-  int gm = m0 + r; gm = gm < M ? gm : M - 1;
+  const int rt0 = ((bid >> 3) % RG) * p_rpt, n0 = (isq ? ft : ft - split) * 32;
   // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207); a 32-feature tile is half of one part of one head
   const int head = n0 / 192, j0 = n0 - head * 192, part = j0 >> 6, dbase = j0 & 63;
   const bool rope = isq && part < 2 && dbase == 0;
@@ -343,31 +345,32 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
   // (Every wave issues these few loads, unconditionally: putting them under `if (wave == 0)` / `if (isq)` makes the compiler merge
   // the loaded values with the defaults right behind the branch, i.e. wait a full round trip BEFORE the weight stream is issued.)
   f32x4 bq[4];
-  const int pos = q.rows.pos[gm], slot = q.rows.slot[gm], act = q.rows.active[gm];
-  f32x4 rc = {1.f, 1.f, 1.f, 1.f}, rs = {0.f, 0.f, 0.f, 0.f};
+  int gm = rt0 * 32 + r; gm = gm < M ? gm : M - 1;
+  int pos = q.rows.pos[gm], slot = q.rows.slot[gm], act = q.rows.active[gm];
   {
     const float* bp = (isq ? q.bias : up.bias) + n0 + 4 * h;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) bq[q4] = *reinterpret_cast<const f32x4*>(bp + 8 * q4);
   }
   const bf16* wrow = reinterpret_cast<const bf16*>(isq ? p_Wq : p_Wu) + (long long)(n0 + r) * K;
-  const bf16* xbrow = (isq ? p_Xq : p_Xu) + (long long)gm * (isq ? p_ldxq : p_ldxu);
-  const int kq = K / DS_WAVES, kb = wave * kq, ke = kb + kq;
-  f32x16 acc;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  const bf16* xbase = isq ? p_Xq : p_Xu;
+  const int ldx = isq ? p_ldxq : p_ldxu;
+  const int kq = K / DS_WAVES, kb = wave * kq;
   constexpr int NS = 8 / DS_WAVES * 4;           // 16-wide k-steps per wave at K = 512 (launcher-checked: K == 64 * DS_WAVES * NS / 4)
-  {
-    bf16x8 wf[NS], xf[NS];
+  bf16x8 wf[NS], xf[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+  for (int s = 0; s < NS; ++s) {
 #ifdef ETD_ABL_QKVW
-      wf[s] = bf16x8{(bf16)(float)(((uintptr_t)(wrow + s)) & 7), 0, 0, 0, 0, 0, 0, 0};
+    wf[s] = bf16x8{(bf16)(float)(((uintptr_t)(wrow + s)) & 7), 0, 0, 0, 0, 0, 0, 0};
 #else
-      wf[s] = *reinterpret_cast<const bf16x8*>(wrow + kb + s * 16 + h * 8);
+    wf[s] = *reinterpret_cast<const bf16x8*>(wrow + kb + s * 16 + h * 8);
 #endif
-      xf[s] = *reinterpret_cast<const bf16x8*>(xbrow + kb + s * 16 + h * 8);
-    }
+    xf[s] = *reinterpret_cast<const bf16x8*>(xbase + (long long)gm * ldx + kb + s * 16 + h * 8);
+  }
+  for (int t = 0; t < p_rpt; ++t) {
+    const int m0 = (rt0 + t) * 32;
+    if (m0 >= M) break;                              // (uniform over the workgroup)
+    f32x4 rc = {1.f, 1.f, 1.f, 1.f}, rs = {0.f, 0.f, 0.f, 0.f};
     if (wave == 0 && rope) {
       // partial RoPE factors of dims d = 4h + i (i < 4); the partner d + 8 sits in register i + 4 of the same lane
       rc = *reinterpret_cast<const f32x4*>(q.rope_cos + (long long)pos * 8 + 4 * h);
@@ -375,60 +378,68 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
     }
     __builtin_amdgcn_sched_barrier(0);
     SS_LANDED(); SS(1);
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) acc = mfma32(wf[s], xf[s], acc);
-  }
-  (void)ke;
-  if (wave > 0) {
+    // the next row tile's fragments and row metadata are requested here: their round trip runs under this tile's reduction and epilogue
+    const int posc = pos, slotc = slot, actc = act;
+    if (t + 1 < p_rpt && m0 + 32 < M) {
+      int gn = m0 + 32 + r; gn = gn < M ? gn : M - 1;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
-  }
-  __syncthreads();
-  if (wave != 0) return;
-  SS(2);
-#pragma unroll
-  for (int w = 0; w < DS_WAVES - 1; ++w)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
-  const int m = m0 + r;
-#ifdef ETD_STEP_STAMP
-  if (m >= M) { SS(3); SS_FLUSH(1, isq ? 0 : 1); return; }
-#else
-  if (m >= M) return;
-#endif
-  float v[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
-  if (!isq) {
-    // MLP up: erf-GELU, bf16 rows for the down projection
-#pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int n = n0 + 8 * q4 + 4 * h;
-      if (n < up.N)
-        *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
-            pack4(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
+      for (int s = 0; s < NS; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xbase + (long long)gn * ldx + kb + s * 16 + h * 8);
+      pos = q.rows.pos[gn]; slot = q.rows.slot[gn]; act = q.rows.active[gn];
     }
-    SS(3); SS_FLUSH(1, 1);
-    return;
-  }
-  if (rope) {
+    if (wave > 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float x1 = v[i], x2 = v[i + 4];
-      v[i] = x1 * rc[i] - x2 * rs[i];        // q*cos + rotate_half(q)*sin, first half
-      v[i + 4] = x2 * rc[i] + x1 * rs[i];    // second half
+      for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
     }
-  }
-  if (part == 0) {
-    float* qp = q.Q + (long long)m * (q.n_heads * 64) + head * 64 + dbase;
+    __syncthreads();
+    if (wave == 0) {
+      SS(2);
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) { const f32x4 o = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q4 + 4 * h) = o; }
-  } else if (act && pos < q.max_ctx) {
-    bf16* kp = reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)slot * q.slot_stride + ((long long)head * q.max_ctx + pos) * 64 + dbase;
+      for (int w = 0; w < DS_WAVES - 1; ++w)
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<bf16x4*>(kp + 8 * q4 + 4 * h) = pack4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+        for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
+      const int m = m0 + r;
+      if (m < M) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
+        if (!isq) {
+          // MLP up: erf-GELU, bf16 rows for the down projection
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const int n = n0 + 8 * q4 + 4 * h;
+            if (n < up.N)
+              *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
+                  pack4(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
+          }
+        } else {
+          if (rope) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float x1 = v[i], x2 = v[i + 4];
+              v[i] = x1 * rc[i] - x2 * rs[i];        // q*cos + rotate_half(q)*sin, first half
+              v[i + 4] = x2 * rc[i] + x1 * rs[i];    // second half
+            }
+          }
+          if (part == 0) {
+            float* qp = q.Q + (long long)m * (q.n_heads * 64) + head * 64 + dbase;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) { const f32x4 o = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q4 + 4 * h) = o; }
+          } else if (actc && posc < q.max_ctx) {
+            bf16* kp = reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)slotc * q.slot_stride + ((long long)head * q.max_ctx + posc) * 64 + dbase;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<bf16x4*>(kp + 8 * q4 + 4 * h) = pack4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+          }
+        }
+      }
+    }
+    if (t + 1 < p_rpt) __syncthreads();              // wave 0 has read `red` before the next tile's partial sums land in it
   }
-  SS(3); SS_FLUSH(1, 0);
+  SS(3); SS_FLUSH(1, isq ? 0 : 1);
 }
 
 int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st) {
@@ -438,7 +449,10 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
   const int split = q.Npad / 32;
   const int ftiles = split + up.Npad / 32;
-  hipLaunchKernelGGL(k_dstep_qkv_up, dim3((unsigned)(((ftiles + 7) / 8) * 8 * ((q.M + 31) / 32))), dim3(64 * DS_WAVES), 0, st, q.M, q.K, split, ftiles, q.W, up.W, q.Xb, up.Xb, q.ldx, up.ldx, q, up);
+  static const int rpt_env = getenv("ETD_QKV_RPT") ? atoi(getenv("ETD_QKV_RPT")) : 0;
+  const int rpt = rpt_env > 0 ? rpt_env : (q.M > DS_MAX_ROWS ? 4 : 1);
+  const int RT = (q.M + 31) / 32, RG = (RT + rpt - 1) / rpt;
+  hipLaunchKernelGGL(k_dstep_qkv_up, dim3((unsigned)(((ftiles + 7) / 8) * 8 * RG)), dim3(64 * DS_WAVES), 0, st, q.M, q.K, split, ftiles, q.W, up.W, q.Xb, up.Xb, q.ldx, up.ldx, rpt, q, up);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
