@@ -27,7 +27,7 @@ generate()'s.  value = audio seconds taken through the WHOLE chain per wall seco
   cpu_baseline  the CPU oracle on this node's host cores, bounded sample (rank 0, N = 1 only)
   extras        configs[2] (extractor only), configs[1] (one clip), configs[3] (128 streams at ctx 512 and 3.5 k), outside the timed region
 Harness budget: the driver runs `--steps 20 --warmup 5` under a wall-clock limit.  The first warm-up step is always a full step; if W + K
-full steps do not fit ETD_BENCH_BUDGET_S (default 540 s) the remaining warm-up steps run 4 bars per job (same launches, same widths:
+full steps do not fit ETD_BENCH_BUDGET_S (default 560 s, counted from process start) the remaining warm-up steps run 4 bars per job (same launches, same widths:
 everything is allocated, captured and cached by then), and if K full steps alone do not fit, the batch shrinks to 8 clips per rank --
 both are written into config.workload / config.warmup_step.  The K timed steps are always full steps of the stated batch.
 """
@@ -202,16 +202,17 @@ def main():
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
     ap.add_argument("--ext-engines", type=int, default=int(os.environ.get("ETD_EXT_ENGINES", "2")),
                     help="extractor instances that transcribe different clips at the same time (own stream + host thread each)")
-    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "1")),
-                    help="decoder engines (own HIP stream + KV cache each, driven from host threads).  Default ONE engine holding every job of the rank as a stream "
-                         "(1728 rows per decode-step launch at N = 1): the HBM-bound attention launches then never overlap each other and each runs at its own ~0.7 of the "
-                         "HBM peak; four engines x 432 streams overlap the small kernels and the prefill better (+7 %% audio-s/s, measured) but each attention launch then "
-                         "shares the HBM with three others (0.21 of the peak per launch, 0.6 in aggregate) -- DESIGN.md section 5")
+    ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "0")),
+                    help="decoder engines (own HIP stream + KV cache each, driven from host threads); 0 = by the jobs per rank: ONE engine holding every job as a stream "
+                         "from 1024 jobs up (and from 512 on a single GPU) -- 1728 rows per decode-step launch at N = 1: the HBM-bound attention launches then never overlap "
+                         "each other and each runs at its own ~0.7 of the HBM peak -- and four engines below (216 jobs per rank at N = 8: the latency-bound regime, where "
+                         "four chains of short kernels overlap).  Measured, audio-s/s with 1 / 2 / 4 engines: 64 clips 513 / 516 / 526, 32 clips 491 / 515 / 526, 16 clips "
+                         "459 / 502 / 506, 8 clips 419 / 433 / 457 (tools/runs3/r3_run12.sh): four engines always carry 2-7 %% more, at a quarter of the HBM per attention launch")
     ap.add_argument("--max-streams", type=int, default=2048, help="streams per engine (the fused decode step takes up to 2048 rows per launch)")
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS does not end a bar)")
     ap.add_argument("--synthetic-bars", action="store_true", help="rounds 1-2 workload: ~8-notes/bar synthetic condition bars instead of the clip's own (A/B only)")
     ap.add_argument("--max-bars", type=int, default=0, help="diagnostics / profiling passes only: decode just the first N bars of every job (stated in config.workload)")
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "540")))
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "560")))
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stamp", action="store_true", help="skip the stamped decode stage (roofline then comes from the serial event pass)")
@@ -271,9 +272,12 @@ def main():
 
     def build_engines(n_clips):
         n_jobs = n_clips * len(grid)
-        n_eng = max(1, min(args.engines, n_jobs))
+        want = args.engines if args.engines > 0 else (1 if (n_jobs >= 1024 or (world == 1 and n_jobs >= 512)) else 4)
+        n_eng = max(1, min(want, n_jobs))
         per_eng = min(args.max_streams, (n_jobs + n_eng - 1) // n_eng)
-        decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng)]
+        # one batched-prefill pass carries up to 256 k prompt rows (~500 prompts at the 512-token truncation): a bar boundary of 1728 streams is then
+        # four passes, and the host assembles / stages pass k + 1 while the GPU runs pass k (one 886 k-row pass left the queue empty for ~6 ms per bar)
+        decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng, max_prefill_rows=min(262144, per_eng * 520))]
         decs += [decs[0].clone() for _ in range(n_eng - 1)]            # engines share one weight set (own KV caches and state)
         return decs, n_jobs, per_eng
 
@@ -327,7 +331,7 @@ def main():
     warm_mode = "full step"
     shrunk_from = None
     batch64 = None
-    OVERHEAD_S = 55.0            # stamped decode stage (24 bars) + short event pass + extras + CPU baseline + teardown
+    OVERHEAD_S = 42.0            # stamped decode stage (24 bars) + short event pass + extras + CPU baseline + teardown (measured 35 s; extras and the CPU baseline are dropped if the run is late)
     if args.warmup > 0:
         tw = time.perf_counter()
         a, b, c_, ntok1 = step()
@@ -503,7 +507,10 @@ def main():
         result.setdefault("extras", {})["batch64"] = batch64
 
     # ---- extras outside the timed region
-    if not args.no_extras and rank == 0:
+    late = lambda margin: since_process_start() > args.budget_s - margin           # noqa: E731  (the ONE JSON line matters more than its optional parts)
+    if not args.no_extras and rank == 0 and late(30.0):
+        result.setdefault("extras", {})["skipped"] = "the run is within 30 s of its harness budget"
+    elif not args.no_extras and rank == 0:
         extras = result.setdefault("extras", {})
         ex = exs[0]
         try:
@@ -543,7 +550,9 @@ def main():
             except Exception as e:
                 extras[key] = {"error": repr(e)}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and late(20.0):
+        result["cpu_baseline"] = {"skipped": "the run is within 20 s of its harness budget"}
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cd0 = conds[0]
             bars0 = [cd0.bars.bar(i) for i in range(min(5, len(cd0.bars)))]

@@ -14,7 +14,7 @@ import os as _os
 
 # Four decoder engines (run_engines) want four hardware queues that sit on four different compute pipes.  The HIP runtime's
 # default of four queues puts the fourth engine's stream on a queue it shares with the null stream: with the default, four engines
-# stepping together reach 7.8 engine-steps per ms instead of 10.0 (tools/runs/r2_run15.sh vs r2_run16.sh).  The runtime reads
+# stepping together reach 7.8 engine-steps per ms instead of 10.0 ((history: 4ac2f57) tools/runs/r2_run15.sh vs r2_run16.sh).  The runtime reads
 # this when it initialises, so it only takes effect if etude_amd is imported before the first HIP call of the process.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 

@@ -228,7 +228,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     const bool catk = small || big;     // attention.dense folded into the down projection: [W2 | Wd] [gelu(..) ; attn] + (b2 + bd), one GEMM and no fp32 round trip of the dense output
     // batched prefill on the fused MLP kernel: it also writes the NEXT layer's LayerNorm rows, so only layer 0 needs the row kernel
     // ON by default, ETD_FUSED_PMLP=0 turns it off (read at create time for the packed stream, and per call so that the A/B test can toggle it): measured round 2
-    // (tools/runs/r2_run47.sh) at 195 us per launch against 166 + 16 us for the launches it replaces, +1.3 % in the job -- csrc/dec_fused.hip
+    // ((history: 4ac2f57) tools/runs/r2_run47.sh) at 195 us per launch against 166 + 16 us for the launches it replaces, +1.3 % in the job -- csrc/dec_fused.hip
     const bool fmlp = big && w.mlp_frag && d->H == 512 && d->I == 2048 && fused_pmlp_on();
     if (bpipe && (!small || (l == 0 && !ln0_done)) && !ln_ready) ETD_TRY(launch_ln_rows(hin, M, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
     ln_ready = false;
@@ -308,7 +308,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
       // ETD_ROWFIN=1: the row kernel (split-K sum + bias + residual + next LayerNorms) rides in the attention launch -- the last
       // contributor of a row finishes it (DRowFin; 17 launches per step instead of 25, bit-identical results).  Measured round 2
-      // (tools/runs/r2_run21/24/27.sh): a step of one engine 0.197 -> 0.185 ms, four engines stepping 9.9 -> 10.1 engine-steps/ms,
+      // ((history: 4ac2f57) tools/runs/r2_run21/24/27.sh): a step of one engine 0.197 -> 0.185 ms, four engines stepping 9.9 -> 10.1 engine-steps/ms,
       // but the JOB 569-575 -> 567 audio-s/s (the attention workgroups live 19 instead of 15.5 us and hold 128 registers per
       // wave while the other engines' prefill GEMMs want the same CUs).  Off by default.
       static const bool rowfin = getenv("ETD_ROWFIN") && atoi(getenv("ETD_ROWFIN")) > 0;
@@ -460,10 +460,12 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
                       const int32_t* attrs4, const int32_t* init7 /* [n][7] or null */, Staged* sg, float** hfinal, hipStream_t st, bool* last_only = nullptr) {
   if (!d || n < 1 || n > d->S || !slots || !T || !ids || !cls || !attrs4) ETD_FAIL(ETD_EINVAL, "prefill: bad arguments");
   long long Mtot = 0;
+  std::vector<char> seen((size_t)d->S, 0);
   for (int i = 0; i < n; ++i) {
     ETD_TRY(check_slot(d, slots[i]));
     if (T[i] <= 0 || T[i] > d->ctx) ETD_FAIL(ETD_EINVAL, "prefill: prompt %d has T=%d (max_ctx=%d)", i, T[i], d->ctx);
-    for (int j = 0; j < i; ++j) if (slots[j] == slots[i]) ETD_FAIL(ETD_EINVAL, "prefill: slot %d listed twice", slots[i]);
+    if (seen[slots[i]]) ETD_FAIL(ETD_EINVAL, "prefill: slot %d listed twice", slots[i]);
+    seen[slots[i]] = 1;
     Mtot += T[i];
   }
   if (Mtot > d->Mcap) ETD_FAIL(ETD_EINVAL, "prefill: %lld prompt rows exceed max_prefill_rows=%d", Mtot, d->Mcap);
@@ -479,10 +481,9 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   const bool pinned = d->pin_stage && sv_ints <= d->pin_stage_ints;
   if (pinned) {
     HIP_TRY(hipEventSynchronize(d->pin_stage_evt));            // the previous upload (if any) has been read out of the buffer
-    svp = d->pin_stage;
-    memset(svp, 0, sv_ints * 4);
+    svp = d->pin_stage;                                         // (every word of the layout is written below: no memset of ~40 bytes per prompt row)
   } else {
-    d->stage.assign(sv_ints, 0);
+    d->stage.resize(sv_ints);
     svp = d->stage.data();
   }
   memcpy(svp, ids, (size_t)M * 4);
@@ -500,7 +501,7 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
     d->host_len[slots[i]] = T[i];
     kvb += (double)T[i] * d->nh * 64 * (2.0 * (d->bf16w ? 2 : 4) + 4 + 4);   // prefill: Q, K, V read once, O written once (K/V re-reads are L2 hits)
   }
-  if (init7) memcpy(in7, init7, (size_t)7 * n * 4);
+  if (init7) memcpy(in7, init7, (size_t)7 * n * 4); else memset(in7, 0, (size_t)7 * n * 4);
   d->attn_bytes_hint = kvb;
   HIP_TRY(hipMemcpyAsync(d->ids, svp, sv_ints * 4, hipMemcpyHostToDevice, st));   // pinned: an async DMA; pageable fallback: returns after staging
   if (pinned) HIP_TRY(hipEventRecord(d->pin_stage_evt, st));

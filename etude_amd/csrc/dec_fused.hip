@@ -8,7 +8,7 @@
 // from L2).  Here the token tile stays in registers for the whole branch, as in the extractor's k_ffn_fused.
 //
 // STATUS: correct and bit-identical (logits of a 600-token prompt, token streams of 48 batched jobs), on by default since the end of round 2 (ETD_FUSED_PMLP=0 turns it off): +0.7-1.7 % in the job in every A/B pair.
-// Measured on MI355X (54 prompts x ~340 tokens per launch; tools/runs/r2_run47.sh, serial event pass): 195 us per launch against
+// Measured on MI355X (54 prompts x ~340 tokens per launch; (history: 4ac2f57) tools/runs/r2_run47.sh, serial event pass): 195 us per launch against
 // 166 us for the two GEMMs + 16 us for the row kernel it replaces; in the four-engine job 581-589 against 572-586 audio-s/s
 // (+1.3 % over six pairs: it occupies 144 CUs and moves a quarter of the bytes, so it disturbs the other engines' steps less).
 // It stays off by default because its inner loop is hand-placed asm whose MFMAs the compiler's hazard recognizer cannot see.

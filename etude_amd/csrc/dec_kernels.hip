@@ -1070,7 +1070,7 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 #define D_ARRIVE(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define D_CNT_RESET(p) __hip_atomic_store((p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-// measurement builds (tools/runs/r2_run18.sh): -DETD_ABL_DENSE / -DETD_ABL_GEMMW / -DETD_ABL_QKVW replace a weight stream by a
+// measurement builds ((history: 4ac2f57) tools/runs/r2_run18.sh): -DETD_ABL_DENSE / -DETD_ABL_GEMMW / -DETD_ABL_QKVW replace a weight stream by a
 // constant (wrong results on purpose) to see what that stream costs the OTHER engines' kernels
 #ifdef ETD_ABL_DENSE
 #define ABL_DENSE_LOAD(p) (bf16x8{(bf16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
@@ -1119,7 +1119,7 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 // with op_sel:[0,0,1] op_sel_hi:[1,1,0]: the LOW result takes an operand's HIGH register and vice versa -- and on MI355X such an
 // instruction's low result came out as if that operand were 0 in lanes 48-55 whenever the SIMD was shared with another queue's
 // MFMA waves (batched prefill, Extract stage): a (wave, j = 6) slot's softmax denominator vanished, the head's output grew by
-// ~3 %, tokens changed from run to run.  DESIGN.md section 8, "packed FP32 with crossed op_sel"; tools/probe_trace.py;
+// ~3 %, tokens changed from run to run.  LABNOTES.md, "packed FP32 with crossed op_sel"; tools/probe_trace.py;
 // tests/test_isa_guard.py keeps the form out of the library.
 // (-DETD_AD_CROSSED_PK=1 rebuilds the failing form: tools/probe_trace.py and tests/test_gpu_reproducibility.py then fail again)
 __device__ __forceinline__ float merge_sum(float a, float b, float c, float d) {
@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
 // ================================================================================================
 template <int NW> struct AdOcc { static constexpr int lo = 7, hi = 8; };      // 72 registers; forcing 64 (8 waves per SIMD) spills inside the key loop, and a scratch reload there drains the K/V stream
 #ifndef ETD_AD_OCC
-#define ETD_AD_OCC 5      // built for 5 waves per SIMD (96 registers).  Job level (bench.py, tools/runs/r2_run28.sh): 7 -> 581-583, 5 -> 586-588, 4 -> 588, 3 -> 585 audio-s/s
+#define ETD_AD_OCC 5      // built for 5 waves per SIMD (96 registers).  Job level (bench.py, (history: 4ac2f57) tools/runs/r2_run28.sh): 7 -> 581-583, 5 -> 586-588, 4 -> 588, 3 -> 585 audio-s/s
 #endif
 template <> struct AdOcc<4> { static constexpr int lo = ETD_AD_OCC, hi = 8; };
 #ifndef ETD_FIN_OCC
@@ -1594,12 +1594,12 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? E
   }
 }
 
-// waves per attention workgroup: 4, or ETD_AD_WAVES = 8 / 16 (measurement builds).  Measured on MI355X, round 2 (tools/runs/r2_run1.sh):
+// waves per attention workgroup: 4, or ETD_AD_WAVES = 8 / 16 (measurement builds).  Measured on MI355X, round 2 ((history: 4ac2f57) tools/runs/r2_run1.sh):
 // 54 rows x ctx 320, one engine: 0.197 / 0.230 / 0.238 ms per step at 4 / 8 / 16 waves, four engines 9.98 / 9.17 / 8.21
 // engine-steps per ms; 128 rows x ctx 512: 0.356 / 0.349 / 0.419 ms; 128 rows x ctx 3.5 k: 1.290 / 1.343 / 1.362 ms.  Requesting a
 // (row, head)'s whole context at once does NOT shorten the launch: its ~8 us of fixed cost are not the key loop's round trips.  Nor are
 // they the second pass of dense-weight fragments in the tail: with all 16 requested before the merge (100 registers, 4 waves per SIMD)
-// one engine steps in 0.199 instead of 0.198 ms and four engines reach 9.97-10.03 engine-steps per ms either way (tools/runs/r2_run12.sh).
+// one engine steps in 0.199 instead of 0.198 ms and four engines reach 9.97-10.03 engine-steps per ms either way ((history: 4ac2f57) tools/runs/r2_run12.sh).
 static int ad_waves(int M) {
   static const int env = getenv("ETD_AD_WAVES") ? atoi(getenv("ETD_AD_WAVES")) : 0;
   (void)M;
@@ -1613,7 +1613,7 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
       g.M != a.M || !g.Xb || !g.W || !g.Y || g.ldy != 512 || g.N != 512 || g.Npad != 512 || g.k_splits < 1 || g.k_splits * 512 > g.K || (g.K % 8) || a.n_heads * 64 != 512)
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad arguments");
   // two rows of a head per 8-wave attention workgroup, the head's dense slice read once per pair (ETD_AD_PAIR=0: always one row per 4-wave workgroup).
-  // Bit-identical results; measured at the end of round 2 (tools/runs/r2_run132.sh, r2_run133.sh): the launch 14.8 -> 13.9 us, one engine's step
+  // Bit-identical results; measured at the end of round 2 ((history: 4ac2f57) tools/runs/r2_run132.sh, r2_run133.sh): the launch 14.8 -> 13.9 us, one engine's step
   // 0.1985 -> 0.1894 ms, four engines 9.78 -> 10.03 engine-steps / ms, the job +0.3 % (within its spread)
   // -- at the headline's shape (54 rows x ~340 keys).  Whether it pays depends on rows, context and on how many engines share the chip: the host decides
   // per call (DAttnArgs::pair, api_dec.hip etd_decoder_step); ETD_AD_PAIR=0 / 1 force either form

@@ -366,7 +366,7 @@ def run_engines(engines: Sequence["EtudeDecoder"], jobs, vocab, one_at_a_time: b
     """`generate_many` over several engines at once: the job list is dealt round-robin over ``engines`` (normally one
     EtudeDecoder and its ``clone()``s, which share the device weights) and each engine runs its share from its own host
     thread -- ctypes releases the GIL inside the library calls.  On MI355X four engines is the useful maximum: a GPU has
-    four compute pipes, and a fifth chain of dependent kernels halves the one it shares a pipe with.
+    four compute pipes, and a fifth chain of dependent kernels halves the one it shares a pipe with (LABNOTES.md).
 
     ``ready=(flags, job_index_to_flag)`` is split per engine like the jobs.  Returns ``join``: calling it waits for the
     engines and returns ``(results in job order, per-engine stats dicts)``; exceptions of the workers are re-raised there.

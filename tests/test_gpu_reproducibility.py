@@ -1,4 +1,4 @@
-"""Run-to-run reproducibility of the Decode stage ("packed FP32 with crossed op_sel";
+"""Run-to-run reproducibility of the Decode stage (LABNOTES.md, "packed FP32 with crossed op_sel";
 profiles/r02_reproducibility.txt).
 
 One engine gives the same tokens every time (bf16 and fp32), and so do several engines whose prefills and steps overlap, in both

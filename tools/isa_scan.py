@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Disassemble every gfx950 code object of the built library and list the packed-FP32 instructions (v_pk_mul_f32 / v_pk_add_f32 /
 v_pk_fma_f32) whose op_sel makes the LOW result read an operand's HIGH register (the form that misbehaved beside another queue's
-MFMA waves).  usage: isa_scan.py [library.so]   exit code 1 when any is found."""
+MFMA waves, LABNOTES.md).  usage: isa_scan.py [library.so]   exit code 1 when any is found."""
 import re
 import shutil
 import subprocess

@@ -1,4 +1,4 @@
-// Stand-alone check of the instruction form behind DESIGN.md section 8 "packed FP32 with crossed op_sel": the three-stage softmax merge of
+// Stand-alone check of the instruction form behind LABNOTES.md "packed FP32 with crossed op_sel": the three-stage softmax merge of
 // the decode step's attention core, once as plain C++ (hipcc's SLP vectoriser pairs lr's sum with o[0]'s crosswise: v_pk_mul_f32 x2 +
 // v_pk_add_f32 / v_pk_fma_f32 whose LOW result reads a HIGH register) and once with every sum as scalar VALU instructions of its own
 // (inline asm: mul, mul, add).  Same inputs, same roundings: the two must agree bit for bit.  256 threads, ~10 KiB of LDS, like the

@@ -1,4 +1,4 @@
-// Crossed packed-FP32 ops (v_pk_mul_f32 x2 + v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0], the form of DESIGN.md section 8) issued WHILE
+// Crossed packed-FP32 ops (v_pk_mul_f32 x2 + v_pk_add_f32 op_sel:[0,1] op_sel_hi:[1,0], the form of LABNOTES.md) issued WHILE
 // asynchronous VGPR writers of the same wave are in flight: eight ds_bpermute_b32 results (mode bit 0) and/or four global_load_dwordx4
 // results (mode bit 1) land in other registers around the packed sequence.  Every packed result is compared with scalar v_mul_f32 /
 // v_add_f32 on the same inputs; the exchanged / loaded values are checked too.  Run beside another stream's MFMA kernels

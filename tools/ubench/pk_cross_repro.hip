@@ -1,7 +1,7 @@
 // Stand-alone reproducer (no library, no Python): on MI355X a packed-FP32 add whose op_sel swaps the halves of an operand
 //     v_pk_add_f32 D, A, B op_sel:[0,1] op_sel_hi:[1,0]        (D.lo = A.lo + B.hi, D.hi = A.hi + B.lo)
 // returns D.lo = A.lo (as if B.hi were 0) in lanes 48-63, now and then, while another stream's MFMA kernel shares the SIMD.  The
-// uncrossed add on the same operands never fails; alone the crossed add never fails.  DESIGN.md section 8, "packed FP32 with crossed op_sel".
+// uncrossed add on the same operands never fails; alone the crossed add never fails.  LABNOTES.md, "packed FP32 with crossed op_sel".
 //   build: hipcc -O3 --offload-arch=gfx950 pk_cross_repro.hip -o pk_cross_repro.bin        run: ./pk_cross_repro.bin [seconds per case = 2]
 // Victim: 432 workgroups x 256 threads, ~10 KiB LDS, occupancy 5 (the decode step's attention workgroups).  Aggressors, one at a time on a
 // second stream: 0 none, 1 register-only MFMA loop, 2 MFMA fed by ds_read_b128 from a 64 KiB LDS ring, 3 the same + global_load_lds
