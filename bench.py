@@ -441,10 +441,11 @@ def main():
     # engine stamping its k_dstep_attn_down launches on the device (first workgroup's start .. last workgroup's end)
     roof = {"kernel": "k_dstep_attn_down", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
     if not args.no_stamp:
-        for d in decs:
-            d.stamp(True)
-            d.stats_reset()
         stamp_bars = args.max_bars or 24
+        skip_bars = 4 if stamp_bars > 8 else 0                  # the bars in which the 4-pair history (and with it the context) is still growing
+        for d in decs:
+            d.stamp(True, skip_steps=skip_bars * (args.bar_tokens - 1))
+            d.stats_reset()
         pipe.decode_stage(conds, max_bars=stamp_bars)
         torch.cuda.synchronize(dev)
         st = [d.stats() for d in decs]
@@ -458,7 +459,7 @@ def main():
             roof.update(achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBS, 4), launches=int(launches), avg_launch_ms=round(1e3 * secs / launches, 5),
                         alg_bytes_per_launch=byts / launches,
                         frac_source=("device stamps (etd_decoder_stamp): s_memrealtime of the first workgroup's start and the last workgroup's end of EVERY k_dstep_attn_down launch "
-                                     f"of one extra decode stage over the same jobs (their first {stamp_bars} bars: 20 of them at the steady-state prompt size) with all {len(decs)} "
+                                     f"of one extra decode stage over the same jobs (bars {skip_bars} .. {stamp_bars - 1}: the steady-state prompt size, 96 % of a job's bars) with all {len(decs)} "
                                      "engine(s) running, i.e. the kernel's own span in the timed configuration -- what a rocprofv3 kernel trace of this command averages; "
                                      "algorithmic bytes = K+V rows of every (row, head) context + the down / dense weights a launch streams, counted exactly by the library"))
     result["roofline"] = roof

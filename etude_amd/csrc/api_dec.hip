@@ -84,7 +84,7 @@ struct etd_dec {
   double stat_steps = 0, stat_row_steps = 0, stat_kv_bytes = 0, stat_attn_launches = 0, stat_stamp_bytes = 0;
   int force_pair = -1;                           // test hook (etd_debug_decoder_force_pair): -1 = the rule above, 0 / 1 = one-row / paired-rows attention form
   unsigned long long* stamp_dev = nullptr;       // device-side span accumulator of k_dstep_attn_down (etd_decoder_stamp); its own allocation
-  bool stamp_on = false;
+  bool stamp_on = false, stamp_armed = false; long long stamp_skip = 0;      // armed: requested; on: this call's steps are stamped (after `stamp_skip` more steps)
   float* logits_dbg = nullptr; bool logits_dbg_on = false, last_step_fused = false;   // test hook: the fused step's logits [S][V] (etd_debug_decoder_step_logits)
   // weight sharing (etd_decoder_clone): a clone reads the owner's weight buffers and has its own KV cache, workspaces and
   // stream state.  `allocs` of an owner = weights first (n_weight_allocs of them), then its workspaces; a clone's = workspaces only.
@@ -899,6 +899,8 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   const bool fused = d->bf16w && n_active > 1 && n_active <= DS_STEP_MAX_ROWS && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
                      vpad <= d->head.Npad && d->head_frag && !getenv("ETD_NO_FUSED_STEP");
   d->last_step_fused = fused;
+  d->stamp_on = d->stamp_armed && d->stamp_skip <= 0;          // (a whole call is stamped or not: the scheduler issues one bar's steps per call)
+  if (d->stamp_armed && d->stamp_skip > 0) d->stamp_skip -= n_steps;
   auto embed = [&](hipStream_t s_) -> int {
     DEmbedArgs e = {};
     e.slots = d->slots_dev; e.len = d->len; e.done = d->done; e.row_slot_out = d->row_slot; e.row_pos_out = d->row_pos; e.row_active_out = d->row_active; e.row_sp_out = d->row_sp;
@@ -1029,14 +1031,14 @@ extern "C" int etd_decoder_stats_reset(etd_dec* d, void* stream) {
   return ETD_OK;
 }
 
-extern "C" int etd_decoder_stamp(etd_dec* d, int on, void* stream) {
-  if (!d) ETD_FAIL(ETD_EINVAL, "decoder_stamp: null handle");
+extern "C" int etd_decoder_stamp(etd_dec* d, int on, int skip_steps, void* stream) {
+  if (!d || skip_steps < 0) ETD_FAIL(ETD_EINVAL, "decoder_stamp: bad arguments");
   if (on && !d->stamp_dev) {
     HIP_TRY(hipMalloc((void**)&d->stamp_dev, ETD_STAMP_WORDS * 8));
     HIP_TRY(hipMemset(d->stamp_dev, 0, ETD_STAMP_WORDS * 8));
   }
   HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-  d->stamp_on = on != 0;
+  d->stamp_armed = on != 0; d->stamp_on = false; d->stamp_skip = on ? skip_steps : 0;
   return ETD_OK;
 }
 

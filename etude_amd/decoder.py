@@ -337,10 +337,11 @@ class EtudeDecoder:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().etd_decoder_stats_reset(self._h, self._stream()), "etd_decoder_stats_reset")
 
-    def stamp(self, on: bool) -> None:
-        """Device-side span measurement of every k_dstep_attn_down launch (measurement runs only; own captured graphs)."""
+    def stamp(self, on: bool, skip_steps: int = 0) -> None:
+        """Device-side span measurement of every k_dstep_attn_down launch (measurement runs only; own captured graphs); the first
+        ``skip_steps`` decode steps after switching on are left out."""
         with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().etd_decoder_stamp(self._h, 1 if on else 0, self._stream()), "etd_decoder_stamp")
+            _lib.check(_lib.lib().etd_decoder_stamp(self._h, 1 if on else 0, int(skip_steps), self._stream()), "etd_decoder_stamp")
 
     def debug_step_logits(self, on: bool, n_active: int = 0) -> Optional[np.ndarray]:
         """Test hook: switch the per-step logit store on / off; with n_active > 0 also return the LAST step's logits [n_active, V]."""

@@ -227,13 +227,14 @@ double etd_decoder_step_bytes(const etd_dec*, int n_streams, int ctx);
  *   out[0] steps, out[1] rows x steps (= tokens generated by steps), out[2] algorithmic K/V bytes the steps' attention read (all layers),
  *   out[3] attention launches, out[4] launches measured by the device stamps, out[5] their summed duration in seconds,
  *   out[6] algorithmic bytes (K/V + streamed weights) of the stamped launches, out[7] weight bytes one step streams (SURVEY 8d "W").
- * etd_decoder_stamp(on): while on, every k_dstep_attn_down launch of this handle records its own span on the device
+ * etd_decoder_stamp(on, skip_steps): while on, every k_dstep_attn_down launch of this handle records its own span on the device
  * (s_memrealtime of its first workgroup's start and last workgroup's end) -- the kernel's duration in the configuration it
- * actually runs in, other engines included, which HIP events cannot give inside hipGraph replays.  Stamped steps use their own
- * captured graphs; production graphs carry no stamp code path.  Both synchronise `stream`. */
+ * actually runs in, other engines included, which HIP events cannot give inside hipGraph replays.  The first `skip_steps` decode
+ * steps after switching on are left out (bytes and spans alike), e.g. the bars in which a job's 4-pair history is still filling up.
+ * Stamped steps use their own captured graphs; production graphs carry no stamp code path.  All three synchronise `stream`. */
 int etd_decoder_stats(etd_dec*, double* out, int n, void* stream);
 int etd_decoder_stats_reset(etd_dec*, void* stream);
-int etd_decoder_stamp(etd_dec*, int on, void* stream);
+int etd_decoder_stamp(etd_dec*, int on, int skip_steps, void* stream);
 /* ---- TinyREMITokenizer glue on either side of the decoder (host code, no GPU) ----
  * etd_tok_create      TinyREMITokenizer.__init__ / _create_measures      etude/data/tokenizer.py:24-41,166-229
  * etd_tok_encode      encode (+ _assign_notes, grace-note linking)        :231-252, :78-116, :265-297

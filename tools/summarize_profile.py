@@ -77,11 +77,24 @@ def main():
         name = next((g for g, members in groups.items() if k in members), k)
         if k.startswith("k_dstep_attn_down<"):      # <waves per workgroup, row finish>: one kernel for the bench's profiler
             name = "k_dstep_attn_down"
+        name = re.sub(r"<.*", "", name)              # any other template instance goes under its kernel's name
         b = bench.setdefault(name, [0.0, 0])
         b[0] += v["bytes_per_launch"] * v["launches"]; b[1] += v["launches"]
     out = {k: b[0] / max(b[1], 1) for k, b in bench.items() if k and not k.startswith("__amd")}
-    out["_note"] = ("HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc passes) of `bench.py --clips 8 --attr-grid 27 "
-                    "--bars 24` (same rows per engine and, after 4 bars, the same contexts as the full 92-bar run); see the round's profile_summary.txt")
+    out["_note"] = ("HBM bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc passes) of `bench.py --steps 1 --warmup 0 --max-bars 8` "
+                    "(the headline's batch and engine layout, first 8 bars of every job: same rows per launch and, from bar 4 on, the same contexts as the full run); see the round's profile_summary.txt")
+    # the algorithmic bytes of the SAME launches, from the PMC run's own bench line (exact counters of the library)
+    try:
+        line = json.load(open(os.path.join(root, "prof_fetch.json")))
+        n_attn = traffic.get(next(k for k in traffic if k.startswith("k_dstep_attn_down<8")), {}).get("launches", 0) or 1
+        ds = line["roofline"]["decode_stage"]["alg_bytes_per_step"]
+        steps = n_attn / 8.0
+        w = 50.3e6
+        alg = (ds - steps * w) / n_attn + (2048 + 512) * 512 * 2
+        out["_alg_bytes_per_launch_k_dstep_attn_down_in_the_pmc_run"] = alg
+        print(f"== k_dstep_attn_down in the PMC run: algorithmic {alg/1e6:.1f} MB per launch (K+V of every row's context + down / dense weights) vs measured {out.get('k_dstep_attn_down', 0)/1e6:.1f} MB")
+    except Exception as e:      # noqa: BLE001
+        print("(no algorithmic byte count for the PMC run:", e, ")")
     with open(os.path.join(root, "traffic_bench.json"), "w") as fh:
         json.dump(out, fh, indent=1)
 
