@@ -200,8 +200,9 @@ def main():
     ap.add_argument("--batch-clips", type=int, default=64, help="clips in the batch (all ranks together); each rank takes batch / N")
     ap.add_argument("--clips", type=int, default=0, help="clips per rank (overrides --batch-clips / N)")
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
-    ap.add_argument("--ext-engines", type=int, default=int(os.environ.get("ETD_EXT_ENGINES", "2")),
-                    help="extractor instances that transcribe different clips at the same time (own stream + host thread each)")
+    ap.add_argument("--ext-engines", type=int, default=int(os.environ.get("ETD_EXT_ENGINES", "0")),
+                    help="extractor instances that transcribe different clips at the same time (own stream + host thread each); 0 = three beside one decoder engine, "
+                         "two beside four (hardware queues).  Measured on the 64-clip extract stage: 2 -> 4 850, 3 -> 5 040, 4 -> 5 080 audio-s/s")
     ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "0")),
                     help="decoder engines (own HIP stream + KV cache each, driven from host threads); 0 = by the jobs per rank: ONE engine holding every job as a stream "
                          "from 1024 jobs up (and from 512 on a single GPU) -- 1728 rows per decode-step launch at N = 1: the HBM-bound attention launches then never overlap "
@@ -215,6 +216,7 @@ def main():
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "560")))
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-serial-pass", action="store_true", help="skip the short HIP-event pass (PMC profiling runs: its eager launches would be counted with the step's)")
     ap.add_argument("--no-stamp", action="store_true", help="skip the stamped decode stage (roofline then comes from the serial event pass)")
     args = ap.parse_args()
 
@@ -265,7 +267,10 @@ def main():
         clips = args.batch_clips // world
     cfg = ExtractorConfig()
     wb = int(os.environ.get("ETD_WB", "4"))
-    exs = [AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=wb) for _ in range(max(1, args.ext_engines))]
+    n_jobs0 = (args.clips if args.clips > 0 else args.batch_clips // world) * args.attr_grid
+    one_engine = (args.engines == 1) or (args.engines == 0 and (n_jobs0 >= 1024 or (world == 1 and n_jobs0 >= 512)))
+    n_ext = args.ext_engines if args.ext_engines > 0 else (3 if one_engine else 2)
+    exs = [AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=wb) for _ in range(n_ext)]
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
     grid = attr_grid(args.attr_grid)
     vocab = make_vocab()
@@ -482,6 +487,8 @@ def main():
     # ---- per-kernel HIP-event breakdown: a SHORT serial pass (4 bars per job, stages and engines one at a time, launches eager with an
     # event pair each -- event records cannot sit inside hipGraph replays).  Indicative: serial durations, not the timed configuration's.
     try:
+        if args.no_serial_pass:
+            raise RuntimeError("skipped (--no-serial-pass)")
         _lib.prof_reset()
         _lib.prof_enable(True)
         torch.cuda.synchronize(dev)

@@ -12,7 +12,7 @@ rm -rf $OUT/prof_trace $OUT/prof_fetch $OUT/prof_write
 ARGS="--steps 1 --warmup 1 --no-cpu-baseline --no-extras ${BENCH_ARGS:-}"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_trace -- python3 $ROOT/bench.py $ARGS > $OUT/prof_trace.json 2> $OUT/prof_trace.err || { tail -20 $OUT/prof_trace.err; exit 1; }
-PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-stamp --max-bars ${PMC_BARS:-8} ${BENCH_ARGS:-}"
+PARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-stamp --no-serial-pass --max-bars ${PMC_BARS:-8} ${BENCH_ARGS:-}"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/prof_fetch -- python3 $ROOT/bench.py $PARGS > $OUT/prof_fetch.json 2> $OUT/prof_fetch.err || { tail -20 $OUT/prof_fetch.err; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/prof_write -- python3 $ROOT/bench.py $PARGS > $OUT/prof_write.json 2> $OUT/prof_write.err || { tail -20 $OUT/prof_write.err; exit 1; }
 cd $ROOT

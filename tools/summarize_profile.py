@@ -86,7 +86,7 @@ def main():
     # the algorithmic bytes of the SAME launches, from the PMC run's own bench line (exact counters of the library)
     try:
         line = json.load(open(os.path.join(root, "prof_fetch.json")))
-        n_attn = traffic.get(next(k for k in traffic if k.startswith("k_dstep_attn_down<8")), {}).get("launches", 0) or 1
+        n_attn = sum(v["launches"] for k, v in traffic.items() if k.startswith("k_dstep_attn_down<")) or 1      # both attention forms: the line's bytes cover every step
         ds = line["roofline"]["decode_stage"]["alg_bytes_per_step"]
         steps = n_attn / 8.0
         w = 50.3e6
