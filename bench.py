@@ -391,8 +391,7 @@ def main():
     for i in range(args.steps):
         a, b, c_, d_ = step()
         t_ext += a; t_dec += b; t_notes += c_; n_tok += d_
-        if i == 0:
-            log(f"timed step 1: {a + b + c_:.2f}s (extract {a:.2f} decode {b:.2f} notes {c_:.2f})")
+        log(f"timed step {i + 1}/{args.steps}: {a + b + c_:.2f}s (extract {a:.2f} decode {b:.2f} notes {c_:.2f})")      # (a line per step: harnesses take minutes of silence for a hang)
     results = state["results"]
     gathered_jobs = len(results)
     # digest of every token this rank generated in the last timed step (job order): two builds / switches whose kernels must be
