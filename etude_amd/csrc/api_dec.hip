@@ -234,7 +234,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     ln_ready = false;
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
-    q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
+    q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.Wf = w.qkv.Wf; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
     if (bpipe) q.Xb = d->X1b; else { q.ln_g = w.ln1g; q.ln_b = w.ln1b; q.ln_eps = d->cfg.layer_norm_eps; }
     q.Y = d->qkv_raw; q.ldy = 3 * d->H;
     q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
@@ -254,7 +254,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
         DGemmArgs q2 = q;
         q2.X = d->hlast; q2.M = n; q2.rows = lo->rows; q2.Xb = d->X1b; q2.Qb = nullptr; q2.Kp = nullptr; q2.VTp = nullptr;
         DGemmArgs up2 = {};
-        up2.X = d->hlast; up2.ldx = d->H; up2.W = w.up.W; up2.bias = w.up.b; up2.M = n; up2.N = d->I; up2.Npad = w.up.Npad; up2.K = d->H;
+        up2.X = d->hlast; up2.ldx = d->H; up2.W = w.up.W; up2.Wf = w.up.Wf; up2.bias = w.up.b; up2.M = n; up2.N = d->I; up2.Npad = w.up.Npad; up2.K = d->H;
         up2.Y = d->M1; up2.Xb = d->X2b; up2.Yb = d->Xcat; up2.ldy = d->I + d->H;
         ETD_TRY(launch_dstep_qkv_up(q2, up2, st));
         DAttnArgs at = {};
@@ -273,7 +273,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     } else if (small) {
       // decode step: QKV (+RoPE, KV append) and MLP up (+GELU -> Xcat) share one launch
       DGemmArgs up = {};
-      up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
+      up.X = hin; up.ldx = d->H; up.W = w.up.W; up.Wf = w.up.Wf; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
       up.Y = d->M1; up.Xb = d->X2b; up.Yb = d->Xcat; up.ldy = d->I + d->H;
       ETD_TRY(launch_dstep_qkv_up(q, up, st));
       if (d->trace) {

@@ -26,6 +26,7 @@ enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV =
 struct DGemmArgs {
   const float* X; int ldx;       // [M, K] fp32 activations
   const void* W;                 // [Npad, K] weights (float or bf16), K contiguous
+  const void* Wf;                // optional: the same bf16 weights in MFMA-fragment order (pack_wfrag_host) -- k_dstep_qkv_up_mt
   const float* bias;             // [Npad] or null
   int M, N, K;                   // N = valid output features (stores guarded), Npad % 128 == 0
   int Npad;

@@ -322,6 +322,64 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, 
 // [0, split) belong to the first problem, the rest to the second.  Same 32x32 / 8-wave K-split body as k_dgemm_s
 // (bf16 inputs, K = hidden).  One dependent kernel boundary less per layer of a latency-bound chain.
 // ================================================================================================
+// Epilogue of one 32-feature x 32-token tile of the decode step's QKV|up GEMM: lane = token m, register i = feature n0 + acc_row(i, h).
+// QKV tiles ([head][q|k|v][64], modeling_gpt_neox.py:204-207): bias, partial RoPE on the first 16 dims of q / k, Q as fp32 rows, K / V appended
+// to the slot's cache rows; up tiles: bias + erf-GELU -> bf16 rows of Xcat.  Shared by k_dstep_qkv_up and k_dstep_qkv_up_mt (same operations in the
+// same order: bit-identical results).
+__device__ __forceinline__ void qkv_up_tile_values(const f32x16& acc, const f32x4 (&bq)[4], bool isq, bool rope, const f32x4& rc, const f32x4& rs, float (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
+  if (!isq) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = gelu_fast(v[i]);     // MLP up: erf-GELU
+    return;
+  }
+  if (rope) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x1 = v[i], x2 = v[i + 4];
+      v[i] = x1 * rc[i] - x2 * rs[i];        // q*cos + rotate_half(q)*sin, first half
+      v[i + 4] = x2 * rc[i] + x1 * rs[i];    // second half
+    }
+  }
+}
+// (k_dstep_qkv_up's own form: the same operations, each group of four values rounded and stored as soon as it is formed -- forming all sixteen first, as
+// qkv_up_tile_values does for the LDS-staged stores of the mid-tile kernel, costs this kernel 30 registers and its second wave per SIMD)
+__device__ __forceinline__ void qkv_up_store_tile(const f32x16& acc, const f32x4 (&bq)[4], bool isq, bool rope, const f32x4& rc, const f32x4& rs, int part, int head, int dbase,
+                                                  int n0, int m, int h, int pos, int slot, int act, const DGemmArgs& q, const DGemmArgs& up) {
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
+  if (!isq) {
+    // MLP up: erf-GELU, bf16 rows for the down projection
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int n = n0 + 8 * q4 + 4 * h;
+      if (n < up.N)
+        *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
+            pack4(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
+    }
+    return;
+  }
+  if (rope) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x1 = v[i], x2 = v[i + 4];
+      v[i] = x1 * rc[i] - x2 * rs[i];        // q*cos + rotate_half(q)*sin, first half
+      v[i + 4] = x2 * rc[i] + x1 * rs[i];    // second half
+    }
+  }
+  if (part == 0) {
+    float* qp = q.Q + (long long)m * (q.n_heads * 64) + head * 64 + dbase;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) { const f32x4 o = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q4 + 4 * h) = o; }
+  } else if (act && pos < q.max_ctx) {
+    bf16* kp = reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)slot * q.slot_stride + ((long long)head * q.max_ctx + pos) * 64 + dbase;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<bf16x4*>(kp + 8 * q4 + 4 * h) = pack4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+  }
+}
+
 __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K, int split, int p_ftiles, const void* p_Wq, const void* p_Wu, const bf16* p_Xq,
                                                                const bf16* p_Xu, int p_ldxq, int p_ldxu, int p_rpt, DGemmArgs q, DGemmArgs up) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
@@ -403,43 +461,181 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
       const int m = m0 + r;
-      if (m < M) {
-        float v[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
-        if (!isq) {
-          // MLP up: erf-GELU, bf16 rows for the down projection
-#pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            const int n = n0 + 8 * q4 + 4 * h;
-            if (n < up.N)
-              *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
-                  pack4(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
-          }
-        } else {
-          if (rope) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const float x1 = v[i], x2 = v[i + 4];
-              v[i] = x1 * rc[i] - x2 * rs[i];        // q*cos + rotate_half(q)*sin, first half
-              v[i + 4] = x2 * rc[i] + x1 * rs[i];    // second half
-            }
-          }
-          if (part == 0) {
-            float* qp = q.Q + (long long)m * (q.n_heads * 64) + head * 64 + dbase;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) { const f32x4 o = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q4 + 4 * h) = o; }
-          } else if (actc && posc < q.max_ctx) {
-            bf16* kp = reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)slotc * q.slot_stride + ((long long)head * q.max_ctx + posc) * 64 + dbase;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<bf16x4*>(kp + 8 * q4 + 4 * h) = pack4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
-          }
-        }
-      }
+      if (m < M) qkv_up_store_tile(acc, bq, isq, rope, rc, rs, part, head, dbase, n0, m, h, posc, slotc, actc, q, up);
     }
     if (t + 1 < p_rpt) __syncthreads();              // wave 0 has read `red` before the next tile's partial sums land in it
   }
   SS(3); SS_FLUSH(1, isq ? 0 : 1);
+}
+
+// k_dstep_qkv_up_mt: the same GEMM for MANY rows (above DS_MAX_ROWS: 1 728 streams of a 64-clip batch in one launch).  What the 32 x 32 form costs there
+// (38-41 us at 1 728 rows, whether or not a workgroup keeps its weights for several row tiles) is neither its operand bytes from L2 nor its stores: a fragment load
+// straight from a ROW-MAJOR operand touches 32 rows x 32 bytes -- 32 cache lines per instruction, a quarter of each used -- and the CU's address path, not the L2,
+// sets the pace (a 128 x 128 tile fed the same way took the same 39 us; so did LDS-staged row-segment stores alone).  Here a workgroup owns 128 features x 128
+// rows, each of its 4 waves 64 x 64 (2 x 2 MFMA tiles):
+//   * weights from the FRAGMENT-ORDERED copy the batched prefill already uses (pack_wfrag_host: one contiguous KiB per fragment, lane l's 16 bytes at 16 l);
+//   * activations through LDS: a 64-deep K chunk of the 128 rows arrives as full 128-byte row segments (8 lanes per row), double-buffered, fragments by
+//     conflict-free ds_read_b128 from 144-byte rows;
+//   * outputs leave as full row segments through the same LDS (below).
+// Bit-identical to the 32 x 32 form: a tile's sum is still (k 0 .. 255 chained) + (k 256 .. 511 chained), as that kernel's two K-half waves form it.
+#define QMT_PITCH 144                                    // bytes per LDS row of 64 bf16 (+16: conflict-free 16-byte fragment reads)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dstep_qkv_up_mt(int p_M, int split128, int p_ftiles128, const bf16* p_Wfq, const bf16* p_Wfu, const bf16* p_Xq, const bf16* p_Xu,
+                                                         int p_ldxq, int p_ldxu, DGemmArgs q, DGemmArgs up) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * QMT_PITCH];      // K loop: two [128 rows][64 k] chunks of X; epilogue: four [64 rows][64 features] wave regions
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, fh = wave & 1, rh = wave >> 1;
+  const int M = p_M, K = 512;
+  const int RT = (M + 127) / 128, bid = blockIdx.x, ft = ((bid >> 3) / RT) * 8 + (bid & 7);      // row tiles of one weight tile back to back on one XCD
+  if (ft >= p_ftiles128) return;
+  const bool isq = ft < split128;
+  const int mwg = ((bid >> 3) % RT) * 128, m0 = mwg + rh * 64, n0 = (isq ? ft : ft - split128) * 128 + fh * 64;
+  const bf16* wfrag = (isq ? p_Wfq : p_Wfu) + ((long long)(n0 / 32) * (K / 16) * 64 + lane) * 8;      // fragment (tile n0 / 32 + t, k-step s) at + ((t * 32 + s) * 64) * 8
+  const bf16* xbase = isq ? p_Xq : p_Xu;
+  const int ldx = isq ? p_ldxq : p_ldxu;
+  // this thread's four 16-byte pieces of a chunk: piece p = tid + 256 i -> row p >> 3, 16-byte column p & 7
+  const bf16* xsrc[4]; int xdst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pce = tid + 256 * i, row = pce >> 3, c = pce & 7;
+    int gmr = mwg + row; gmr = gmr < M ? gmr : M - 1;
+    xsrc[i] = xbase + (long long)gmr * ldx + c * 8;
+    xdst[i] = row * QMT_PITCH + c * 16;
+  }
+  int gm[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { gm[t] = m0 + 32 * t + r; gm[t] = gm[t] < M ? gm[t] : M - 1; }
+  // row metadata and bias first (the epilogue's dependent loads ride under the K loop)
+  int pos[2], slot[2], act[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) { pos[t] = q.rows.pos[gm[t]]; slot[t] = q.rows.slot[gm[t]]; act[t] = q.rows.active[gm[t]]; }
+  f32x4 bq[2][4];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const float* bp = (isq ? q.bias : up.bias) + n0 + 32 * f + 4 * h;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) bq[f][q4] = *reinterpret_cast<const f32x4*>(bp + 8 * q4);
+  }
+  f32x16 acc[2][2], accA[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;
+  u32x4 xr[4];                                           // the next chunk's pieces on their way to LDS
+  bf16x8 wf[2][4][2];                                    // [buffer][k-step of the chunk][feature tile]
+  auto xrequest = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + c * 64);
+  };
+  auto wrequest = [&](int c, int b) {
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+      for (int f = 0; f < 2; ++f) wf[b][s4][f] = *reinterpret_cast<const bf16x8*>(wfrag + (long long)((f * 32 + c * 4 + s4) * 64) * 8);
+  };
+  xrequest(0); wrequest(0, 0);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = half * 4 + cc, b = c & 1;
+      unsigned char* xb = smem + b * (128 * QMT_PITCH);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(xb + xdst[i]) = xr[i];
+      __syncthreads();                                   // chunk c is in LDS; every wave is done reading chunk c - 1's buffer twin (c - 2 used this one)
+      if (c + 1 < 8) { xrequest(c + 1); wrequest(c + 1, b ^ 1); }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        bf16x8 xf[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xb + (rh * 64 + 32 * t + r) * QMT_PITCH + s4 * 32 + h * 16);
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) acc[f][t] = mfma32(wf[b][s4][f], xf[t], acc[f][t]);
+      }
+    }
+    if (half == 0) {                                     // k 0 .. 255 done: what the 32 x 32 kernel's first K-half wave holds
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          accA[f][t] = acc[f][t];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;
+        }
+    }
+  }
+  __syncthreads();                                       // the X buffers become the waves' output staging regions
+  // ---- epilogue.  With the token on the lane a direct store puts 8 (bf16) or 16 (fp32) bytes into each of 32 different rows per instruction: 1.5 M partial
+  // writes per 1 728-row launch, and THAT, not the operand traffic, set the 39 us of both tile shapes.  The wave's 64 features are exactly one (head, part) of the
+  // fused QKV -- one 128-byte K / V cache row, one 256-byte run of a Q row -- or 128 bytes of an Xcat row: the values go through the wave's own LDS region
+  // ([64 rows][64 features], row pitch + 16 B: conflict-free) and leave as full row segments, 8 lanes per 128 bytes.
+  unsigned char* sw = smem + wave * (64 * QMT_PITCH);
+  const int head = n0 / 192, part = (n0 - head * 192) >> 6;       // (QKV tiles; n0 is a multiple of 64)
+  const int er = lane >> 3, ec = lane & 7;                        // read-back: 8 rows x 8 sixteen-byte chunks per instruction
+  float vv[2][2][16];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const bool rope = isq && part < 2 && f == 0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x16 a2;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a2[i] = accA[f][t][i] + acc[f][t][i];      // (first half) + (second half): the order of the two-wave reduction
+      f32x4 rc = {1.f, 1.f, 1.f, 1.f}, rs = {0.f, 0.f, 0.f, 0.f};
+      if (rope) {
+        rc = *reinterpret_cast<const f32x4*>(q.rope_cos + (long long)pos[t] * 8 + 4 * h);
+        rs = *reinterpret_cast<const f32x4*>(q.rope_sin + (long long)pos[t] * 8 + 4 * h);
+      }
+      qkv_up_tile_values(a2, bq[f], isq, rope, rc, rs, vv[f][t]);
+    }
+  }
+  if (!isq || part != 0) {
+    // bf16 rows: Xcat (up) or the K / V cache row of (slot, head, position)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+          *reinterpret_cast<bf16x4*>(sw + (32 * t + r) * 144 + (32 * f + 8 * q4 + 4 * h) * 2) = pack4(vv[f][t][4 * q4], vv[f][t][4 * q4 + 1], vv[f][t][4 * q4 + 2], vv[f][t][4 * q4 + 3]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + er, m = m0 + row;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(sw + row * 144 + ec * 16);
+      if (m >= M) continue;
+      if (!isq) {
+        if (n0 + ec * 8 < up.N) *reinterpret_cast<u32x4*>(up.Yb + (long long)m * up.ldy + n0 + ec * 8) = val;
+      } else {
+        const int rl = row & 31, tt = row >> 5;
+        const int ps = __shfl(pos[tt], rl, 64), sl = __shfl(slot[tt], rl, 64), ac = __shfl(act[tt], rl, 64);
+        if (ac && ps < q.max_ctx)
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)sl * q.slot_stride + ((long long)head * q.max_ctx + ps) * 64 + ec * 8) = val;
+      }
+    }
+  } else {
+    // Q: fp32 rows, 256 bytes per (row, head): two passes of 32 features through the same region
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 o = {vv[f][t][4 * q4], vv[f][t][4 * q4 + 1], vv[f][t][4 * q4 + 2], vv[f][t][4 * q4 + 3]};
+          *reinterpret_cast<f32x4*>(sw + (32 * t + r) * 144 + (8 * q4 + 4 * h) * 4) = o;
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + er, m = m0 + row;
+        const u32x4 val = *reinterpret_cast<const u32x4*>(sw + row * 144 + ec * 16);
+        if (m < M) *reinterpret_cast<u32x4*>(q.Q + (long long)m * (q.n_heads * 64) + head * 64 + 32 * f + ec * 4) = val;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
 }
 
 int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st) {
@@ -449,6 +645,13 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
   const int split = q.Npad / 32;
   const int ftiles = split + up.Npad / 32;
+  static const bool mt_on = !(getenv("ETD_QKV_MT") && atoi(getenv("ETD_QKV_MT")) == 0);
+  if (mt_on && q.M > DS_MAX_ROWS && q.Npad % 128 == 0 && up.Npad % 128 == 0 && q.Wf && up.Wf) {
+    const int split128 = q.Npad / 128, ft128 = split128 + up.Npad / 128, RT128 = (q.M + 127) / 128;
+    hipLaunchKernelGGL(k_dstep_qkv_up_mt, dim3((unsigned)(((ft128 + 7) / 8) * 8 * RT128)), dim3(256), 0, st, q.M, split128, ft128, (const bf16*)q.Wf, (const bf16*)up.Wf, q.Xb, up.Xb, q.ldx, up.ldx, q, up);
+    HIP_TRY(hipGetLastError());
+    return ETD_OK;
+  }
   static const int rpt_env = getenv("ETD_QKV_RPT") ? atoi(getenv("ETD_QKV_RPT")) : 0;
   const int rpt = rpt_env > 0 ? rpt_env : (q.M > DS_MAX_ROWS ? 4 : 1);
   const int RT = (q.M + 31) / 32, RG = (RT + rpt - 1) / rpt;
