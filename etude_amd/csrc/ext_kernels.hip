@@ -642,16 +642,21 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int nh = a.n_heads > 0 ? a.n_heads : 4;
   const int seq = blockIdx.y / nh, head = blockIdx.y - seq * nh;
-  const int q0 = blockIdx.x * 128 + wave * 32;
   int Sq = a.Sq, Sk = a.Sk;
   long long qbase = (long long)seq * a.q_seq_stride, kbase_off = (long long)seq * a.k_seq_stride, obase = (long long)seq * a.o_seq_stride;
+  // Ragged causal batches (the decoder's batched prefill): the 128-query tiles are aligned to the END of the sequence.  A prompt is 512 + 1 tokens after
+  // generate()'s truncation; left-aligned, its 513th token gets a tile of its own that walks all 9 key tiles (29 tile-steps per (sequence, head)); right-aligned the
+  // ragged tile is the FIRST, with one key tile to visit (25).  Per query the same keys in the same order: bit-identical.
+  int off = 0;
   if (a.seq_len) {                                   // ragged batch: rows of this sequence
     Sq = Sk = a.seq_len[seq];
     const long long r0 = a.seq_row0[seq];
     qbase = r0 * a.ldq; kbase_off = r0 * a.ldk; obase = r0 * a.ldo;
-    if (blockIdx.x * 128 >= Sq) return;              // whole workgroup beyond this (shorter) sequence
+    if (a.causal) off = (128 - (Sq & 127)) & 127;
+    if ((int)blockIdx.x * 128 - off >= Sq) return;   // whole workgroup beyond this (shorter) sequence
   }
-  int qi = q0 + r; const bool qvalid = qi < Sq; if (!qvalid) qi = Sq - 1;
+  const int q0 = (int)blockIdx.x * 128 + wave * 32 - off;
+  int qi = q0 + r; const bool qvalid = qi >= 0 && qi < Sq; qi = qi < 0 ? 0 : (qi < Sq ? qi : Sq - 1);
 
   const bf16* qp = a.Q + qbase + (long long)qi * a.ldq + head * 64;
   bf16x8 qf[4];
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   float mrun = -INFINITY, lrun = 0.f;
 
   int ntile = (Sk + 63) >> 6;
-  if (a.causal) { const int lim = (blockIdx.x * 128 + 127) / 64 + 1; ntile = ntile < lim ? ntile : lim; }   // tiles past the diagonal are fully masked
+  if (a.causal) { const int lim = ((int)blockIdx.x * 128 + 127 - off) / 64 + 1; ntile = ntile < lim ? ntile : lim; }   // tiles past the diagonal are fully masked
   // K/V tiles are prefetched one tile ahead into registers (global latency hides under the previous tile's MFMA/softmax)
   u32x4 kreg[2], vreg[2];
   auto tile_gload = [&](int kv0_) {
