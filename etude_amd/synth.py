@@ -205,7 +205,7 @@ def decoder_state_dict_ctx(seed: int = 0, dims: Dict[str, int] | None = None, fo
       * query / key projections are scaled by `qk_gain` (sharp, content-addressed attention: which past token a head locks onto changes
         from step to step and with every change of the context), values and the two output projections by `v_gain` / `out_gain`, so
         what attention retrieves is as large in the residual stream as the current token's embedding.
-    Measured on the configs[1] condition bars (tests/golden/README): ~44-55 % of the ids are predictable from the previous one, 60+ distinct
+    Measured on the configs[1] condition bars (tests/golden/make_golden.py): ~44-55 % of the ids are predictable from the previous one, 60+ distinct
     ids per 16 bars, most bars end in Bar_EOS; dropping a key block, a wrong RoPE position or a wrong row changes the ids within a few tokens."""
     d = decoder_dims(**(dims or {}))
     sd = decoder_state_dict(seed, dims, gain=1.0, emb_gain=emb_gain, follow=0.0)
