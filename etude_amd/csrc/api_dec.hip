@@ -216,7 +216,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
   if (compact) *compact = false;
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
-  const bool bpipe = d->bf16w && M > 1;
+  const bool bpipe = d->bf16w && (M > 1 || is_step);     // (is_step with M == 1: the fused step kernels for a single stream, ETD_FUSED_M1)
   // a decode step (is_step: one row per stream, M <= DS_STEP_MAX_ROWS) stays on the fused step kernels whatever its row count
   const bool big = bpipe && !is_step && M > DS_MAX_ROWS && d->layers[0].qkv.Wf && d->layers[0].up.Wf && d->layers[0].cat.Wf;
   bool ln_ready = false;            // X1b / X2b already hold this layer's LayerNorm rows (written by the previous layer's k_dmlp_fused)
@@ -896,7 +896,10 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   // bf16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
   // (QKV|up, attention, down|dense, residual + LayerNorm) and one head launch that also prepares the next step's rows
   const int vpad = (d->V + 31) / 32 * 32;
-  const bool fused = d->bf16w && n_active > 1 && n_active <= DS_STEP_MAX_ROWS && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
+  // A single stream steps on the fused kernels too (round 3; ETD_FUSED_M1=0: the GEMV sequence of rounds 1-2): 25 launches per step instead of ~36 and the same
+  // arithmetic as inside a batch -- one job of 92 bars x 48 tokens 1.09 -> 0.66 s (tools/runs3/r3_run20.sh), every decoder golden unchanged.
+  static const bool fused_m1 = !(getenv("ETD_FUSED_M1") && atoi(getenv("ETD_FUSED_M1")) == 0);
+  const bool fused = d->bf16w && (n_active > 1 || fused_m1) && n_active <= DS_STEP_MAX_ROWS && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
                      vpad <= d->head.Npad && d->head_frag && !getenv("ETD_NO_FUSED_STEP");
   d->last_step_fused = fused;
   d->stamp_on = d->stamp_armed && d->stamp_skip <= 0;          // (a whole call is stamped or not: the scheduler issues one bar's steps per call)
