@@ -646,7 +646,10 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
   const int split = q.Npad / 32;
   const int ftiles = split + up.Npad / 32;
   static const bool mt_on = !(getenv("ETD_QKV_MT") && atoi(getenv("ETD_QKV_MT")) == 0);
-  if (mt_on && q.M > DS_MAX_ROWS && q.Npad % 128 == 0 && up.Npad % 128 == 0 && q.Wf && up.Wf) {
+  // rows from which the 128 x 128 form runs.  Measured (tools/runs3/r3_run21.sh, us per launch, 32 x 32 form / 128 x 128 form): 54 rows 7.2 / 12.3, 128: 9.2 / 12.6,
+  // 216: 12.9 / 12.8, 320: 15.8 / 13.3, 432: 18.9 / 13.1, 512: 19.5 / 13.3, 1 728: 40 / 18 -- the two cross at ~220 rows; bit-identical either way
+  static const int mt_min = getenv("ETD_QKV_MT_MIN") ? atoi(getenv("ETD_QKV_MT_MIN")) : 256;
+  if (mt_on && q.M >= mt_min && q.Npad % 128 == 0 && up.Npad % 128 == 0 && q.Wf && up.Wf) {
     const int split128 = q.Npad / 128, ft128 = split128 + up.Npad / 128, RT128 = (q.M + 127) / 128;
     hipLaunchKernelGGL(k_dstep_qkv_up_mt, dim3((unsigned)(((ft128 + 7) / 8) * 8 * RT128)), dim3(256), 0, st, q.M, split128, ft128, (const bf16*)q.Wf, (const bf16*)up.Wf, q.Xb, up.Xb, q.ldx, up.ldx, q, up);
     HIP_TRY(hipGetLastError());
