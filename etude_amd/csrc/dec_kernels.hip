@@ -605,12 +605,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int it = 0; it < 8; ++it) {
       const int row = it * 8 + er, m = m0 + row;
       const u32x4 val = *reinterpret_cast<const u32x4*>(sw + row * 144 + ec * 16);
+      // the row's metadata sits in lane (row & 31) of the wave: fetched with EVERY lane active (a shuffle from a lane that has left the loop is undefined --
+      // a ragged last tile, e.g. a 300-row prefill, would append K / V rows at garbage positions)
+      const int rl = row & 31, tt = row >> 5;
+      const int ps = __shfl(tt ? pos[1] : pos[0], rl, 64), sl = __shfl(tt ? slot[1] : slot[0], rl, 64), ac = __shfl(tt ? act[1] : act[0], rl, 64);
       if (m >= M) continue;
       if (!isq) {
         if (n0 + ec * 8 < up.N) *reinterpret_cast<u32x4*>(up.Yb + (long long)m * up.ldy + n0 + ec * 8) = val;
       } else {
-        const int rl = row & 31, tt = row >> 5;
-        const int ps = __shfl(pos[tt], rl, 64), sl = __shfl(slot[tt], rl, 64), ac = __shfl(act[tt], rl, 64);
         if (ac && ps < q.max_ctx)
           *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)sl * q.slot_stride + ((long long)head * q.max_ctx + ps) * 64 + ec * 8) = val;
       }
