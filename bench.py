@@ -578,9 +578,9 @@ def main():
         dist.destroy_process_group()
 
 
-def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 64, engines: int = 2, streams=None):
-    """BASELINE configs[3]: 128 concurrent streams, each prefilled to ctx0 then `steps` greedy decode steps
-    (EOS suppressed so every stream runs the full length -- throughput does not depend on the token values).
+def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps: int = 512, engines: int = 2, streams=None):
+    """BASELINE configs[3]: 128 concurrent streams, each prefilled to ctx0 then `steps` (512: SURVEY 8(d) config 4) greedy decode steps in a
+    4 096-position KV ring (EOS suppressed so every stream runs the full length -- throughput does not depend on the token values).
     The streams are dealt over `engines` decoder engines (own stream, KV cache and captured graphs, shared weights) that
     step concurrently from one host thread each, like the headline's decode stage: one step of the figure below = every one
     of the n_streams streams advanced by one token.
