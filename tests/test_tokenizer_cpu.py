@@ -141,3 +141,50 @@ def test_full_clip_notes_to_bars_match_reference(golden_dir, tmp_path):
     bars = tk.split_sequence_into_bars(ids, v.get_bar_bos_id(), v.get_bar_eos_id())
     assert [len(b) for b in bars] == g["bar_lens"].tolist()
     assert [t for b in bars for t in b] == g["bar_ids"].tolist()
+
+
+def test_array_paths_of_the_batch_pipeline_match_the_object_paths():
+    """etude_amd/pipeline.py hands notes -> events -> ids -> bars from stage to stage as arrays (no per-note Python objects): every array path must give exactly what the
+    reference-shaped object path gives -- `id_lookup` / `events_to_ids` vs `Vocab.encode_sequence`, `split_ids_into_packed_bars` vs `split_sequence_into_bars`, `PackedBars`."""
+    import numpy as np
+    from etude_amd import synth
+    from etude_amd.decoder import PackedBars
+    from etude_amd.extractor import NOTE_DTYPE
+    from etude_amd.pipeline import attr_grid, synthetic_tempo
+    from etude_amd.tokenizer import TinyREMITokenizer
+    from etude_amd.vocab import Vocab
+    v = Vocab()
+    v.token_to_id = synth.vocab_json()["token_to_id"]
+    v.id_to_token = [""] * len(v.token_to_id)
+    for t, i in v.token_to_id.items():
+        v.id_to_token[i] = t
+    lut = TinyREMITokenizer.id_lookup(v)
+    table = TinyREMITokenizer.event_table(v)
+    # every vocabulary token that is an event maps back to its own id
+    for i in range(len(v)):
+        t, val = int(table[i]["type"]), int(table[i]["value"])
+        if t < 5:
+            assert int(lut[t, val + 2048]) == i, v.id_to_token[i]
+    rng = np.random.default_rng(3)
+    for trial in range(4):
+        n = 300 + 50 * trial
+        notes = np.zeros(n, NOTE_DTYPE)
+        notes["onset"] = np.sort(rng.uniform(0, 40, n)); notes["offset"] = notes["onset"] + rng.uniform(0.05, 2.0, n)
+        notes["pitch"] = rng.integers(10, 120, n); notes["velocity"] = rng.integers(1, 127, n)      # pitches outside 21..108 become <UNK>
+        tempo = synthetic_tempo(n_downbeats=20)
+        tk_a, tk_o = TinyREMITokenizer.from_tempo_data(tempo), TinyREMITokenizer.from_tempo_data(tempo)
+        ids_a = tk_a.events_to_ids(tk_a.encode_note_array_to_events(notes), lut)
+        ids_o = v.encode_sequence(tk_o.encode_notes(notes))
+        assert ids_a.tolist() == ids_o
+        bi, bo = tk_a.split_ids_into_packed_bars(ids_a, v.get_bar_bos_id(), v.get_bar_eos_id())
+        bars = tk_o.split_sequence_into_bars(ids_o, v.get_bar_bos_id(), v.get_bar_eos_id())
+        pb = PackedBars(bi, bo)
+        assert len(pb) == len(bars) and [pb.bar(i) for i in range(len(pb))] == bars
+        pb2 = PackedBars.from_lists(bars)
+        assert np.array_equal(pb2.ids, pb.ids) and np.array_equal(pb2.offsets, pb.offsets)
+    g = attr_grid(27)
+    assert len({(a["polyphony_bin"], a["rhythm_intensity_bin"], a["sustain_bin"]) for a in g}) == 27 and all(a["pitch_overlap_bin"] == 2 for a in g)
+    assert attr_grid(1) == [dict(polyphony_bin=1, rhythm_intensity_bin=1, sustain_bin=1, pitch_overlap_bin=2)]
+    import pytest
+    with pytest.raises(ValueError):
+        PackedBars(np.zeros(4, np.int32), np.asarray([0, 5], np.int32))
