@@ -441,12 +441,14 @@ def main():
         "cover_notes_per_job": float(np.mean([n.size for n in state["notes"]])), "jobs_gathered": gathered_jobs, "tokens_sha256_rank0": tok_digest,
     }
 
+    late = lambda margin: since_process_start() > args.budget_s - margin           # noqa: E731  (the ONE JSON line matters more than its optional parts)
     # ---- roofline of the dominant kernel, in the timed configuration: one more decode stage over the same conditions with every
     # engine stamping its k_dstep_attn_down launches on the device (first workgroup's start .. last workgroup's end)
     roof = {"kernel": "k_dstep_attn_down", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
     if not args.no_stamp:
-        stamp_bars = args.max_bars or 24
-        skip_bars = 4 if stamp_bars > 8 else 0                  # the bars in which the 4-pair history (and with it the context) is still growing
+        # short runs (profiling: tools/profile.sh) stamp every bar of the extra stage, the harness's 25-step run 24 bars (its budget is tight)
+        stamp_bars = args.max_bars or (0 if args.steps + args.warmup <= 4 and not late(90.0) else 24)
+        skip_bars = 4 if (stamp_bars == 0 or stamp_bars > 8) else 0     # the bars in which the 4-pair history (and with it the context) is still growing
         for d in decs:
             d.stamp(True, skip_steps=skip_bars * (args.bar_tokens - 1))
             d.stats_reset()
@@ -463,7 +465,7 @@ def main():
             roof.update(achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBS, 4), launches=int(launches), avg_launch_ms=round(1e3 * secs / launches, 5),
                         alg_bytes_per_launch=byts / launches,
                         frac_source=("device stamps (etd_decoder_stamp): s_memrealtime of the first workgroup's start and the last workgroup's end of EVERY k_dstep_attn_down launch "
-                                     f"of one extra decode stage over the same jobs (bars {skip_bars} .. {stamp_bars - 1}: the steady-state prompt size, 96 % of a job's bars) with all {len(decs)} "
+                                     f"of one extra decode stage over the same jobs (bars {skip_bars} .. {(stamp_bars or int(np.mean(nbars))) - 1}: the steady-state prompt size, 96 % of a job's bars) with all {len(decs)} "
                                      "engine(s) running, i.e. the kernel's own span in the timed configuration -- what a rocprofv3 kernel trace of this command averages; "
                                      "algorithmic bytes = K+V rows of every (row, head) context + the down / dense weights a launch streams, counted exactly by the library"))
     result["roofline"] = roof
@@ -514,7 +516,6 @@ def main():
         result.setdefault("extras", {})["batch64"] = batch64
 
     # ---- extras outside the timed region
-    late = lambda margin: since_process_start() > args.budget_s - margin           # noqa: E731  (the ONE JSON line matters more than its optional parts)
     if not args.no_extras and rank == 0 and late(30.0):
         result.setdefault("extras", {})["skipped"] = "the run is within 30 s of its harness budget"
     elif not args.no_extras and rank == 0:
