@@ -55,6 +55,12 @@ sys.path.insert(0, str(ROOT))
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 T_START = time.perf_counter()
+# cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r04_parity_mode.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
+# extract, the fp32 decode of its 27 jobs x all bars, and the bf16 decode of the same jobs
+PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "12"))
+PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.6"))
+PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "4.0"))
+PARITY_BF16_S_PER_CLIP = float(os.environ.get("ETD_PARITY_BF16_S", "0.5"))
 
 
 def since_process_start() -> float:
@@ -190,6 +196,87 @@ def cpu_baseline(bars, seconds_budget: float = 25.0, clip_seconds: float = 180.0
             "extract_audio_s_per_s": round(nwin * 8.192 / t_ext, 4),
             "decoder_tokens_per_s": round(bar_tokens / t_bar, 2), "decoder_cores": dthreads}
 
+def bar_divergence(ra, rb):
+    """per-bar comparison of two result lists [(flat ids, bar lengths)] of the same jobs (tests/test_gpu_full_configs.py: a bar can only be compared
+    while the two histories are still equal): -> (bars identical, comparable bars, jobs identical end to end)"""
+    same = comparable = jobs_same = 0
+    for (fa, la), (fb, lb) in zip(ra, rb):
+        oa, ob = np.concatenate([[0], np.cumsum(la)]), np.concatenate([[0], np.cumsum(lb)])
+        nb = min(len(la), len(lb))
+        k = 0
+        while k < nb and la[k] == lb[k] and np.array_equal(fa[oa[k]:oa[k + 1]], fb[ob[k]:ob[k + 1]]):
+            k += 1
+        same += k
+        comparable += min(k + 1, nb)
+        jobs_same += int(k == nb and len(la) == len(lb))
+    return same, comparable, jobs_same
+
+
+def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_engines, time_left):
+    """extras.parity_mode: what exact parity costs.  north_star's "identical token-id sequences under greedy decode" holds in the fp32 mode (the reference
+    runs fp32: etude_decoder.py:333); the headline is timed in bf16.  The SAME chain (extract .. notes) on the first `n_clips` clips of this rank with the fp32
+    extractor and fp32 decoder engines, ONE timed pass after a 2-bar warm-up pass; then the bf16 decoder on the SAME condition bars (the fp32 extractor's) for
+    the per-bar divergence of the two decoders."""
+    import torch
+    from etude_amd import synth
+    from etude_amd.config import ExtractorConfig
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    from etude_amd.extractor import AMTAPC_Extractor
+    from etude_amd.pipeline import ClipBatchPipeline, synthetic_tempo
+    t_in = time.perf_counter()
+    n_jobs = n_clips * len(grid)
+    n_eng = 4 if n_jobs >= 64 else 1
+    per_eng = (n_jobs + n_eng - 1) // n_eng
+    ex32 = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(0), dev, max_windows=4, precision="fp32")
+    d32 = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="fp32", max_streams=per_eng,
+                        max_prefill_rows=min(65536, per_eng * 520))]
+    d32 += [d32[0].clone() for _ in range(n_eng - 1)]
+    pipe32 = ClipBatchPipeline([ex32], d32, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+    sub = wavs[:n_clips]
+    conds = pipe32.extract_stage(sub)
+    pipe32.decode_stage(conds, max_bars=2)                     # allocations, graph captures
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    conds = pipe32.extract_stage(sub)
+    t1 = time.perf_counter()
+    res32, st32 = pipe32.decode_stage(conds, max_bars=max_bars)
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter()
+    pipe32.notes_stage(conds, res32)
+    t3 = time.perf_counter()
+    ntok = sum(s["tokens"] for s in st32)
+    bars_done = int(np.mean([len(r[1]) for r in res32]))
+    frac = 1.0
+    if max_bars:
+        frac = bars_done / max(1.0, float(np.mean([len(cd.bars) for cd in conds])))
+    out = {"workload": f"the headline's chain on {n_clips} of its clips x {len(grid)} tuples = {n_jobs} jobs in the EXACT-PARITY mode: fp32 extractor (etd_ext_cfg.precision 1) "
+                       f"+ fp32 decoder (weights, KV cache, activations; {n_eng} engine(s) x {per_eng} streams), {args.bar_tokens} tokens per bar"
+                       + (f"; ONLY THE FIRST {max_bars} BARS of every job were decoded to stay inside the harness budget (audio_s_per_s scales the decode stage to all bars)" if max_bars else ""),
+           "extract_s": round(t1 - t0, 3), "decode_s": round(t2 - t1, 3), "notes_s": round(t3 - t2, 3),
+           "audio_s_per_s": round(args.seconds * n_clips / ((t1 - t0) + (t2 - t1) / frac + (t3 - t2) / frac), 2),
+           "extract_audio_s_per_s": round(args.seconds * n_clips / (t1 - t0), 1), "decoder_tokens_per_s": round(ntok / (t2 - t1), 1),
+           "tokens_sha256": hashlib.sha256(np.concatenate([r[0] for r in res32]).astype(np.int32).tobytes()).hexdigest()[:16]}
+    for d in reversed(d32):
+        d.close()
+    pipe32.close()
+    # the bf16 decoder on the same condition bars: the headline's engines when they hold enough streams, else nothing (no new allocations this late)
+    if time_left() > 25.0 and bf16_engines and sum(d.max_streams for d in bf16_engines) >= n_jobs:
+        pipe16 = ClipBatchPipeline([ex32], bf16_engines, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+        t4 = time.perf_counter()
+        res16, st16 = pipe16.decode_stage(conds, max_bars=max_bars)
+        torch.cuda.synchronize(dev)
+        t5 = time.perf_counter()
+        pipe16.close()
+        same, comparable, jobs_same = bar_divergence(res32, res16)
+        out["bf16_same_conditions"] = {"decode_s": round(t5 - t4, 3), "decoder_tokens_per_s": round(sum(s["tokens"] for s in st16) / (t5 - t4), 1),
+                                       "bars_identical": same, "bars_comparable": comparable, "bar_divergence_rate": round(1.0 - same / max(1, comparable), 5),
+                                       "jobs_identical_end_to_end": jobs_same, "jobs": len(res32),
+                                       "note": "bf16 decoder engines of the headline on the fp32 extractor's condition bars; a bar is comparable while both histories are still equal"}
+        out["fp32_over_bf16_decode_time"] = round((t2 - t1) / (t5 - t4), 2)
+    ex32.close()
+    out["wall_s"] = round(time.perf_counter() - t_in, 2)
+    return out
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -215,6 +302,10 @@ def main():
     ap.add_argument("--max-bars", type=int, default=0, help="diagnostics / profiling passes only: decode just the first N bars of every job (stated in config.workload)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "560")))
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--parity-clips", type=int, default=int(os.environ.get("ETD_PARITY_CLIPS", "8")),
+                    help="extras.parity_mode: clips taken through the chain in the exact-parity mode (fp32 extractor + fp32 decoder); 0 = skip.  Runs only when the harness "
+                         "budget has room for it (fewer bars per job, then fewer clips, are the first things shed)")
+    ap.add_argument("--parity-bars", type=int, default=0, help="extras.parity_mode: decode only the first N bars of every job (0 = by the time left)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the short HIP-event pass (PMC profiling runs: its eager launches would be counted with the step's)")
     ap.add_argument("--no-stamp", action="store_true", help="skip the stamped decode stage (roofline then comes from the serial event pass)")
@@ -286,10 +377,15 @@ def main():
         decs += [decs[0].clone() for _ in range(n_eng - 1)]            # engines share one weight set (own KV caches and state)
         return decs, n_jobs, per_eng
 
+    def my_clip_ids(n_clips):
+        """global indices of this rank's clips: parallel.shard over the batch (rank r of R takes clips r, r + R, ...: tests/test_parallel_gloo.py), so that
+        parallel.unshard of the gathered results restores the batch order whatever N is"""
+        return parallel.shard(list(range(n_clips * world)), rank, world)
+
     def make_wavs(n_clips):
         base = synth.clip_audio(seed=1234, seconds=args.seconds)
         wavs = []
-        for ci in [rank * n_clips + c for c in range(n_clips)]:          # global clip index = rank-major shard; distinct clips, resident in HBM
+        for ci in my_clip_ids(n_clips):                                  # distinct clips, resident in HBM
             rng = np.random.default_rng(1234 + ci)
             w = np.roll(base, int(rng.integers(0, base.shape[1])), axis=1) * np.float32(rng.uniform(0.6, 1.0))
             wavs.append(torch.from_numpy(np.ascontiguousarray(w)).to(dev))
@@ -304,7 +400,7 @@ def main():
         """rounds 1-2 workload (A/B): replace each clip's own bars by the synthetic ~8-notes/bar song"""
         out = []
         for c, cd in enumerate(conds):
-            out.append(ClipConditions(cd.notes, cd.volume, PackedBars.from_lists(synth.song_bars(seed=1234 + rank * clips + c, n_bars=92)), cd.tokenizer))
+            out.append(ClipConditions(cd.notes, cd.volume, PackedBars.from_lists(synth.song_bars(seed=1234 + my_clip_ids(clips)[c], n_bars=92)), cd.tokenizer))
         return out
 
     state = {}
@@ -336,7 +432,10 @@ def main():
     warm_mode = "full step"
     shrunk_from = None
     batch64 = None
-    OVERHEAD_S = 42.0            # stamped decode stage (24 bars) + short event pass + extras + CPU baseline + teardown (measured 35 s; extras and the CPU baseline are dropped if the run is late)
+    # What follows the timed steps, in the order it is SHED when the run is late (time_left() below): extras.parity_mode (bars, then clips, then all of it), the extras
+    # (configs[1..3], ~12 s), the serial event pass (~4 s), the stamped stage 24 -> 8 bars; the CPU baseline (~25 s) and an 8-bar stamped stage (~2 s) are what the
+    # line cannot do without.  The batch per step shrinks only if K full steps + that minimum do not fit.
+    OVERHEAD_S = 34.0            # the minimum: 8 stamped bars + the CPU baseline + JSON + teardown
     if args.warmup > 0:
         tw = time.perf_counter()
         a, b, c_, ntok1 = step()
@@ -397,12 +496,19 @@ def main():
     # digest of every token this rank generated in the last timed step (job order): two builds / switches whose kernels must be
     # equivalent print the same value under the real four-engine load
     tok_digest = hashlib.sha256(np.concatenate([r[0] for r in results]).astype(np.int32).tobytes()).hexdigest()[:16]
+    per_rank_ids = [[np.asarray(r[0], np.int32) for r in results]]
     if use_dist:
         # the path's only exchange: ONE final gather of the small variable-length results (token ids of every job)
-        g = parallel.gather_int_arrays([np.asarray(r[0], np.int32) for r in results], device=dev, force=True)
-        gathered_jobs = sum(len(x) for x in g)
+        per_rank_ids = parallel.gather_int_arrays(per_rank_ids[0], device=dev, force=True)
+        gathered_jobs = sum(len(x) for x in per_rank_ids)
     barrier()
     elapsed = time.perf_counter() - t0
+    # digest of the WHOLE batch in global clip order (clip c = its 27 jobs in tuple order): parallel.unshard of the per-rank clip lists.  A job's ids do not
+    # depend on which jobs share its launches (the batch-invariance the GPU suite asserts), so an N-rank run must print the value the 1-rank run prints.
+    na = len(grid)
+    per_rank_clips = [[np.concatenate(lst[c * na:(c + 1) * na]) if na else np.zeros(0, np.int32) for c in range(len(lst) // max(1, na))] for lst in per_rank_ids]
+    all_clips = parallel.unshard(per_rank_clips, sum(len(x) for x in per_rank_clips))
+    tok_digest_all = hashlib.sha256(np.concatenate(all_clips).astype(np.int32).tobytes()).hexdigest()[:16]
     timed_stats = [d.stats() for d in decs]
 
     tmax = torch.tensor([elapsed, t_ext, t_dec, t_notes], dtype=torch.float64, device=dev)
@@ -438,16 +544,21 @@ def main():
         "decoder_tokens_per_s": round(n_tok_all / t_dec, 2),
         "notes_stage_s_per_step": round(t_notes / args.steps, 4),
         "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": float(np.mean([cd.notes.size for cd in conds])),
-        "cover_notes_per_job": float(np.mean([n.size for n in state["notes"]])), "jobs_gathered": gathered_jobs, "tokens_sha256_rank0": tok_digest,
+        "cover_notes_per_job": float(np.mean([n.size for n in state["notes"]])), "jobs_gathered": gathered_jobs, "tokens_sha256_rank0": tok_digest, "tokens_sha256_all": tok_digest_all,
     }
 
-    late = lambda margin: since_process_start() > args.budget_s - margin           # noqa: E731  (the ONE JSON line matters more than its optional parts)
+    time_left = lambda: args.budget_s - since_process_start()                       # noqa: E731  (the ONE JSON line matters more than its optional parts)
+    CPU_RESERVE_S = 30.0 if (rank == 0 and world == 1 and not args.no_cpu_baseline) else 4.0
+    late = lambda margin: time_left() < margin                                       # noqa: E731
     # ---- roofline of the dominant kernel, in the timed configuration: one more decode stage over the same conditions with every
     # engine stamping its k_dstep_attn_down launches on the device (first workgroup's start .. last workgroup's end)
     roof = {"kernel": "k_dstep_attn_down", "bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s", "traffic": None}
     if not args.no_stamp:
         # short runs (profiling: tools/profile.sh) stamp every bar of the extra stage, the harness's 25-step run 24 bars (its budget is tight)
-        stamp_bars = args.max_bars or (0 if args.steps + args.warmup <= 4 and not late(90.0) else 24)
+        step_dec_s = t_dec / max(1, args.steps)
+        nb_mean = max(1.0, float(np.mean(nbars)))
+        stamp_bars = args.max_bars or (0 if args.steps + args.warmup <= 4 and time_left() > CPU_RESERVE_S + step_dec_s + 30.0 else
+                                       (24 if time_left() > CPU_RESERVE_S + step_dec_s * 24 / nb_mean + 22.0 else 8))
         skip_bars = 4 if (stamp_bars == 0 or stamp_bars > 8) else 0     # the bars in which the 4-pair history (and with it the context) is still growing
         for d in decs:
             d.stamp(True, skip_steps=skip_bars * (args.bar_tokens - 1))
@@ -472,9 +583,14 @@ def main():
     tp = ROOT / "profiles" / "traffic.json"
     if tp.exists():
         try:
-            roof["traffic"] = json.loads(tp.read_text()).get("k_dstep_attn_down")
-            roof["traffic_source"] = ("static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch from separate profiling passes of "
-                                      "this command, committed with the tree; NOT measured in this run")
+            tj = json.loads(tp.read_text())
+            sj = tj.get("k_dstep_attn_down_steady")
+            if sj and roof.get("alg_bytes_per_launch"):
+                # PMC bytes of the SAME attention form at the SAME contexts as the stamped launches (steady-state bars), so traffic / alg_bytes_per_launch reads directly
+                roof["traffic"] = sj["bytes_per_launch"]
+                roof["traffic_over_algorithmic"] = round(sj["bytes_per_launch"] / roof["alg_bytes_per_launch"], 4)
+                roof["traffic_source"] = ("static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of " + sj["form"] + " over the steady-state "
+                                          "bars (4..7) of separate 8-bar profiling passes of this command, committed with the tree; NOT measured in this run")
         except Exception:
             pass
     # the whole decode stage as ONE figure that needs no per-kernel timing: SURVEY 8(d)'s step bytes (weights once per engine-step + K/V of
@@ -490,6 +606,8 @@ def main():
     try:
         if args.no_serial_pass:
             raise RuntimeError("skipped (--no-serial-pass)")
+        if late(CPU_RESERVE_S + 8.0):
+            raise RuntimeError("skipped: the run is close to its harness budget")
         _lib.prof_reset()
         _lib.prof_enable(True)
         torch.cuda.synchronize(dev)
@@ -516,8 +634,8 @@ def main():
         result.setdefault("extras", {})["batch64"] = batch64
 
     # ---- extras outside the timed region
-    if not args.no_extras and rank == 0 and late(30.0):
-        result.setdefault("extras", {})["skipped"] = "the run is within 30 s of its harness budget"
+    if not args.no_extras and rank == 0 and late(CPU_RESERVE_S + 16.0):
+        result.setdefault("extras", {})["skipped"] = "the run is close to its harness budget"
     elif not args.no_extras and rank == 0:
         extras = result.setdefault("extras", {})
         ex = exs[0]
@@ -558,8 +676,25 @@ def main():
             except Exception as e:
                 extras[key] = {"error": repr(e)}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and late(20.0):
-        result["cpu_baseline"] = {"skipped": "the run is within 20 s of its harness budget"}
+    # ---- extras.parity_mode: the cost of exact parity (fp32 extractor + fp32 decoder), sized to the time that is left
+    if not args.no_extras and rank == 0 and args.parity_clips > 0:
+        extras = result.setdefault("extras", {})
+        nb_mean = float(np.mean(nbars))
+        cost = lambda c, b: PARITY_FIXED_S + c * (PARITY_EXTRACT_S_PER_CLIP + (PARITY_DECODE_S_PER_CLIP + PARITY_BF16_S_PER_CLIP) * (b or nb_mean) / nb_mean)   # noqa: E731
+        cands = [(args.parity_clips, args.parity_bars)] if args.parity_bars else \
+                [(c, b) for c in sorted({args.parity_clips, max(1, args.parity_clips // 2), max(1, args.parity_clips // 4)}, reverse=True) for b in (0, 24, 8)]
+        pick = next(((c, b) for c, b in cands if c <= len(wavs) and cost(c, b) < time_left() - CPU_RESERVE_S - 5.0), None)
+        if pick is None:
+            extras["parity_mode"] = {"skipped": f"{time_left():.0f} s of the harness budget left: not enough for the smallest exact-parity pass ({cost(*cands[-1]):.0f} s estimated); "
+                                                "python bench.py --steps 1 --warmup 1 runs it whole (profiles/)"}
+        else:
+            try:
+                extras["parity_mode"] = parity_mode_extras(args, dev, wavs, grid, vocab, pick[0], pick[1], decs, lambda: time_left() - CPU_RESERVE_S)
+            except Exception as e:      # extras must never take the headline down
+                extras["parity_mode"] = {"error": repr(e)}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and late(6.0):
+        result["cpu_baseline"] = {"skipped": "the run is within 6 s of its harness budget"}
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cd0 = conds[0]

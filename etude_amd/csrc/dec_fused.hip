@@ -11,7 +11,7 @@
 // Measured on MI355X (54 prompts x ~340 tokens per launch; (history: 4ac2f57) tools/runs/r2_run47.sh, serial event pass): 195 us per launch against
 // 166 us for the two GEMMs + 16 us for the row kernel it replaces; in the four-engine job 581-589 against 572-586 audio-s/s
 // (+1.3 % over six pairs: it occupies 144 CUs and moves a quarter of the bytes, so it disturbs the other engines' steps less).
-// It stays off by default because its inner loop is hand-placed asm whose MFMAs the compiler's hazard recognizer cannot see.
+// (Its inner loop is hand-placed asm whose MFMAs the compiler's hazard recognizer cannot see: the wait states are written out by hand, see s_nop below.)
 // How it got from 290 to 195 us, in order (every step kept the bit-identity test green, and every one is needed):
 //   1. a token's input fragments (128 registers) and 512 fp32 outputs (256) leave 128 of a wave's 512 registers: hipcc put all
 //      256 accumulator registers into AGPRs, the fragments into VGPRs and copied them through ONE AGPR quad (272 v_accvgpr moves

@@ -47,6 +47,21 @@ def pmc(d, counter):
     return rows
 
 
+def pmc_steady(d, counter, kernel_prefix, skip_frac=0.5):
+    """per-launch mean of `counter` over the LAST (1 - skip_frac) of the dispatches of one kernel, in dispatch order: the PMC passes decode the first 8 bars
+    of every job, and from bar 4 on every prompt sits at generate()'s 512-token truncation -- the second half of the attention launches runs at the
+    contexts of the full run's steady state (96 % of a job's bars)"""
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") == counter and short(r.get("Kernel_Name", "")).startswith(kernel_prefix):
+                    rows.append((int(r.get("Dispatch_Id", len(rows))), float(r["Counter_Value"])))
+    rows.sort()
+    tail = rows[int(len(rows) * skip_frac):]
+    return (len(tail), sum(v for _, v in tail) / max(1, len(tail)))
+
+
 def main():
     root = sys.argv[1]
     kt = kernel_trace(os.path.join(root, "prof_trace"))
@@ -95,6 +110,19 @@ def main():
         print(f"== k_dstep_attn_down in the PMC run: algorithmic {alg/1e6:.1f} MB per launch (K+V of every row's context + down / dense weights) vs measured {out.get('k_dstep_attn_down', 0)/1e6:.1f} MB")
     except Exception as e:      # noqa: BLE001
         print("(no algorithmic byte count for the PMC run:", e, ")")
+    # the headline's attention form at the steady-state contexts: what bench.py prints as roofline.traffic next to the stamped launches' algorithmic bytes
+    try:
+        form = "k_dstep_attn_down<8, false, true>"
+        nf, f = pmc_steady(os.path.join(root, "prof_fetch"), "FETCH_SIZE", form)
+        nw, w = pmc_steady(os.path.join(root, "prof_write"), "WRITE_SIZE", form)
+        if nf and nw:
+            out["k_dstep_attn_down_steady"] = {"form": form, "launches": min(nf, nw), "fetch_bytes_per_launch": 2.0 * f * 1024, "write_bytes_per_launch": w * 1024,
+                                               "bytes_per_launch": 2.0 * f * 1024 + w * 1024,
+                                               "what": "second half of the form's launches in dispatch order = bars 4..7 of the 8-bar PMC passes: prompts at the 512-token truncation, "
+                                                       "the contexts of the stamped launches"}
+            print(f"== {form}, steady-state half of the PMC run: {nf} launches, {(2.0 * f * 1024 + w * 1024) / 1e6:.1f} MB per launch")
+    except Exception as e:      # noqa: BLE001
+        print("(no steady-state traffic:", e, ")")
     with open(os.path.join(root, "traffic_bench.json"), "w") as fh:
         json.dump(out, fh, indent=1)
 
