@@ -57,10 +57,10 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec
 T_START = time.perf_counter()
 # cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r04_parity_mode.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
 # extract, the fp32 decode of its 27 jobs x all bars, and the bf16 decode of the same jobs
-PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "12"))
-PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.6"))
-PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "4.0"))
-PARITY_BF16_S_PER_CLIP = float(os.environ.get("ETD_PARITY_BF16_S", "0.5"))
+PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "6"))
+PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.55"))
+PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "2.3"))
+PARITY_BF16_S_PER_CLIP = float(os.environ.get("ETD_PARITY_BF16_S", "0.45"))
 
 
 def since_process_start() -> float:
