@@ -14,13 +14,19 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "csrc" / "_obj"
 LIB = Path(os.environ["ETD_LIB_OUT"]).resolve() if os.environ.get("ETD_LIB_OUT") else HERE / "libetude_hip.so"      # (ETD_LIB_OUT: measurement builds side by side; load them with ETD_LIB_PATH)
-SOURCES = ["ext_kernels.hip", "ext_fused.hip", "ext_fp32.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "dec_fused.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp", "midi.cpp"]
+SOURCES = ["ext_kernels.hip", "ext_fused.hip", "ext_fp32.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "dec_fused.hip", "dec_prefill.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp", "midi.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result",
          "-I", str(HERE.parent / "include")]
 # gfx950 can hand the first kernel arguments to a wave in SGPRs at launch (kernarg preload): kernels whose hot arguments are
 # leading scalars / pointers then start without the initial s_load round trip.  ETD_KERNARG_PRELOAD=0 turns it off.
 if os.environ.get("ETD_KERNARG_PRELOAD", "1") != "0":
     FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
+# MFMA results in VGPRs (gfx950's register file is unified): left to its default, hipcc puts every compiler-selected MFMA accumulator into AGPRs and copies it to
+# VGPRs and back around each VALU use (online-softmax rescale, epilogues): 2 209 v_accvgpr moves across the library, 256 of them per key tile in the prefill
+# attention.  With the VGPR form there are none, the kernels need 15-40 % fewer registers (k_attn 200 -> 134, k_embed 424 -> 250) and the arithmetic is unchanged.
+# (k_dmlp_fused places its operands by asm constraints and is not affected.)  ETD_MFMA_VGPR_FORM=0 turns it off.
+if os.environ.get("ETD_MFMA_VGPR_FORM", "1") != "0":
+    FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 FLAGS += os.environ.get("ETD_EXTRA_FLAGS", "").split()      # diagnostic builds (e.g. -DETD_HEAD_STAMP, -DETD_LIN_STAMP)
 # -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
 

@@ -59,7 +59,7 @@ struct etd_dec {
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
   float* qkv_raw = nullptr;                      // [3H] scratch row of the M == 1 QKV path
   bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
-  bf16 *Qb = nullptr, *Kp = nullptr, *VTp = nullptr; int vt_spad = 0;     // batched-prefill scratch of the MFMA attention
+  bf16* Qb = nullptr;                            // batched prefill: RoPE'd queries [M][H] of the MFMA attention (k_pattn reads K / V from the cache)
   float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
   DSampleCfg* samp_dev = nullptr;                // sampling parameters (device-resident: captured graphs follow set_sampling)
   unsigned long long* rng_key = nullptr;         // [S] per-stream draw keys
@@ -240,7 +240,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
     q.Kc = Kl; q.Vc = Vl; q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
     const bool mfma_attn = big && pf != nullptr;
-    if (mfma_attn) { q.Qb = d->Qb; q.Kp = d->Kp; q.VTp = d->VTp; q.vt_spad = d->vt_spad; }
+    if (mfma_attn) q.Qb = d->Qb;       // (K / V: the attention reads the cache rows this epilogue writes)
     if (big) {
       LinArgs a = {};
       a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.Wf; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
@@ -252,7 +252,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
         ETD_TRY(launch_gather_rows(hin, lo->idx, n, d->H, d->hlast, st));
         ETD_TRY(launch_ln_rows(d->hlast, n, d->H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1b, d->X2b, st));
         DGemmArgs q2 = q;
-        q2.X = d->hlast; q2.M = n; q2.rows = lo->rows; q2.Xb = d->X1b; q2.Qb = nullptr; q2.Kp = nullptr; q2.VTp = nullptr;
+        q2.X = d->hlast; q2.M = n; q2.rows = lo->rows; q2.Xb = d->X1b; q2.Qb = nullptr;
         DGemmArgs up2 = {};
         up2.X = d->hlast; up2.ldx = d->H; up2.W = w.up.W; up2.Wf = w.up.Wf; up2.bias = w.up.b; up2.M = n; up2.N = d->I; up2.Npad = w.up.Npad; up2.K = d->H;
         up2.Y = d->M1; up2.Xb = d->X2b; up2.Yb = d->Xcat; up2.ldy = d->I + d->H;
@@ -337,12 +337,12 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     }
     // ---- causal attention against the slot's KV cache
     if (mfma_attn) {
-      // ragged causal flash attention on the MFMA kernel of the Extract stage (prompts of all streams at once)
-      AttnArgs t = {};
-      t.Q = d->Qb; t.ldq = d->H; t.K = d->Kp; t.ldk = d->H; t.VT = d->VTp; t.Spad = d->vt_spad; t.O = d->Xcat + d->I; t.ldo = d->I + d->H;
-      t.n_seq = pf->n; t.Sq = pf->max_len; t.Sk = pf->max_len; t.scale_log2e = 0.125f * 1.4426950408889634f;
-      t.n_heads = d->nh; t.seq_row0 = pf->seq_row0; t.seq_len = pf->seq_len; t.causal = 1; t.flops_hint = pf->attn_flops;
-      ETD_TRY(launch_attn(t, st));
+      // ragged causal MFMA flash attention over the prompts of all streams at once, K / V straight from the cache rows (csrc/dec_prefill.hip)
+      PAttnArgs t = {};
+      t.Q = d->Qb; t.ldq = d->H; t.Kc = (const bf16*)Kl; t.Vc = (const bf16*)Vl; t.slot_stride = d->slot_stride; t.max_ctx = d->ctx; t.n_heads = d->nh;
+      t.O = d->Xcat + d->I; t.ldo = d->I + d->H; t.seq_row0 = pf->seq_row0; t.seq_len = pf->seq_len; t.row_slot = rows.slot;
+      t.n_seq = pf->n; t.max_len = pf->max_len; t.scale_log2e = 0.125f * 1.4426950408889634f; t.flops_hint = pf->attn_flops;
+      ETD_TRY(launch_pattn(t, st));
     } else {
       DAttnArgs at = {};
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
@@ -522,7 +522,7 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   e.rows = DecRows{sg->row_slot, sg->row_pos, sg->row_active, sg->row_seq};
   ETD_TRY(launch_dembed(e, st));
   PrefillInfo pf{n, sg->seq_row0, sg->seq_len, max_len, aflops};
-  const bool can_mfma_attn = d->VTp != nullptr && max_len <= d->vt_spad && !getenv("ETD_NO_MFMA_PREFILL_ATTN");
+  const bool can_mfma_attn = d->Qb != nullptr && !getenv("ETD_NO_MFMA_PREFILL_ATTN");
   LastOnly lo{n, sg->last_idx, DecRows{sg->last_slot, sg->last_pos, sg->last_active}};
   ETD_TRY(forward_body(d, M, e.rows, hfinal, st, can_mfma_attn ? &pf : nullptr, false, last_only ? &lo : nullptr, last_only));
   return ETD_OK;
@@ -550,9 +550,7 @@ int alloc_workspaces(etd_dec* d) {
     rc = rc ? rc : d->alloc(&d->Pk, (size_t)12 * DS_STEP_MAX_ROWS * H);     // split-K slabs of the decode step: 5 (down | dense) or 4 (down) + one per head (dense inside the attention workgroups)
     rc = rc ? rc : d->alloc(&d->row_cnt, (size_t)d->L * DS_STEP_MAX_ROWS, true);
     rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
-    rc = rc ? rc : d->alloc(&d->Qb, M * H); rc = rc ? rc : d->alloc(&d->Kp, M * H);
-    d->vt_spad = ((d->ctx + 63) / 64) * 64; if (d->vt_spad > 1088) d->vt_spad = 1088;
-    rc = rc ? rc : d->alloc(&d->VTp, (size_t)d->S * d->nh * 64 * d->vt_spad, true);   // pad columns must stay finite (they are multiplied by P = 0)
+    rc = rc ? rc : d->alloc(&d->Qb, M * H);      // RoPE'd queries of a batched prefill (K / V: the cache rows)
   }
   rc = rc ? rc : d->alloc(&d->samp_dev, (size_t)1, true); rc = rc ? rc : d->alloc(&d->rng_key, (size_t)d->S, true);
   rc = rc ? rc : d->alloc(&d->row_sp, (size_t)2 * d->Mmax, true);
@@ -1166,7 +1164,7 @@ __global__ void k_sum_words(const unsigned* __restrict__ p, long long n, unsigne
   if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 // out[0] = the sum over everything; out[1 + i] = allocation i of alloc_workspaces (in its order: K cache, V cache, h, h2, Q, AO, DO, M1,
-// logits, qkv_raw, hlast, X1b, X2b, AOb, M1b, Pk, row_cnt, Xcat, Qb, Kp, VTp, samp, rng_key, row_sp, row_slot, ...) while cap allows
+// logits, qkv_raw, hlast, X1b, X2b, AOb, M1b, Pk, row_cnt, Xcat, Qb, samp, rng_key, row_sp, row_slot, ...) while cap allows
 extern "C" int etd_debug_decoder_checksum(etd_dec* d, unsigned long long* out, int cap, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!d || !out || cap < 1) ETD_FAIL(ETD_EINVAL, "decoder_checksum: bad arguments");

@@ -42,17 +42,11 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
         v[i + 4] = x2 * c + x1 * s;    // second half: x2*cos + x1*sin
       }
     }
-    if (a.Qb) {
-      // batched prefill: bf16 row-major Q / K and pre-transposed V for the MFMA attention kernel
-      if (part < 2) {
-        bf16* dp = (part == 0 ? a.Qb : a.Kp) + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
+    if (a.Qb && part == 0) {
+      // batched prefill: bf16 row-major Q for the MFMA attention kernel (K / V: the cache rows below)
+      bf16* dp = a.Qb + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(dp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-      } else {
-        bf16* vp = a.VTp + ((long long)(a.rows.seq[m] * a.n_heads + head) * 64 + dbase) * a.vt_spad + pos;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) vp[(long long)acc_row(i, h) * a.vt_spad] = (bf16)v[i];
-      }
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(dp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
     if (part == 0) {
       if (!a.Qb) {

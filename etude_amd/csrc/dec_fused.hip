@@ -233,6 +233,15 @@ template <int... Js> __device__ __forceinline__ void pm_down_only(bf16x8 (&buf)[
   (pm_down_group<8 + Js, true>(buf, addr, acc2, hf, nx), ...);
 }
 
+// Diagnostic build (-DETD_PMLP_STAMP, tools/bench_prefill.py --stamps): s_memtime at the phase boundaries of chunks 1 .. 63, summed per wave in SGPRs
+// (workgroups 0 .. 63) and read back with etd_debug_pmlp_stamps: [0] down phase, [1] wait for the chunk's LDS-DMA, [2] barrier, [3] up phase + GELU,
+// [4] hidden fragments.  The shipped build has no stamp.
+#ifdef ETD_PMLP_STAMP
+__device__ unsigned long long g_pmlp_stamp[64 * 4 * 8];
+#define PMS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps_acc[i] += t_ - ps_t; ps_t = t_; } while (0)
+#else
+#define PMS(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dmlp_fused(DMlpArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PM_SLOT_ELEMS * 2 + 2048 * 4];
   bf16* ring = reinterpret_cast<bf16*>(smem);
@@ -293,19 +302,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pm_up_only(buf, ring_lds, acc1, unused, xf, sbu, h, next_of(0), seq8{});
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc1) : : "memory");      // (MFMA -> VALU wait states: the next chunk's GELU reads acc1)
   }
+#ifdef ETD_PMLP_STAMP
+  unsigned long long ps_acc[5] = {0, 0, 0, 0, 0}, ps_t = __builtin_amdgcn_s_memtime();
+#endif
   // chunks 1 .. 63: [down(k - 1) | up(k)] -- GELU of chunk k - 1 beside the MFMAs of up(k), then down(k - 1)
   for (int k = 1; k < 64; ++k) {
+#ifdef ETD_PMLP_STAMP
+    if (k > 1) PMS(0); else ps_t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    PMS(1);
+    __syncthreads();
+    PMS(2);
+#else
     PM_TOP(k);
+#endif
     const unsigned sa = ring_lds + (k & 1) * (PM_SLOT_ELEMS * 2);
     f32x16 accn;
     PM_ZERO(accn);
     const PmNext nx = next_of(k);
     pm_up_gelu(buf, sa, accn, acc1, xf, sbu, sbu_lds + (k - 1) * 128, h, nx, seq8{});
+    PMS(3);
     pm_hidden_frags(acc1, hf);
+    PMS(4);
     pm_down(buf, sa, acc2, hf, nx, seq8{});
     asm volatile("" : "+v"(accn));          // accn's asm MFMAs ended a whole down phase ago: no copy of it may be scheduled before this point
     acc1 = accn;
   }
+#ifdef ETD_PMLP_STAMP
+  PMS(0);
+  if (lane == 0 && blockIdx.x < 64)
+    for (int i = 0; i < 5; ++i) g_pmlp_stamp[(blockIdx.x * 4 + wave) * 8 + i] = ps_acc[i];
+#endif
   // chunk 64: [down(63) | -- ]; the attention rows replace x2 in the fragment registers
   {
     PM_TOP(64);
@@ -408,6 +435,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
 }
 
+#ifdef ETD_PMLP_STAMP
+extern "C" int etd_debug_pmlp_stamps(unsigned long long* out) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pmlp_stamp), sizeof(unsigned long long) * 64 * 4 * 8));
+  return ETD_OK;
+}
+#endif
 int launch_dmlp_fused(const DMlpArgs& a, hipStream_t st) {
   if (a.M <= 0 || !a.X2 || !a.AO || a.ldao < 512 || (a.ldao % 8) || !a.hin || !a.hout || a.hin == a.hout || !a.Wm || !a.b_up || !a.b_cat ||
       (((uintptr_t)a.X2 | (uintptr_t)a.AO | (uintptr_t)a.Wm | (uintptr_t)a.hin | (uintptr_t)a.hout | (uintptr_t)a.nx1 | (uintptr_t)a.nx2) & 15) ||

@@ -47,9 +47,8 @@ struct DGemmArgs {
   void* Kc; void* Vc;            // KV cache base of this LAYER: [slot][head][max_ctx][64]
   long long slot_stride;         // elements between slots
   int max_ctx, n_heads;
-  // batched-prefill scratch for the MFMA flash-attention kernel (all null outside the bf16 big-M path):
-  bf16* Qb; bf16* Kp;            // [M][hidden] bf16 row-major copies of RoPE'd Q and K
-  bf16* VTp; int vt_spad;        // V^T[(seq*n_heads+head)*64 + d][vt_spad]
+  // batched prefill on the MFMA flash-attention kernel (null outside the bf16 big-M path):
+  bf16* Qb;                      // [M][hidden] bf16 row-major RoPE'd Q (K / V are read from the cache rows: k_pattn)
 };
 int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st);
 // decode step, bf16: fused-QKV(+RoPE, KV append) and MLP-up(+GELU) projections of one layer in a single launch
@@ -106,6 +105,20 @@ struct DRowFin {
 // workgroups -- the MLP down projection (which depends on the QKV|up launch only): `down` is a DEPI_PARTIAL request
 // (k_splits slabs of K / k_splits each, over the first K columns of the (down | dense) weight).
 int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& down, const DRowFin* fin, hipStream_t st);
+
+// batched prefill, bf16 (csrc/dec_prefill.hip): ragged causal MFMA flash attention over all prompts of a pass, K / V read from the KV cache rows the QKV
+// epilogue has just written (no scratch copies)
+struct PAttnArgs {
+  const bf16* Q; int ldq;              // [M][hidden] RoPE'd queries, bf16 row-major (row stride ldq)
+  const bf16* Kc; const bf16* Vc;      // this LAYER's cache: [slot][head][max_ctx][64]
+  long long slot_stride; int max_ctx, n_heads;
+  bf16* O; int ldo;                    // [M][..] attention output rows (row stride ldo)
+  const int* seq_row0; const int* seq_len; const int* row_slot;   // prompt s covers rows [seq_row0[s], + seq_len[s]); its slot = row_slot[seq_row0[s]]
+  int n_seq, max_len;
+  float scale_log2e;                   // (1 / sqrt(64)) * log2(e)
+  double flops_hint;
+};
+int launch_pattn(const PAttnArgs& a, hipStream_t st);
 
 // h fp32 [M,H] -> LayerNorm with (g1,b1) and (g2,b2) -> two bf16 matrices (the two parallel-residual branches read the same h)
 int launch_ln_rows(const float* h, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,

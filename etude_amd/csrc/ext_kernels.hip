@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
         }
       } else {
         // fused QKV laid out [head][q|k|v][64] (modeling_gpt_neox.py:204-207): a 64-feature pair of accumulator tiles is one
-        // (head, part).  RoPE on the token-on-lane values, then Q / K rows and the KV-cache rows leave as 128-byte segments.
+        // (head, part).  RoPE on the token-on-lane values, then the Q rows and the KV-cache rows leave as 128-byte segments: 3 KB per
+        // prompt row (the prefill attention reads K / V from those cache rows, csrc/dec_prefill.hip).
         const int er8 = lane >> 3, ec8 = lane & 7;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
@@ -359,24 +360,14 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 #pragma unroll
               for (int q = 0; q < 4; ++q)
                 *reinterpret_cast<bf16x4*>(stg + r * EPP + nn * 32 + 8 * q + 4 * h) = pack4(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
-            if (part == 2 && ml < a.M) {
-              // V^T scratch of the MFMA attention kernel: [(seq, head)][d][pos]
-              bf16* vp = g.VTp + ((long long)(g.rows.seq[ml] * g.n_heads + head) * 64) * g.vt_spad + pos_l;
-#pragma unroll
-              for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) vp[(long long)(nn * 32 + acc_row(i, h)) * g.vt_spad] = (bf16)v[nn][i];
-            }
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
               const int row = it * 8 + er8, m = mw + mt * 32 + row;
               if (m < a.M) {
                 const u32x4 val = *reinterpret_cast<const u32x4*>(stg + row * EPP + ec8 * 8);
-                const long long ro = (long long)m * (g.n_heads * 64) + head * 64 + ec8 * 8;
-                if (part == 0) *reinterpret_cast<u32x4*>(g.Qb + ro) = val;
+                if (part == 0) *reinterpret_cast<u32x4*>(g.Qb + (long long)m * (g.n_heads * 64) + head * 64 + ec8 * 8) = val;
                 else {
-                  if (part == 1) *reinterpret_cast<u32x4*>(g.Kp + ro) = val;
                   if (ract[it] && rpos[it] < g.max_ctx) {
                     bf16* cp = reinterpret_cast<bf16*>(part == 1 ? g.Kc : g.Vc) + (long long)rslot[it] * g.slot_stride + ((long long)head * g.max_ctx + rpos[it]) * 64 + ec8 * 8;
                     *reinterpret_cast<u32x4*>(cp) = val;
@@ -598,7 +589,7 @@ int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
   if (a.K % 128 || a.N % 256 || a.M <= 0 || !a.bias) ETD_FAIL(ETD_EINVAL, "linear_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (dec_epi == DEPI_GELU && (!a.dec.Yb || a.dec.ldy % 8 || ((uintptr_t)a.dec.Yb & 15))) ETD_FAIL(ETD_EINVAL, "linear_dec: GELU needs 16-byte aligned bf16 rows");
   if (dec_epi == DEPI_RESID && (!a.dec.hin || !a.dec.hout || a.dec.N % 4)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad residual arguments");
-  if (dec_epi == DEPI_QKV && a.dec.Qb && (!a.dec.Kp || !a.dec.VTp || a.dec.rot_half != 8 || a.N % 192 || !a.dec.rows.seq)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad QKV arguments");
+  if (dec_epi == DEPI_QKV && a.dec.Qb && (a.dec.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad QKV arguments");
   ETD_LAUNCH_FILTER("k_linear_dec");
   ProfScope ps("k_linear_dec", st, 2.0 * a.M * a.N * a.K, ((double)a.M * a.K + (double)a.N * a.K) * 2);
   dim3 g(lin_grid_x(a.M, a.N / 256), 1, 1);

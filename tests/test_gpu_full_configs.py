@@ -206,7 +206,7 @@ def test_config3_128_streams_at_4k_context(dev):
     # ---- oracle: greedy continuation of the two prompts (positions 3500 .. 3500 + n: far beyond max_position_embeddings = 1024,
     # where HF's rotary embedding is computed on the fly, modeling_gpt_neox.py:72-107)
     n_chk = 12
-    want = []
+    want, want_lg = [], []
     for ids, cls, a4 in base:
         at = {"pitch_overlap": torch.from_numpy(a4[0])[None], "polyphony": torch.from_numpy(a4[1])[None],
               "note_sustain": torch.from_numpy(a4[2])[None], "rhythm_intensity": torch.from_numpy(a4[3])[None]}
@@ -215,6 +215,7 @@ def test_config3_128_streams_at_4k_context(dev):
         for _ in range(n_chk + 1):
             nxt = int(torch.argmax(lg[:, -1, :], -1))
             seq.append(nxt)
+            want_lg.append(lg[0, -1, :].numpy().copy())
             one = lambda x: torch.tensor([[x]])                             # noqa: E731
             lg, kv = neox.forward_logits(sd, nd, one(nxt), one(2), {"pitch_overlap": one(tgt[0]), "polyphony": one(tgt[1]),
                                                                     "note_sustain": one(tgt[2]), "rhythm_intensity": one(tgt[3])}, kv)
@@ -233,7 +234,15 @@ def test_config3_128_streams_at_4k_context(dev):
         assert np.array_equal(got16[s], got16[s % 2]), s
     agree = [int(np.argmax(np.r_[got16[k][: n_chk + 1] != np.asarray(want[k]), True])) for k in range(2)]
     print(f"configs[3]: fp32 ids == oracle over {n_chk + 1} tokens at ctx {ctx0}; bf16 first divergence from fp32 after {agree} tokens")
-    assert min(agree) >= 1                                                   # at least the prefill's token (greedy paths may part later)
+    # greedy paths may part -- but only at a near tie: where the bf16 stream first leaves the fp32 ids, the token it chose sits within the bf16 logit tolerance
+    # (2 x 5e-2: both candidates move) of the reference's maximum at that step.  (Until round 4 prompts longer than 1 088 tokens took the fp32-query
+    # attention and this test asked for >= 1 equal token; they now run on the MFMA prefill attention like every other prompt.)
+    for k in range(2):
+        if agree[k] <= n_chk:
+            lgk = want_lg[k * (n_chk + 1) + agree[k]]
+            gap = float(lgk[want[k][agree[k]]] - lgk[int(got16[k][agree[k]])])
+            print(f"  prompt {k}: bf16 token {int(got16[k][agree[k]])} vs {want[k][agree[k]]} at step {agree[k]}: reference logit gap {gap:.4f}")
+            assert 0.0 <= gap < 0.1, (k, agree[k], gap)
 
 
 def test_generate_kv_window_bound_with_large_overlap_ratio(dev):

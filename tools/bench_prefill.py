@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--ragged", type=int, default=0, help="prompt lengths uniform in [tokens - ragged, tokens]")
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--digest", action="store_true")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic build -DETD_PMLP_STAMP: per-phase shader clocks of k_dmlp_fused's chunks 1 .. 63")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
@@ -77,6 +78,17 @@ def main():
         sums = np.zeros(n, np.uint32)
         _lib.check(lib.etd_debug_decoder_kv_rowsums(dec._h, sums.ctypes.data, n, st), "kv_rowsums")
         out["kv_rowsums_sha256"] = hashlib.sha256(sums.tobytes()).hexdigest()[:16]
+    if a.stamps:
+        import ctypes as C
+        if not hasattr(lib, "etd_debug_pmlp_stamps"):
+            sys.exit("library built without -DETD_PMLP_STAMP")
+        buf = np.zeros(64 * 4 * 8, np.uint64)
+        lib.etd_debug_pmlp_stamps(C.c_void_p(buf.ctypes.data))
+        b = buf.reshape(64, 4, 8)[:, :, :5].astype(np.float64) / 63.0            # per chunk
+        names = ["down", "dma_wait", "barrier", "up+gelu", "hidden_frags"]
+        out["pmlp_clk_per_chunk"] = {n: round(float(b[:, :, i].mean()), 1) for i, n in enumerate(names)}
+        out["pmlp_clk_per_chunk"]["total"] = round(float(b.sum(-1).mean()), 1)
+        out["pmlp_clk_per_chunk_by_wave"] = {f"wave{w}": [round(float(b[:, w, i].mean()), 1) for i in range(5)] for w in range(4)}
     print(json.dumps(out))
     dec.close()
 
