@@ -233,9 +233,109 @@ template <int... Js> __device__ __forceinline__ void pm_down_only(bf16x8 (&buf)[
   (pm_down_group<8 + Js, true>(buf, addr, acc2, hf, nx), ...);
 }
 
+// ---- round 4: chunks 1 .. 63 as 16 UNIFORM groups.  Phase stamps of the round-3 schedule (tools/bench_prefill.py --stamps, clocks per chunk of 2 048 MFMA clocks):
+// up phase + GELU 2 264, down phase 1 382, wait for the chunk's LDS-DMA 715, barrier 138, hidden fragments 124 = 4 623.  One wave per SIMD issues in order, an MFMA
+// leaves ~24 of its 32 clocks for other issue, and the round-3 stream put all sixteen GELUs (~76 issue clocks each) into the 32 gaps of the up phase while the down
+// phase's gaps held one DMA and four LDS reads; the last DMA piece of chunk k + 1 was issued ~130 clocks before the wait for it.  Now:
+//   * every group is 4 MFMAs + ONE GELU (halves behind MFMA 0 and MFMA 1) + at most two DMA pieces (behind MFMAs 2 and 3).  The sixteen GELUs of up(k - 1)'s
+//     accumulator are spread over FOUR phases: registers 0 .. 3 in the last four groups of chunk k - 1 itself (down k-step 1: the up accumulator has been complete
+//     since group 7), 4 .. 7 beside up(k) k-steps 0 .. 15, 8 .. 11 beside k-steps 16 .. 31, 12 .. 15 beside down(k - 1) k-step 0; the hidden fragment of k-step 0
+//     (registers 0 .. 7) is packed behind group 7, that of k-step 1 behind group 11.  Same operations on the same values in the same order per element, and per
+//     accumulator tile the same MFMA order: bit-identical to the round-3 schedule (tests/test_gpu_decoder.py, tools/bench_prefill.py --digest);
+//   * the 16 DMA pieces of chunk k + 1 leave in groups 0 .. 11 (2, 2, 1, 1 | 2, 2, 1, 1 | 1, 1, 1, 1): the last one has the whole k-step-1 phase to land;
+//   * four pieces share one address computation (the instruction's immediate offset serves the global and the LDS address alike);
+//   * the two up accumulators swap roles from chunk to chunk (no 16-register copy), and the first MFMA of a chain takes C = 0 (no zero fill).
+template <int I> __device__ __forceinline__ void pm_dma4(const PmNext& n) {
+  if (n.on) __builtin_amdgcn_global_load_lds((pm_gptr_t)(n.src + (I >> 2) * 2048), (pm_lptr_t)(n.dst + (I >> 2) * 2048), 16, (I & 3) * 1024, 0);
+}
+// acc (VGPR) = A (VGPR) . B (AGPR): the first MFMA of an up chain
+__device__ __forceinline__ void pm_mfma_v_a0(f32x16& acc, const bf16x8& af, const bf16x8& bf) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(af), "a"(bf));      // early clobber: the 16 result registers must not overlap the A operand
+}
+// group J of chunk [down(k - 1): groups 8 .. 15 | up(k): groups 0 .. 7]; GR >= 0: GELU of register GR of `g` (bias word at bias_addr + its offset); ND pieces from D0
+template <int J, int GR, int D0, int ND>
+__device__ __forceinline__ void pm_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accu, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], const bf16x8& hfk,
+                                         f32x16& g, unsigned bias_addr, const PmNext& nx) {
+  constexpr bool UP = J < 8, GELU = GR >= 0, LAST = J == 15;
+  constexpr int g8 = UP ? 0 : J - 8, t0 = 4 * (g8 & 3);
+  float bb = 0.f;
+  if constexpr (GELU) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bb) : "v"(bias_addr), "n"((8 * ((GR < 0 ? 0 : GR) >> 2) + ((GR < 0 ? 0 : GR) & 3)) * 4));
+  // request group J + 1 (the bias word went first: LDS returns in order), then wait until group J has landed
+  if constexpr (!LAST) { pm_rd4<PmMlpGroup<J + 1>::f0>(buf[(J + 1) & 1], addr); pm_wait_lds<GELU ? 5 : 4>(); }
+  else pm_wait_lds<GELU ? 1 : 0>();
+#define PM_PIN(x) asm volatile("" : "+v"(x))
+#define PM_MFMA(q)                                                                                                              \
+  do {                                                                                                                          \
+    if constexpr (UP) { if constexpr (J == 0 && (q) == 0) pm_mfma_v_a0(accu, buf[J & 1][q], xf[4 * J + (q)]); else pm_mfma_v_a(accu, buf[J & 1][q], xf[(UP ? 4 * J : 0) + (q)]); } \
+    else pm_mfma_out<t0 + (q), false>(acc2[t0 + (q)], buf[J & 1][q], hfk);                                                      \
+  } while (0)
+  PM_MFMA(0);
+  float x0 = 0.f, tt = 0.f, ee = 0.f;
+  if constexpr (GELU) {
+    // the bias word has landed (nothing younger than group J + 1's fragments is outstanding); bb is an operand of the wait so that no use of it moves above
+    if constexpr (!LAST) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bb) : : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb) : : "memory");
+    x0 = g[GR < 0 ? 0 : GR] + bb;
+    const float z0 = fabsf(x0) * 0.70710678118654752440f;
+    tt = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z0, 1.f));
+    ee = __builtin_amdgcn_exp2f(-1.4426950408889634f * z0 * z0);
+    PM_PIN(x0); PM_PIN(tt); PM_PIN(ee);
+  }
+  PM_MFMA(1);
+  if constexpr (GELU) {
+    PM_PIN(x0); PM_PIN(tt); PM_PIN(ee);
+    float p = fmaf(1.061405429f, tt, -1.453152027f);
+    p = fmaf(p, tt, 1.421413741f); p = fmaf(p, tt, -0.284496736f); p = fmaf(p, tt, 0.254829592f);
+    const float er = fmaf(-p * tt, ee, 1.f);
+    float r0 = 0.5f * x0 * (1.f + copysignf(er, x0));
+    PM_PIN(r0);
+    g[GR < 0 ? 0 : GR] = r0;
+  }
+  PM_MFMA(2);
+  if constexpr (ND >= 1) pm_dma4<D0>(nx);
+  PM_MFMA(3);
+  if constexpr (ND >= 2) pm_dma4<D0 + 1>(nx);
+#undef PM_MFMA
+#undef PM_PIN
+  __builtin_amdgcn_sched_barrier(0);
+}
+// the GELU'd hidden features of k-step KS (registers 8 KS .. 8 KS + 7) as the natural-order B fragment (pm_hidden_frags, one k-step)
+template <int KS> __device__ __forceinline__ void pm_hidden_frag1(const f32x16& acc1, bf16x8& hfk) {
+  const bf16x4 p0 = pack4(acc1[8 * KS], acc1[8 * KS + 1], acc1[8 * KS + 2], acc1[8 * KS + 3]);
+  const bf16x4 p1 = pack4(acc1[8 * KS + 4], acc1[8 * KS + 5], acc1[8 * KS + 6], acc1[8 * KS + 7]);
+  const u32x2 v0 = __builtin_bit_cast(u32x2, p0), v1 = __builtin_bit_cast(u32x2, p1);
+  const auto s0 = __builtin_amdgcn_permlane32_swap(v0[0], v1[0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane32_swap(v0[1], v1[1], false, false);
+  const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+  hfk = __builtin_bit_cast(bf16x8, o);
+  asm volatile("s_nop 4" : "+v"(hfk) : : "memory");      // (VALU -> MFMA source wait states: the compiler does not know the asm below is an MFMA)
+}
+// one chunk k in 1 .. 63.  prev = up(k - 1)'s accumulator (registers 0 .. 3 already GELU'd), cur = up(k)'s (written here; its registers 0 .. 3 leave GELU'd)
+__device__ __forceinline__ void pm_chunk(bf16x8 (&buf)[2][4], unsigned sa, f32x16& prev, f32x16& cur, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], bf16x8 (&hf)[2],
+                                         unsigned bias_prev, unsigned bias_cur, const PmNext& nx) {
+  pm_rd4<PmMlpGroup<0>::f0>(buf[0], sa);
+  pm_group<0, 4, 0, 2>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<1, 5, 2, 2>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<2, 6, 4, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<3, 7, 5, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<4, 8, 6, 2>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<5, 9, 8, 2>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<6, 10, 10, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<7, 11, 11, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_hidden_frag1<0>(prev, hf[0]);
+  pm_group<8, 12, 12, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<9, 13, 13, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<10, 14, 14, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_group<11, 15, 15, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  pm_hidden_frag1<1>(prev, hf[1]);
+  pm_group<12, 0, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+  pm_group<13, 1, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+  pm_group<14, 2, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+  pm_group<15, 3, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+}
+
 // Diagnostic build (-DETD_PMLP_STAMP, tools/bench_prefill.py --stamps): s_memtime at the phase boundaries of chunks 1 .. 63, summed per wave in SGPRs
-// (workgroups 0 .. 63) and read back with etd_debug_pmlp_stamps: [0] down phase, [1] wait for the chunk's LDS-DMA, [2] barrier, [3] up phase + GELU,
-// [4] hidden fragments.  The shipped build has no stamp.
+// (workgroups 0 .. 63) and read back with etd_debug_pmlp_stamps: [0] the chunk's 16 groups, [1] wait for the chunk's LDS-DMA, [2] barrier
+// (round 3's schedule: [0] down phase, [3] up phase + GELU, [4] hidden fragments).  The shipped build has no stamp.
 #ifdef ETD_PMLP_STAMP
 __device__ unsigned long long g_pmlp_stamp[64 * 4 * 8];
 #define PMS(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ps_acc[i] += t_ - ps_t; ps_t = t_; } while (0)
@@ -288,64 +388,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   for (int t = 0; t < 16; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
-  f32x16 acc1;
+  f32x16 accA, accB;
   bf16x8 buf[2][4], hf[2];
   using seq8 = std::make_integer_sequence<int, 8>;
   using seq16 = std::make_integer_sequence<int, 16>;
 #define PM_ZERO(x) _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) x[i_] = 0.f
 
-  // chunk 0: [ -- | up(0)]
+  // chunk 0: [ -- | up(0)], then the GELU of its registers 0 .. 3 (what the last four groups of every later chunk do for their own up accumulator)
   {
     PM_TOP(0);
-    PM_ZERO(acc1);
-    f32x16 unused = acc1;
-    pm_up_only(buf, ring_lds, acc1, unused, xf, sbu, h, next_of(0), seq8{});
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc1) : : "memory");      // (MFMA -> VALU wait states: the next chunk's GELU reads acc1)
+    PM_ZERO(accA);
+    f32x16 unused = accA;
+    pm_up_only(buf, ring_lds, accA, unused, xf, sbu, h, next_of(0), seq8{});
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accA) : : "memory");      // (MFMA -> VALU wait states: the GELU reads the accumulator)
+    pm_gelu2<0>(accA, sbu, 0, h); pm_gelu2<1>(accA, sbu, 0, h);
   }
 #ifdef ETD_PMLP_STAMP
   unsigned long long ps_acc[5] = {0, 0, 0, 0, 0}, ps_t = __builtin_amdgcn_s_memtime();
-#endif
-  // chunks 1 .. 63: [down(k - 1) | up(k)] -- GELU of chunk k - 1 beside the MFMAs of up(k), then down(k - 1)
-  for (int k = 1; k < 64; ++k) {
-#ifdef ETD_PMLP_STAMP
-    if (k > 1) PMS(0); else ps_t = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    PMS(1);
-    __syncthreads();
-    PMS(2);
+#define PM_TOP_S(k)                                                                         \
+  do {                                                                                      \
+    if ((k) > 1) PMS(0); else ps_t = __builtin_amdgcn_s_memtime();                          \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                             \
+    PMS(1);                                                                                 \
+    __syncthreads();                                                                        \
+    PMS(2);                                                                                 \
+  } while (0)
 #else
-    PM_TOP(k);
+#define PM_TOP_S(k) PM_TOP(k)
 #endif
-    const unsigned sa = ring_lds + (k & 1) * (PM_SLOT_ELEMS * 2);
-    f32x16 accn;
-    PM_ZERO(accn);
-    const PmNext nx = next_of(k);
-    pm_up_gelu(buf, sa, accn, acc1, xf, sbu, sbu_lds + (k - 1) * 128, h, nx, seq8{});
-    PMS(3);
-    pm_hidden_frags(acc1, hf);
-    PMS(4);
-    pm_down(buf, sa, acc2, hf, nx, seq8{});
-    asm volatile("" : "+v"(accn));          // accn's asm MFMAs ended a whole down phase ago: no copy of it may be scheduled before this point
-    acc1 = accn;
+  // chunks 1 .. 63: [down(k - 1) | up(k)], 16 uniform groups each (pm_chunk); the two up accumulators alternate
+#define PM_CHUNK(k, prev, cur)                                                                                                                  \
+  do {                                                                                                                                          \
+    PM_TOP_S(k);                                                                                                                                \
+    pm_chunk(buf, ring_lds + ((k) & 1) * (PM_SLOT_ELEMS * 2), prev, cur, acc2, xf, hf, sbu_lds + ((k) - 1) * 128, sbu_lds + (k) * 128, next_of(k)); \
+  } while (0)
+  for (int k = 1; k < 63; k += 2) {
+    PM_CHUNK(k, accA, accB);
+    PM_CHUNK(k + 1, accB, accA);
   }
+  PM_CHUNK(63, accA, accB);
 #ifdef ETD_PMLP_STAMP
   PMS(0);
   if (lane == 0 && blockIdx.x < 64)
     for (int i = 0; i < 5; ++i) g_pmlp_stamp[(blockIdx.x * 4 + wave) * 8 + i] = ps_acc[i];
 #endif
-  // chunk 64: [down(63) | -- ]; the attention rows replace x2 in the fragment registers
+  // chunk 64: [down(63) | -- ]; registers 4 .. 15 of up(63) still want their GELU; the attention rows replace x2 in the fragment registers
   {
     PM_TOP(64);
     const unsigned sa = ring_lds;
-    pm_gelu2<0>(acc1, sbu, 63, h); pm_gelu2<1>(acc1, sbu, 63, h); pm_gelu2<2>(acc1, sbu, 63, h); pm_gelu2<3>(acc1, sbu, 63, h);
-    pm_gelu2<4>(acc1, sbu, 63, h); pm_gelu2<5>(acc1, sbu, 63, h); pm_gelu2<6>(acc1, sbu, 63, h); pm_gelu2<7>(acc1, sbu, 63, h);
+    pm_gelu2<2>(accB, sbu, 63, h); pm_gelu2<3>(accB, sbu, 63, h);
+    pm_gelu2<4>(accB, sbu, 63, h); pm_gelu2<5>(accB, sbu, 63, h); pm_gelu2<6>(accB, sbu, 63, h); pm_gelu2<7>(accB, sbu, 63, h);
     {
       const bf16* ap = a.AO + (long long)mc * a.ldao + 8 * h;
 #pragma unroll
       for (int s = 0; s < 32; ++s) PM_LOADX(xf[s], ap + 16 * s);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    pm_hidden_frags(acc1, hf);
+    pm_hidden_frags(accB, hf);
     pm_down_only(buf, sa, acc2, hf, next_of(64), seq8{});
   }
   // chunks 65 .. 72: attention.dense, 4 k-steps x 16 tiles each
