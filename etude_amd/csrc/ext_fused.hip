@@ -503,12 +503,20 @@ void pack_proj_weights(const float* W, bool permute_rows, uint16_t* dst, uint16_
 #define ENC_NSLOT 5
 #define ENC_AHEAD 4
 #define ENC_NHC 64
-#define ENC_LDS_RING 0
-#define ENC_LDS_K (ENC_NSLOT * ENC_HC_ELEMS * 2)
+#define ENC_LDS_PAR 0
+#define ENC_LDS_RING ((768 + 256 * 3 + 512 + 256) * 4)
+#define ENC_LDS_K (ENC_LDS_RING + ENC_NSLOT * ENC_HC_ELEMS * 2)
 #define ENC_LDS_V (ENC_LDS_K + 32768)
-#define ENC_LDS_PAR (ENC_LDS_V + 32768)
-#define ENC_LDS_BYTES (ENC_LDS_PAR + (768 + 256 * 3 + 512 + 256) * 4)
+#define ENC_LDS_BYTES (ENC_LDS_V + 32768)
 
+// LDS reads / writes as `opaque per-lane base register + immediate offset`.  This kernel's LDS is 155 KiB and a ds instruction's offset field reaches 64 KiB: handed
+// plain pointers, hipcc folds every image's constant base (80 .. 147 KiB) into each access's constant part, finds it does not fit and keeps ONE address register per
+// distinct access -- with the head loop unrolled that was ~100 live address registers, the source of the kernel's 91 spills and of accumulator copies between MFMAs
+// (LABNOTES round 4).  The bases below pass through an empty asm, so each access is `ds_read_b128 v, base offset:imm`.
+typedef __attribute__((address_space(3))) const bf16x8* enc_lds_cp;
+typedef __attribute__((address_space(3))) bf16x8* enc_lds_p;
+#define ENC_RD8(base, off) (*(enc_lds_cp)(uintptr_t)((base) + (unsigned)(off)))
+#define ENC_WR8(base, off) (*(enc_lds_p)(uintptr_t)((base) + (unsigned)(off)))
 __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[ENC_LDS_BYTES];
   bf16* ring = reinterpret_cast<bf16*>(smem + ENC_LDS_RING);
@@ -519,6 +527,12 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const long long row = (long long)blockIdx.x * 256 + wave * 32 + r;        // this lane's token
 
+  // byte addresses of this lane's 16 bytes in: ring slot 0 (slots 0 .. 3 by immediate) / ring slot 4; the K / V images (reads: tile by immediate; writes: this wave's block)
+  unsigned ringA = (unsigned)reinterpret_cast<uintptr_t>(ring) + lane * 16, ringB = ringA + 4 * ENC_HC_ELEMS * 2;
+  unsigned kimg_l = (unsigned)reinterpret_cast<uintptr_t>(Kimg) + lane * 16, vimg_l = (unsigned)reinterpret_cast<uintptr_t>(Vimg) + lane * 16;
+  unsigned kimg_w = kimg_l + wave * 4096, vimg_w = vimg_l + wave * 4096;
+  asm volatile("" : "+v"(ringA), "+v"(ringB), "+v"(kimg_l), "+v"(vimg_l), "+v"(kimg_w), "+v"(vimg_w));
+#define ENC_SLOT(hc) (((hc) % ENC_NSLOT) == 4 ? ringB : ringA + ((hc) % ENC_NSLOT) * (ENC_HC_ELEMS * 2))
   auto issue = [&](int hc) {                             // half-chunk hc -> slot hc % 5: 16 one-KiB pieces, 2 per wave
     const bf16* src = a.Wl + (long long)hc * ENC_HC_ELEMS + wave * (2 * 512) + lane * 8;
     bf16* dst = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + wave * (2 * 512);
@@ -544,10 +558,23 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
 #define ENC_HALF(sl, BODY)                                                                                             \
   {                                                                                                                    \
     bf16x8 af[2][4];                                                                                                   \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>((sl) + k * 512);          \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) af[0][k] = ENC_RD8(sl, k * 1024);                                   \
     _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                                 \
-      if (gq < 3) { _Pragma("unroll") for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>((sl) + ((gq + 1) * 4 + k) * 512); }   \
+      if (gq < 3) { _Pragma("unroll") for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = ENC_RD8(sl, ((gq + 1) * 4 + k) * 1024); }   \
       _Pragma("unroll") for (int k = 0; k < 4; ++k) { const bf16x8 fa = af[gq & 1][k]; BODY }                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                  \
+  }
+
+  // the same with TWO fragments per group (fc_o and the feed-forward block: 128 accumulator registers + the 64-register token tile leave no room for two
+  // 4-fragment buffers -- with them hipcc parked 91 registers of the LayerNorm'ed tile in scratch once per sequence; the partner wave of the SIMD hides the shorter lead)
+#define ENC_HALF2(sl, BODY)                                                                                            \
+  {                                                                                                                    \
+    bf16x8 af[2][2];                                                                                                   \
+    _Pragma("unroll") for (int k = 0; k < 2; ++k) af[0][k] = ENC_RD8(sl, k * 1024);                                   \
+    _Pragma("unroll") for (int g2 = 0; g2 < 8; ++g2) {                                                                 \
+      if (g2 < 7) { _Pragma("unroll") for (int k = 0; k < 2; ++k) af[(g2 + 1) & 1][k] = ENC_RD8(sl, ((g2 + 1) * 2 + k) * 1024); }   \
+      _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) { const bf16x8 fa = af[g2 & 1][k2]; const int gq = g2 >> 1, k = 2 * (g2 & 1) + k2; (void)gq; (void)k; BODY }   \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                  \
   }
@@ -583,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       for (int hf2 = 0; hf2 < 2; ++hf2) {
         const int hc = (hd * 3 + part) * 2 + hf2;
         ENC_TOP(hc);
-        const bf16* sl = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
+        const unsigned sl = ENC_SLOT(hc);
         // fragment 4 gq + k of this half = k-step 8 hf2 + 2 gq + (k >> 1), tile k & 1
         if (part == 2) ENC_HALF(sl, acc[k & 1] = mfma32(xf[8 * hf2 + 2 * gq + (k >> 1)], fa, acc[k & 1]);)
         else           ENC_HALF(sl, acc[k & 1] = mfma32(fa, xf[8 * hf2 + 2 * gq + (k >> 1)], acc[k & 1]);)
@@ -611,7 +638,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
           for (int s = 0; s < 4; ++s) qf[s] = fr[s];
         } else {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) *reinterpret_cast<bf16x8*>(Kimg + ((wave * 4 + s) * 64 + lane) * 8) = fr[s];
+          for (int s = 0; s < 4; ++s) ENC_WR8(kimg_w, s * 1024) = fr[s];
         }
       } else {
         // acc[dt][i]: key (i & 3) + 8 (i >> 2) + 4 h of the wave's 32, feature 32 dt + r; registers 8 ks .. + 8 = A fragment of k-step ks
@@ -623,7 +650,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
             bf16x8 fr;
 #pragma unroll
             for (int j = 0; j < 8; ++j) fr[j] = (bf16)(acc[dt][8 * ks + j] + bv);
-            *reinterpret_cast<bf16x8*>(Vimg + (((wave * 2 + ks) * 2 + dt) * 64 + lane) * 8) = fr;
+            ENC_WR8(vimg_w, (ks * 2 + dt) * 1024) = fr;
           }
         }
       }
@@ -646,7 +673,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
         for (int i = 0; i < 16; ++i) sT[kt][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s)
-          sT[kt] = mfma32(*reinterpret_cast<const bf16x8*>(Kimg + (((2 * kp + kt) * 4 + s) * 64 + lane) * 8), qf[s], sT[kt]);
+          sT[kt] = mfma32(ENC_RD8(kimg_l, ((2 * kp + kt) * 4 + s) * 1024), qf[s], sT[kt]);
       }
       float mx = -INFINITY;
 #pragma unroll
@@ -677,7 +704,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
           for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[kt][8 * ks + j];
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            o[dt] = mfma32(*reinterpret_cast<const bf16x8*>(Vimg + ((((2 * kp + kt) * 2 + ks) * 2 + dt) * 64 + lane) * 8), pf, o[dt]);
+            o[dt] = mfma32(ENC_RD8(vimg_l, (((2 * kp + kt) * 2 + ks) * 2 + dt) * 1024), pf, o[dt]);
         }
     }
     lrun += xhalf(lrun);
@@ -703,9 +730,9 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
     for (int hf2 = 0; hf2 < 2; ++hf2) {
       const int hc = 24 + hd * 2 + hf2;
       ENC_TOP(hc);
-      const bf16* sl = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
+      const unsigned sl = ENC_SLOT(hc);
       // fragment 4 gq + k of this half = k-step 2 hf2 + (gq >> 1) of the head, tile 4 (gq & 1) + k
-      ENC_HALF(sl, acc2[4 * (gq & 1) + k] = mfma32(fa, ofr[4 * hd + 2 * hf2 + (gq >> 1)], acc2[4 * (gq & 1) + k]);)
+      ENC_HALF2(sl, acc2[4 * (gq & 1) + k] = mfma32(fa, ofr[4 * hd + 2 * hf2 + (gq >> 1)], acc2[4 * (gq & 1) + k]);)
     }
   bf16x8 xf[16];
   {
@@ -713,16 +740,24 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);       // residual
   }
-  // LayerNorm of (acc2 + bias + resid) -> xf (bf16 fragments); statistics in fp32
+  // LayerNorm of (acc2 + bias + resid) -> xf (bf16 fragments); statistics in fp32.
+  // (The parameter vectors sit at the BOTTOM of this kernel's LDS: a ds_read reaches 64 KiB from its base register with its offset field.  In rounds 2-3 they sat
+  // above the ring and the K / V images, at 0x24000: hipcc then materialised all 96 read addresses (0x25000 | lane part ...) in registers, kept them for the second
+  // LayerNorm behind the feed-forward block and spilled them there -- the kernel's 91 spilled registers were addresses.)
+  const float* lnp_bo = sbo; const float* lnp_b2 = sb2; const float* lnp_g = sg; const float* lnp_be = sbe;
+  int lnoff = 8 * h;                    // (opaque to the scheduler from tile to tile, see the macro)
 #define ENC_RESID_LN(BIAS)                                                                                                   \
   {                                                                                                                          \
     float s1 = 0.f;                                                                                                          \
-    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
-      const f32x4 bb = *reinterpret_cast<const f32x4*>((BIAS) + 32 * t + 16 * u + 8 * h + 4 * q);                           \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
-        const float v = acc2[t][8 * u + 4 * q + j] + bb[j] + bf2f(xf[2 * t + u][4 * q + j]);                                \
-        acc2[t][8 * u + 4 * q + j] = v; s1 += v;                                                                             \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                                          \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {                          \
+        const f32x4 bb = *reinterpret_cast<const f32x4*>((BIAS) + lnoff + 32 * t + 16 * u + 4 * q);                         \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                      \
+          const float v = acc2[t][8 * u + 4 * q + j] + bb[j] + bf2f(xf[2 * t + u][4 * q + j]);                              \
+          acc2[t][8 * u + 4 * q + j] = v; s1 += v;                                                                           \
+        }                                                                                                                    \
       }                                                                                                                      \
+      asm volatile("" : "+v"(lnoff) : "v"(s1));   /* (tile t + 1's parameter reads depend on tile t's sum: the scheduler otherwise requests all 96 parameter vectors up front and the allocator spills them) */ \
     }                                                                                                                        \
     s1 += xhalf(s1);                                                                                                         \
     const float mean = s1 * (1.f / 256.f);                                                                                   \
@@ -730,13 +765,16 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
     _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int i = 0; i < 16; ++i) { const float d = acc2[t][i] - mean; s2 += d * d; }   \
     s2 += xhalf(s2);                                                                                                         \
     const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);                                                                   \
-    _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
-      const int f0 = 32 * t + 16 * u + 8 * h + 4 * q;                                                                        \
-      const f32x4 gg = *reinterpret_cast<const f32x4*>(sg + f0), be = *reinterpret_cast<const f32x4*>(sbe + f0);            \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (bf16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
+    _Pragma("unroll") for (int t = 0; t < 8; ++t) {                                                                          \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {                          \
+        const int f0 = lnoff + 32 * t + 16 * u + 4 * q;                                                                      \
+        const f32x4 gg = *reinterpret_cast<const f32x4*>(lnp_g + f0), be = *reinterpret_cast<const f32x4*>(lnp_be + f0);    \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (bf16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
+      }                                                                                                                      \
+      asm volatile("" : "+v"(lnoff) : "v"(xf[2 * t + 1]));                                                                   \
     }                                                                                                                        \
   }
-  ENC_RESID_LN(sbo)
+  ENC_RESID_LN(lnp_bo)
 
   // ---- feed-forward block (half-chunks 32 .. 63: per 32 hidden features one half of W1 fragments, one of W2 fragments)
 #pragma unroll
@@ -746,11 +784,11 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   for (int sc = 0; sc < FFN_NSUB; ++sc) {
     const int hc = 32 + 2 * sc;
     ENC_TOP(hc);
-    const bf16* sl = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
+    const unsigned sl = ENC_SLOT(hc);
     f32x16 acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
-    ENC_HALF(sl, acc1 = mfma32(fa, xf[gq * 4 + k], acc1);)
+    ENC_HALF2(sl, acc1 = mfma32(fa, xf[gq * 4 + k], acc1);)
     bf16x8 hfr[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -759,15 +797,17 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       for (int j = 0; j < 4; ++j) hfr[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
     }
     ENC_TOP(hc + 1);
-    const bf16* sl2 = ring + ((hc + 1) % ENC_NSLOT) * ENC_HC_ELEMS + lane * 8;
-    ENC_HALF(sl2, acc2[4 * (gq & 1) + k] = mfma32(fa, hfr[gq >> 1], acc2[4 * (gq & 1) + k]);)
+    const unsigned sl2 = ENC_SLOT(hc + 1);
+    ENC_HALF2(sl2, acc2[4 * (gq & 1) + k] = mfma32(fa, hfr[gq >> 1], acc2[4 * (gq & 1) + k]);)
   }
-  ENC_RESID_LN(sb2)
+  ENC_RESID_LN(lnp_b2)
   bf16* yp = a.Y + row * 256 + 8 * h;
 #pragma unroll
   for (int s = 0; s < 16; ++s) *reinterpret_cast<bf16x8*>(yp + 16 * s) = xf[s];
 #undef ENC_RESID_LN
 #undef ENC_HALF
+#undef ENC_HALF2
+#undef ENC_SLOT
 #undef ENC_TOP
 }
 

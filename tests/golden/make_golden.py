@@ -11,6 +11,7 @@ checkpoints of ``etude_amd.synth`` (numpy PCG64), loaded into the reference's ow
 Outputs are DATA only (inputs + expected outputs), never reference source:
   hft_tiny.npz        tiny-config model: input, per-layer taps hashes, 8 outputs
   hft_full.npz        default-config model, ONE window: onset/offset/mpe B + velocity argmax + a few logit rows
+  hft_full_cal.npz    the same window with the well-conditioned checkpoint (synth.extractor_state_dict_cal)
   transcript_tiny.npz reference ``_transcript`` on 40 frames at the tiny config (ragged: 3 windows)
   mpe2note.json       crafted + random frame arrays -> reference ``_mpe2note`` / ``_note2json`` lists
   decoder_tiny.npz    tiny GPT-NeoX config: logits for a prompt, greedy ids for a few bars
@@ -53,7 +54,7 @@ def _t(sd):
     return {k: torch.from_numpy(v) for k, v in sd.items()}
 
 
-def ref_extractor(dims, seed):
+def ref_extractor(dims, seed, cal=False):
     from etude.config.schema import ExtractorConfig
     from etude.data.extractor import AMTAPC_Extractor, _Spec2MIDI
     from etude.models.amt_apc import Decoder_SPEC2MIDI, Encoder_SPEC2MIDI
@@ -63,7 +64,7 @@ def ref_extractor(dims, seed):
     dec = Decoder_SPEC2MIDI(d["n_frame"], d["n_bin"], d["n_note"], d["n_velocity"], d["hid_dim"], d["n_layers_dec"],
                             d["n_heads"], d["pf_dim"], 0.1, "cpu")
     model = _Spec2MIDI(enc, dec, sv_dim=0)
-    sd = synth.extractor_state_dict(seed, dims)
+    sd = synth.extractor_state_dict_cal(seed, dims) if cal else synth.extractor_state_dict(seed, dims)
     model.load_state_dict(_t(sd), strict=True)
     model.eval()
     cfg = ExtractorConfig()
@@ -100,6 +101,19 @@ def gen_hft_full():
                         onset_B=r[5][0].numpy(), offset_B=r[6][0].numpy(), mpe_B=r[7][0].numpy(),
                         velocity_B_argmax=r[8][0].argmax(2).numpy().astype(np.int8),
                         velocity_B_rows=r[8][0, ::64].numpy(),       # logits of every 64th frame [8,88,128]
+                        velocity_B_top2gap=(lambda t: (t[..., 0] - t[..., 1]))(torch.topk(r[8][0], 2, dim=-1).values).numpy().astype(np.float16))
+
+
+def gen_hft_full_cal():
+    """hft_full with the well-conditioned checkpoint (synth.extractor_state_dict_cal: first-layer attention scores with sigma ~ 3 instead of ~3 700)"""
+    ex, d = ref_extractor({}, seed=7, cal=True)
+    x = synth.window_features(5, 1)
+    with torch.no_grad():
+        r = ex.model(torch.from_numpy(x))
+    np.savez_compressed(HERE / "hft_full_cal.npz",
+                        onset_A=r[0][0].numpy().astype(np.float16), mpe_A=r[2][0].numpy().astype(np.float16),
+                        onset_B=r[5][0].numpy(), offset_B=r[6][0].numpy(), mpe_B=r[7][0].numpy(),
+                        velocity_B_argmax=r[8][0].argmax(2).numpy().astype(np.int8),
                         velocity_B_top2gap=(lambda t: (t[..., 0] - t[..., 1]))(torch.topk(r[8][0], 2, dim=-1).values).numpy().astype(np.float16))
 
 
@@ -512,7 +526,7 @@ def gen_clip_ctx():
     np.savez_compressed(HERE / "clip_ctx.npz", gen_ids=np.asarray(gen_ids, np.int32))
 
 
-ALL = dict(decoder_ctx=gen_decoder_ctx, clip_ctx=gen_clip_ctx, clip_full=gen_clip_full, mpe2note_modes=gen_mpe2note_modes, tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
+ALL = dict(hft_full_cal=gen_hft_full_cal, decoder_ctx=gen_decoder_ctx, clip_ctx=gen_clip_ctx, clip_full=gen_clip_full, mpe2note_modes=gen_mpe2note_modes, tokenizer=gen_tokenizer, hft_wrapper=gen_hft_wrapper, hft_tiny=gen_hft_tiny, hft_full=gen_hft_full, transcript_tiny=gen_transcript_tiny, mpe2note=gen_mpe2note,
            decoder_tiny=gen_decoder_tiny, decoder_full=gen_decoder_full)
 
 if __name__ == "__main__":

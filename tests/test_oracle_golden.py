@@ -35,6 +35,20 @@ def test_hft_full_window(golden_dir):
     assert (am == g["velocity_B_argmax"]).mean() > 0.999
 
 
+def test_hft_full_window_calibrated_weights(golden_dir):
+    """the same window through the well-conditioned checkpoint (synth.extractor_state_dict_cal: first-layer scores with sigma ~ 3): the oracle == the reference"""
+    g = np.load(golden_dir / "hft_full_cal.npz")
+    d = hft_dims({})
+    sd = torch_sd(synth.extractor_state_dict_cal(7, {}))
+    x = torch.from_numpy(synth.window_features(5, 1))
+    r = hft.model_forward(sd, x, d)
+    for n, i in (("onset_B", 5), ("offset_B", 6), ("mpe_B", 7)):
+        np.testing.assert_allclose(r[i][0].numpy(), g[n], rtol=1e-4, atol=2e-5, err_msg=n)
+    am = r[8][0].argmax(2).numpy().astype(np.int8)
+    clear = g["velocity_B_top2gap"].astype(np.float32) > 1e-3
+    assert (am == g["velocity_B_argmax"])[clear].all()
+
+
 def test_transcript_tiny_ragged(golden_dir):
     g = np.load(golden_dir / "transcript_tiny.npz")
     d = hft_dims(TINY_EXT)
