@@ -54,8 +54,9 @@ def _ffn(rng, sd, pfx, hid, pf):
 def extractor_state_dict(seed: int = 0, dims: Dict[str, int] | None = None, head_gain: float = 4.0, emb_gain: float = 1.0) -> Dict[str, np.ndarray]:
     """emb_gain scales encoder.tok_embedding_freq AFTER every tensor has been drawn (the other tensors do not depend on it).  With emb_gain = 1 (every golden
     of rounds 1-3, the benchmark) the first encoder layer sees x = 16 emb + pos with |x| ~ 75: its attention scores have a standard deviation of ~3 700, the
-    softmax is a hard argmax, and ANY rounding of the layer input or of K flips winners -- that one layer makes the whole 1.2 % rms / 6.6e-2 max error of the
-    bf16 extractor on these weights (tools/diag_rounding_budget.py, profiles/r04_rounding_budget.txt); a layer fed a LayerNorm output adds 0.3 %.
+    softmax is a hard argmax, and ANY rounding of the layer input or of K flips winners -- that one layer makes the 1.2 % rms the bf16 extractor's ENCODER taps
+    show on these weights (tools/diag_rounding_budget.py, profiles/r04_rounding_budget.txt); a layer fed a LayerNorm output adds 0.3 %.  (The final probabilities
+    are another matter: they are as close to the reference with either checkpoint, tests/test_gpu_extractor.py.)
     `extractor_state_dict_cal` (emb_gain = 1 / 48: scores of layer 0 with sigma ~ 3, like the layers behind it) is the well-conditioned variant of the same weights."""
     d = extractor_dims(**(dims or {}))
     rng = np.random.default_rng(seed)
