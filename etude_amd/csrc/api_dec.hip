@@ -242,9 +242,20 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     const bool mfma_attn = big && pf != nullptr;
     if (mfma_attn) q.Qb = d->Qb;       // (K / V: the attention reads the cache rows this epilogue writes)
     if (big) {
-      LinArgs a = {};
-      a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.Wf; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
-      ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
+      static const bool pqkv_on = !getenv("ETD_NO_PQKV");
+      if (mfma_attn && pqkv_on && M >= 49152 && d->H == 512 && d->nh == 8 && w.qkv.N == 1536) {
+        // QKV with the token block stationary in registers and the weights streamed through LDS (csrc/dec_prefill.hip): 256-token workgroups that walk all 48 weight
+        // tiles -- from ~192 workgroups up (below that k_linear's 128 x 256 tiles fill the chip better: 6 466 rows 24 us against 86)
+        PQkvArgs pa = {};
+        pa.X = d->X1b; pa.ldx = d->H; pa.Wf = (const bf16*)w.qkv.Wf; pa.bias = w.qkv.b; pa.M = M; pa.N = w.qkv.N; pa.rows = rows;
+        pa.rope_cos = d->rope_cos; pa.rope_sin = d->rope_sin; pa.Qb = d->Qb; pa.Kc = (bf16*)Kl; pa.Vc = (bf16*)Vl; pa.slot_stride = d->slot_stride;
+        pa.max_ctx = d->ctx; pa.n_heads = d->nh;
+        ETD_TRY(launch_pqkv(pa, st));
+      } else {
+        LinArgs a = {};
+        a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.Wf; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
+        ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
+      }
       if (l == d->L - 1 && lo && mfma_attn && lo->n > 1 && lo->n <= DS_STEP_MAX_ROWS && d->H == 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && !getenv("ETD_NO_LAST_ONLY")) {
         // last layer, last positions only: every position's K/V is in the cache now; what remains of the layer is needed for
         // n rows, not M (attention, MLP up, (down | dense), residual = 9 % of the prefill's FLOPs at 8 layers)

@@ -120,6 +120,20 @@ struct PAttnArgs {
 };
 int launch_pattn(const PAttnArgs& a, hipStream_t st);
 
+// batched prefill, bf16 (csrc/dec_prefill.hip): the fused QKV projection with the token block stationary in registers (hidden 512, 8 heads): RoPE'd Q rows
+// to Qb, K / V rows to the cache
+struct PQkvArgs {
+  const bf16* X; int ldx;              // [M][512] input_layernorm(h) (bf16)
+  const bf16* Wf;                      // query_key_value.weight [1536][512] in MFMA-fragment order (pack_wfrag_host)
+  const float* bias;                   // [1536]
+  int M, N;
+  DecRows rows;
+  const float* rope_cos; const float* rope_sin;   // [max_ctx][8]
+  bf16* Qb;                            // [M][512]
+  bf16* Kc; bf16* Vc; long long slot_stride; int max_ctx, n_heads;
+};
+int launch_pqkv(const PQkvArgs& a, hipStream_t st);
+
 // h fp32 [M,H] -> LayerNorm with (g1,b1) and (g2,b2) -> two bf16 matrices (the two parallel-residual branches read the same h)
 int launch_ln_rows(const float* h, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,
                    bf16* x1, bf16* x2, hipStream_t st);

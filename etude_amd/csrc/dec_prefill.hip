@@ -170,3 +170,144 @@ int launch_pattn(const PAttnArgs& a, hipStream_t st) {
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
+
+// ================================================================================================
+// k_pqkv: the fused QKV projection of a batched prefill, X-STATIONARY              modeling_gpt_neox.py:195-207 (+ rotary :209-225, cache append)
+//
+// Rounds 1-3 ran this GEMM (M x 1536 x 512) on k_linear's 128 x 256 tile with the weight fragments loaded from global memory straight into operand registers:
+// every wave pulls 4 KiB of fragments per 16-deep k-step through its CU's vector L1 -- eight waves ask for 128 B / clk of a 64 B / clk path, and the kernel ran at
+// 635-780 TFLOP/s however its epilogue was arranged.  K = 512 is small enough to turn the loop inside out: a wave keeps its 32 tokens' whole input row block in
+// registers (32 B-operand fragments = 128 registers, loaded once), the 1.5 MiB weight matrix streams through LDS in 32-feature tiles of 32 KiB (fragment order:
+// an LDS-DMA piece is a plain copy, a fragment read a conflict-free ds_read_b128) shared by the workgroup's EIGHT waves -- 256 tokens per weight byte pulled from
+// L2, two waves per SIMD -- and each tile is one chain of 32 MFMAs into 16 accumulator registers.  Two tiles are one (head, q | k | v) block of 64 features: bias,
+// rotary embedding (lane-local: the pair (d, d + 8) sits in one lane) and bf16 rounding on the token-on-lane accumulators, a transpose through the wave's own LDS
+// block, and the rows leave as 128-byte segments: Q to the attention kernel's scratch, K / V to their cache rows -- 3 KB per prompt row, nothing else.
+// The arithmetic is k_linear<QKV>'s (same MFMA, same k order, same epilogue formulas): bit-identical cache rows and queries (tools/bench_prefill.py --digest).
+// Ring: two 32 KiB slots; tile t + 1 is requested at the top of tile t, behind the barrier that says every wave is done with tile t - 1's slot, and is waited
+// for -- vmcnt(0), a whole tile of MFMAs later -- at the top of tile t + 1.  The row stores of a finished block are issued at the top of the NEXT tile, ahead
+// of its 32 MFMAs, so that wait never waits for a store either.
+// ================================================================================================
+#define PQ_EPP 136                       // staging row stride (bf16 elements): 272 B
+#define PQ_TILE_ELEMS (32 * 512)         // one 32-feature tile of the fragment-ordered weights: 32 k-steps x 1 KiB
+typedef const __attribute__((address_space(1))) void* pq_gptr_t;
+typedef __attribute__((address_space(3))) void* pq_lptr_t;
+
+__global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PQ_TILE_ELEMS * 2 + 8 * 32 * PQ_EPP * 2 + 1536 * 4];
+  bf16* ring = reinterpret_cast<bf16*>(smem);
+  bf16* stg_all = reinterpret_cast<bf16*>(smem + 2 * PQ_TILE_ELEMS * 2);
+  float* sb = reinterpret_cast<float*>(smem + 2 * PQ_TILE_ELEMS * 2 + 8 * 32 * PQ_EPP * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  bf16* stg = stg_all + wave * (32 * PQ_EPP);
+  const int NT = a.N >> 5;                                   // 48 tiles
+  const int mw = blockIdx.x * 256 + wave * 32;               // the wave's first token
+  const int m = mw + r, mc = m < a.M ? m : a.M - 1;
+
+  // tile t -> slot t & 1: 32 one-KiB pieces, 4 per wave
+  auto issue = [&](int t) {
+    const bf16* src = a.Wf + (long long)t * PQ_TILE_ELEMS + wave * (4 * 512) + lane * 8;
+    bf16* dst = ring + (t & 1) * PQ_TILE_ELEMS + wave * (4 * 512);
+    // (one address, four immediate offsets: the offset field serves the global and the LDS address alike)
+    __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 1024, 0);
+    __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 2048, 0);
+    __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 3072, 0);
+  };
+  issue(0);
+  for (int i = tid; i < a.N; i += 512) sb[i] = a.bias[i];
+  // the wave's 32 tokens as B fragments: lane (token r, half h) holds x[token][16 s + 8 h .. + 8]
+  bf16x8 xf[32];
+  {
+    const bf16* xp = a.X + (long long)mc * a.ldx + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+  }
+  // rotary factors of this lane's token: dims 4 h .. 4 h + 3 (pair partner d + 8 = register i + 4)
+  const int pos_l = a.rows.pos[mc];
+  const f32x4 c4 = *reinterpret_cast<const f32x4*>(a.rope_cos + (long long)pos_l * 8 + 4 * h);
+  const f32x4 s4 = *reinterpret_cast<const f32x4*>(a.rope_sin + (long long)pos_l * 8 + 4 * h);
+  // the row-segment view of the wave's 32 x 64 block: lane -> row it * 8 + (lane >> 3), 16-byte chunk lane & 7
+  const int er8 = lane >> 3, ec8 = lane & 7;
+  long long qoff[4], coff[4];          // element offsets of the row's Q segment / cache row (without the head term); -1: nothing to store
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int mr = mw + it * 8 + er8, mrc = mr < a.M ? mr : a.M - 1;
+    const int rpos = a.rows.pos[mrc], rslot = a.rows.slot[mrc], ract = a.rows.active[mrc];
+    qoff[it] = mr < a.M ? (long long)mr * (a.n_heads * 64) + ec8 * 8 : -1;
+    coff[it] = (mr < a.M && ract && rpos < a.max_ctx) ? (long long)rslot * a.slot_stride + (long long)rpos * 64 + ec8 * 8 : -1;
+  }
+  const unsigned ring_l = (unsigned)reinterpret_cast<uintptr_t>(ring) + lane * 16;
+
+  f32x16 acc[2];
+  // the rows of block u (features 64 u .. + 64: head u / 3, part u % 3) from the staging block to global memory
+  auto store_block = [&](int u) {
+    const int head = u / 3, part = u - head * 3;
+    bf16* cbase = (part == 1 ? a.Kc : a.Vc) + (long long)head * a.max_ctx * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const u32x4 val = *reinterpret_cast<const u32x4*>(stg + (it * 8 + er8) * PQ_EPP + ec8 * 8);
+      if (part == 0) { if (qoff[it] >= 0) *reinterpret_cast<u32x4*>(a.Qb + qoff[it] + head * 64) = val; }
+      else if (coff[it] >= 0) *reinterpret_cast<u32x4*>(cbase + coff[it]) = val;
+    }
+  };
+  for (int t = 0; t < NT; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed (and the stores of the block before)
+    __syncthreads();                                          // ... everybody's; every wave is done reading tile t - 1's slot
+    if (t + 1 < NT) issue(t + 1);
+    if (t >= 2 && !(t & 1)) store_block((t - 2) >> 1);
+    const unsigned sl = ring_l + (t & 1) * (PQ_TILE_ELEMS * 2);
+    typedef __attribute__((address_space(3))) const bf16x8* lds_cp;
+    f32x16 c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    bf16x8 wf[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wf[0][k] = *(lds_cp)(uintptr_t)(sl + k * 1024);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      if (g < 7) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wf[(g + 1) & 1][k] = *(lds_cp)(uintptr_t)(sl + ((g + 1) * 4 + k) * 1024);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c = mfma32(wf[g & 1][k], xf[4 * g + k], c);
+      // (hipcc folds the two fragment buffers into "read two, wait, multiply twice"; forcing four-fragment groups with sched_group_barrier measured 4 % SLOWER:
+      // the partner wave of the SIMD covers the short lead)
+    }
+    acc[t & 1] = c;
+    if (t & 1) {
+      // block u = t >> 1 complete: bias, rotary embedding on Q / K, bf16, transpose through the wave's staging block
+      const int u = t >> 1, part = u % 3;
+      float v[2][16];
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[nn][i] = acc[nn][i] + sb[64 * u + nn * 32 + acc_row(i, h)];
+      if (part < 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float x1 = v[0][i], x2 = v[0][i + 4];
+          v[0][i] = x1 * c4[i] - x2 * s4[i];
+          v[0][i + 4] = x2 * c4[i] + x1 * s4[i];
+        }
+      }
+#pragma unroll
+      for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<bf16x4*>(stg + r * PQ_EPP + nn * 32 + 8 * q + 4 * h) = pack4(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
+    }
+  }
+  store_block((NT >> 1) - 1);
+}
+
+int launch_pqkv(const PQkvArgs& a, hipStream_t st) {
+  if (a.M <= 0 || a.N != 1536 || a.ldx < 512 || (a.ldx % 8) || !a.X || !a.Wf || !a.bias || !a.Qb || !a.Kc || !a.Vc || !a.rows.pos || !a.rows.slot || !a.rows.active ||
+      !a.rope_cos || !a.rope_sin || a.n_heads != 8 || (((uintptr_t)a.X | (uintptr_t)a.Wf | (uintptr_t)a.Qb | (uintptr_t)a.Kc | (uintptr_t)a.Vc) & 15) || (a.slot_stride % 8))
+    ETD_FAIL(ETD_EINVAL, "pqkv: bad arguments");
+  ETD_LAUNCH_FILTER("k_linear_dec");
+  ProfScope ps("k_linear_dec", st, 2.0 * a.M * a.N * 512.0, ((double)a.M * 512 + (double)a.N * 512 + 3.0 * a.M * 512) * 2);
+  hipLaunchKernelGGL(k_pqkv, dim3((a.M + 255) / 256), dim3(512), 0, st, a);
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
