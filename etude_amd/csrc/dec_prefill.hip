@@ -238,7 +238,6 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
   }
   const unsigned ring_l = (unsigned)reinterpret_cast<uintptr_t>(ring) + lane * 16;
 
-  f32x16 acc[2];
   // the rows of block u (features 64 u .. + 64: head u / 3, part u % 3) from the staging block to global memory
   auto store_block = [&](int u) {
     const int head = u / 3, part = u - head * 3;
@@ -250,39 +249,51 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
       else if (coff[it] >= 0) *reinterpret_cast<u32x4*>(cbase + coff[it]) = val;
     }
   };
-  for (int t = 0; t < NT; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of tile t have landed (and the stores of the block before)
-    __syncthreads();                                          // ... everybody's; every wave is done reading tile t - 1's slot
-    if (t + 1 < NT) issue(t + 1);
-    if (t >= 2 && !(t & 1)) store_block((t - 2) >> 1);
-    const unsigned sl = ring_l + (t & 1) * (PQ_TILE_ELEMS * 2);
-    typedef __attribute__((address_space(3))) const bf16x8* lds_cp;
-    f32x16 c;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) c[i] = 0.f;
-    bf16x8 wf[2][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) wf[0][k] = *(lds_cp)(uintptr_t)(sl + k * 1024);
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g < 7) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) wf[(g + 1) & 1][k] = *(lds_cp)(uintptr_t)(sl + ((g + 1) * 4 + k) * 1024);
-      }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) c = mfma32(wf[g & 1][k], xf[4 * g + k], c);
-      // (hipcc folds the two fragment buffers into "read two, wait, multiply twice"; forcing four-fragment groups with sched_group_barrier measured 4 % SLOWER:
-      // the partner wave of the SIMD covers the short lead)
-    }
-    acc[t & 1] = c;
-    if (t & 1) {
-      // block u = t >> 1 complete: bias, rotary embedding on Q / K, bf16, transpose through the wave's staging block
-      const int u = t >> 1, part = u % 3;
+  // ---- the tile's 32 chained MFMAs, hand-placed: hipcc reads two fragments, waits for them and multiplies twice (the chain then stalls on every pair of LDS reads); here
+  // group g + 1's four fragment reads are in flight behind group g's four MFMAs (volatile asm in program order, counted lgkmcnt as in csrc/dec_fused.hip)
+#define PQ_RD4(buf, F0)                                                                                                  \
+  do {                                                                                                                   \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(buf[0]) : "v"(sl), "n"((F0) * 1024));                            \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(buf[1]) : "v"(sl), "n"((F0) * 1024 + 1024));                     \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(buf[2]) : "v"(sl), "n"((F0) * 1024 + 2048));                     \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(buf[3]) : "v"(sl), "n"((F0) * 1024 + 3072));                     \
+  } while (0)
+#define PQ_MFMA(c, af, bfr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(af), "v"(bfr))
+#define PQ_MFMA0(c, af, bfr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(af), "v"(bfr))
+#define PQ_GROUP(c, G)                                                                                                   \
+  do {                                                                                                                   \
+    if constexpr ((G) < 7) { PQ_RD4(wf[((G) + 1) & 1], ((G) + 1) * 4); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); } \
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                              \
+    if constexpr ((G) == 0) PQ_MFMA0(c, wf[0][0], xf[0]); else PQ_MFMA(c, wf[(G) & 1][0], xf[4 * (G)]);                  \
+    PQ_MFMA(c, wf[(G) & 1][1], xf[4 * (G) + 1]);                                                                         \
+    PQ_MFMA(c, wf[(G) & 1][2], xf[4 * (G) + 2]);                                                                         \
+    PQ_MFMA(c, wf[(G) & 1][3], xf[4 * (G) + 3]);                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+  } while (0)
+#define PQ_TILE(c, t)                                                                                                    \
+  do {                                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   /* this wave's pieces of tile t have landed (and the row stores of the block before) */ \
+    __syncthreads();                                              /* ... everybody's; every wave is done reading tile t - 1's slot */ \
+    if ((t) + 1 < NT) issue((t) + 1);                                                                                    \
+    if ((t) >= 2 && !((t) & 1)) store_block(((t) - 2) >> 1);                                                              \
+    const unsigned sl = ring_l + ((t) & 1) * (PQ_TILE_ELEMS * 2);                                                        \
+    bf16x8 wf[2][4];                                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            /* (the staging reads of store_block are compiler-counted; start the hand count from zero) */ \
+    __builtin_amdgcn_sched_barrier(0);                                                                                   \
+    PQ_RD4(wf[0], 0);                                                                                                    \
+    PQ_GROUP(c, 0); PQ_GROUP(c, 1); PQ_GROUP(c, 2); PQ_GROUP(c, 3); PQ_GROUP(c, 4); PQ_GROUP(c, 5); PQ_GROUP(c, 6); PQ_GROUP(c, 7); \
+  } while (0)
+  for (int u = 0; u < (NT >> 1); ++u) {
+    f32x16 c0, c1;
+    PQ_TILE(c0, 2 * u);
+    PQ_TILE(c1, 2 * u + 1);
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c1) : : "memory");      // (MFMA -> VALU wait states behind the asm MFMAs; c0's ended a whole tile ago)
+    {
+      // block u complete: bias, rotary embedding on Q / K, bf16, transpose through the wave's staging block
+      const int part = u % 3;
       float v[2][16];
 #pragma unroll
-      for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v[nn][i] = acc[nn][i] + sb[64 * u + nn * 32 + acc_row(i, h)];
+      for (int i = 0; i < 16; ++i) { v[0][i] = c0[i] + sb[64 * u + acc_row(i, h)]; v[1][i] = c1[i] + sb[64 * u + 32 + acc_row(i, h)]; }
       if (part < 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -298,6 +309,11 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
           *reinterpret_cast<bf16x4*>(stg + r * PQ_EPP + nn * 32 + 8 * q + 4 * h) = pack4(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
     }
   }
+#undef PQ_TILE
+#undef PQ_GROUP
+#undef PQ_MFMA
+#undef PQ_MFMA0
+#undef PQ_RD4
   store_block((NT >> 1) - 1);
 }
 
