@@ -7,12 +7,10 @@
 // token through HBM and run their 128 x 256 tiles at 460-520 TFLOP/s -- bound by L2 -> CU traffic (52 FLOP per byte the tile pulls
 // from L2).  Here the token tile stays in registers for the whole branch, as in the extractor's k_ffn_fused.
 //
-// STATUS: correct and bit-identical (logits of a 600-token prompt, token streams of 48 batched jobs), on by default since the end of round 2 (ETD_FUSED_PMLP=0 turns it off): +0.7-1.7 % in the job in every A/B pair.
-// Measured on MI355X (54 prompts x ~340 tokens per launch; (history: 4ac2f57) tools/runs/r2_run47.sh, serial event pass): 195 us per launch against
-// 166 us for the two GEMMs + 16 us for the row kernel it replaces; in the four-engine job 581-589 against 572-586 audio-s/s
-// (+1.3 % over six pairs: it occupies 144 CUs and moves a quarter of the bytes, so it disturbs the other engines' steps less).
-// (Its inner loop is hand-placed asm whose MFMAs the compiler's hazard recognizer cannot see: the wait states are written out by hand, see s_nop below.)
-// How it got from 290 to 195 us, in order (every step kept the bit-identity test green, and every one is needed):
+// STATUS: on by default since the end of round 2 (ETD_FUSED_PMLP=0 turns it off); bit-identical to the three-launch path (logits of a 600-token prompt, token
+// streams of 48 batched jobs: tests/test_gpu_decoder.py; first tokens and K/V cache row sums of a 256 k-row pass: tools/bench_prefill.py --digest).
+// Per 256 500-row launch: round 3 1.70 ms (711 TFLOP/s), round 4 **1.49 ms** (810).  What each step was, in order:
+//   round 2 (every step kept the bit-identity test green, and every one is needed):
 //   1. a token's input fragments (128 registers) and 512 fp32 outputs (256) leave 128 of a wave's 512 registers: hipcc put all
 //      256 accumulator registers into AGPRs, the fragments into VGPRs and copied them through ONE AGPR quad (272 v_accvgpr moves
 //      per 64-MFMA chunk); with the fragments loaded straight into AGPRs (global_load ... a[n:n+3]) and read from there as the
@@ -21,13 +19,18 @@
 //      hides that): the fragment reads, counted waits and MFMAs are volatile asm in program order, one 4-fragment group ahead
 //      (two groups ahead spills 19 registers, and a scratch reload's vmcnt(0) drains the LDS-DMA);
 //   3. the bias values of the GELU are read by hand too (a compiler-placed ds_read brings lgkmcnt(0) and drains the prefetch);
-//   4. the next chunk's 16 LDS-DMA pieces per wave are issued one per group instead of as a burst at the chunk top;
-//   5. the GELU halves are pinned BETWEEN the chained MFMAs (empty volatile asms): LLVM otherwise sinks all sixteen behind the up
-//      phase, where they block the in-order issue for ~1100 clocks per chunk.
-// What is left (~40 % MFMA duty): 16 LDS-DMA issues (~60 clocks each) and 16 GELUs (~70) per wave and chunk against 2048 clocks
-// of MFMAs, in one instruction stream; the barrier and first-read latency at every chunk top.  Dead end on the way: the DMA issue
-// BETWEEN the independent MFMAs of a down group gave wrong results (a register the compiler took for free was still the A operand
-// of a queued MFMA) -- the asm form is only safe where the compiler's reuse distance is known.
+//   4. the GELU halves are pinned BETWEEN the chained MFMAs (empty volatile asms): LLVM otherwise sinks all sixteen behind the up
+//      phase, where they block the in-order issue for ~1100 clocks per chunk;
+//   round 4 (phase stamps: tools/bench_prefill.py --stamps on a -DETD_PMLP_STAMP build; a workgroup lived 428 k clocks of which 131 k were its epilogue):
+//   5. chunks 1 .. 63 as 16 uniform groups -- one GELU and at most two LDS-DMA pieces per 4 MFMAs, the sixteen GELUs of a chunk spread over four phases, the DMA
+//      pieces of the next chunk issued in groups 0 .. 11 with one address per four (pm_group / pm_chunk below): 4 623 -> 3 707 clocks per chunk;
+//   6. the epilogue's rows through the idle ring as full 512-byte segments (token-on-lane accesses touched 32 rows x 32 bytes per instruction) and its five
+//      parameter vectors from LDS: 131 k -> 88 k clocks.
+// What is left of a workgroup's 389 k clocks: chunks 1 .. 63 235 k (3 730 per chunk against 2 048 of MFMAs: one wave per SIMD issues everything in order, and GELU
+// alone is 1 216 clocks of VALU per chunk), the token fragments' loads 18 k + 10 k (x2, attention rows: fragment-shaped), chunk 64 + the dense chunks 42 k, epilogue 88 k
+// (768 KB per workgroup: 12 B / clk per CU with every CU streaming).  A dead end on the way: the DMA issue BETWEEN the independent MFMAs of a down group gave wrong
+// results in round 2 (a register the compiler took for free was still the A operand of a queued MFMA) -- the asm form is only safe where the compiler's reuse
+// distance is known; starting a launch's first round of workgroups staggered (s_sleep by blockIdx & 7) only added the idle time (round 4).
 //   * a wave owns 32 tokens; x2 enters once as the 32 B-operand fragments of v_mfma_f32_32x32x16_bf16 (128 registers);
 //   * the 2048-wide hidden layer exists 32 features at a time: acc1 = W1[32 rows] . x2 (32 chained MFMAs), bias + erf-GELU +
 //     bf16 rounding in registers; two v_permlane32_swap per k-step turn the accumulator's row order into the natural k order of a
@@ -45,6 +48,7 @@
 #include "dec_kernels.h"
 #include "prof.h"
 
+#include <cstdlib>
 #include <utility>
 #define PM_SLOT_ELEMS (32 * 1024)          // bf16 elements per ring slot: 64 fragments of 512 elements (64 KiB)
 
@@ -85,7 +89,8 @@ template <int T, bool B_AGPR> __device__ __forceinline__ void pm_mfma_out(f32x16
 // group's MFMAs: issued as one burst at the chunk top they cost the wave ~100 clocks each with an idle MFMA pipe.
 struct PmNext { const bf16* src; bf16* dst; bool on; };
 template <int I> __device__ __forceinline__ void pm_dma(const PmNext& n) {
-  if (n.on) __builtin_amdgcn_global_load_lds((pm_gptr_t)(n.src + I * 512), (pm_lptr_t)(n.dst + I * 512), 16, 0, 0);
+  // four pieces share one address computation: the instruction's immediate offset serves the global and the LDS address alike
+  if (n.on) __builtin_amdgcn_global_load_lds((pm_gptr_t)(n.src + (I >> 2) * 2048), (pm_lptr_t)(n.dst + (I >> 2) * 2048), 16, (I & 3) * 1024, 0);
 }
 // fragments of group J of an MLP chunk [down(k - 1): 0 .. 31 | up(k): 32 .. 63]: groups 0 .. 7 = up, 8 .. 15 = down
 template <int J> struct PmMlpGroup { static constexpr int f0 = J < 8 ? 32 + 4 * J : 4 * (J - 8); };
@@ -103,69 +108,12 @@ template <int J> __device__ __forceinline__ void pm_gelu2(f32x16& acc1, const fl
     acc1[i] = gelu_fast(acc1[i] + sbu[32 * kc + 8 * (i >> 2) + 4 * h + (i & 3)]);
   }
 }
-// up group J (0 .. 7) of chunk k into accn, with the GELU of two registers of the previous chunk's accumulator beside it
-template <int J, bool GELU> __device__ __forceinline__ void pm_up_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, f32x16& acc1, const bf16x8 (&xf)[32],
-                                                                        const float* sbu, unsigned bias_addr, int h, const PmNext& nx) {
-  if constexpr (GELU) {
-    // the two bias values of this group's GELU are read by hand as well, AHEAD of group J + 1's fragments: a read the compiler places
-    // comes with s_waitcnt lgkmcnt(0) and drains the fragment reads that are meant to stay in flight.  Outstanding at the first wait:
-    // group J (4), the bias (1), group J + 1 (4) -> lgkmcnt(5) = group J has landed; behind the MFMAs lgkmcnt(4) = the bias has
-    f32x2 bb;
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(bb) : "v"(bias_addr), "n"((8 * (J >> 1) + 2 * (J & 1)) * 4));
-    pm_rd4<PmMlpGroup<J + 1>::f0>(buf[(J + 1) & 1], addr);
-    pm_wait_lds<5>();
-    // One wave per SIMD issues in order: VALU work that follows four chained MFMAs in program order waits out all four (128 clocks
-    // of blocked issue), so the two GELUs of this group are cut in halves and placed BETWEEN the MFMAs -- ~24 of an MFMA's 32 clocks
-    // are free for other issue.  gelu_fast's operations in gelu_fast's order (dec_epilogue.h), only spread over the statements.
-    pm_mfma_v_a(accn, buf[J & 1][0], xf[4 * J]);
-    // the bias pair has landed (nothing younger than group J + 1's fragments is outstanding).  bb is an operand of the wait: the
-    // compiler takes an asm's output for ready at once and is free to move the (non-asm) GELU arithmetic above a bare s_waitcnt.
-    // PM_PIN: an empty volatile asm with the value as in/out operand -- volatile asms keep their order, so arithmetic whose inputs
-    // come out of one pin and whose results go into the next stays between the two MFMAs it was written between (left alone, LLVM
-    // sinks all sixteen GELUs behind the last MFMA of the up phase, where they block the issue for ~1100 clocks)
-#define PM_PIN(x) asm volatile("" : "+v"(x))
-    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bb) : : "memory");
-    float x0 = acc1[2 * J] + bb[0];
-    float z0 = fabsf(x0) * 0.70710678118654752440f;
-    float t0 = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z0, 1.f));
-    float e0 = __builtin_amdgcn_exp2f(-1.4426950408889634f * z0 * z0);
-    PM_PIN(x0); PM_PIN(t0); PM_PIN(e0);
-    pm_mfma_v_a(accn, buf[J & 1][1], xf[4 * J + 1]);
-    PM_PIN(x0); PM_PIN(t0); PM_PIN(e0);
-    {
-      float p = fmaf(1.061405429f, t0, -1.453152027f);
-      p = fmaf(p, t0, 1.421413741f); p = fmaf(p, t0, -0.284496736f); p = fmaf(p, t0, 0.254829592f);
-      const float er = fmaf(-p * t0, e0, 1.f);
-      float r0 = 0.5f * x0 * (1.f + copysignf(er, x0));
-      PM_PIN(r0);
-      acc1[2 * J] = r0;
-    }
-    float a1 = acc1[2 * J + 1], b1 = bb[1];
-    pm_mfma_v_a(accn, buf[J & 1][2], xf[4 * J + 2]);
-    PM_PIN(a1); PM_PIN(b1);
-    float x1 = a1 + b1;
-    float z1 = fabsf(x1) * 0.70710678118654752440f;
-    float t1 = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z1, 1.f));
-    float e1 = __builtin_amdgcn_exp2f(-1.4426950408889634f * z1 * z1);
-    PM_PIN(x1); PM_PIN(t1); PM_PIN(e1);
-    pm_mfma_v_a(accn, buf[J & 1][3], xf[4 * J + 3]);
-    PM_PIN(x1); PM_PIN(t1); PM_PIN(e1);
-    {
-      float p = fmaf(1.061405429f, t1, -1.453152027f);
-      p = fmaf(p, t1, 1.421413741f); p = fmaf(p, t1, -0.284496736f); p = fmaf(p, t1, 0.254829592f);
-      const float er = fmaf(-p * t1, e1, 1.f);
-      float r1 = 0.5f * x1 * (1.f + copysignf(er, x1));
-      PM_PIN(r1);
-      acc1[2 * J + 1] = r1;
-    }
-#undef PM_PIN
-    pm_dma<J>(nx);
-  } else {
-    pm_roll<J, 8>(buf, addr);
+// up group J (0 .. 7) of chunk 0 into accn (no GELU beside it: there is no previous chunk)
+template <int J> __device__ __forceinline__ void pm_up_group0(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, const bf16x8 (&xf)[32], const PmNext& nx) {
+  pm_roll<J, 8>(buf, addr);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pm_mfma_v_a(accn, buf[J & 1][q], xf[4 * J + q]);
-    pm_dma<2 * J>(nx); pm_dma<2 * J + 1>(nx);
-  }
+  for (int q = 0; q < 4; ++q) pm_mfma_v_a(accn, buf[J & 1][q], xf[4 * J + q]);
+  pm_dma<2 * J>(nx); pm_dma<2 * J + 1>(nx);
   __builtin_amdgcn_sched_barrier(0);
 }
 // down group J (8 .. 15): k-step (J - 8) >> 2, tiles 4 ((J - 8) & 3) .. + 4
@@ -214,18 +162,9 @@ __device__ __forceinline__ void pm_hidden_frags(const f32x16& acc1, bf16x8 (&hf)
   // that the arithmetic producing them cannot be scheduled behind it.)
   asm volatile("s_nop 4" : "+v"(hf[0]), "+v"(hf[1]) : : "memory");
 }
-template <int... Js> __device__ __forceinline__ void pm_up_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, f32x16& acc1, const bf16x8 (&xf)[32], const float* sbu, int h,
-                                                                const PmNext& nx, std::integer_sequence<int, Js...>) {
+template <int... Js> __device__ __forceinline__ void pm_up_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, const bf16x8 (&xf)[32], const PmNext& nx, std::integer_sequence<int, Js...>) {
   pm_rd4<PmMlpGroup<0>::f0>(buf[0], addr);
-  (pm_up_group<Js, false>(buf, addr, accn, acc1, xf, sbu, 0u, h, nx), ...);
-}
-template <int... Js> __device__ __forceinline__ void pm_up_gelu(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, f32x16& acc1, const bf16x8 (&xf)[32], const float* sbu, unsigned bias_addr, int h,
-                                                                const PmNext& nx, std::integer_sequence<int, Js...>) {
-  pm_rd4<PmMlpGroup<0>::f0>(buf[0], addr);
-  (pm_up_group<Js, true>(buf, addr, accn, acc1, xf, sbu, bias_addr, h, nx), ...);
-}
-template <int... Js> __device__ __forceinline__ void pm_down(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&hf)[2], const PmNext& nx, std::integer_sequence<int, Js...>) {
-  (pm_down_group<8 + Js, false>(buf, addr, acc2, hf, nx), ...);
+  (pm_up_group0<Js>(buf, addr, accn, xf, nx), ...);
 }
 template <int... Js> __device__ __forceinline__ void pm_down_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&hf)[2], const PmNext& nx, std::integer_sequence<int, Js...>) {
   // chunk 64: only the down half exists -- groups 8 .. 15 with their own lead
@@ -245,9 +184,6 @@ template <int... Js> __device__ __forceinline__ void pm_down_only(bf16x8 (&buf)[
 //   * the 16 DMA pieces of chunk k + 1 leave in groups 0 .. 11 (2, 2, 1, 1 | 2, 2, 1, 1 | 1, 1, 1, 1): the last one has the whole k-step-1 phase to land;
 //   * four pieces share one address computation (the instruction's immediate offset serves the global and the LDS address alike);
 //   * the two up accumulators swap roles from chunk to chunk (no 16-register copy), and the first MFMA of a chain takes C = 0 (no zero fill).
-template <int I> __device__ __forceinline__ void pm_dma4(const PmNext& n) {
-  if (n.on) __builtin_amdgcn_global_load_lds((pm_gptr_t)(n.src + (I >> 2) * 2048), (pm_lptr_t)(n.dst + (I >> 2) * 2048), 16, (I & 3) * 1024, 0);
-}
 // acc (VGPR) = A (VGPR) . B (AGPR): the first MFMA of an up chain
 __device__ __forceinline__ void pm_mfma_v_a0(f32x16& acc, const bf16x8& af, const bf16x8& bf) {
   asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(af), "a"(bf));      // early clobber: the 16 result registers must not overlap the A operand
@@ -291,9 +227,9 @@ __device__ __forceinline__ void pm_group(bf16x8 (&buf)[2][4], unsigned addr, f32
     g[GR < 0 ? 0 : GR] = r0;
   }
   PM_MFMA(2);
-  if constexpr (ND >= 1) pm_dma4<D0>(nx);
+  if constexpr (ND >= 1) pm_dma<D0>(nx);
   PM_MFMA(3);
-  if constexpr (ND >= 2) pm_dma4<D0 + 1>(nx);
+  if constexpr (ND >= 2) pm_dma<D0 + 1>(nx);
 #undef PM_MFMA
 #undef PM_PIN
   __builtin_amdgcn_sched_barrier(0);
@@ -334,7 +270,8 @@ __device__ __forceinline__ void pm_chunk(bf16x8 (&buf)[2][4], unsigned sa, f32x1
 }
 
 // Diagnostic build (-DETD_PMLP_STAMP, tools/bench_prefill.py --stamps): s_memtime at the phase boundaries of chunks 1 .. 63, summed per wave in SGPRs
-// (workgroups 0 .. 63) and read back with etd_debug_pmlp_stamps: [0] the chunk's 16 groups, [1] wait for the chunk's LDS-DMA, [2] barrier
+// (workgroups 0 .. 63) and read back with etd_debug_pmlp_stamps: [0] the chunk's 16 groups, [1] wait for the chunk's LDS-DMA, [2] barrier (sums over chunks 1 .. 63); [3] prologue + chunk 0, [4] chunks 1 .. 63, [5] chunks 64 .. 72,
+// [6] residual + h_out, [7] the wave's whole life
 // (round 3's schedule: [0] down phase, [3] up phase + GELU, [4] hidden fragments).  The shipped build has no stamp.
 #ifdef ETD_PMLP_STAMP
 __device__ unsigned long long g_pmlp_stamp[64 * 4 * 8];
@@ -350,6 +287,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int m = blockIdx.x * 128 + wave * 32 + r;
   const int mc = m < a.M ? m : a.M - 1;
   const unsigned ring_lds = (unsigned)reinterpret_cast<uintptr_t>(ring) + lane * 16;      // LDS byte address of this lane's 16 bytes of fragment 0, slot 0
+#ifdef ETD_PMLP_STAMP
+  const unsigned long long ps_t0 = __builtin_amdgcn_s_memtime();
+#endif
   const unsigned sbu_lds = (unsigned)reinterpret_cast<uintptr_t>(sbu) + h * 16;            // ... of b_up[4 h]: register 4 q + j of a hidden accumulator wants b_up[32 kc + 8 q + 4 h + j]
 
   // ring slot (k & 1) <- stream chunk k: 64 one-KiB pieces, 16 per wave
@@ -381,6 +321,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int s = 0; s < 32; ++s) PM_LOADX(xf[s], xp + 16 * s);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+#ifdef ETD_PMLP_STAMP
+  const unsigned long long ps_tx = __builtin_amdgcn_s_memtime();      // token fragments loaded
+#endif
   for (int i = tid; i < 2048; i += 256) sbu[i] = a.b_up[i];
 
   f32x16 acc2[16];
@@ -398,13 +341,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   {
     PM_TOP(0);
     PM_ZERO(accA);
-    f32x16 unused = accA;
-    pm_up_only(buf, ring_lds, accA, unused, xf, sbu, h, next_of(0), seq8{});
+    pm_up_only(buf, ring_lds, accA, xf, next_of(0), seq8{});
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(accA) : : "memory");      // (MFMA -> VALU wait states: the GELU reads the accumulator)
     pm_gelu2<0>(accA, sbu, 0, h); pm_gelu2<1>(accA, sbu, 0, h);
   }
 #ifdef ETD_PMLP_STAMP
   unsigned long long ps_acc[5] = {0, 0, 0, 0, 0}, ps_t = __builtin_amdgcn_s_memtime();
+  const unsigned long long ps_t1 = ps_t;          // prologue + chunk 0 done
 #define PM_TOP_S(k)                                                                         \
   do {                                                                                      \
     if ((k) > 1) PMS(0); else ps_t = __builtin_amdgcn_s_memtime();                          \
@@ -429,8 +372,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   PM_CHUNK(63, accA, accB);
 #ifdef ETD_PMLP_STAMP
   PMS(0);
-  if (lane == 0 && blockIdx.x < 64)
-    for (int i = 0; i < 5; ++i) g_pmlp_stamp[(blockIdx.x * 4 + wave) * 8 + i] = ps_acc[i];
+  const unsigned long long ps_t2 = ps_t;          // chunk 63 done
 #endif
   // chunk 64: [down(63) | -- ]; registers 4 .. 15 of up(63) still want their GELU; the attention rows replace x2 in the fragment registers
   {
@@ -447,6 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     pm_hidden_frags(accB, hf);
     pm_down_only(buf, sa, acc2, hf, next_of(64), seq8{});
   }
+#ifdef ETD_PMLP_STAMP
+  const unsigned long long ps_t2b = __builtin_amdgcn_s_memtime();     // chunk 64 done
+#endif
   // chunks 65 .. 72: attention.dense, 4 k-steps x 16 tiles each
   { PM_TOP(65); pm_dense_chunk<0>(buf, ring_lds + (65 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(65), seq16{}); }
   { PM_TOP(66); pm_dense_chunk<1>(buf, ring_lds + (66 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(66), seq16{}); }
@@ -457,37 +402,87 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   { PM_TOP(71); pm_dense_chunk<6>(buf, ring_lds + (71 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(71), seq16{}); }
   { PM_TOP(72); pm_dense_chunk<7>(buf, ring_lds + (72 & 1) * (PM_SLOT_ELEMS * 2), acc2, xf, next_of(72), seq16{}); }
 
+#ifdef ETD_PMLP_STAMP
+  const unsigned long long ps_t3 = __builtin_amdgcn_s_memtime();      // chunks 64 .. 72 done
+#endif
   // (MFMA -> VALU wait states behind the asm MFMAs; the tiles are operands, so no read of them can be scheduled before the nops)
   asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc2[0]), "+a"(acc2[1]), "+a"(acc2[2]), "+a"(acc2[3]), "+a"(acc2[4]), "+a"(acc2[5]), "+a"(acc2[6]), "+a"(acc2[7]) : : "memory");
   asm volatile("" : "+v"(acc2[8]), "+v"(acc2[9]), "+v"(acc2[10]), "+v"(acc2[11]), "+v"(acc2[12]), "+v"(acc2[13]), "+v"(acc2[14]), "+v"(acc2[15]));
   // ---- epilogue: h_out = (acc + bias) + h_in (the order of k_linear's residual epilogue), then the next layer's LayerNorms with
   // k_ln_rows's arithmetic: its lane l holds features 8 l .. 8 l + 7 = group (t, u, h) here, l = 4 t + 2 u + h; its butterfly
-  // folds lane bits 5 .. 0 = t bits 3 .. 0, u, h in that order
-  const long long ro = (long long)m * 512;
+  // folds lane bits 5 .. 0 = t bits 3 .. 0, u, h in that order.
+  // Every row travels through the (now idle) ring as full 512-byte segments.  With the token on the lane a direct access touches 32 rows x 32 bytes per
+  // instruction: the residual read, the h_out store and the two LayerNorm stores were ~320 such instructions per wave and took 131 k of a workgroup's 428 k clocks
+  // (tools/bench_prefill.py --stamps, round 4) -- a third of the kernel.  Now a group of four tiles (128 features) of the wave's 32 tokens is one [32][132]-float
+  // block of the wave's own LDS region: rows come in and go out 16 bytes per lane, two whole 512-byte segments per instruction; the token-on-lane view reads and
+  // writes 32-byte pieces (row pitch 132 floats = 4 banks: eight consecutive rows tile the 32 banks, conflict-free ds_*_b128).  Same values, same order of operations.
+  __syncthreads();                                      // every wave is done with the last weight chunk: the ring is staging space now
+  constexpr int SROW = 132;                             // floats per staged row (128 + 4)
+  float* stg = reinterpret_cast<float*>(smem) + wave * (32 * SROW + 128);
+  // the five parameter vectors of the epilogue (b_cat | g1 | b1 | g2 | b2, 512 floats each) behind the four staging blocks: 320 global loads per wave become LDS reads
+  float* spar = reinterpret_cast<float*>(smem) + 4 * (32 * SROW + 128);
+  for (int i = tid; i < 512; i += 256) {
+    spar[i] = a.b_cat[i];
+    if (a.nx1) { spar[512 + i] = a.g1[i]; spar[1024 + i] = a.b1[i]; spar[1536 + i] = a.g2[i]; spar[2048 + i] = a.b2[i]; }
+  }
+  __syncthreads();
+  const int m0w = blockIdx.x * 128 + wave * 32;          // the wave's first token
+  const int rrow = lane >> 5, rcol = lane & 31;          // row view: rows 2 it + rrow, 16-byte chunk rcol of the 512-byte segment
+  f32x4 hv[16];
+  auto load_rows = [&](int g) {
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      int mm = m0w + 2 * it + rrow; mm = mm < a.M ? mm : a.M - 1;
+      hv[it] = *reinterpret_cast<const f32x4*>(a.hin + (long long)mm * 512 + g * 128 + rcol * 4);
+    }
+  };
+  load_rows(0);
   float gs[16][2];
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int g = 0; g < 4; ++g) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f0 = 32 * t + 16 * u + 8 * h;
-      const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b_cat + f0), bb = *reinterpret_cast<const f32x4*>(a.b_cat + f0 + 4);
-      const f32x4 ha = *reinterpret_cast<const f32x4*>(a.hin + (long long)mc * 512 + f0), hb = *reinterpret_cast<const f32x4*>(a.hin + (long long)mc * 512 + f0 + 4);
-      float s = 0.f;
+    for (int it = 0; it < 16; ++it) *reinterpret_cast<f32x4*>(stg + (2 * it + rrow) * SROW + rcol * 4) = hv[it];
+    if (g < 3) load_rows(g + 1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float va = (acc2[t][8 * u + j] + ba[j]) + ha[j], vb = (acc2[t][8 * u + 4 + j] + bb[j]) + hb[j];
-        acc2[t][8 * u + j] = va; acc2[t][8 * u + 4 + j] = vb;
-      }
+    for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += acc2[t][8 * u + j];
-      gs[t][u] = s;
-      if (m < a.M) {
+      for (int u = 0; u < 2; ++u) {
+        const int t = 4 * g + tt, f0 = 32 * t + 16 * u + 8 * h;
+        float* sp = stg + r * SROW + 32 * tt + 16 * u + 8 * h;
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(spar + f0), bb = *reinterpret_cast<const f32x4*>(spar + f0 + 4);
+        const f32x4 ha = *reinterpret_cast<const f32x4*>(sp), hb = *reinterpret_cast<const f32x4*>(sp + 4);
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float va = (acc2[t][8 * u + j] + ba[j]) + ha[j], vb = (acc2[t][8 * u + 4 + j] + bb[j]) + hb[j];
+          acc2[t][8 * u + j] = va; acc2[t][8 * u + 4 + j] = vb;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sm += acc2[t][8 * u + j];
+        gs[t][u] = sm;
         const f32x4 oa = {acc2[t][8 * u], acc2[t][8 * u + 1], acc2[t][8 * u + 2], acc2[t][8 * u + 3]};
         const f32x4 ob = {acc2[t][8 * u + 4], acc2[t][8 * u + 5], acc2[t][8 * u + 6], acc2[t][8 * u + 7]};
-        *reinterpret_cast<f32x4*>(a.hout + ro + f0) = oa;
-        *reinterpret_cast<f32x4*>(a.hout + ro + f0 + 4) = ob;
+        *reinterpret_cast<f32x4*>(sp) = oa;
+        *reinterpret_cast<f32x4*>(sp + 4) = ob;
       }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int mm = m0w + 2 * it + rrow;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(stg + (2 * it + rrow) * SROW + rcol * 4);
+      if (mm < a.M) *reinterpret_cast<f32x4*>(a.hout + (long long)mm * 512 + g * 128 + rcol * 4) = v;
     }
+  }
+#ifdef ETD_PMLP_STAMP
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ps_t4 = __builtin_amdgcn_s_memtime();    // residual read + hout written
+    if (lane == 0 && blockIdx.x < 64) {
+      unsigned long long* o = g_pmlp_stamp + (blockIdx.x * 4 + wave) * 8;
+      o[0] = ps_t2b - ps_t2; o[1] = ps_tx - ps_t0; o[2] = ps_acc[1] + ps_acc[2];
+      o[3] = ps_t1 - ps_t0; o[4] = ps_t2 - ps_t1; o[5] = ps_t3 - ps_t2; o[6] = ps_t4 - ps_t3;
+    }
+  }
+#endif
   if (!a.nx1) return;
   // fold t bits 3, 2, 1, 0, then u, then h (the partner lane): at every level both operands are sums over the same kind of set, so
   // the value is the one every lane of k_ln_rows ends with (fp32 addition commutes)
@@ -513,25 +508,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float qt;
   PM_FOLD(gs, qt);
   const float rstd = rsqrtf(qt / 512.f + a.eps);
-  if (m >= a.M) return;
+  // the two normalised rows, bf16: halves of 256 features = 512-byte segments through the same staging block ([32][264] bf16: the same 528-byte row pitch)
+  bf16* stb = reinterpret_cast<bf16*>(stg);
 #pragma unroll
-  for (int t = 0; t < 16; ++t)
+  for (int which = 0; which < 2; ++which) {
+    const float* gam = spar + (which ? 1536 : 512); const float* bet = spar + (which ? 2048 : 1024);
+    bf16* dstp = which ? a.nx2 : a.nx1;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int f0 = 32 * t + 16 * u + 8 * h;
-      const f32x4 ga = *reinterpret_cast<const f32x4*>(a.g1 + f0), gb = *reinterpret_cast<const f32x4*>(a.g1 + f0 + 4);
-      const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b1 + f0), bb = *reinterpret_cast<const f32x4*>(a.b1 + f0 + 4);
-      const f32x4 ha = *reinterpret_cast<const f32x4*>(a.g2 + f0), hb = *reinterpret_cast<const f32x4*>(a.g2 + f0 + 4);
-      const f32x4 ca = *reinterpret_cast<const f32x4*>(a.b2 + f0), cb = *reinterpret_cast<const f32x4*>(a.b2 + f0 + 4);
-      bf16x8 o1, o2;
+    for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o1[j] = (bf16)((acc2[t][8 * u + j] - mean) * rstd * ga[j] + ba[j]); o1[4 + j] = (bf16)((acc2[t][8 * u + 4 + j] - mean) * rstd * gb[j] + bb[j]);
-        o2[j] = (bf16)((acc2[t][8 * u + j] - mean) * rstd * ha[j] + ca[j]); o2[4 + j] = (bf16)((acc2[t][8 * u + 4 + j] - mean) * rstd * hb[j] + cb[j]);
+      for (int tt = 0; tt < 8; ++tt)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 8 * hh + tt, f0 = 32 * t + 16 * u + 8 * h;
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + f0), gb = *reinterpret_cast<const f32x4*>(gam + f0 + 4);
+          const f32x4 ba = *reinterpret_cast<const f32x4*>(bet + f0), bb = *reinterpret_cast<const f32x4*>(bet + f0 + 4);
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = (bf16)((acc2[t][8 * u + j] - mean) * rstd * ga[j] + ba[j]); o[4 + j] = (bf16)((acc2[t][8 * u + 4 + j] - mean) * rstd * gb[j] + bb[j]);
+          }
+          *reinterpret_cast<bf16x8*>(stb + r * (2 * SROW) + 32 * tt + 16 * u + 8 * h) = o;
+        }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int mm = m0w + 2 * it + rrow;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stb + (2 * it + rrow) * (2 * SROW) + rcol * 8);
+        if (mm < a.M) *reinterpret_cast<u32x4*>(dstp + (long long)mm * 512 + hh * 256 + rcol * 8) = v;
       }
-      *reinterpret_cast<bf16x8*>(a.nx1 + ro + f0) = o1;
-      *reinterpret_cast<bf16x8*>(a.nx2 + ro + f0) = o2;
     }
+  }
+#ifdef ETD_PMLP_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && blockIdx.x < 64) g_pmlp_stamp[(blockIdx.x * 4 + wave) * 8 + 7] = __builtin_amdgcn_s_memtime() - ps_t0;       // the wave's whole life
+#endif
 }
 
 #ifdef ETD_PMLP_STAMP

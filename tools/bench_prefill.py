@@ -84,11 +84,10 @@ def main():
             sys.exit("library built without -DETD_PMLP_STAMP")
         buf = np.zeros(64 * 4 * 8, np.uint64)
         lib.etd_debug_pmlp_stamps(C.c_void_p(buf.ctypes.data))
-        b = buf.reshape(64, 4, 8)[:, :, :5].astype(np.float64) / 63.0            # per chunk
-        names = ["down", "dma_wait", "barrier", "up+gelu", "hidden_frags"]
-        out["pmlp_clk_per_chunk"] = {n: round(float(b[:, :, i].mean()), 1) for i, n in enumerate(names)}
-        out["pmlp_clk_per_chunk"]["total"] = round(float(b.sum(-1).mean()), 1)
-        out["pmlp_clk_per_chunk_by_wave"] = {f"wave{w}": [round(float(b[:, w, i].mean()), 1) for i in range(5)] for w in range(4)}
+        raw = buf.reshape(64, 4, 8).astype(np.float64)
+        out["pmlp_clk_misc"] = {"chunk64": round(float(raw[:, :, 0].mean()), 0), "token_fragments_loaded": round(float(raw[:, :, 1].mean()), 0),
+                                "dma_wait+barrier_per_chunk": round(float(raw[:, :, 2].mean()) / 63.0, 1)}
+        out["pmlp_clk_wave_life"] = {n: round(float(raw[:, :, 3 + i].mean()), 0) for i, n in enumerate(["prologue+chunk0", "chunks1-63", "chunks64-72", "residual+hout", "whole"])}
     print(json.dumps(out))
     dec.close()
 
