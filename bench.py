@@ -443,7 +443,10 @@ def main():
         log(f"first warm-up step: {t_first:.2f}s (extract {a:.2f} decode {b:.2f} notes {c_:.2f}); {since:.0f}s since the process started")
         rest = args.warmup - 1
         short = lambda t: 0.12 * t + 0.5                      # noqa: E731  (a 4-bar step: the whole extract stage + 4 of 92 bars)
-        if since + (rest + args.steps) * t_first + OVERHEAD_S > args.budget_s:
+        # full warm-up steps only if they leave room for EVERYTHING that follows the timed steps (24 stamped bars, serial pass, extras incl. the exact-parity pass,
+        # CPU baseline: ~90 s); otherwise the warm-up steps shrink first -- they are untimed and everything is allocated, captured and cached after the first one
+        FULL_POST_S = 0.27 * t_first + 4.0 + 14.0 + (PARITY_FIXED_S + args.parity_clips * (PARITY_EXTRACT_S_PER_CLIP + PARITY_DECODE_S_PER_CLIP + PARITY_BF16_S_PER_CLIP)) + 30.0
+        if since + (rest + args.steps) * t_first + max(OVERHEAD_S, FULL_POST_S if rest > 0 else 0.0) > args.budget_s:
             if since + args.steps * t_first + rest * short(t_first) + OVERHEAD_S <= args.budget_s:
                 warm_mode = "first warm-up step full, the others 4 bars per job (W + K full steps exceed the harness budget)"
                 for _ in range(rest):
@@ -559,7 +562,7 @@ def main():
         nb_mean = max(1.0, float(np.mean(nbars)))
         stamp_bars = args.max_bars or (0 if args.steps + args.warmup <= 4 and time_left() > CPU_RESERVE_S + step_dec_s + 30.0 else
                                        (24 if time_left() > CPU_RESERVE_S + step_dec_s * 24 / nb_mean + 22.0 else 8))
-        skip_bars = 4 if (stamp_bars == 0 or stamp_bars > 8) else 0     # the bars in which the 4-pair history (and with it the context) is still growing
+        skip_bars = 4 if (stamp_bars == 0 or stamp_bars >= 8) else 0    # the bars in which the 4-pair history (and with it the context) is still growing
         for d in decs:
             d.stamp(True, skip_steps=skip_bars * (args.bar_tokens - 1))
             d.stats_reset()
