@@ -246,8 +246,15 @@ template <int KS> __device__ __forceinline__ void pm_hidden_frag1(const f32x16& 
   asm volatile("s_nop 4" : "+v"(hfk) : : "memory");      // (VALU -> MFMA source wait states: the compiler does not know the asm below is an MFMA)
 }
 // one chunk k in 1 .. 63.  prev = up(k - 1)'s accumulator (registers 0 .. 3 already GELU'd), cur = up(k)'s (written here; its registers 0 .. 3 leave GELU'd)
-__device__ __forceinline__ void pm_chunk(bf16x8 (&buf)[2][4], unsigned sa, f32x16& prev, f32x16& cur, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], bf16x8 (&hf)[2],
-                                         unsigned bias_prev, unsigned bias_cur, const PmNext& nx) {
+// AOL (chunk 63 only): the attention rows that replace x2 in the fragment registers for attention.dense are requested HERE, four fragments behind each of the eight down groups --
+// x2's last use is group 7 -- instead of at the top of chunk 64, where the 32 fragment-shaped loads + their wait cost a wave ~8 k clocks with an idle MFMA pipe
+#define PM_LOADX(dst, ptr, S) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(ptr), "n"(32 * (S)) : "memory")      /* fragment S of the lane's row: one base register, immediate offsets */
+template <bool AOL>
+__device__ __forceinline__ void pm_chunk(bf16x8 (&buf)[2][4], unsigned sa, f32x16& prev, f32x16& cur, f32x16 (&acc2)[16], bf16x8 (&xf)[32], bf16x8 (&hf)[2],
+                                         unsigned bias_prev, unsigned bias_cur, const PmNext& nx, const bf16* ao, long long ao_off) {
+  const bf16* ap = nullptr;
+  if constexpr (AOL) { ap = ao + ao_off; asm volatile("" : "+v"(ap)); }      // (formed here, not held through the 62 chunks before)
+#define PM_AOL(G) do { if constexpr (AOL) { PM_LOADX(xf[4 * (G)], ap, 4 * (G)); PM_LOADX(xf[4 * (G) + 1], ap, 4 * (G) + 1); PM_LOADX(xf[4 * (G) + 2], ap, 4 * (G) + 2); PM_LOADX(xf[4 * (G) + 3], ap, 4 * (G) + 3); } } while (0)
   pm_rd4<PmMlpGroup<0>::f0>(buf[0], sa);
   pm_group<0, 4, 0, 2>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
   pm_group<1, 5, 2, 2>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
@@ -259,14 +266,23 @@ __device__ __forceinline__ void pm_chunk(bf16x8 (&buf)[2][4], unsigned sa, f32x1
   pm_group<7, 11, 11, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
   pm_hidden_frag1<0>(prev, hf[0]);
   pm_group<8, 12, 12, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  PM_AOL(0);
   pm_group<9, 13, 13, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  PM_AOL(1);
   pm_group<10, 14, 14, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  PM_AOL(2);
   pm_group<11, 15, 15, 1>(buf, sa, cur, acc2, xf, hf[0], prev, bias_prev, nx);
+  PM_AOL(3);
   pm_hidden_frag1<1>(prev, hf[1]);
   pm_group<12, 0, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+  PM_AOL(4);
   pm_group<13, 1, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+  PM_AOL(5);
   pm_group<14, 2, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+  PM_AOL(6);
   pm_group<15, 3, 0, 0>(buf, sa, cur, acc2, xf, hf[1], cur, bias_cur, nx);
+  PM_AOL(7);
+#undef PM_AOL
 }
 
 // Diagnostic build (-DETD_PMLP_STAMP, tools/bench_prefill.py --stamps): s_memtime at the phase boundaries of chunks 1 .. 63, summed per wave in SGPRs
@@ -309,7 +325,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   auto next_of = [&](int k) {
     return PmNext{a.Wm + (long long)(k + 1) * PM_SLOT_ELEMS + wave * (16 * 512) + lane * 8, ring + ((k + 1) & 1) * PM_SLOT_ELEMS + wave * (16 * 512), k + 1 < DMLP_NCHUNK};
   };
-#define PM_LOADX(dst, ptr) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(dst) : "v"(ptr) : "memory")
 
   issue(0);
   // the token tile as B fragments: lane (token r, half h) holds x2[token][16 s + 8 h .. + 8], s = 0 .. 31 -- loaded straight into
@@ -317,8 +332,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   bf16x8 xf[32];
   {
     const bf16* xp = a.X2 + (long long)mc * 512 + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 32; ++s) PM_LOADX(xf[s], xp + 16 * s);
+#define PM_X4(S) PM_LOADX(xf[S], xp, S); PM_LOADX(xf[(S) + 1], xp, (S) + 1); PM_LOADX(xf[(S) + 2], xp, (S) + 2); PM_LOADX(xf[(S) + 3], xp, (S) + 3)
+    PM_X4(0); PM_X4(4); PM_X4(8); PM_X4(12); PM_X4(16); PM_X4(20); PM_X4(24); PM_X4(28);
+#undef PM_X4
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
 #ifdef ETD_PMLP_STAMP
@@ -360,16 +376,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #define PM_TOP_S(k) PM_TOP(k)
 #endif
   // chunks 1 .. 63: [down(k - 1) | up(k)], 16 uniform groups each (pm_chunk); the two up accumulators alternate
-#define PM_CHUNK(k, prev, cur)                                                                                                                  \
+#define PM_CHUNK(k, prev, cur, AOLV)                                                                                                                \
   do {                                                                                                                                          \
     PM_TOP_S(k);                                                                                                                                \
-    pm_chunk(buf, ring_lds + ((k) & 1) * (PM_SLOT_ELEMS * 2), prev, cur, acc2, xf, hf, sbu_lds + ((k) - 1) * 128, sbu_lds + (k) * 128, next_of(k)); \
+    pm_chunk<(AOLV)>(buf, ring_lds + ((k) & 1) * (PM_SLOT_ELEMS * 2), prev, cur, acc2, xf, hf, sbu_lds + ((k) - 1) * 128, sbu_lds + (k) * 128, next_of(k), a.AO, (long long)mc * a.ldao + 8 * h); \
   } while (0)
   for (int k = 1; k < 63; k += 2) {
-    PM_CHUNK(k, accA, accB);
-    PM_CHUNK(k + 1, accB, accA);
+    PM_CHUNK(k, accA, accB, false);
+    PM_CHUNK(k + 1, accB, accA, false);
   }
-  PM_CHUNK(63, accA, accB);
+  PM_CHUNK(63, accA, accB, true);
 #ifdef ETD_PMLP_STAMP
   PMS(0);
   const unsigned long long ps_t2 = ps_t;          // chunk 63 done
@@ -380,12 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const unsigned sa = ring_lds;
     pm_gelu2<2>(accB, sbu, 63, h); pm_gelu2<3>(accB, sbu, 63, h);
     pm_gelu2<4>(accB, sbu, 63, h); pm_gelu2<5>(accB, sbu, 63, h); pm_gelu2<6>(accB, sbu, 63, h); pm_gelu2<7>(accB, sbu, 63, h);
-    {
-      const bf16* ap = a.AO + (long long)mc * a.ldao + 8 * h;
-#pragma unroll
-      for (int s = 0; s < 32; ++s) PM_LOADX(xf[s], ap + 16 * s);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    // (the attention rows were requested behind the down groups of chunk 63; PM_TOP(64)'s vmcnt(0) has waited for them)
     pm_hidden_frags(accB, hf);
     pm_down_only(buf, sa, acc2, hf, next_of(64), seq8{});
   }
