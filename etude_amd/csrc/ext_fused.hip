@@ -587,16 +587,17 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
 
   const float qscale = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) and the base-2 exponent, folded into Q
   bf16x8 ofr[16];                                         // the four heads' normalised outputs as B fragments (k-step 4 head + ks)
+  // ---- the wave's 32 tokens as B / A fragments, loaded ONCE and held through the four heads and the residual (rounds 2-3 re-read them per head -- 80 fragment-shaped
+  // loads per wave, 32 rows x 32 bytes per instruction -- to save 64 registers during the attention; since the LDS accesses stopped costing ~100 address registers
+  // (ENC_RD8 / ENC_WR8) there is room)
+  bf16x8 xf[16];
+  {
+    const bf16* xp = a.X + row * 256 + 8 * h;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+  }
 #pragma unroll
   for (int hd = 0; hd < 4; ++hd) {
-    // ---- the wave's 32 tokens as B / A fragments (re-read per head: 16 KiB from L2 instead of 64 registers held through the attention)
-    bf16x8 xf[16];
-    {
-      const bf16* xp = a.X + row * 256 + 8 * h;
-      asm volatile("" : "+v"(xp));                        // (keeps the loads inside this head's iteration)
-#pragma unroll
-      for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
-    }
     bf16x8 qf[4];
     // ---- Q (part 0), K (part 1): token on the lane; V (part 2): feature on the lane.  A part = two half-chunks (k-steps 0..7, 8..15)
 #pragma unroll
@@ -734,12 +735,6 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       // fragment 4 gq + k of this half = k-step 2 hf2 + (gq >> 1) of the head, tile 4 (gq & 1) + k
       ENC_HALF2(sl, acc2[4 * (gq & 1) + k] = mfma32(fa, ofr[4 * hd + 2 * hf2 + (gq >> 1)], acc2[4 * (gq & 1) + k]);)
     }
-  bf16x8 xf[16];
-  {
-    const bf16* xp = a.X + row * 256 + 8 * h;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);       // residual
-  }
   // LayerNorm of (acc2 + bias + resid) -> xf (bf16 fragments); statistics in fp32.
   // (The parameter vectors sit at the BOTTOM of this kernel's LDS: a ds_read reaches 64 KiB from its base register with its offset field.  In rounds 2-3 they sat
   // above the ring and the K / V images, at 0x24000: hipcc then materialised all 96 read addresses (0x25000 | lane part ...) in registers, kept them for the second
