@@ -25,11 +25,14 @@ generate()'s.  value = audio seconds taken through the WHOLE chain per wall seco
                 decode stage with all engines running (etd_decoder_stamp), algorithmic bytes from the library's exact counters;
                 decode_stage = all decode-step bytes of the timed steps / the decode stage's wall time
   cpu_baseline  the CPU oracle on this node's host cores, bounded sample (rank 0, N = 1 only)
-  extras        configs[2] (extractor only), configs[1] (one clip), configs[3] (128 streams at ctx 512 and 3.5 k), outside the timed region
-Harness budget: the driver runs `--steps 20 --warmup 5` under a wall-clock limit.  The first warm-up step is always a full step; if W + K
-full steps do not fit ETD_BENCH_BUDGET_S (default 560 s, counted from process start) the remaining warm-up steps run 4 bars per job (same launches, same widths:
-everything is allocated, captured and cached by then), and if K full steps alone do not fit, the batch shrinks to 8 clips per rank --
-both are written into config.workload / config.warmup_step.  The K timed steps are always full steps of the stated batch.
+  extras        configs[2] (extractor only), configs[1] (one clip), configs[3] (128 streams at ctx 512 and 3.5 k), parity_mode (the chain with fp32 extractor + fp32
+                decoder on 8 of the clips: what exact parity costs), outside the timed region
+Harness budget: the driver runs `--steps 20 --warmup 5` under a 600 s wall-clock limit; bench.py plans against ETD_BENCH_BUDGET_S (default 560 s, counted from process
+start).  The first warm-up step is always a full step (and the estimate).  The other warm-up steps are full steps only if that leaves room for everything that follows the
+timed steps (~90 s: 24 stamped bars, serial event pass, extras incl. the exact-parity pass, CPU baseline); otherwise they run 4 bars per job (same launches, same widths:
+everything is allocated, captured and cached by then).  Behind the timed steps the optional parts are shed in this order when the run is late: extras.parity_mode (bars, then
+clips), the extras, the serial pass, the stamped stage 24 -> 8 bars; the CPU baseline goes last.  Only if K full steps + that minimum cannot fit does the batch per step shrink
+(32 / 16 / 8 clips per rank) -- all of it written into config.workload / config.warmup_step.  The K timed steps are always full steps of the stated batch.
 """
 from __future__ import annotations
 
@@ -508,10 +511,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # digest of the WHOLE batch in global clip order (clip c = its 27 jobs in tuple order): parallel.unshard of the per-rank clip lists.  A job's ids do not
     # depend on which jobs share its launches (the batch-invariance the GPU suite asserts), so an N-rank run must print the value the 1-rank run prints.
-    na = len(grid)
-    per_rank_clips = [[np.concatenate(lst[c * na:(c + 1) * na]) if na else np.zeros(0, np.int32) for c in range(len(lst) // max(1, na))] for lst in per_rank_ids]
-    all_clips = parallel.unshard(per_rank_clips, sum(len(x) for x in per_rank_clips))
-    tok_digest_all = hashlib.sha256(np.concatenate(all_clips).astype(np.int32).tobytes()).hexdigest()[:16]
+    tok_digest_all = parallel.digest_in_global_clip_order(per_rank_ids, len(grid))
     timed_stats = [d.stats() for d in decs]
 
     tmax = torch.tensor([elapsed, t_ext, t_dec, t_notes], dtype=torch.float64, device=dev)

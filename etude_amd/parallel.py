@@ -31,6 +31,20 @@ def unshard(per_rank: Sequence[Sequence], n_items: int) -> List:
     return out
 
 
+def digest_in_global_clip_order(per_rank_jobs: Sequence[Sequence[np.ndarray]], jobs_per_clip: int) -> str:
+    """sha256 (first 16 hex digits) over every job's int32 ids with the CLIPS in global order: rank r holds the jobs of clips r, r + R, ... (``shard``), ``jobs_per_clip``
+    consecutive jobs per clip.  The value does not depend on R -- what bench.py prints as ``tokens_sha256_all`` (a job's ids do not depend on what shares its launches)."""
+    import hashlib
+    per_rank_clips = []
+    for lst in per_rank_jobs:
+        assert len(lst) % max(1, jobs_per_clip) == 0, "every rank holds whole clips"
+        per_rank_clips.append([np.concatenate([np.asarray(x, np.int32).reshape(-1) for x in lst[c * jobs_per_clip:(c + 1) * jobs_per_clip]]) if jobs_per_clip else np.zeros(0, np.int32)
+                               for c in range(len(lst) // max(1, jobs_per_clip))])
+    clips = unshard(per_rank_clips, sum(len(x) for x in per_rank_clips))
+    flat = np.concatenate(clips).astype(np.int32) if clips else np.zeros(0, np.int32)
+    return hashlib.sha256(flat.tobytes()).hexdigest()[:16]
+
+
 def _pack(arrays: Sequence[np.ndarray]) -> np.ndarray:
     arrs = [np.ascontiguousarray(a, np.int32).reshape(-1) for a in arrays]
     head = np.asarray([len(arrs)] + [a.size for a in arrs], np.int32)

@@ -69,3 +69,23 @@ def test_shard_unshard_roundtrip_and_single_process_gather():
     assert len(out) == 1 and np.array_equal(out[0][0], np.arange(5)) and out[0][1].size == 0
     notes = [{"pitch": 60, "onset": 0.1234567890123, "offset": 1.5, "velocity": 99}]
     assert parallel.array_to_notes(parallel.notes_to_array(notes)) == notes
+
+
+def test_global_clip_order_digest_is_the_same_at_every_world_size():
+    """bench.py's `tokens_sha256_all`: every job's ids with the clips in global order (rank r holds clips r, r + R, ...).  The digest of a 64-clip x 3-tuple batch
+    is the same whether 1, 2, 4 or 8 ranks held it -- what lets an N-rank run be compared with the 1-rank run."""
+    rng = np.random.default_rng(3)
+    n_clips, na = 64, 3
+    jobs = [[rng.integers(0, 154, int(rng.integers(5, 40))).astype(np.int32) for _ in range(na)] for _ in range(n_clips)]      # clip-major, tuple-minor
+    want = None
+    for world in (1, 2, 4, 8):
+        per_rank = []
+        for r in range(world):
+            mine = parallel.shard(list(range(n_clips)), r, world)
+            per_rank.append([jobs[c][t] for c in mine for t in range(na)])
+        d = parallel.digest_in_global_clip_order(per_rank, na)
+        want = want or d
+        assert d == want, world
+    # and it is the plain digest of the batch in clip order
+    import hashlib
+    assert want == hashlib.sha256(np.concatenate([jobs[c][t] for c in range(n_clips) for t in range(na)]).astype(np.int32).tobytes()).hexdigest()[:16]
