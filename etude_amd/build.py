@@ -14,7 +14,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 OBJ = HERE / "csrc" / "_obj"
 LIB = Path(os.environ["ETD_LIB_OUT"]).resolve() if os.environ.get("ETD_LIB_OUT") else HERE / "libetude_hip.so"      # (ETD_LIB_OUT: measurement builds side by side; load them with ETD_LIB_PATH)
-SOURCES = ["ext_kernels.hip", "ext_fused.hip", "ext_fp32.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "dec_fused.hip", "dec_prefill.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp", "midi.cpp"]
+SOURCES = ["ext_kernels.hip", "ext_fused.hip", "ext_fp32.hip", "api_ext.hip", "frontend.hip", "dec_kernels.hip", "dec_fused.hip", "dec_prefill.hip", "gemm3.hip", "api_dec.hip", "mpe2note.cpp", "mpe2note_dev.hip", "prof.hip", "sched_dec.cpp", "tokenizer.cpp", "midi.cpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-Wno-unused-result",
          "-I", str(HERE.parent / "include")]
 # gfx950 can hand the first kernel arguments to a wave in SGPRs at launch (kernarg preload): kernels whose hot arguments are

@@ -15,6 +15,7 @@
 
 #include "../../include/etude_hip_debug.h"
 #include "dec_kernels.h"
+#include "gemm3.h"
 #include "ext_kernels.h"
 #include "prof.h"
 
@@ -27,11 +28,14 @@ inline uint16_t f2bf_h(float f) {
 }
 
 struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0;
-             void* Wf = nullptr; };   // bf16 weights: a second copy in MFMA-fragment order for k_linear (the batched prefill); W stays row-major for the step kernels
+             void* Wf = nullptr;      // bf16 weights: a second copy in MFMA-fragment order for k_linear (the batched prefill); W stays row-major for the step kernels
+             void* Wp = nullptr; int w_log2 = 0; };   // fp32 weights: again as hi / lo f16 planes for k_gemm3 (csrc/gemm3.h; W stays fp32 for the weight-streaming kernels below 513 rows)
 struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
                void* dense_hw = nullptr;   // bf16 [heads][H][64]: attention.dense regrouped per head for k_dstep_attn_down
                Lin cat;      // decode step: [dense_4h_to_h | attention.dense] along K, so mlp + attn come out of ONE GEMM
-               void* mlp_frag = nullptr; };   // batched prefill: up | (down | dense) as k_dmlp_fused's weight stream (H 512, I 2048)
+               void* mlp_frag = nullptr;   // batched prefill: up | (down | dense) as k_dmlp_fused's weight stream (H 512, I 2048)
+               // fp32 mode on the f16 matrix cores: log2 of the plane scales of every GEMM / attention operand, from provable bounds (etd_decoder_create)
+               int x1_log2 = 0, x2_log2 = 0, q_log2 = 0, k_log2 = 0, v_log2 = 0, m_log2 = 0; };
 
 }  // namespace
 
@@ -45,7 +49,9 @@ struct etd_dec {
   float *word = nullptr, *cls_emb = nullptr, *attr_tab = nullptr;
   std::vector<Layer> layers;
   float *lnfg = nullptr, *lnfb = nullptr;
-  Lin head;
+  Lin head; int xf_log2 = 0;                     // (fp32 mode: plane scale of final_layer_norm's output)
+  float *X1f = nullptr, *X2f = nullptr;          // fp32 mode, >= G3_MIN_ROWS rows: the two LayerNorm branches as fp32 rows
+  float *t_q = nullptr, *t_ao = nullptr, *t_do = nullptr, *t_m1 = nullptr;   // fp32 mode: the last layer's tail on the prompts' last rows only ([S][H], [S][I])
   void* head_frag = nullptr;                     // lm_head in MFMA-fragment order for k_dstep_head: [tile][k-step][lane][8] (bf16 weights, H == 512)
   float *rope_cos = nullptr, *rope_sin = nullptr;
   void *Kc = nullptr, *Vc = nullptr;             // [layer][slot][head][ctx][64]
@@ -148,6 +154,13 @@ int load_lin(etd_dec* d, Loader& L, const std::string& pfx, int N, int K, bool h
     float* p; ETD_TRY(d->alloc(&p, hf.size()));
     HIP_TRY(hipMemcpy(p, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
     w->W = p;
+    if (K % 32 == 0) {
+      std::vector<uint16_t> planes(g3_packed_elems(Npad, K));
+      w->w_log2 = g3_pack_weights_host(W, N, Npad, K, planes.data());
+      uint16_t* pp; ETD_TRY(d->alloc(&pp, planes.size()));
+      HIP_TRY(hipMemcpy(pp, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
+      w->Wp = pp;
+    }
   }
   std::vector<float> hb2(Npad, 0.f);
   if (b) memcpy(hb2.data(), b, (size_t)N * 4);
@@ -211,9 +224,75 @@ static int trace_rows(etd_dec* d, const void* buf, long long row_stride, int wor
 static inline bool fused_pmlp_on() { const char* e = getenv("ETD_FUSED_PMLP"); return !e || atoi(e) > 0; }
 struct LastOnly { int n; const int* idx; DecRows rows; };
 
+static DGemmArgs g3_args(const float* X, int ldx, const Lin& w, int x_log2, int M) {
+  DGemmArgs a = {};
+  a.X = X; a.ldx = ldx; a.W = w.W; a.Wp = w.Wp; a.w_log2 = w.w_log2; a.x_log2 = x_log2; a.bias = w.b; a.M = M; a.N = w.N; a.Npad = w.Npad; a.K = w.K;
+  return a;
+}
+
+// ---- fp32 mode, >= G3_MIN_ROWS rows: the layer as LayerNorm rows -> QKV (+RoPE, KV append) -> attention -> dense -> up + GELU -> down + residual with every
+// contraction on the f16 matrix cores at fp32 grade (csrc/gemm3.h).  Prefill: ragged causal attention over the prompts straight from the fp32 cache rows the QKV
+// epilogue has just written, and the last layer's tail only for each prompt's last position; decode step: k_dattn<float> per (row, head).
+int forward_body_x3(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf, const LastOnly* lo, bool* compact) {
+  float* hin = d->h; float* hout = d->h2;
+  const int H = d->H;
+  for (int l = 0; l < d->L; ++l) {
+    const Layer& w = d->layers[l];
+    void* Kl = (char*)d->Kc + (size_t)l * d->layer_stride * 4;
+    void* Vl = (char*)d->Vc + (size_t)l * d->layer_stride * 4;
+    ETD_TRY(launch_ln_rows_f32(hin, M, H, w.ln1g, w.ln1b, w.ln2g, w.ln2b, d->cfg.layer_norm_eps, d->X1f, d->X2f, st));
+    DGemmArgs q = g3_args(d->X1f, H, w.qkv, w.x1_log2, M);
+    q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
+    q.Kc = Kl; q.Vc = Vl; q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
+    ETD_TRY(launch_gemm3(q, DEPI_QKV, st));
+    if (l == d->L - 1 && lo && pf && lo->n >= 1 && lo->n < G3_MIN_ROWS && lo->n <= d->S) {
+      // last layer: every position's K / V is in the cache now; attention, MLP and residual are needed for the prompts' last rows only
+      const int n = lo->n;
+      ETD_TRY(launch_gather_rows(hin, lo->idx, n, H, d->hlast, st));
+      ETD_TRY(launch_gather_rows(d->Q, lo->idx, n, H, d->t_q, st));
+      DAttnArgs at = {};
+      at.Q = d->t_q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
+      at.rows = lo->rows; at.M = n; at.O = d->t_ao; at.scale = 0.125f; at.bytes_hint = 0;
+      ETD_TRY(launch_dattn(at, false, st));
+      DGemmArgs de = g3_args(d->t_ao, H, w.dense, 0, n); de.Y = d->t_do; de.ldy = H;
+      ETD_TRY(launch_dgemm(de, DEPI_BIAS, false, st));
+      DGemmArgs up = g3_args(d->hlast, H, w.up, 0, n); up.Y = d->t_m1; up.ldy = d->I; up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps;
+      ETD_TRY(launch_dgemm(up, DEPI_GELU, false, st));
+      DGemmArgs dn = g3_args(d->t_m1, d->I, w.down, 0, n); dn.add = d->t_do; dn.hin = d->hlast; dn.hout = hout;
+      ETD_TRY(launch_dgemm(dn, DEPI_RESID, false, st));
+      *hfinal = hout;                          // rows 0 .. n-1 = the prompts' last positions, in prompt order
+      if (compact) *compact = true;
+      return ETD_OK;
+    }
+    if (pf) {
+      Attn3Args t = {};
+      t.Q = d->Q; t.ldq = H; t.K = (const float*)Kl; t.V = (const float*)Vl; t.O = d->AO; t.ldo = H; t.n_seq = pf->n; t.n_heads = d->nh;
+      t.seq_row0 = pf->seq_row0; t.seq_len = pf->seq_len; t.row_slot = rows.slot; t.slot_stride = d->slot_stride; t.max_ctx = d->ctx; t.max_len = pf->max_len;
+      t.scale = 0.125f; t.q_log2 = w.q_log2; t.k_log2 = w.k_log2; t.v_log2 = w.v_log2; t.flops_hint = pf->attn_flops;
+      ETD_TRY(launch_attn3(t, st));
+    } else {
+      DAttnArgs at = {};
+      at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
+      at.rows = rows; at.M = M; at.O = d->AO; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
+      if (rows.slot == d->row_slot) { at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0; }
+      ETD_TRY(launch_dattn(at, false, st));
+    }
+    DGemmArgs de = g3_args(d->AO, H, w.dense, w.v_log2, M); de.Y = d->DO; de.ldy = H;      // (attention output: a convex combination of V rows)
+    ETD_TRY(launch_gemm3(de, DEPI_BIAS, st));
+    DGemmArgs up = g3_args(d->X2f, H, w.up, w.x2_log2, M); up.Y = d->M1; up.ldy = d->I;
+    ETD_TRY(launch_gemm3(up, DEPI_GELU, st));
+    DGemmArgs dn = g3_args(d->M1, d->I, w.down, w.m_log2, M); dn.add = d->DO; dn.hin = hin; dn.hout = hout;
+    ETD_TRY(launch_gemm3(dn, DEPI_RESID, st));
+    float* t = hin; hin = hout; hout = t;
+  }
+  *hfinal = hin;
+  return ETD_OK;
+}
+
 int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false,
                  const LastOnly* lo = nullptr, bool* compact = nullptr, bool is_step = false) {
   if (compact) *compact = false;
+  if (!d->bf16w && M >= G3_MIN_ROWS && d->X1f && d->layers[0].qkv.Wp && d->layers[0].down.Wp && !getenv("ETD_NO_GEMM3")) return forward_body_x3(d, M, rows, hfinal, st, pf, lo, compact);
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && (M > 1 || is_step);     // (is_step with M == 1: the fused step kernels for a single stream, ETD_FUSED_M1)
@@ -426,6 +505,12 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
 
 // final LayerNorm + lm_head for `n` rows of X (fp32 [n][H]) -> logits [n][V]
 int head_logits(etd_dec* d, const float* X, int n, float* logits, hipStream_t st) {
+  if (!d->bf16w && n >= G3_MIN_ROWS && d->X1f && d->head.Wp && !getenv("ETD_NO_GEMM3")) {
+    ETD_TRY(launch_ln_rows_f32(X, n, d->H, d->lnfg, d->lnfb, nullptr, nullptr, d->cfg.layer_norm_eps, d->X1f, nullptr, st));
+    DGemmArgs lm = g3_args(d->X1f, d->H, d->head, d->xf_log2, n);
+    lm.bias = nullptr; lm.Y = logits; lm.ldy = d->V;
+    return launch_gemm3(lm, DEPI_LOGITS, st);
+  }
   DGemmArgs lm = {};
   lm.X = X; lm.ldx = d->H; lm.W = d->head.W; lm.bias = nullptr; lm.M = n; lm.N = d->V; lm.Npad = d->head.Npad; lm.K = d->H;
   lm.ln_g = d->lnfg; lm.ln_b = d->lnfb; lm.ln_eps = d->cfg.layer_norm_eps; lm.Y = logits; lm.ldy = d->V;
@@ -533,7 +618,7 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   e.rows = DecRows{sg->row_slot, sg->row_pos, sg->row_active, sg->row_seq};
   ETD_TRY(launch_dembed(e, st));
   PrefillInfo pf{n, sg->seq_row0, sg->seq_len, max_len, aflops};
-  const bool can_mfma_attn = d->Qb != nullptr && !getenv("ETD_NO_MFMA_PREFILL_ATTN");
+  const bool can_mfma_attn = (d->bf16w ? d->Qb != nullptr : d->X1f != nullptr) && !getenv("ETD_NO_MFMA_PREFILL_ATTN");
   LastOnly lo{n, sg->last_idx, DecRows{sg->last_slot, sg->last_pos, sg->last_active}};
   ETD_TRY(forward_body(d, M, e.rows, hfinal, st, can_mfma_attn ? &pf : nullptr, false, last_only ? &lo : nullptr, last_only));
   return ETD_OK;
@@ -562,6 +647,11 @@ int alloc_workspaces(etd_dec* d) {
     rc = rc ? rc : d->alloc(&d->row_cnt, (size_t)d->L * DS_STEP_MAX_ROWS, true);
     rc = rc ? rc : d->alloc(&d->Xcat, M * (d->I + H));
     rc = rc ? rc : d->alloc(&d->Qb, M * H);      // RoPE'd queries of a batched prefill (K / V: the cache rows)
+  }
+  if (!d->bf16w) {
+    rc = rc ? rc : d->alloc(&d->X1f, M * H); rc = rc ? rc : d->alloc(&d->X2f, M * H);
+    const size_t Sr = d->S > 1 ? d->S : 1;
+    rc = rc ? rc : d->alloc(&d->t_q, Sr * H); rc = rc ? rc : d->alloc(&d->t_ao, Sr * H); rc = rc ? rc : d->alloc(&d->t_do, Sr * H); rc = rc ? rc : d->alloc(&d->t_m1, Sr * d->I);
   }
   rc = rc ? rc : d->alloc(&d->samp_dev, (size_t)1, true); rc = rc ? rc : d->alloc(&d->rng_key, (size_t)d->S, true);
   rc = rc ? rc : d->alloc(&d->row_sp, (size_t)2 * d->Mmax, true);
@@ -646,6 +736,23 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
     if ((rc = load_lin(d, Ld, p + "attention.dense", H, H, true, &w.dense))) return fail(rc);
     if ((rc = load_lin(d, Ld, p + "mlp.dense_h_to_4h", d->I, H, true, &w.up))) return fail(rc);
     if ((rc = load_lin(d, Ld, p + "mlp.dense_4h_to_h", H, d->I, true, &w.down))) return fail(rc);
+    if (!d->bf16w) {
+      // plane scales of the fp32-grade f16 path from provable bounds (csrc/gemm3.h): LayerNorm outputs by their parameters, projections of them by Cauchy-Schwarz on the
+      // weight rows; the rotary embedding mixes two dims of a row (|x1 c - x2 s| <= |x1| + |x2|); the attention output is a convex combination of V rows; |gelu(u)| <= |u|
+      const float* g1 = Ld.get(p + "input_layernorm.weight", H); const float* b1 = Ld.get(p + "input_layernorm.bias", H);
+      const float* g2 = Ld.get(p + "post_attention_layernorm.weight", H); const float* b2 = Ld.get(p + "post_attention_layernorm.bias", H);
+      const float* Wq = Ld.get(p + "attention.query_key_value.weight", (int64_t)3 * H * H); const float* bq = Ld.get(p + "attention.query_key_value.bias", 3 * H);
+      const float* Wu = Ld.get(p + "mlp.dense_h_to_4h.weight", (int64_t)d->I * H); const float* bu = Ld.get(p + "mlp.dense_h_to_4h.bias", d->I);
+      if (!g1 || !b1 || !g2 || !b2 || !Wq || !bq || !Wu || !bu) return fail(ETD_EINVAL);
+      w.x1_log2 = g3_scale_log2(g3_bound_ln(g1, b1, H));
+      w.x2_log2 = g3_scale_log2(g3_bound_ln(g2, b2, H));
+      std::vector<float> rb((size_t)3 * H);
+      g3_row_bounds_of_ln(Wq, bq, 3 * H, H, g1, b1, rb.data());
+      float bnd[3] = {0.f, 0.f, 0.f};
+      for (int j = 0; j < 3 * H; ++j) { const int part = (j % 192) >> 6; bnd[part] = fmaxf(bnd[part], rb[j]); }
+      w.q_log2 = g3_scale_log2(2.f * bnd[0]); w.k_log2 = g3_scale_log2(2.f * bnd[1]); w.v_log2 = g3_scale_log2(bnd[2]);
+      w.m_log2 = g3_scale_log2(g3_bound_linear_of_ln(Wu, bu, d->I, H, g2, b2));
+    }
     if (d->bf16w) {
       // h_new - h = W2 gelu(..) + b2 + Wd attn + bd  ==  [W2 | Wd] [gelu(..) ; attn] + (b2 + bd)
       const float* W2 = Ld.get(p + "mlp.dense_4h_to_h.weight", (int64_t)H * d->I);
@@ -695,6 +802,11 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
   if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.weight", H, &d->lnfg))) return fail(rc);
   if ((rc = load_vec(d, Ld, "transformer.final_layer_norm.bias", H, &d->lnfb))) return fail(rc);
   if ((rc = load_lin(d, Ld, "lm_head", d->V, H, false, &d->head))) return fail(rc);
+  if (!d->bf16w) {
+    const float* gf = Ld.get("transformer.final_layer_norm.weight", H); const float* bf_ = Ld.get("transformer.final_layer_norm.bias", H);
+    if (!gf || !bf_) return fail(ETD_EINVAL);
+    d->xf_log2 = g3_scale_log2(g3_bound_ln(gf, bf_, H));
+  }
   if (d->bf16w && H % 16 == 0) {
     // the same bf16 values in the order one wave's A-operand loads want them: (tile t, k-step s, lane l) holds row
     // 32 t + (l & 31), columns 16 s + 8 (l >> 5) .. +8 -- each load instruction then reads one contiguous 1 KiB block
@@ -754,7 +866,7 @@ extern "C" int etd_decoder_clone(etd_dec* src, etd_dec** out) {
   d->H = own->H; d->I = own->I; d->V = own->V; d->L = own->L; d->nh = own->nh; d->S = own->S; d->ctx = own->ctx;
   d->Mmax = own->Mmax; d->Mcap = own->Mcap; d->out_cap = own->out_cap;
   d->word = own->word; d->cls_emb = own->cls_emb; d->attr_tab = own->attr_tab; d->layers = own->layers;
-  d->lnfg = own->lnfg; d->lnfb = own->lnfb; d->head = own->head; d->head_frag = own->head_frag;
+  d->lnfg = own->lnfg; d->lnfb = own->lnfb; d->head = own->head; d->head_frag = own->head_frag; d->xf_log2 = own->xf_log2;
   d->rope_cos = own->rope_cos; d->rope_sin = own->rope_sin;
   d->host_len.assign(d->S, 0);
   d->host_key.resize(d->S);

@@ -49,6 +49,9 @@ struct DGemmArgs {
   int max_ctx, n_heads;
   // batched prefill on the MFMA flash-attention kernel (null outside the bf16 big-M path):
   bf16* Qb;                      // [M][hidden] bf16 row-major RoPE'd Q (K / V are read from the cache rows: k_pattn)
+  // exact-parity mode on the f16 matrix cores (csrc/gemm3.h): the fp32 weights again as hi / lo f16 planes in k_gemm3's streaming order
+  const void* Wp; int w_log2;    // planes and log2 of the power-of-two scale they carry
+  int x_log2;                    // log2 of the scale X is split at (|X| 2^x_log2 < 2^15 by a provable bound)
 };
 int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st);
 // decode step, bf16: fused-QKV(+RoPE, KV append) and MLP-up(+GELU) projections of one layer in a single launch

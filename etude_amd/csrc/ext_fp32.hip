@@ -1,19 +1,24 @@
 // fp32 parity mode of the Extract stage -- see ext_fp32.h.  Reference ops: etude/models/amt_apc.py (cited per kernel).
-// Everything is the plain, unfused arithmetic of the reference in fp32: GEMMs on the exact-fp32 MFMA tile of the Decode
-// stage's parity mode (k_dgemm: v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain), attention / LayerNorm / heads as
-// straightforward fmaf kernels.  Activations are fp32 row-major [token][256] throughout.
+// The plain, unfused op sequence of the reference with fp32 activations (row-major [token][256]) and fp32-grade products: every linear and both attention
+// products run on the f16 matrix cores as two-plane splits of their fp32 operands, three MFMAs per product tile (csrc/gemm3.h: the error of an fp32 fmaf
+// chain at 5 x its rate); LayerNorm, softmax, sigmoid and the head argmax are fp32 VALU code.  Every operand's plane scale comes from a provable bound
+// computed here at load time (LayerNorm parameters and weight-row norms), so no f16 plane can overflow.
 #include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "ext_fp32.h"
-#include "dec_kernels.h"
+#include "gemm3.h"
 
 namespace {
 
-struct Lin32 { float* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0; };
-struct Enc32 { Lin32 qkv, o, f1, f2; float *g = nullptr, *be = nullptr; };
-struct Dec32 { Lin32 qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; };
+struct Lin32 { uint16_t* Wp = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0, w_log2 = 0, x_log2 = 0; };   // weights as hi / lo f16 planes (g3_pack_weights_host)
+struct Enc32 { Lin32 qkv, o, f1, f2; float *g = nullptr, *be = nullptr; int q_log2 = 0, k_log2 = 0, v_log2 = 0; };
+struct Dec32 { Lin32 qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false;
+               int qs_log2 = 0, ks_log2 = 0, vs_log2 = 0, qc_log2 = 0, kc_log2 = 0, vc_log2 = 0; };
+// what is known about a GEMM input at load time: the output of a LayerNorm with (g, b) over n features, or anything bounded elementwise by `elem`
+struct InB { const float* g = nullptr; const float* b = nullptr; int n = 256; float elem = 0.f; };
+inline float in_bound(const InB& i) { return i.g ? g3_bound_ln(i.g, i.b, i.n) : i.elem; }
 
 }  // namespace
 
@@ -53,23 +58,30 @@ int up(Ext32* e, float** dst, const float* src, size_t n) {
   HIP_TRY(hipMemcpy(*dst, src, n * 4, hipMemcpyHostToDevice));
   return ETD_OK;
 }
-// several [out_i][K] linears stacked along the output dimension, rows padded with zeros to a multiple of 128
-int load_stack(Ext32* e, const WeightMap& w, const std::vector<std::string>& pfx, const std::vector<int>& outs, int K, Lin32* l) {
+// several [out_i][K] linears stacked along the output dimension, rows padded with zeros to a multiple of 128; `in` describes the input (plane scale of X and
+// the bounds of the outputs, one per stacked linear, which become the plane scales of whatever consumes them)
+int load_stack(Ext32* e, const WeightMap& w, const std::vector<std::string>& pfx, const std::vector<int>& outs, int K, const InB& in, Lin32* l, std::vector<float>* out_bounds = nullptr) {
   int N = 0;
   for (int o : outs) N += o;
   const int Npad = (N + 127) / 128 * 128;
-  std::vector<float> W((size_t)Npad * K, 0.f), b(Npad, 0.f);
+  std::vector<float> W((size_t)N * K, 0.f), b(Npad, 0.f);
   int r = 0;
+  if (out_bounds) out_bounds->clear();
   for (size_t i = 0; i < pfx.size(); ++i) {
     const float* Wi = wget(w, pfx[i] + ".weight", (int64_t)outs[i] * K);
     const float* bi = wget(w, pfx[i] + ".bias", outs[i]);
     if (!Wi || !bi) return ETD_EINVAL;
     memcpy(W.data() + (size_t)r * K, Wi, (size_t)outs[i] * K * 4);
     memcpy(b.data() + r, bi, (size_t)outs[i] * 4);
+    if (out_bounds) out_bounds->push_back(in.g ? g3_bound_linear_of_ln(Wi, bi, outs[i], K, in.g, in.b) : g3_bound_linear(Wi, bi, outs[i], K, in.elem));
     r += outs[i];
   }
   l->N = N; l->Npad = Npad; l->K = K;
-  ETD_TRY(up(e, &l->W, W.data(), W.size()));
+  std::vector<uint16_t> planes(g3_packed_elems(Npad, K));
+  l->w_log2 = g3_pack_weights_host(W.data(), N, Npad, K, planes.data());
+  l->x_log2 = g3_scale_log2(in_bound(in));
+  ETD_TRY(e->alloc(&l->Wp, planes.size()));
+  HIP_TRY(hipMemcpy(l->Wp, planes.data(), planes.size() * 2, hipMemcpyHostToDevice));
   ETD_TRY(up(e, &l->b, b.data(), b.size()));
   return ETD_OK;
 }
@@ -81,11 +93,19 @@ int load_ln(Ext32* e, const WeightMap& w, const std::string& p, float** g, float
   ETD_TRY(up(e, b, bw, 256));
   return ETD_OK;
 }
-int load_enc(Ext32* e, const WeightMap& w, const std::string& p, Enc32* l) {
-  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, &l->qkv));
-  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, &l->o));
-  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, &l->f1));
-  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, &l->f2));
+// one EncoderLayer (amt_apc.py:236-259); `in` = what is known about its input; *out = its output (the layer's own LayerNorm)
+int load_enc(Ext32* e, const WeightMap& w, const std::string& p, const InB& in, Enc32* l, InB* out) {
+  const float* gw = wget(w, p + ".layer_norm.weight", 256);
+  const float* bw = wget(w, p + ".layer_norm.bias", 256);
+  if (!gw || !bw) return ETD_EINVAL;
+  const InB ln{gw, bw, 256, 0.f};
+  std::vector<float> ob;
+  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, in, &l->qkv, &ob));
+  l->q_log2 = g3_scale_log2(ob[0]); l->k_log2 = g3_scale_log2(ob[1]); l->v_log2 = g3_scale_log2(ob[2]);
+  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, InB{nullptr, nullptr, 256, ob[2]}, &l->o));          // attention output: a convex combination of V rows
+  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, ln, &l->f1, &ob));
+  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, InB{nullptr, nullptr, 512, ob[0]}, &l->f2));    // ReLU does not grow anything
+  *out = ln;
   return load_ln(e, w, p + ".layer_norm", &l->g, &l->be);
 }
 
@@ -156,71 +176,6 @@ __global__ __launch_bounds__(256) void k32_add_ln(const float* __restrict__ A, c
   *reinterpret_cast<f32x4*>(Y + (long long)m * 256 + lane * 4) = o;
 }
 
-// softmax(Q K^T / sqrt(64)) V per (sequence, head), head_dim 64, 4 heads                              amt_apc.py:349-368
-// workgroup = 32 queries (4 waves x 8), key tiles of 64 through LDS, online softmax with expf (fp32 like torch.softmax)
-struct Attn32Args {
-  const float* Q; int ldq; long long q_seq;
-  const float* K; int ldk; long long k_seq;
-  const float* V; int ldv; long long v_seq;
-  float* O; int ldo; long long o_seq;
-  int Sq, Sk;
-};
-__global__ __launch_bounds__(256) void k32_attn(Attn32Args a) {
-  __shared__ float Ks[64][65], Vs[64][65], Qs[32][64], Ps[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int seq = blockIdx.y >> 2, head = blockIdx.y & 3, q0 = blockIdx.x * 32;
-  const float* Qb = a.Q + seq * a.q_seq + head * 64;
-  const float* Kb = a.K + seq * a.k_seq + head * 64;
-  const float* Vb = a.V + seq * a.v_seq + head * 64;
-  for (int c = tid; c < 32 * 64; c += 256) {
-    const int qi = c >> 6, d = c & 63;
-    int q = q0 + qi; q = q < a.Sq ? q : a.Sq - 1;
-    Qs[qi][d] = Qb[(long long)q * a.ldq + d];
-  }
-  float mrun[8], lrun[8], o[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) { mrun[i] = -INFINITY; lrun[i] = 0.f; o[i] = 0.f; }
-  for (int k0 = 0; k0 < a.Sk; k0 += 64) {
-    __syncthreads();
-    for (int c = tid; c < 64 * 64; c += 256) {
-      const int kj = c >> 6, d = c & 63;
-      int key = k0 + kj; key = key < a.Sk ? key : a.Sk - 1;
-      Ks[kj][d] = Kb[(long long)key * a.ldk + d];
-      Vs[kj][d] = Vb[(long long)key * a.ldv + d];
-    }
-    __syncthreads();
-    const bool kvalid = k0 + lane < a.Sk;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float* qrow = Qs[wave * 8 + i];
-      float s = 0.f;
-#pragma unroll 16
-      for (int d = 0; d < 64; ++d) s = fmaf(qrow[d], Ks[lane][d], s);
-      s = kvalid ? s * 0.125f : -INFINITY;
-      const float mx = wave_max(s);
-      const float mnew = fmaxf(mrun[i], mx);
-      const float alpha = expf(mrun[i] - mnew);              // first tile: exp(-inf) = 0
-      const float p = kvalid ? expf(s - mnew) : 0.f;
-      lrun[i] = lrun[i] * alpha + wave_sum(p);
-      mrun[i] = mnew;
-      Ps[wave][lane] = p;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      float acc = 0.f;
-#pragma unroll 16
-      for (int j = 0; j < 64; ++j) acc = fmaf(Ps[wave][j], Vs[j][lane], acc);
-      o[i] = o[i] * alpha + acc;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int q = q0 + wave * 8 + i;
-    if (q < a.Sq) a.O[seq * a.o_seq + (long long)q * a.ldo + head * 64 + lane] = o[i] / lrun[i];
-  }
-}
-
 // logits [M][ld] (0..127 velocity, 128 onset, 129 offset, 130 mpe) -> sigmoid (fp32) / argmax (lowest index on ties)
 //                                                                amt_apc.py:186-189,217-220 + extractor.py:242,248
 __global__ __launch_bounds__(256) void k32_heads_epi(const float* __restrict__ L, int ld, HeadsArgs a) {
@@ -272,20 +227,22 @@ __global__ void k32_freq2time(const float* __restrict__ src, float* __restrict__
 // ================================================================================================ launch helpers
 int gemm32(const float* X, int ldx, const Lin32& w, int M, float* Y, int ldy, hipStream_t st) {
   DGemmArgs a = {};
-  a.X = X; a.ldx = ldx; a.W = w.W; a.bias = w.b; a.M = M; a.N = w.N; a.Npad = w.Npad; a.K = w.K; a.Y = Y; a.ldy = ldy;
-  return launch_dgemm(a, DEPI_BIAS, false, st);
+  a.X = X; a.ldx = ldx; a.Wp = w.Wp; a.w_log2 = w.w_log2; a.x_log2 = w.x_log2; a.bias = w.b; a.M = M; a.N = w.N; a.Npad = w.Npad; a.K = w.K; a.Y = Y; a.ldy = ldy;
+  return launch_gemm3(a, DEPI_BIAS, st);
 }
 int add_ln(const float* A, const float* R, int r_mod, const float* g, const float* b, float* Y, int M, hipStream_t st) {
   hipLaunchKernelGGL(k32_add_ln, dim3((M + 3) / 4), dim3(256), 0, st, A, R, r_mod, g, b, Y, M);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
+// softmax(Q K^T / sqrt(64)) V per (sequence, head), head_dim 64, 4 heads                              amt_apc.py:349-368
 int attn32(const float* Q, int ldq, long long q_seq, const float* K, int ldk, long long k_seq, const float* V, int ldv, long long v_seq,
-           float* O, int ldo, long long o_seq, int n_seq, int Sq, int Sk, hipStream_t st) {
-  Attn32Args a{Q, ldq, q_seq, K, ldk, k_seq, V, ldv, v_seq, O, ldo, o_seq, Sq, Sk};
-  hipLaunchKernelGGL(k32_attn, dim3((Sq + 31) / 32, n_seq * 4), dim3(256), 0, st, a);
-  HIP_TRY(hipGetLastError());
-  return ETD_OK;
+           float* O, int ldo, long long o_seq, int n_seq, int Sq, int Sk, int q_log2, int k_log2, int v_log2, hipStream_t st) {
+  Attn3Args a = {};
+  a.Q = Q; a.ldq = ldq; a.q_seq = q_seq; a.K = K; a.ldk = ldk; a.k_seq = k_seq; a.V = V; a.ldv = ldv; a.v_seq = v_seq; a.O = O; a.ldo = ldo; a.o_seq = o_seq;
+  a.n_seq = n_seq; a.n_heads = 4; a.Sq = Sq; a.Sk = Sk; a.scale = 0.125f; a.q_log2 = q_log2; a.k_log2 = k_log2; a.v_log2 = v_log2;
+  a.flops_hint = 4.0 * n_seq * (double)Sq * Sk * 256;
+  return launch_attn3(a, st);
 }
 int relu32(float* x, long long n, hipStream_t st) {
   hipLaunchKernelGGL(k32_relu, dim3(2048), dim3(256), 0, st, x, n / 4);
@@ -297,7 +254,7 @@ int relu32(float* x, long long n, hipStream_t st) {
 int enc_layer32(Ext32* e, const Enc32& w, float* X, int M, int n_seq, int S, hipStream_t st) {
   ETD_TRY(gemm32(X, 256, w.qkv, M, e->QKV, 768, st));
   ETD_TRY(attn32(e->QKV, 768, (long long)S * 768, e->QKV + 256, 768, (long long)S * 768, e->QKV + 512, 768, (long long)S * 768,
-                 e->AO, 256, (long long)S * 256, n_seq, S, S, st));
+                 e->AO, 256, (long long)S * 256, n_seq, S, S, w.q_log2, w.k_log2, w.v_log2, st));
   ETD_TRY(gemm32(e->AO, 256, w.o, M, e->T, 256, st));
   ETD_TRY(add_ln(e->T, X, 0, w.g, w.be, e->X1, M, st));
   ETD_TRY(gemm32(e->X1, 256, w.f1, M, e->HF, 512, st));
@@ -318,6 +275,7 @@ int ext32_create(const etd_ext_cfg& c, const WeightMap& w, Ext32** out) {
   Ext32* e = new Ext32();
   e->cfg = c; e->nf = c.n_frame; e->nn = c.n_note; e->margin = c.n_margin;
   auto fail = [&](int rc) { ext32_destroy(e); return rc; };
+  float x0_bound = 0.f;
   {
     const float* cw = wget(w, "encoder.conv.weight", 4 * 5);
     const float* cb = wget(w, "encoder.conv.bias", 4);
@@ -341,47 +299,76 @@ int ext32_create(const etd_ext_cfg& c, const WeightMap& w, Ext32** out) {
     int rc = up(e, &e->Wf, Wf.data(), Wf.size()); if (rc) return fail(rc);
     rc = up(e, &e->bfold, bf.data(), 256); if (rc) return fail(rc);
     rc = up(e, &e->pos_freq_enc, pe, 256 * 256); if (rc) return fail(rc);
+    // bound of the embedding (acc + b) * 16 + pos for log-mel features in [-F, F]: log(mel + 1e-8) >= -18.4, and |audio| <= 1 keeps it below 15; the padding value
+    // of the HFT_Transformer wrapper is -80
+    const float F = fmaxf(fabsf(c.min_value), 32.f);
+    float pmax = 0.f;
+    for (int i = 0; i < 256 * 256; ++i) pmax = fmaxf(pmax, fabsf(pe[i]));
+    x0_bound = 16.f * g3_bound_linear(Wf.data(), bf.data(), 256, 65, F) + pmax;
   }
-  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "encoder.layers_freq." + std::to_string(i), &e->enc[i]); if (rc) return fail(rc); }
-  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "decoder.layers_time." + std::to_string(i), &e->tim[i]); if (rc) return fail(rc); }
-  for (int i = 0; i < 3; ++i) {
-    const std::string p = i == 0 ? std::string("decoder.layer_zero_freq") : "decoder.layers_freq." + std::to_string(i - 1);
-    Dec32& d = e->dec[i];
-    d.has_self = i > 0;
-    int rc;
-    if (d.has_self) {
-      rc = load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, &d.qkv_s); if (rc) return fail(rc);
-      rc = load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, &d.o_s); if (rc) return fail(rc);
-    }
-    rc = load_stack(e, w, {p + ".encoder_attention.fc_q"}, {256}, 256, &d.q_c); if (rc) return fail(rc);
-    rc = load_stack(e, w, {p + ".encoder_attention.fc_k", p + ".encoder_attention.fc_v"}, {256, 256}, 256, &d.kv_c); if (rc) return fail(rc);
-    rc = load_stack(e, w, {p + ".encoder_attention.fc_o"}, {256}, 256, &d.o_c); if (rc) return fail(rc);
-    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, &d.f1); if (rc) return fail(rc);
-    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, &d.f2); if (rc) return fail(rc);
-    rc = load_ln(e, w, p + ".layer_norm", &d.g, &d.be); if (rc) return fail(rc);
-  }
+  InB cur{nullptr, nullptr, 256, x0_bound};
+  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "encoder.layers_freq." + std::to_string(i), cur, &e->enc[i], &cur); if (rc) return fail(rc); }
+  const InB enc_out = cur;
+  const int nn = e->nn;
+  const float* pe_d = wget(w, "decoder.pos_embedding_freq.weight", (int64_t)nn * 256);
+  const float* pt = wget(w, "decoder.pos_embedding_time.weight", (int64_t)e->nf * 256);
+  if (!pe_d || !pt) return fail(ETD_EINVAL);
+  float q0_bound = 0.f;
   {
-    const int nn = e->nn;
-    const float* pe = wget(w, "decoder.pos_embedding_freq.weight", (int64_t)nn * 256);
     const float* qw = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.weight", 256 * 256);
     const float* qb = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.bias", 256);
-    const float* pt = wget(w, "decoder.pos_embedding_time.weight", (int64_t)e->nf * 256);
-    if (!pe || !qw || !qb || !pt) return fail(ETD_EINVAL);
+    if (!qw || !qb) return fail(ETD_EINVAL);
     std::vector<float> q0((size_t)nn * 256);          // layer-zero queries are input independent: fc_q(pos_embedding_freq)   amt_apc.py:168-175
     for (int r = 0; r < nn; ++r)
       for (int o = 0; o < 256; ++o) {
         float s = 0.f;                                 // fp32 dot products in k order, + bias: what F.linear computes up to summation order
-        for (int k = 0; k < 256; ++k) s = fmaf(pe[r * 256 + k], qw[o * 256 + k], s);
+        for (int k = 0; k < 256; ++k) s = fmaf(pe_d[r * 256 + k], qw[o * 256 + k], s);
         q0[(size_t)r * 256 + o] = s + qb[o];
+        q0_bound = fmaxf(q0_bound, fabsf(s + qb[o]));
       }
     int rc = up(e, &e->q0, q0.data(), q0.size()); if (rc) return fail(rc);
-    rc = up(e, &e->trg0, pe, (size_t)nn * 256); if (rc) return fail(rc);
+    rc = up(e, &e->trg0, pe_d, (size_t)nn * 256); if (rc) return fail(rc);
     rc = up(e, &e->pos_time, pt, (size_t)e->nf * 256); if (rc) return fail(rc);
   }
-  for (int t = 0; t < 2; ++t) {
-    const std::string sfx = t == 0 ? "time" : "freq";
-    int rc = load_stack(e, w, {"decoder.fc_velocity_" + sfx, "decoder.fc_onset_" + sfx, "decoder.fc_offset_" + sfx, "decoder.fc_mpe_" + sfx}, {128, 1, 1, 1}, 256,
-                        t == 0 ? &e->head_time : &e->head_freq);
+  // frequency decoder (amt_apc.py:261-320): layer 0 = cross attention of the constant note queries + FFN; layers 1-2 = self attention, cross attention, FFN; one LayerNorm per layer
+  InB dcur{};     // layers 1-2: the previous layer's LayerNorm output
+  for (int i = 0; i < 3; ++i) {
+    const std::string p = i == 0 ? std::string("decoder.layer_zero_freq") : "decoder.layers_freq." + std::to_string(i - 1);
+    Dec32& d = e->dec[i];
+    d.has_self = i > 0;
+    const float* gw = wget(w, p + ".layer_norm.weight", 256);
+    const float* bw = wget(w, p + ".layer_norm.bias", 256);
+    if (!gw || !bw) return fail(ETD_EINVAL);
+    const InB ln{gw, bw, 256, 0.f};
+    std::vector<float> ob;
+    int rc;
+    if (d.has_self) {
+      rc = load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, dcur, &d.qkv_s, &ob); if (rc) return fail(rc);
+      d.qs_log2 = g3_scale_log2(ob[0]); d.ks_log2 = g3_scale_log2(ob[1]); d.vs_log2 = g3_scale_log2(ob[2]);
+      rc = load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, InB{nullptr, nullptr, 256, ob[2]}, &d.o_s); if (rc) return fail(rc);
+    }
+    // cross-attention queries: layer 0 the precomputed q0 (no GEMM at run time: the Lin32 is loaded for its bias / shape only), layers 1-2 fc_q of the self-attention block's LayerNorm output
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_q"}, {256}, 256, d.has_self ? ln : InB{nullptr, nullptr, 256, 1.f}, &d.q_c, &ob); if (rc) return fail(rc);
+    d.qc_log2 = g3_scale_log2(d.has_self ? ob[0] : q0_bound);
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_k", p + ".encoder_attention.fc_v"}, {256, 256}, 256, enc_out, &d.kv_c, &ob); if (rc) return fail(rc);
+    d.kc_log2 = g3_scale_log2(ob[0]); d.vc_log2 = g3_scale_log2(ob[1]);
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_o"}, {256}, 256, InB{nullptr, nullptr, 256, ob[1]}, &d.o_c); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, ln, &d.f1, &ob); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, InB{nullptr, nullptr, 512, ob[0]}, &d.f2); if (rc) return fail(rc);
+    rc = load_ln(e, w, p + ".layer_norm", &d.g, &d.be); if (rc) return fail(rc);
+    dcur = ln;
+  }
+  {
+    int rc = load_stack(e, w, {"decoder.fc_velocity_freq", "decoder.fc_onset_freq", "decoder.fc_offset_freq", "decoder.fc_mpe_freq"}, {128, 1, 1, 1}, 256, dcur, &e->head_freq);
+    if (rc) return fail(rc);
+  }
+  // time decoder (amt_apc.py:203-220): its input is freq-decoder output * 16 + pos_embedding_time
+  float ptmax = 0.f;
+  for (size_t i = 0; i < (size_t)e->nf * 256; ++i) ptmax = fmaxf(ptmax, fabsf(pt[i]));
+  cur = InB{nullptr, nullptr, 256, 16.f * in_bound(dcur) + ptmax};
+  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "decoder.layers_time." + std::to_string(i), cur, &e->tim[i], &cur); if (rc) return fail(rc); }
+  {
+    int rc = load_stack(e, w, {"decoder.fc_velocity_time", "decoder.fc_onset_time", "decoder.fc_offset_time", "decoder.fc_mpe_time"}, {128, 1, 1, 1}, 256, cur, &e->head_time);
     if (rc) return fail(rc);
   }
   const size_t Me = (size_t)e->nf * 256, Mq = (size_t)e->nf * e->nn;
@@ -429,7 +416,7 @@ int ext32_run(Ext32* e, const EmbedArgs& src, int n_windows, Outs32 B, Outs32 A,
       if (d.has_self) {
         ETD_TRY(gemm32(D0, 256, d.qkv_s, Mq, e->QKV, 768, st));
         ETD_TRY(attn32(e->QKV, 768, (long long)nn * 768, e->QKV + 256, 768, (long long)nn * 768, e->QKV + 512, 768, (long long)nn * 768,
-                       e->AO, 256, (long long)nn * 256, nf, nn, nn, st));
+                       e->AO, 256, (long long)nn * 256, nf, nn, nn, d.qs_log2, d.ks_log2, d.vs_log2, st));
         ETD_TRY(gemm32(e->AO, 256, d.o_s, Mq, e->T, 256, st));
         ETD_TRY(add_ln(e->T, D0, 0, d.g, d.be, D1, Mq, st));
         cross_in = D1;
@@ -437,7 +424,7 @@ int ext32_run(Ext32* e, const EmbedArgs& src, int n_windows, Outs32 B, Outs32 A,
       const float* Qp; long long q_seq;
       if (l == 0) { Qp = e->q0; q_seq = 0; }
       else { ETD_TRY(gemm32(cross_in, 256, d.q_c, Mq, e->Qd, 256, st)); Qp = e->Qd; q_seq = (long long)nn * 256; }
-      ETD_TRY(attn32(Qp, 256, q_seq, KVl, 512, 256LL * 512, KVl + 256, 512, 256LL * 512, e->AO, 256, (long long)nn * 256, nf, nn, 256, st));
+      ETD_TRY(attn32(Qp, 256, q_seq, KVl, 512, 256LL * 512, KVl + 256, 512, 256LL * 512, e->AO, 256, (long long)nn * 256, nf, nn, 256, d.qc_log2, d.kc_log2, d.vc_log2, st));
       ETD_TRY(gemm32(e->AO, 256, d.o_c, Mq, e->T, 256, st));
       ETD_TRY(add_ln(e->T, cross_in, r_mod, d.g, d.be, D2, Mq, st));
       ETD_TRY(gemm32(D2, 256, d.f1, Mq, e->HF, 512, st));

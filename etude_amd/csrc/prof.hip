@@ -39,6 +39,13 @@ bool launch_skipped(const char* name) {
   return true;
 }
 
+bool launch_log_on() { static const bool on = getenv("ETD_LAUNCH_LOG") && atoi(getenv("ETD_LAUNCH_LOG")) > 0; return on; }
+void launch_log(const char* name, hipStream_t st, bool after) {
+  if (!after) { fprintf(stderr, "[launch] %s\n", name); fflush(stderr); return; }
+  const hipError_t e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { fprintf(stderr, "[launch] %s FAILED: %s\n", name, hipGetErrorString(e)); fflush(stderr); }
+}
+
 hipEvent_t prof_begin(hipStream_t st) {
   if (!g_on) return nullptr;
   hipEvent_t e;
