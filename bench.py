@@ -58,11 +58,11 @@ sys.path.insert(0, str(ROOT))
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 T_START = time.perf_counter()
-# cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r04_parity_mode.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
+# cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r05_parity_mode.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
 # extract, the fp32 decode of its 27 jobs x all bars, and the bf16 decode of the same jobs
-PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "6"))
-PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.55"))
-PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "2.3"))
+PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "8"))
+PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.2"))
+PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "1.5"))
 PARITY_BF16_S_PER_CLIP = float(os.environ.get("ETD_PARITY_BF16_S", "0.45"))
 
 
@@ -218,8 +218,9 @@ def bar_divergence(ra, rb):
 def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_engines, time_left):
     """extras.parity_mode: what exact parity costs.  north_star's "identical token-id sequences under greedy decode" holds in the fp32 mode (the reference
     runs fp32: etude_decoder.py:333); the headline is timed in bf16.  The SAME chain (extract .. notes) on the first `n_clips` clips of this rank with the fp32
-    extractor and fp32 decoder engines, ONE timed pass after a 2-bar warm-up pass; then the bf16 decoder on the SAME condition bars (the fp32 extractor's) for
-    the per-bar divergence of the two decoders."""
+    extractor and fp32 decoder engines (every dense contraction at fp32 grade on the f16 matrix cores: csrc/gemm3.h), ONE timed pass after a 2-bar warm-up pass;
+    then a few stamped steady-state bars for the roofline of the fp32 attention launches; then the bf16 decoder on the SAME condition bars (the fp32 extractor's)
+    for the per-bar divergence of the two decoders.  Whatever happens, every engine and the extractor are closed on the way out."""
     import torch
     from etude_amd import synth
     from etude_amd.config import ExtractorConfig
@@ -228,57 +229,100 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_eng
     from etude_amd.pipeline import ClipBatchPipeline, synthetic_tempo
     t_in = time.perf_counter()
     n_jobs = n_clips * len(grid)
-    n_eng = 4 if n_jobs >= 64 else 1
+    n_eng = 1 if n_jobs >= 512 else (4 if n_jobs >= 64 else 1)
     per_eng = (n_jobs + n_eng - 1) // n_eng
-    ex32 = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(0), dev, max_windows=4, precision="fp32")
-    d32 = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="fp32", max_streams=per_eng,
-                        max_prefill_rows=min(65536, per_eng * 520))]
-    d32 += [d32[0].clone() for _ in range(n_eng - 1)]
-    pipe32 = ClipBatchPipeline([ex32], d32, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
-    sub = wavs[:n_clips]
-    conds = pipe32.extract_stage(sub)
-    pipe32.decode_stage(conds, max_bars=2)                     # allocations, graph captures
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    conds = pipe32.extract_stage(sub)
-    t1 = time.perf_counter()
-    res32, st32 = pipe32.decode_stage(conds, max_bars=max_bars)
-    torch.cuda.synchronize(dev)
-    t2 = time.perf_counter()
-    pipe32.notes_stage(conds, res32)
-    t3 = time.perf_counter()
-    ntok = sum(s["tokens"] for s in st32)
-    bars_done = int(np.mean([len(r[1]) for r in res32]))
-    frac = 1.0
-    if max_bars:
-        frac = bars_done / max(1.0, float(np.mean([len(cd.bars) for cd in conds])))
-    out = {"workload": f"the headline's chain on {n_clips} of its clips x {len(grid)} tuples = {n_jobs} jobs in the EXACT-PARITY mode: fp32 extractor (etd_ext_cfg.precision 1) "
-                       f"+ fp32 decoder (weights, KV cache, activations; {n_eng} engine(s) x {per_eng} streams), {args.bar_tokens} tokens per bar"
-                       + (f"; ONLY THE FIRST {max_bars} BARS of every job were decoded to stay inside the harness budget (audio_s_per_s scales the decode stage to all bars)" if max_bars else ""),
-           "extract_s": round(t1 - t0, 3), "decode_s": round(t2 - t1, 3), "notes_s": round(t3 - t2, 3),
-           "audio_s_per_s": round(args.seconds * n_clips / ((t1 - t0) + (t2 - t1) / frac + (t3 - t2) / frac), 2),
-           "extract_audio_s_per_s": round(args.seconds * n_clips / (t1 - t0), 1), "decoder_tokens_per_s": round(ntok / (t2 - t1), 1),
-           "tokens_sha256": hashlib.sha256(np.concatenate([r[0] for r in res32]).astype(np.int32).tobytes()).hexdigest()[:16]}
-    for d in reversed(d32):
-        d.close()
-    pipe32.close()
-    # the bf16 decoder on the same condition bars: the headline's engines when they hold enough streams, else nothing (no new allocations this late)
-    if time_left() > 25.0 and bf16_engines and sum(d.max_streams for d in bf16_engines) >= n_jobs:
-        pipe16 = ClipBatchPipeline([ex32], bf16_engines, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
-        t4 = time.perf_counter()
-        res16, st16 = pipe16.decode_stage(conds, max_bars=max_bars)
+    ex32 = None; d32 = []; pipe32 = None; pipe16 = None
+    try:
+        ex32 = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(0), dev, max_windows=4, precision="fp32")
+        d32 = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="fp32", max_streams=per_eng,
+                            max_prefill_rows=min(131072, per_eng * 520))]
+        d32 += [d32[0].clone() for _ in range(n_eng - 1)]
+        pipe32 = ClipBatchPipeline([ex32], d32, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+        sub = wavs[:n_clips]
+        conds = pipe32.extract_stage(sub)
+        tw = time.perf_counter()
+        pipe32.decode_stage(conds, max_bars=2)                     # allocations, graph captures
         torch.cuda.synchronize(dev)
-        t5 = time.perf_counter()
-        pipe16.close()
-        same, comparable, jobs_same = bar_divergence(res32, res16)
-        out["bf16_same_conditions"] = {"decode_s": round(t5 - t4, 3), "decoder_tokens_per_s": round(sum(s["tokens"] for s in st16) / (t5 - t4), 1),
-                                       "bars_identical": same, "bars_comparable": comparable, "bar_divergence_rate": round(1.0 - same / max(1, comparable), 5),
-                                       "jobs_identical_end_to_end": jobs_same, "jobs": len(res32),
-                                       "note": "bf16 decoder engines of the headline on the fp32 extractor's condition bars; a bar is comparable while both histories are still equal"}
-        out["fp32_over_bf16_decode_time"] = round((t2 - t1) / (t5 - t4), 2)
-    ex32.close()
-    out["wall_s"] = round(time.perf_counter() - t_in, 2)
-    return out
+        # the warm-up pass measured this box: 2 bars (the cheap, short-context ones) -> a bound on the full pass; shed bars if the time left is short of it
+        per_bar = (time.perf_counter() - tw) / 2.0
+        nb_mean = float(np.mean([len(cd.bars) for cd in conds]))
+        if not max_bars and 2.2 * per_bar * nb_mean > time_left() - 8.0:
+            max_bars = int(max(4, min(nb_mean, (time_left() - 8.0) / (2.2 * per_bar))))
+        for d in d32:
+            d.stats_reset()
+        t0 = time.perf_counter()
+        conds = pipe32.extract_stage(sub)
+        t1 = time.perf_counter()
+        res32, st32 = pipe32.decode_stage(conds, max_bars=max_bars)
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        pipe32.notes_stage(conds, res32)
+        t3 = time.perf_counter()
+        ntok = sum(s["tokens"] for s in st32)
+        frac = 1.0
+        if max_bars:
+            frac = min(1.0, max_bars / max(1.0, nb_mean))
+        out = {"workload": f"the headline's chain on {n_clips} of its clips x {len(grid)} tuples = {n_jobs} jobs in the EXACT-PARITY mode: fp32 extractor (etd_ext_cfg.precision 1) "
+                           f"+ fp32 decoder (fp32 weights, KV cache and activations; every dense contraction as a two-plane f16 split, three MFMAs per product, fp32 accumulate: "
+                           f"csrc/gemm3.h; {n_eng} engine(s) x {per_eng} streams), {args.bar_tokens} tokens per bar"
+                           + (f"; ONLY THE FIRST {max_bars} BARS of every job were decoded to stay inside the harness budget (audio_s_per_s scales the decode stage to all bars)" if max_bars else ""),
+               "extract_s": round(t1 - t0, 3), "decode_s": round(t2 - t1, 3), "notes_s": round(t3 - t2, 3),
+               "audio_s_per_s": round(args.seconds * n_clips / ((t1 - t0) + (t2 - t1) / frac + (t3 - t2) / frac), 2),
+               "extract_audio_s_per_s": round(args.seconds * n_clips / (t1 - t0), 1), "decoder_tokens_per_s": round(ntok / (t2 - t1), 1),
+               "tokens_sha256": hashlib.sha256(np.concatenate([r[0] for r in res32]).astype(np.int32).tobytes()).hexdigest()[:16],
+               "full_batch": "profiles/r05_parity_full.json: the same mode on the whole 64-clip batch (one engine x 1728 streams), a gpurun of tools/bench_parity.py --clips 64 --stamp"}
+        # roofline of the fp32 attention launches (k_dattn<float>: 4-byte K / V, no weights in the launch), steady-state bars, device stamps as for the headline
+        if time_left() > 20.0 and nb_mean >= 8:
+            for d in d32:
+                d.stamp(True, skip_steps=4 * (args.bar_tokens - 1))
+                d.stats_reset()
+            pipe32.decode_stage(conds, max_bars=8)
+            torch.cuda.synchronize(dev)
+            s2 = [d.stats() for d in d32]
+            for d in d32:
+                d.stamp(False)
+            launches = sum(s["stamped_launches"] for s in s2); secs = sum(s["stamped_seconds"] for s in s2); byts = sum(s["stamped_alg_bytes"] for s in s2)
+            if launches > 0 and secs > 0:
+                out["roofline"] = {"kernel": "k_dattn<float>", "bound": "hbm", "achieved": round(byts / secs / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": round(byts / secs / 1e9 / PEAK_HBM_GBS, 4), "launches": int(launches), "avg_launch_ms": round(1e3 * secs / launches, 5),
+                                   "alg_bytes_per_launch": byts / launches, "traffic": None,
+                                   "note": "device stamps of every attention launch of bars 4-7 (steady-state contexts), all engines running; algorithmic bytes = fp32 K + V rows of every (row, head) context"}
+        for d in reversed(d32):
+            d.close()
+        d32 = []
+        pipe32.close(); pipe32 = None
+        # the bf16 decoder on the same condition bars: the headline's engines when they hold enough streams, else nothing (no new allocations this late)
+        if time_left() > 25.0 and bf16_engines and sum(d.max_streams for d in bf16_engines) >= n_jobs:
+            pipe16 = ClipBatchPipeline([ex32], bf16_engines, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+            t4 = time.perf_counter()
+            res16, st16 = pipe16.decode_stage(conds, max_bars=max_bars)
+            torch.cuda.synchronize(dev)
+            t5 = time.perf_counter()
+            same, comparable, jobs_same = bar_divergence(res32, res16)
+            out["bf16_same_conditions"] = {"decode_s": round(t5 - t4, 3), "decoder_tokens_per_s": round(sum(s["tokens"] for s in st16) / (t5 - t4), 1),
+                                           "bars_identical": same, "bars_comparable": comparable, "bar_divergence_rate": round(1.0 - same / max(1, comparable), 5),
+                                           "jobs_identical_end_to_end": jobs_same, "jobs": len(res32),
+                                           "note": "bf16 decoder engines of the headline on the fp32 extractor's condition bars; a bar is comparable while both histories are still equal"}
+            out["fp32_over_bf16_decode_time"] = round((t2 - t1) / (t5 - t4), 2)
+        out["wall_s"] = round(time.perf_counter() - t_in, 2)
+        return out
+    finally:
+        for d in reversed(d32):
+            try:
+                d.close()
+            except Exception:      # noqa: BLE001
+                pass
+        for p_ in (pipe32, pipe16):
+            if p_ is not None:
+                try:
+                    p_.close()
+                except Exception:      # noqa: BLE001
+                    pass
+        if ex32 is not None:
+            try:
+                ex32.close()
+            except Exception:      # noqa: BLE001
+                pass
 
 
 def main():
@@ -386,13 +430,9 @@ def main():
         return parallel.shard(list(range(n_clips * world)), rank, world)
 
     def make_wavs(n_clips):
-        base = synth.clip_audio(seed=1234, seconds=args.seconds)
-        wavs = []
-        for ci in my_clip_ids(n_clips):                                  # distinct clips, resident in HBM
-            rng = np.random.default_rng(1234 + ci)
-            w = np.roll(base, int(rng.integers(0, base.shape[1])), axis=1) * np.float32(rng.uniform(0.6, 1.0))
-            wavs.append(torch.from_numpy(np.ascontiguousarray(w)).to(dev))
-        return wavs
+        # "64 clips as config 2 with seeds 0..63" -- clip c of the batch is synth.clip_audio's construction with seed c, evaluated on the
+        # GPU (etude_amd/synth.py: clip_audio_device), resident in HBM before anything is timed
+        return [synth.clip_audio_device(seed=ci, seconds=args.seconds, device=dev) for ci in my_clip_ids(n_clips)]
 
     decs, n_jobs, per_eng = build_engines(clips)
     wavs = make_wavs(clips)

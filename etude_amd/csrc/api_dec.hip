@@ -275,6 +275,7 @@ int forward_body_x3(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipS
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = rows; at.M = M; at.O = d->AO; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
       if (rows.slot == d->row_slot) { at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0; }
+      at.stamp = d->stamp_on ? d->stamp_dev : nullptr; at.stamp_par = l & 1;
       ETD_TRY(launch_dattn(at, false, st));
     }
     DGemmArgs de = g3_args(d->AO, H, w.dense, w.v_log2, M); de.Y = d->DO; de.ldy = H;      // (attention output: a convex combination of V rows)
@@ -438,7 +439,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       at.Q = d->Q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = rows; at.M = M; at.O = d->AO;
       at.Ob = bpipe ? d->AOb : nullptr; at.scale = 0.125f; at.bytes_hint = d->attn_bytes_hint;
-      if (rows.slot == d->row_slot) { at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0; }     // decode step: the step's (slot, pos) pairs
+      if (rows.slot == d->row_slot) { at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0; at.stamp = d->stamp_on ? d->stamp_dev : nullptr; at.stamp_par = l & 1; }     // decode step: the step's (slot, pos) pairs
       if (catk) { at.Ob = d->Xcat + d->I; at.ldob = d->I + d->H; }
       ETD_TRY(launch_dattn(at, d->bf16w, st));
     }
@@ -1117,7 +1118,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
     for (int s2 = 0; s2 < n_steps; ++s2) kv += step_kv_bytes(s2);
     kv *= d->L;
     d->stat_steps += n_steps; d->stat_row_steps += (double)n_steps * n_active; d->stat_kv_bytes += kv; d->stat_attn_launches += (double)n_steps * d->L;
-    if (d->stamp_on) d->stat_stamp_bytes += kv + (double)n_steps * d->L * ((double)d->I + d->H) * d->H * 2.0;     // + the down and dense weights each launch streams
+    if (d->stamp_on) d->stat_stamp_bytes += kv + (fused ? (double)n_steps * d->L * ((double)d->I + d->H) * d->H * 2.0 : 0.0);     // + the down and dense weights each fused launch streams (fp32: the attention launch alone)
     for (int i = 0; i < n_active; ++i) { int& hl = d->host_len[slots[i]]; hl = hl + n_steps < d->ctx - 1 ? hl + n_steps : d->ctx - 1; }
   }
   return ETD_OK;

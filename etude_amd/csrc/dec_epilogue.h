@@ -78,6 +78,7 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
         v[j] = acc[4 * q + j];
         if (EPI != DEPI_LOGITS && EPI != DEPI_PARTIAL) v[j] += a.bias[n + j];
         if (EPI == DEPI_GELU) v[j] = WBF16 ? gelu_fast(v[j]) : gelu_erf(v[j]);
+        if (EPI == DEPI_RELU) v[j] = fmaxf(v[j], 0.f);
       }
       if constexpr (EPI == DEPI_RESID) {
         const f32x4 ad = *reinterpret_cast<const f32x4*>(a.add + (long long)m * a.N + n);

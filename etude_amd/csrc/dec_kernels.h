@@ -21,7 +21,7 @@ struct DecRows {
 // bar): results do not depend on which slot or engine a job lands on.
 struct DSampleCfg { float inv_temp; float top_p; unsigned long long seed; };
 
-enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4, DEPI_PARTIAL = 5 };
+enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4, DEPI_PARTIAL = 5, DEPI_RELU = 6 /* k_gemm3 only */ };
 
 struct DGemmArgs {
   const float* X; int ldx;       // [M, K] fp32 activations

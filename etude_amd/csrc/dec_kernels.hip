@@ -1637,13 +1637,37 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     }
   }
 }
+// device-side span stamps of a launch (`a.stamp`, null in every production graph; layout and protocol: k_dstep_attn_down below)
+__device__ __forceinline__ void attn_stamp_begin(unsigned long long* stp, int par, int flat_block) {
+  if (stp && flat_block == 0 && threadIdx.x < 64) {
+    const int bank = par & 1, prev = bank ^ 1, lane = threadIdx.x;
+    const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    unsigned long long e = atomicExch(stp + 8 + 64 * prev + lane, 0ull);          // read-and-clear at L2, 64 slots in one round trip
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(e, o, 64); e = x > e ? x : e; }
+    if (lane == 0) {
+      const unsigned long long s0 = atomicExch(stp + 2 + prev, 0ull);
+      if (s0 != 0 && e > s0) { atomicAdd(stp, e - s0); atomicAdd(stp + 1, 1ull); }
+      atomicExch(stp + 2 + bank, now);
+    }
+  }
+}
+__device__ __forceinline__ void attn_stamp_end(unsigned long long* stp, int par, int flat_block) {
+  if (stp) {
+    __syncthreads();                     // every wave of the workgroup is back from the body (its early exits return here)
+    if (threadIdx.x == 0) atomicMax(stp + 8 + 64 * (par & 1) + (flat_block & 63), (unsigned long long)__builtin_amdgcn_s_memrealtime());
+  }
+}
+
 template <typename KVT>
 // (leading scalar arguments: gfx950 preloads the first 16 kernarg dwords into SGPRs at wave launch, so the prologue's address
 // arithmetic starts without the kernarg s_load round trip; the struct carries everything that is needed later)
 __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                                int p_max_ctx, int p_n_heads, float p_scale, int p_identity, DAttnArgs a) {
   __shared__ float red[4][8][10];            // per wave, per dim-chunk: m, l, o[8]
+  const int flat = blockIdx.y * gridDim.x + blockIdx.x;
+  attn_stamp_begin(a.stamp, a.stamp_par, flat);
   dattn_core<KVT, false, 4>(blockIdx.x, blockIdx.y, red, nullptr, nullptr, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a);
+  attn_stamp_end(a.stamp, a.stamp_par, flat);
 }
 
 #undef EXPF
@@ -1783,23 +1807,9 @@ template <int NW, bool FIN, bool PAIR = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? ETD_FIN_OCC : (PAIR ? ETD_AD_OCC : AdOcc<NW>::lo), AdOcc<NW>::hi))) void k_dstep_attn_down(const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                                          int p_max_ctx, int p_n_heads, float p_scale, int p_identity, int p_gemm_wgs, int p_M,
                                                          DAttnArgs a, DGemmArgs g, DRowFin fin) {
-  unsigned long long* const stp = a.stamp;
-  if (stp && blockIdx.x == 0 && threadIdx.x < 64) {
-    const int bank = a.stamp_par & 1, prev = bank ^ 1, lane = threadIdx.x;
-    const unsigned long long now = (unsigned long long)__builtin_amdgcn_s_memrealtime();
-    unsigned long long e = atomicExch(stp + 8 + 64 * prev + lane, 0ull);          // read-and-clear at L2, 64 slots in one round trip
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(e, o, 64); e = x > e ? x : e; }
-    if (lane == 0) {
-      const unsigned long long s0 = atomicExch(stp + 2 + prev, 0ull);
-      if (s0 != 0 && e > s0) { atomicAdd(stp, e - s0); atomicAdd(stp + 1, 1ull); }
-      atomicExch(stp + 2 + bank, now);
-    }
-  }
+  attn_stamp_begin(a.stamp, a.stamp_par, (int)blockIdx.x);
   dstep_attn_down_body<NW, FIN, PAIR>(p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, p_gemm_wgs, p_M, a, g, fin);
-  if (stp) {
-    __syncthreads();                     // every wave of the workgroup is back from the body (its early exits return here)
-    if (threadIdx.x == 0) atomicMax(stp + 8 + 64 * (a.stamp_par & 1) + (blockIdx.x & 63), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-  }
+  attn_stamp_end(a.stamp, a.stamp_par, (int)blockIdx.x);
 }
 
 // waves per attention workgroup: 4, or ETD_AD_WAVES = 8 / 16 (measurement builds).  Measured on MI355X, round 2 ((history: 4ac2f57) tools/runs/r2_run1.sh):

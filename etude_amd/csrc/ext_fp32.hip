@@ -140,16 +140,6 @@ __global__ __launch_bounds__(256) void k32_embed(EmbedArgs a, const float* __res
   }
 }
 
-__global__ void k32_relu(float* __restrict__ x, long long n4) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < n4; i += stride) {
-    f32x4 v = reinterpret_cast<f32x4*>(x)[i];
-    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
-    reinterpret_cast<f32x4*>(x)[i] = v;
-  }
-}
-
 // Y = LayerNorm(A + R) * g + b over 256 features, one wave per row; R row = r_mod > 0 ? m % r_mod : m      amt_apc.py:250,256
 __global__ __launch_bounds__(256) void k32_add_ln(const float* __restrict__ A, const float* __restrict__ R, int r_mod, const float* __restrict__ g,
                                                   const float* __restrict__ b, float* __restrict__ Y, int M) {
@@ -225,10 +215,10 @@ __global__ void k32_freq2time(const float* __restrict__ src, float* __restrict__
 }
 
 // ================================================================================================ launch helpers
-int gemm32(const float* X, int ldx, const Lin32& w, int M, float* Y, int ldy, hipStream_t st) {
+int gemm32(const float* X, int ldx, const Lin32& w, int M, float* Y, int ldy, hipStream_t st, int epi = DEPI_BIAS) {
   DGemmArgs a = {};
   a.X = X; a.ldx = ldx; a.Wp = w.Wp; a.w_log2 = w.w_log2; a.x_log2 = w.x_log2; a.bias = w.b; a.M = M; a.N = w.N; a.Npad = w.Npad; a.K = w.K; a.Y = Y; a.ldy = ldy;
-  return launch_gemm3(a, DEPI_BIAS, st);
+  return launch_gemm3(a, epi, st);
 }
 int add_ln(const float* A, const float* R, int r_mod, const float* g, const float* b, float* Y, int M, hipStream_t st) {
   hipLaunchKernelGGL(k32_add_ln, dim3((M + 3) / 4), dim3(256), 0, st, A, R, r_mod, g, b, Y, M);
@@ -244,12 +234,6 @@ int attn32(const float* Q, int ldq, long long q_seq, const float* K, int ldk, lo
   a.flops_hint = 4.0 * n_seq * (double)Sq * Sk * 256;
   return launch_attn3(a, st);
 }
-int relu32(float* x, long long n, hipStream_t st) {
-  hipLaunchKernelGGL(k32_relu, dim3(2048), dim3(256), 0, st, x, n / 4);
-  HIP_TRY(hipGetLastError());
-  return ETD_OK;
-}
-
 // x = LN(x + MHA(x)); x = LN(x + FFN(x)), one shared LayerNorm                                          amt_apc.py:244-259
 int enc_layer32(Ext32* e, const Enc32& w, float* X, int M, int n_seq, int S, hipStream_t st) {
   ETD_TRY(gemm32(X, 256, w.qkv, M, e->QKV, 768, st));
@@ -257,8 +241,7 @@ int enc_layer32(Ext32* e, const Enc32& w, float* X, int M, int n_seq, int S, hip
                  e->AO, 256, (long long)S * 256, n_seq, S, S, w.q_log2, w.k_log2, w.v_log2, st));
   ETD_TRY(gemm32(e->AO, 256, w.o, M, e->T, 256, st));
   ETD_TRY(add_ln(e->T, X, 0, w.g, w.be, e->X1, M, st));
-  ETD_TRY(gemm32(e->X1, 256, w.f1, M, e->HF, 512, st));
-  ETD_TRY(relu32(e->HF, (long long)M * 512, st));
+  ETD_TRY(gemm32(e->X1, 256, w.f1, M, e->HF, 512, st, DEPI_RELU));      // fc_1 + ReLU (amt_apc.py:389) in the epilogue
   ETD_TRY(gemm32(e->HF, 512, w.f2, M, e->T, 256, st));
   ETD_TRY(add_ln(e->T, e->X1, 0, w.g, w.be, X, M, st));
   return ETD_OK;
@@ -427,8 +410,7 @@ int ext32_run(Ext32* e, const EmbedArgs& src, int n_windows, Outs32 B, Outs32 A,
       ETD_TRY(attn32(Qp, 256, q_seq, KVl, 512, 256LL * 512, KVl + 256, 512, 256LL * 512, e->AO, 256, (long long)nn * 256, nf, nn, 256, d.qc_log2, d.kc_log2, d.vc_log2, st));
       ETD_TRY(gemm32(e->AO, 256, d.o_c, Mq, e->T, 256, st));
       ETD_TRY(add_ln(e->T, cross_in, r_mod, d.g, d.be, D2, Mq, st));
-      ETD_TRY(gemm32(D2, 256, d.f1, Mq, e->HF, 512, st));
-      ETD_TRY(relu32(e->HF, (long long)Mq * 512, st));
+      ETD_TRY(gemm32(D2, 256, d.f1, Mq, e->HF, 512, st, DEPI_RELU));
       ETD_TRY(gemm32(e->HF, 512, d.f2, Mq, e->T, 256, st));
       ETD_TRY(add_ln(e->T, D2, 0, d.g, d.be, D0, Mq, st));
       ETD_TRY(tap32(tap, 4 + l, D0, Mq, first, st));

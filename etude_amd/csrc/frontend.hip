@@ -221,11 +221,11 @@ extern "C" long long etd_frontend_num_frames(const etd_frontend* f, long long n_
 extern "C" int etd_frontend_run(etd_frontend* f, const float* wav_dev, int channels, long long n_in, float* resampled_dev,
                                 float* feat_dev, long long feat_capacity_frames, long long* n_frames_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!f || !wav_dev || !resampled_dev || !feat_dev || channels <= 0 || n_in <= 0) ETD_FAIL(ETD_EINVAL, "frontend_run: bad args");
+  if (!f || !wav_dev || !resampled_dev || channels <= 0 || n_in <= 0) ETD_FAIL(ETD_EINVAL, "frontend_run: bad args");
   const long long n16 = etd_frontend_resampled_len(f, n_in);
   const long long T = 1 + n16 / f->hop;
-  if (!f->pad_zero && n16 <= f->n_fft / 2) ETD_FAIL(ETD_EINVAL, "frontend_run: clip shorter than n_fft/2 after resampling (reflect pad undefined)");
-  if (T > feat_capacity_frames) ETD_FAIL(ETD_EINVAL, "frontend_run: feature buffer too small (%lld > %lld)", T, feat_capacity_frames);
+  if (feat_dev && !f->pad_zero && n16 <= f->n_fft / 2) ETD_FAIL(ETD_EINVAL, "frontend_run: clip shorter than n_fft/2 after resampling (reflect pad undefined)");
+  if (feat_dev && T > feat_capacity_frames) ETD_FAIL(ETD_EINVAL, "frontend_run: feature buffer too small (%lld > %lld)", T, feat_capacity_frames);
   {
   ProfScope ps("k_resample", st, 2.0 * n16 * f->K, (double)n_in * channels * 4 + (double)n16 * 4);
   if (f->sr_in == f->sr_out) {
@@ -236,6 +236,11 @@ extern "C" int etd_frontend_run(etd_frontend* f, const float* wav_dev, int chann
     hipLaunchKernelGGL(k_resample, dim3((unsigned)((nblk + RB - 1) / RB)), dim3(256), span * sizeof(float), st, wav_dev, channels, n_in,
                        f->kernT, f->K, f->width, f->orig, f->nw, resampled_dev, n16);
   }
+  }
+  if (!feat_dev) {                       // channel mean + resample only (analyze_volume needs no spectrogram)
+    HIP_TRY(hipGetLastError());
+    if (n_frames_out) *n_frames_out = 0;
+    return ETD_OK;
   }
   ProfScope ps2("k_stft_mel", st, 0, (double)n16 * 4 + (double)T * f->n_mels * 4);
   const size_t sm = (size_t)(2 * f->n_fft + f->n_fft / 2 + 1) * sizeof(float);

@@ -173,13 +173,14 @@ int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st) {
   if (epi == DEPI_RESID && (a.N % 4)) ETD_FAIL(ETD_EINVAL, "gemm3: resid needs N %% 4 == 0");
   if (a.ln_g || a.Xb || a.Yb || a.Qb || a.k_splits > 1) ETD_FAIL(ETD_EINVAL, "gemm3: fp32 operands only (no fused LayerNorm, bf16 buffers or split-K)");
   ETD_LAUNCH_FILTER("k_gemm3");
-  ProfScope ps("k_gemm3", st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * 4 + (double)a.M * a.K * 4);
+  ProfScope ps(a.M >= 8192 ? "k_gemm3" : "k_gemm3_step", st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * 4 + (double)a.M * a.K * 4);
   const dim3 g((a.M + 127) / 128, a.Npad / 128);
   const float xs = ldexpf(1.f, a.x_log2), inv = ldexpf(1.f, -(a.x_log2 + a.w_log2));
 #define G3_LAUNCH(E) hipLaunchKernelGGL((k_gemm3<E>), g, dim3(256), 0, st, a.X, a.ldx, (const f16*)a.Wp, a.M, a.K, xs, inv, a)
   switch (epi) {
     case DEPI_BIAS: G3_LAUNCH(DEPI_BIAS); break;
     case DEPI_GELU: G3_LAUNCH(DEPI_GELU); break;
+    case DEPI_RELU: G3_LAUNCH(DEPI_RELU); break;
     case DEPI_RESID: G3_LAUNCH(DEPI_RESID); break;
     case DEPI_LOGITS: G3_LAUNCH(DEPI_LOGITS); break;
     case DEPI_QKV: G3_LAUNCH(DEPI_QKV); break;

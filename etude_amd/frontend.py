@@ -104,6 +104,16 @@ class FrontEnd:
         self.last_resampled = res
         return feat
 
+    def resample(self, wav: torch.Tensor) -> torch.Tensor:
+        """channel mean + resample only: wav (device, [C][L] fp32) -> mono [L'] fp32 at sr_out (no STFT / mel)"""
+        assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2 and wav.is_contiguous()
+        lib = _lib.lib()
+        c, n = wav.shape
+        res = torch.empty(int(lib.etd_frontend_resampled_len(self._h, n)), dtype=torch.float32, device=wav.device)
+        st = torch.cuda.current_stream(wav.device).cuda_stream
+        _lib.check(lib.etd_frontend_run(self._h, wav.data_ptr(), c, n, res.data_ptr(), None, 0, None, C.c_void_p(st)), "etd_frontend_run")
+        return res
+
     def close(self):
         if getattr(self, "_h", None):
             _lib.lib().etd_frontend_destroy(self._h)

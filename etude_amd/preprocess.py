@@ -38,8 +38,7 @@ class VolumeAnalyzer:
             w = w[None]
         w = w.to(self.dev).contiguous()
         with torch.cuda.device(self.dev):
-            self.fe(w)                                      # mono mean + resample (the mel output of this call is not used)
-            y = self.fe.last_resampled
+            y = self.fe.resample(w)                         # mono mean + resample (no spectrogram: librosa.load does neither)
             hop = self.sr // self.resolution
             T = 1 + y.numel() // hop
             out = torch.empty(T, dtype=torch.float32, device=self.dev)
@@ -63,8 +62,7 @@ def volume_contour_tensor(wave: Union[np.ndarray, torch.Tensor], sr_in: int, sr:
     w = w.to(dev).contiguous()
     with torch.cuda.device(dev):
         fe = FrontEnd(int(sr_in), sr_out=int(sr), pad_mode="constant")
-        fe(w)                                               # mono mean + resample (the mel output of this call is not used)
-        y = fe.last_resampled
+        y = fe.resample(w)                                  # mono mean + resample (no spectrogram)
         hop = int(sr) // int(resolution)
         frame = 2 * hop
         T = 1 + y.numel() // hop

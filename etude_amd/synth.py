@@ -135,6 +135,40 @@ def clip_audio(seed: int = 1234, seconds: float = 180.0, sr: int = 44100) -> np.
     return out
 
 
+def clip_audio_device(seed: int, seconds: float = 180.0, sr: int = 44100, device="cuda"):
+    """`clip_audio`'s construction evaluated on the GPU (64 distinct 3-minute clips in a second instead of minutes of numpy: bench.py's batch, SURVEY 8(d) config 5:
+    "64 clips as config 2 with seeds 0..63"): the same per-segment draws from the same numpy generator (8 MIDI pitches 40-90, phases, pan per 0.25 s segment, decaying
+    envelope), sinusoids in float64 on the device, the -30 dB white noise from a seeded device generator (so the samples are NOT bit-equal to `clip_audio(seed)`;
+    the goldens keep using that one).  Returns a float32 [2, L] tensor on `device`, peak 0.5."""
+    import torch
+    dev = torch.device(device)
+    rng = np.random.default_rng(seed)
+    L = int(round(seconds * sr))
+    seg = int(0.25 * sr)
+    nseg = (L + seg - 1) // seg
+    midi = np.empty((nseg, 8)); ph = np.empty((nseg, 8)); pan = np.empty(nseg)
+    for i in range(nseg):                        # (the draw order of clip_audio: pitches, phases, pan per segment)
+        midi[i] = rng.integers(40, 91, size=8)
+        ph[i] = rng.uniform(0, 2 * np.pi, size=8)
+        pan[i] = rng.uniform(0.3, 0.7)
+    f = torch.from_numpy(440.0 * 2.0 ** ((midi - 69) / 12.0)).to(dev)                  # [nseg, 8] float64
+    pht = torch.from_numpy(ph).to(dev)
+    pant = torch.from_numpy(pan).to(dev)
+    t = torch.arange(seg, dtype=torch.float64, device=dev) / sr
+    env = torch.exp(-3.0 * t)
+    x = torch.zeros((nseg, seg), dtype=torch.float64, device=dev)
+    for k in range(8):                           # one [nseg, seg] float64 plane at a time (a [nseg, 8, seg] tensor would be 0.5 GB)
+        x += torch.sin(2 * np.pi * f[:, k:k + 1] * t[None, :] + pht[:, k:k + 1])
+    x = (x * env[None, :] / 8.0)
+    left = (x * (pant[:, None] * 2)).reshape(-1)[:L].float()
+    right = (x * ((1 - pant[:, None]) * 2)).reshape(-1)[:L].float()
+    out = torch.stack([left, right])
+    g = torch.Generator(device=dev); g.manual_seed(int(seed))
+    out += (10 ** (-30 / 20) * 0.5) * torch.randn(out.shape, generator=g, device=dev, dtype=torch.float32)
+    out *= 0.5 / max(1e-9, float(out.abs().max()))
+    return out.contiguous()
+
+
 # ----------------------------------------------------------------------------- decoder
 
 

@@ -79,7 +79,8 @@ int etd_rms_frames(const float* x_dev, long long n, int frame_length, int hop_le
 long long etd_frontend_resampled_len(const etd_frontend*, long long n_in);
 long long etd_frontend_num_frames(const etd_frontend*, long long n_in);
 /* wav_dev: planar [channels][n_in] fp32.  resampled_dev: scratch >= resampled_len floats.
- * feat_dev: [T][n_mels] fp32 log-mel, T = 1 + resampled_len / hop (written to *n_frames_out). */
+ * feat_dev: [T][n_mels] fp32 log-mel, T = 1 + resampled_len / hop (written to *n_frames_out); NULL = channel mean + resample only (what
+ * analyze_volume needs of this stage: etude/utils/preprocess.py:135), *n_frames_out = 0. */
 int etd_frontend_run(etd_frontend*, const float* wav_dev, int channels, long long n_in, float* resampled_dev,
                      float* feat_dev, long long feat_capacity_frames, long long* n_frames_out, void* stream);
 

@@ -309,3 +309,49 @@ def test_bf16_greedy_divergence_rate_full_song_all_tuples(dev):
           f"{tok_same / max(1, tok):.4f} on those bars; jobs identical end to end: {sum(1 for k, a in zip(first_div, r32) if k == len(a))}/27; "
           f"first differing bar per job: min {min(first_div)} median {int(np.median(first_div))}")
     assert same / max(1, comparable) >= 0.90
+
+
+def test_config2_sixteen_window_batch(dev, golden_dir):
+    """BASELINE configs[2]: `transcript_windows` on 16 x 512-frame windows (synth.window_features(5, 16): SURVEY 8(d) config 3), the extractor-roofline call of bench.py.
+    (1) window 0 is the reference's golden window (`hft_full.npz` was recorded on window_features(5, 1) -- the same first window): inside the stated bf16 tolerance;
+    (2) every window of the batch is bit-identical to the same window transcribed alone (a window's result does not depend on what shares its launches:
+        extractor.py:227-248 runs them one at a time);
+    (3) the exact-parity mode (fp32 extractor) on two sampled windows of the same batch sits within 2e-4 of the oracle's fp32 forward, velocity argmax on the oracle's
+        maximum wherever the oracle's top-2 gap is not a rounding matter."""
+    from etude_amd.config import ExtractorConfig
+    from etude_amd.extractor import AMTAPC_Extractor
+    from oracle import hft
+    x16 = synth.window_features(5, 16)
+    assert np.array_equal(x16[:1], synth.window_features(5, 1))
+    g = np.load(golden_dir / "hft_full.npz")
+    sdn = synth.extractor_state_dict(7, dict(n_frame=512))
+    cfg = ExtractorConfig()
+    ex = AMTAPC_Extractor(cfg, sdn, "cuda", max_windows=4)
+    xd = torch.from_numpy(x16).to(dev)
+    on, off, mpe, vel = [t.cpu().numpy() for t in ex.transcript_windows(xd)]
+    assert on.shape == (16 * 512, 88) and vel.shape == (16 * 512, 88)
+    for name, got in (("onset_B", on[:512]), ("offset_B", off[:512]), ("mpe_B", mpe[:512])):
+        err = np.abs(got - g[name])
+        assert err.max() < P_TOL and err.mean() < 6e-3, (name, float(err.max()), float(err.mean()))
+    for w in range(16):
+        a = [t.cpu().numpy() for t in ex.transcript_windows(xd[w:w + 1])]
+        sl = slice(w * 512, (w + 1) * 512)
+        for got, alone in zip((on[sl], off[sl], mpe[sl], vel[sl]), a):
+            assert np.array_equal(got, alone), f"window {w} of the 16-window batch differs from the window transcribed alone"
+    ex.close()
+    ex32 = AMTAPC_Extractor(cfg, sdn, "cuda", max_windows=4, precision="fp32")
+    on32, off32, mpe32, vel32 = [t.cpu().numpy() for t in ex32.transcript_windows(xd)]
+    ex32.close()
+    tsd = {k: torch.from_numpy(v) for k, v in sdn.items()}
+    worst = 0.0
+    for w in (3, 11):
+        r = hft.model_forward(tsd, torch.from_numpy(x16[w:w + 1]), hft.HftDims(n_frame=512))
+        sl = slice(w * 512, (w + 1) * 512)
+        for got, ref in ((on32[sl], r[5][0].numpy()), (off32[sl], r[6][0].numpy()), (mpe32[sl], r[7][0].numpy())):
+            worst = max(worst, float(np.abs(got - ref).max()))
+        lg = r[8][0].numpy()
+        top2 = np.sort(lg, -1)[..., -2:]
+        clear = (top2[..., 1] - top2[..., 0]) > 1e-3
+        assert (vel32[sl].astype(np.int64) == lg.argmax(-1))[clear].all()
+    print(f"configs[2], exact-parity mode: max |p - oracle| over two sampled windows = {worst:.2e} (tolerance 2e-4)")
+    assert worst < 2e-4

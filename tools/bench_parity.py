@@ -63,12 +63,7 @@ def main():
     decs = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision=a.precision, max_streams=per_eng, max_prefill_rows=rows)]
     decs += [decs[0].clone() for _ in range(n_eng - 1)]
     pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=a.bar_tokens)
-    base = synth.clip_audio(seed=1234, seconds=180.0)
-    wavs = []
-    for ci in range(a.clips):
-        rng = np.random.default_rng(1234 + ci)
-        w = np.roll(base, int(rng.integers(0, base.shape[1])), axis=1) * np.float32(rng.uniform(0.6, 1.0))
-        wavs.append(torch.from_numpy(np.ascontiguousarray(w)).to(dev))
+    wavs = [synth.clip_audio_device(seed=ci, seconds=180.0, device=dev) for ci in range(a.clips)]      # bench.py's batch: seeds 0 .. clips - 1
     conds = pipe.extract_stage(wavs)
     pipe.decode_stage(conds, max_bars=2)
     torch.cuda.synchronize(dev)
@@ -105,7 +100,7 @@ def main():
             d.stamp(False)
         launches = sum(s["stamped_launches"] for s in s2); secs = sum(s["stamped_seconds"] for s in s2); byts = sum(s["stamped_alg_bytes"] for s in s2)
         if launches and secs > 0:
-            out["roofline"] = {"kernel": "k_dstep_attn_down (fp32 K/V)", "bound": "hbm", "achieved": round(byts / secs / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+            out["roofline"] = {"kernel": "k_dattn<float> (fp32 K/V rows)", "bound": "hbm", "achieved": round(byts / secs / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(byts / secs / 8e12, 4), "launches": int(launches), "avg_launch_ms": round(1e3 * secs / launches, 5), "alg_bytes_per_launch": byts / launches}
     if a.events:
         _lib.prof_reset(); _lib.prof_enable(True)
