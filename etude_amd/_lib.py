@@ -75,6 +75,7 @@ SIGNATURES = {
     "etd_version": (C.c_int, []),
     "etd_last_error": (C.c_char_p, []),
     "etd_build_id": (C.c_char_p, []),
+    "etd_extractor_operand_type": (C.c_int, []),
     "etd_prof_enable": (C.c_int, [C.c_int]),
     "etd_prof_reset": (C.c_int, []),
     "etd_prof_collect": (C.c_int, []),
@@ -84,7 +85,7 @@ SIGNATURES = {
     "etd_debug_boundary_cost": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "etd_debug_linear": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
     "etd_debug_kernel_loop": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
-    "etd_debug_gemm3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
+    "etd_debug_gemm3": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "etd_debug_attn3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]),
     "etd_debug_empty_launch": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "etd_frontend_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,

@@ -254,11 +254,11 @@ int forward_body_x3(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipS
       at.Q = d->t_q; at.Kc = Kl; at.Vc = Vl; at.slot_stride = d->slot_stride; at.max_ctx = d->ctx; at.n_heads = d->nh;
       at.rows = lo->rows; at.M = n; at.O = d->t_ao; at.scale = 0.125f; at.bytes_hint = 0;
       ETD_TRY(launch_dattn(at, false, st));
-      DGemmArgs de = g3_args(d->t_ao, H, w.dense, 0, n); de.Y = d->t_do; de.ldy = H;
+      DGemmArgs de = g3_args(d->t_ao, H, w.dense, w.v_log2, n); de.Y = d->t_do; de.ldy = H;
       ETD_TRY(launch_dgemm(de, DEPI_BIAS, false, st));
-      DGemmArgs up = g3_args(d->hlast, H, w.up, 0, n); up.Y = d->t_m1; up.ldy = d->I; up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps;
+      DGemmArgs up = g3_args(d->hlast, H, w.up, w.x2_log2, n); up.Y = d->t_m1; up.ldy = d->I; up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps;
       ETD_TRY(launch_dgemm(up, DEPI_GELU, false, st));
-      DGemmArgs dn = g3_args(d->t_m1, d->I, w.down, 0, n); dn.add = d->t_do; dn.hin = d->hlast; dn.hout = hout;
+      DGemmArgs dn = g3_args(d->t_m1, d->I, w.down, w.m_log2, n); dn.add = d->t_do; dn.hin = d->hlast; dn.hout = hout;
       ETD_TRY(launch_dgemm(dn, DEPI_RESID, false, st));
       *hfinal = hout;                          // rows 0 .. n-1 = the prompts' last positions, in prompt order
       if (compact) *compact = true;
@@ -315,6 +315,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     // ---- fused QKV + RoPE + KV append
     DGemmArgs q = {};
     q.X = hin; q.ldx = d->H; q.W = w.qkv.W; q.Wf = w.qkv.Wf; q.bias = w.qkv.b; q.M = M; q.N = w.qkv.N; q.Npad = w.qkv.Npad; q.K = d->H;
+    q.Wp = w.qkv.Wp; q.w_log2 = w.qkv.w_log2; q.x_log2 = w.x1_log2;
     if (bpipe) q.Xb = d->X1b; else { q.ln_g = w.ln1g; q.ln_b = w.ln1b; q.ln_eps = d->cfg.layer_norm_eps; }
     q.Y = d->qkv_raw; q.ldy = 3 * d->H;
     q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
@@ -333,7 +334,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
         ETD_TRY(launch_pqkv(pa, st));
       } else {
         LinArgs a = {};
-        a.X = d->X1b; a.ldx = d->H; a.W = (const bf16*)w.qkv.Wf; a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
+        a.X = (const e16*)d->X1b; a.ldx = d->H; a.W = (const e16*)w.qkv.Wf;     /* (LinArgs carries the extractor's element type; the decoder modes of k_linear read these as bf16) */ a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
         ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
       }
       if (l == d->L - 1 && lo && mfma_attn && lo->n > 1 && lo->n <= DS_STEP_MAX_ROWS && d->H == 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && !getenv("ETD_NO_LAST_ONLY")) {
@@ -446,7 +447,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     // ---- attention.dense
     DGemmArgs de = {};
     de.X = d->AO; de.ldx = d->H; de.W = w.dense.W; de.bias = w.dense.b; de.M = M; de.N = d->H; de.Npad = w.dense.Npad; de.K = d->H;
-    de.Y = d->DO; de.ldy = d->H;
+    de.Y = d->DO; de.ldy = d->H; de.Wp = w.dense.Wp; de.w_log2 = w.dense.w_log2; de.x_log2 = w.v_log2;
     if (bpipe) de.Xb = d->AOb;
     if (!catk) {                // (otherwise attention.dense is folded into the (down | dense) GEMM below)
       ETD_TRY(launch_dgemm(de, DEPI_BIAS, d->bf16w, st));
@@ -454,7 +455,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     // ---- MLP up + GELU
     DGemmArgs up = {};
     up.X = hin; up.ldx = d->H; up.W = w.up.W; up.bias = w.up.b; up.M = M; up.N = d->I; up.Npad = w.up.Npad; up.K = d->H;
-    up.Y = d->M1; up.ldy = d->I;
+    up.Y = d->M1; up.ldy = d->I; up.Wp = w.up.Wp; up.w_log2 = w.up.w_log2; up.x_log2 = w.x2_log2;
     if (bpipe) { up.Xb = d->X2b; up.Yb = d->M1b; if (catk) { up.Yb = d->Xcat; up.ldy = d->I + d->H; } } else { up.ln_g = w.ln2g; up.ln_b = w.ln2b; up.ln_eps = d->cfg.layer_norm_eps; }
     if (fmlp) {
       // up + GELU, (down | dense), residual and the next layer's LayerNorms: one launch, the hidden layer never leaves the CU
@@ -470,7 +471,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     }
     if (big) {
       LinArgs a = {};
-      a.X = d->X2b; a.ldx = d->H; a.W = (const bf16*)w.up.Wf; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
+      a.X = (const e16*)d->X2b; a.ldx = d->H; a.W = (const e16*)w.up.Wf; a.bias = w.up.b; a.M = M; a.N = d->I; a.K = d->H; a.vt_block = -1; a.dec = up;
       ETD_TRY(launch_linear_dec(a, DEPI_GELU, st));
     } else if (!small) {        // (decode step: already issued together with QKV)
       ETD_TRY(launch_dgemm(up, DEPI_GELU, d->bf16w, st));
@@ -478,12 +479,12 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     // ---- MLP down + parallel residual: h = (mlp + attn) + h   (modeling_gpt_neox.py:272)
     DGemmArgs dn = {};
     dn.X = d->M1; dn.ldx = d->I; dn.W = w.down.W; dn.bias = w.down.b; dn.M = M; dn.N = d->H; dn.Npad = w.down.Npad; dn.K = d->I;
-    dn.add = d->DO; dn.hin = hin; dn.hout = hout;
+    dn.add = d->DO; dn.hin = hin; dn.hout = hout; dn.Wp = w.down.Wp; dn.w_log2 = w.down.w_log2; dn.x_log2 = w.m_log2;
     if (bpipe) dn.Xb = d->M1b;
     if (big) {
       dn.add = nullptr;
       LinArgs a = {};
-      a.X = d->Xcat; a.ldx = d->I + d->H; a.W = (const bf16*)w.cat.Wf; a.bias = w.cat.b; a.M = M; a.N = d->H; a.K = d->I + d->H; a.vt_block = -1; a.dec = dn;
+      a.X = (const e16*)d->Xcat; a.ldx = d->I + d->H; a.W = (const e16*)w.cat.Wf; a.bias = w.cat.b; a.M = M; a.N = d->H; a.K = d->I + d->H; a.vt_block = -1; a.dec = dn;
       ETD_TRY(launch_linear_dec(a, DEPI_RESID, st));
     } else if (small) {
       // (down | dense) projection with K split over workgroups, then ONE row kernel: partial sums + bias + residual and the
@@ -515,6 +516,7 @@ int head_logits(etd_dec* d, const float* X, int n, float* logits, hipStream_t st
   DGemmArgs lm = {};
   lm.X = X; lm.ldx = d->H; lm.W = d->head.W; lm.bias = nullptr; lm.M = n; lm.N = d->V; lm.Npad = d->head.Npad; lm.K = d->H;
   lm.ln_g = d->lnfg; lm.ln_b = d->lnfb; lm.ln_eps = d->cfg.layer_norm_eps; lm.Y = logits; lm.ldy = d->V;
+  lm.Wp = d->head.Wp; lm.w_log2 = d->head.w_log2; lm.x_log2 = d->xf_log2;
   return launch_dgemm(lm, DEPI_LOGITS, d->bf16w, st);
 }
 

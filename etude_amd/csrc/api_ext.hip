@@ -1,4 +1,4 @@
-// C-ABI glue for the Extract stage: weight preparation (fp32 checkpoint -> bf16 device layout,
+// C-ABI glue for the Extract stage: weight preparation (fp32 checkpoint -> e16 device layout,
 // conv+linear folding, QKV concatenation, constant query precompute) and the launch sequence of
 // _Spec2MIDI.forward / AMTAPC_Extractor._transcript (etude/data/extractor.py:53-56,199-253).
 #include <map>
@@ -31,18 +31,25 @@ struct DevPool {   // everything the extractor allocates; freed in destroy
   void free_all() { for (void* p : ptrs) (void)hipFree(p); ptrs.clear(); }
 };
 
-inline uint16_t f2bf(float f) {   // round-to-nearest-even, NaN kept
+// fp32 -> the extractor's 16-bit operand type (ext_kernels.h: IEEE half by default, bf16 under -DETD_EXT_BF16), round-to-nearest-even, NaN kept; and back
+#if ETD_EXT_IS_F16
+inline uint16_t f2bf(float f) { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+inline float e2f(uint16_t q) { _Float16 h; memcpy(&h, &q, 2); return (float)h; }
+#else
+inline uint16_t f2bf(float f) {
   uint32_t u; memcpy(&u, &f, 4);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+inline float e2f(uint16_t q) { const uint32_t u = (uint32_t)q << 16; float w; memcpy(&w, &u, 4); return w; }
+#endif
 
-struct LinW { bf16* W = nullptr; float* b = nullptr; };
+struct LinW { e16* W = nullptr; float* b = nullptr; };
 // p*: the same Linear weights as 256 x 256 blocks in k_proj256's fragment-ordered stream (ext_fused.hip); ffn: k_ffn_fused's stream
-struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; bf16 *ffn = nullptr, *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr;
-                   bf16* lw = nullptr; /* k_enc_layer's whole-layer stream (32 x 32 KiB) */ };
-struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; bf16* ffn = nullptr;
-                   bf16 *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *pqc = nullptr, *pkc = nullptr, *pvc = nullptr, *poc = nullptr; };
+struct EncLayerW { LinW qkv, o, f1, f2; float *g = nullptr, *be = nullptr; e16 *ffn = nullptr, *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr;
+                   e16* lw = nullptr; /* k_enc_layer's whole-layer stream (32 x 32 KiB) */ };
+struct DecLayerW { LinW qkv_s, o_s, q_c, kv_c, o_c, f1, f2; float *g = nullptr, *be = nullptr; bool has_self = false; e16* ffn = nullptr;
+                   e16 *pq = nullptr, *pk = nullptr, *pv = nullptr, *po = nullptr, *pqc = nullptr, *pkc = nullptr, *pvc = nullptr, *poc = nullptr; };
 
 }  // namespace
 
@@ -51,22 +58,22 @@ struct etd_ext {
   DevPool pool;
   int nf, nn, margin, wb, fc;
   // weights
-  bf16* Wf = nullptr; float* bfold = nullptr; bf16* pos_freq_enc = nullptr;
+  e16* Wf = nullptr; float* bfold = nullptr; e16* pos_freq_enc = nullptr;
   EncLayerW enc[3];
   DecLayerW dec[3];
-  bf16* q0 = nullptr;          // fc_q(pos_embedding_freq) of layer zero, [nn][256]
-  bf16* trg0 = nullptr;        // decoder.pos_embedding_freq [nn][256]
+  e16* q0 = nullptr;          // fc_q(pos_embedding_freq) of layer zero, [nn][256]
+  e16* trg0 = nullptr;        // decoder.pos_embedding_freq [nn][256]
   float* pos_time = nullptr;   // [nf][256] fp32
   EncLayerW tim[3];
   LinW head_time, head_freq;   // [160][256]
-  bf16* Wkv_all = nullptr; float* bkv_all = nullptr;   // the 3 cross-attention K/V projections, z-batched [3][512][256]
-  // workspaces (bf16 unless noted)
+  e16* Wkv_all = nullptr; float* bkv_all = nullptr;   // the 3 cross-attention K/V projections, z-batched [3][512][256]
+  // workspaces (e16 unless noted)
   size_t MT = 0, MQ = 0;       // token capacities
-  bf16 *X = nullptr, *X1 = nullptr, *QK = nullptr, *VT = nullptr, *AO = nullptr, *HF = nullptr;
-  bf16 *Kc = nullptr, *VTc = nullptr;              // [3][MTe][256] each
-  bf16 *Tq = nullptr, *T1 = nullptr, *QKd = nullptr, *VTd = nullptr, *AOd = nullptr, *HFd = nullptr, *Qd = nullptr, *Tfreq = nullptr;
-  bf16* TI = nullptr;          // time-decoder input [wb*nn*nf][256]
-  bf16 *KVimg = nullptr, *KVcimg = nullptr;   // K / V MFMA-fragment images for k_attn_frag: self-attention [MT * 512], cross-attention [3][MTe * 512]
+  e16 *X = nullptr, *X1 = nullptr, *QK = nullptr, *VT = nullptr, *AO = nullptr, *HF = nullptr;
+  e16 *Kc = nullptr, *VTc = nullptr;              // [3][MTe][256] each
+  e16 *Tq = nullptr, *T1 = nullptr, *QKd = nullptr, *VTd = nullptr, *AOd = nullptr, *HFd = nullptr, *Qd = nullptr, *Tfreq = nullptr;
+  e16* TI = nullptr;          // time-decoder input [wb*nn*nf][256]
+  e16 *KVimg = nullptr, *KVcimg = nullptr;   // K / V MFMA-fragment images for k_attn_frag: self-attention [MT * 512], cross-attention [3][MTe * 512]
   size_t MTe = 0;              // encoder chunk token capacity (wb*fc*256)
   float* dbg_vel = nullptr;
   void* tap[16] = {nullptr};   // test hook: device destinations for intermediate activations (first chunk only)
@@ -85,7 +92,7 @@ struct Loader {
   }
 };
 
-int up_bf16(DevPool& pool, bf16** dst, const float* src, size_t n) {
+int up_bf16(DevPool& pool, e16** dst, const float* src, size_t n) {
   std::vector<uint16_t> h(n);
   for (size_t i = 0; i < n; ++i) h[i] = f2bf(src[i]);
   ETD_TRY(pool.alloc(dst, n));
@@ -130,7 +137,7 @@ int load_ln(DevPool& pool, Loader& L, const std::string& pfx, float** g, float**
   return ETD_OK;
 }
 // fc_1 / fc_2 of a position-wise feed-forward block in the fused kernel's fragment-ordered stream
-int load_ffn_stream(DevPool& pool, Loader& L, const std::string& p, bf16** dst) {
+int load_ffn_stream(DevPool& pool, Loader& L, const std::string& p, e16** dst) {
   const float* W1 = L.get(p + ".fc_1.weight", 512 * 256);
   const float* W2 = L.get(p + ".fc_2.weight", 256 * 512);
   if (!W1 || !W2) return ETD_EINVAL;
@@ -141,7 +148,7 @@ int load_ffn_stream(DevPool& pool, Loader& L, const std::string& p, bf16** dst) 
   return ETD_OK;
 }
 // one [256][256] Linear as a k_proj256 block (rows permuted for row-major / LayerNorm blocks, natural for V^T blocks)
-int load_proj_block(DevPool& pool, Loader& L, const std::string& name, bool permute_rows, bf16** dst) {
+int load_proj_block(DevPool& pool, Loader& L, const std::string& name, bool permute_rows, e16** dst) {
   const float* W = L.get(name + ".weight", 256 * 256);
   if (!W) return ETD_EINVAL;
   std::vector<uint16_t> h((size_t)256 * 256);
@@ -195,6 +202,8 @@ int load_heads(DevPool& pool, Loader& L, const std::string& sfx, LinW* w) {
 
 }  // namespace
 
+extern "C" int etd_extractor_operand_type(void) { return ETD_EXT_IS_F16; }
+
 extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                                     const int64_t* numels, int n, etd_ext** out) {
   if (!cfg || !names || !host_ptrs || !numels || !out) ETD_FAIL(ETD_EINVAL, "extractor_create: null argument");
@@ -216,7 +225,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
   for (int i = 0; i < n; ++i) L.t[names[i]] = {host_ptrs[i], numels[i]};
   DevPool& P = e->pool;
   auto fail = [&](int rc) { e->pool.free_all(); delete e; return rc; };
-  if (c.precision != 0 && c.precision != 1) { delete e; ETD_FAIL(ETD_EINVAL, "extractor_create: precision must be 0 (bf16) or 1 (fp32 parity mode)"); }
+  if (c.precision != 0 && c.precision != 1) { delete e; ETD_FAIL(ETD_EINVAL, "extractor_create: precision must be 0 (e16) or 1 (fp32 parity mode)"); }
   if (c.precision == 1) {
     const int rc = ext32_create(c, L.t, &e->f32);
     if (rc) return fail(rc);
@@ -247,8 +256,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
       double wsum = 0;
       for (int t = 0; t < 65; ++t) {
         Wf[o * 80 + t] = (float)fold[t];
-        uint16_t q = f2bf((float)fold[t]); uint32_t u = (uint32_t)q << 16; float wq; memcpy(&wq, &u, 4);
-        wsum += wq;                                 // the kernel multiplies by the bf16-rounded weight
+        wsum += e2f(f2bf((float)fold[t]));                                // the kernel multiplies by the e16-rounded weight
       }
       bf[o] = (float)(bacc + (double)center * wsum);  // x = (x - center) + center
     }
@@ -390,11 +398,11 @@ bool frag_attn() { static const bool on = !getenv("ETD_NO_FRAG_ATTN") && !getenv
 // two-launch sequence stays the default
 bool fused_post() { static const bool on = getenv("ETD_POST_ATTN") && atoi(getenv("ETD_POST_ATTN")) != 0 && !getenv("ETD_NO_FUSED_PROJ") && !getenv("ETD_NO_FUSED_FFN"); return on; }
 
-ProjBlock pblock(const bf16* Wf, const float* bias, int kind, bf16* dst, int ldd, int relu = 0) {
+ProjBlock pblock(const e16* Wf, const float* bias, int kind, e16* dst, int ldd, int relu = 0) {
   ProjBlock b = {}; b.Wf = Wf; b.bias = bias; b.kind = kind; b.relu = relu; b.dst = dst; b.ldd = ldd; return b;
 }
 // Q | K row-major into QK[tok][512], V transposed into VT: ONE launch, the token tile is read once
-int proj_qkv(const bf16* X, int M, const bf16* pq, const bf16* pk, const bf16* pv, const float* bias768, bf16* QK, bf16* VT, int S, int Spad, hipStream_t st) {
+int proj_qkv(const e16* X, int M, const e16* pq, const e16* pk, const e16* pv, const float* bias768, e16* QK, e16* VT, int S, int Spad, hipStream_t st) {
   ProjArgs a = {};
   a.X = X; a.ldx = 256; a.M = M; a.nblk = 3; a.S = S; a.Spad = Spad;
   a.blk[0] = pblock(pq, bias768, PROJ_ROW, QK, 512);
@@ -403,15 +411,15 @@ int proj_qkv(const bf16* X, int M, const bf16* pq, const bf16* pk, const bf16* p
   return launch_proj256(a, st);
 }
 // Y = LN(R + X Wo^T + b) * gamma + beta
-int proj_ln(const bf16* X, int M, const bf16* po, const float* bias, const bf16* R, int r_mod, const float* g, const float* be, bf16* Y, hipStream_t st) {
+int proj_ln(const e16* X, int M, const e16* po, const float* bias, const e16* R, int r_mod, const float* g, const float* be, e16* Y, hipStream_t st) {
   ProjArgs a = {};
   a.X = X; a.ldx = 256; a.M = M; a.nblk = 1; a.R = R; a.r_mod = r_mod; a.gamma = g; a.beta = be;
   a.blk[0] = pblock(po, bias, PROJ_LN, Y, 256);
   return launch_proj256(a, st);
 }
 
-int enc_like_layer(etd_ext* e, const EncLayerW& w, bf16* X, bf16* X1, int M, int n_seq, int S, hipStream_t st,
-                   bf16* Yfinal /* where the 2nd LN writes (X to run in place) */) {
+int enc_like_layer(etd_ext* e, const EncLayerW& w, e16* X, e16* X1, int M, int n_seq, int S, hipStream_t st,
+                   e16* Yfinal /* where the 2nd LN writes (X to run in place) */) {
   // x = LN(x + MHA(x)); x = LN(x + FFN(x))          amt_apc.py:244-259
   LinArgs a = {};
   a.X = X; a.ldx = 256; a.W = w.qkv.W; a.bias = w.qkv.b; a.M = M; a.N = 768; a.K = 256;
@@ -522,10 +530,10 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
     }
     // ---- frequency decoder (amt_apc.py:168-177,261-320): queries = 88 note embeddings per frame
     // D0 = layer input/output, D1 = after self-attention LN, D2 = after cross-attention LN
-    bf16 *D0 = e->Tq, *D1 = e->T1, *D2 = e->Tfreq;
+    e16 *D0 = e->Tq, *D1 = e->T1, *D2 = e->Tfreq;
     for (int l = 0; l < 3; ++l) {
       const DecLayerW& w = e->dec[l];
-      const bf16* cross_in = D0;        // residual + query source of the cross-attention block
+      const e16* cross_in = D0;        // residual + query source of the cross-attention block
       int r_mod = 0;
       if (l == 0) { cross_in = e->trg0; r_mod = nn; }
       if (w.has_self) {

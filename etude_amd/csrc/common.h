@@ -9,6 +9,10 @@ typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef _Float16 f16;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -46,6 +50,9 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   // D[row (i&3)+8*(i>>2)+4*(l>>5)][col l&31] in register i.
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {      // v_mfma_f32_32x32x16_f16: the same layout and rate, 11 significant bits per operand instead of 8
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ int acc_row(int i, int half) { return (i & 3) + 8 * (i >> 2) + 4 * half; }
 
 __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
@@ -53,6 +60,11 @@ __device__ __forceinline__ bf16x4 pack4(float a, float b, float c, float d) {
   return r;
 }
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
+__device__ __forceinline__ float bf2f(f16 x) { return (float)x; }
+__device__ __forceinline__ f16x4 pack4h(float a, float b, float c, float d) {
+  f16x4 r = {(f16)a, (f16)b, (f16)c, (f16)d};
+  return r;
+}
 
 // ---- cross-lane exchange without the LDS crossbar.  lane_xor<O>(v) is the value lane (id ^ O) holds -- what
 // __shfl_xor(v, O, 64) returns, but hipcc lowers that to ds_bpermute_b32 (an LDS-pipe round trip, ~100 clk of latency per

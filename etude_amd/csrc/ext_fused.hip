@@ -22,7 +22,7 @@
 #include "ext_kernels.h"
 #include "prof.h"
 
-#define FFN_SLOT_ELEMS (16 * 1024)      // bf16 elements per ring slot: 32 fragments of 512 elements (1 KiB)
+#define FFN_SLOT_ELEMS (16 * 1024)      // e16 elements per ring slot: 32 fragments of 512 elements (1 KiB)
 #define FFN_NSUB 16                     // 512 hidden features / 32
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -30,7 +30,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __global__ __launch_bounds__(256, 2) void k_ffn_fused(FfnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FFN_SLOT_ELEMS * 2 + (512 + 3 * 256) * 4];
-  bf16* ring = reinterpret_cast<bf16*>(smem);
+  e16* ring = reinterpret_cast<e16*>(smem);
   float* sb1 = reinterpret_cast<float*>(smem + 2 * FFN_SLOT_ELEMS * 2);      // b1[512] | b2[256] | gamma[256] | beta[256]
   float* sb2 = sb1 + 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
@@ -39,19 +39,19 @@ __global__ __launch_bounds__(256, 2) void k_ffn_fused(FfnArgs a) {
 
   // ---- ring slot `sl` <- the 32 KiB of sub-chunk `sc`: 32 one-KiB pieces, 8 per wave
   auto issue = [&](int sc, int sl) {
-    const bf16* src = a.Wf + (long long)sc * FFN_SLOT_ELEMS + wave * (8 * 512) + lane * 8;
-    bf16* dst = ring + sl * FFN_SLOT_ELEMS + wave * (8 * 512);
+    const e16* src = a.Wf + (long long)sc * FFN_SLOT_ELEMS + wave * (8 * 512) + lane * 8;
+    e16* dst = ring + sl * FFN_SLOT_ELEMS + wave * (8 * 512);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
   };
   issue(0, 0);
   // the token tile as B fragments: lane (token r, half h) holds X[token][16 s + 8 h .. + 8] for s = 0 .. 15
-  bf16x8 xf[16];
+  e16x8 xf[16];
   {
-    const bf16* xp = a.X + (long long)mc * 256 + 8 * h;
+    const e16* xp = a.X + (long long)mc * 256 + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const e16x8*>(xp + 16 * s);
   }
   for (int i = tid; i < 512; i += 256) sb1[i] = a.b1[i];
   sb2[tid] = a.b2[tid]; sb2[256 + tid] = a.gamma[tid]; sb2[512 + tid] = a.beta[tid];
@@ -66,42 +66,42 @@ __global__ __launch_bounds__(256, 2) void k_ffn_fused(FfnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's pieces of slot sc & 1 have landed ...
     __syncthreads();                                          // ... and everybody's; every wave is done reading the other slot
     if (sc + 1 < FFN_NSUB) issue(sc + 1, (sc + 1) & 1);
-    const bf16* sl = ring + (sc & 1) * FFN_SLOT_ELEMS + lane * 8;
+    const e16* sl = ring + (sc & 1) * FFN_SLOT_ELEMS + lane * 8;
     // hidden features 32 sc .. + 32 of the wave's 32 tokens
     f32x16 acc1;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
     // (fragments are requested four at a time, one group ahead of the MFMAs that use them: left alone, hipcc hoists all 32 reads of
     // a sub-chunk to the top and spills; the other workgroup's wave on this SIMD covers the LDS latency of a group)
-    bf16x8 af[2][4];
+    e16x8 af[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const e16x8*>(sl + k * 512);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       if (g < 3) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) af[(g + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((g + 1) * 4 + k) * 512);
+        for (int k = 0; k < 4; ++k) af[(g + 1) & 1][k] = *reinterpret_cast<const e16x8*>(sl + ((g + 1) * 4 + k) * 512);
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + k) * 512);      // first four W2 fragments (ks 0, tiles 0..3)
+        for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const e16x8*>(sl + (16 + k) * 512);      // first four W2 fragments (ks 0, tiles 0..3)
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc1 = mfma32(af[g & 1][k], xf[g * 4 + k], acc1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    bf16x8 hf[2];
+    e16x8 hf[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + 32 * sc + 8 * q + 4 * h);       // register 4 q + j is hidden feature 32 sc + 8 q + 4 h + j
 #pragma unroll
-      for (int j = 0; j < 4; ++j) hf[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
+      for (int j = 0; j < 4; ++j) hf[q >> 1][4 * (q & 1) + j] = (e16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
     }
     // out[256] += W2[:, these 32 hidden features] . hidden   (two 16-deep k-steps, 8 output tiles)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {                              // group g = fragments 16 + 4 g .. + 4: k-step g >> 1, tiles 4 (g & 1) .. + 4
       if (g < 3) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) af[(g + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + (g + 1) * 4 + k) * 512);
+        for (int k = 0; k < 4; ++k) af[(g + 1) & 1][k] = *reinterpret_cast<const e16x8*>(sl + (16 + (g + 1) * 4 + k) * 512);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc2[4 * (g & 1) + k] = mfma32(af[g & 1][k], hf[g >> 1], acc2[4 * (g & 1) + k]);
@@ -135,20 +135,20 @@ __global__ __launch_bounds__(256, 2) void k_ffn_fused(FfnArgs a) {
     for (int i = 0; i < 16; ++i) { const float d = acc2[t][i] - mean; s2 += d * d; }
   s2 += xhalf(s2);
   const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);
-  bf16* yp = a.Y + (long long)m * 256 + 8 * h;
+  e16* yp = a.Y + (long long)m * 256 + 8 * h;
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      bf16x8 o;
+      e16x8 o;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int f0 = 32 * t + 16 * u + 8 * h + 4 * q;
         const f32x4 gg = *reinterpret_cast<const f32x4*>(sb2 + 256 + f0), be = *reinterpret_cast<const f32x4*>(sb2 + 512 + f0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[4 * q + j] = (bf16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);
+        for (int j = 0; j < 4; ++j) o[4 * q + j] = (e16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);
       }
-      if (m < a.M) *reinterpret_cast<bf16x8*>(yp + 16 * (2 * t + u)) = o;
+      if (m < a.M) *reinterpret_cast<e16x8*>(yp + 16 * (2 * t + u)) = o;
     }
 }
 
@@ -162,7 +162,7 @@ int launch_ffn_fused(const FfnArgs& a, hipStream_t st) {
   return ETD_OK;
 }
 
-// Host side: fc_1 [512][256] and fc_2 [256][512] (fp32, nn.Linear layout) -> the kernel's weight stream, bf16:
+// Host side: fc_1 [512][256] and fc_2 [256][512] (fp32, nn.Linear layout) -> the kernel's weight stream, e16:
 // [sub-chunk sc of 32 hidden features][32 fragments][lane 64][8]; fragments 0..15 = W1 (k-step s), 16..31 = W2 (k-step ks, tile t).
 void pack_ffn_weights(const float* W1, const float* W2, uint16_t* dst, uint16_t (*f2bf)(float)) {
   for (int sc = 0; sc < FFN_NSUB; ++sc)
@@ -200,8 +200,8 @@ void pack_ffn_weights(const float* W1, const float* W2, uint16_t* dst, uint16_t 
 // ================================================================================================
 // one 256-feature block for the wave's 32 tokens; the ring keeps running across blocks (chunk g + 1 may belong to the next block)
 template <int KIND>
-__device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb, const ProjBlock* sblk, const int b, const int nchunk, bf16* ring,
-                                           const bf16x8 (&xf)[16], const int wave, const int lane, const int m0w, float* sbias) {
+__device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb, const ProjBlock* sblk, const int b, const int nchunk, e16* ring,
+                                           const e16x8 (&xf)[16], const int wave, const int lane, const int m0w, float* sbias) {
   const int r = lane & 31, h = lane >> 5, m = m0w + r;
   const int mc = m < a.M ? m : a.M - 1;
   // this block's bias (and the LayerNorm parameters) go to LDS now; the K loop's barriers publish them long before the epilogue
@@ -219,23 +219,23 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (g + 1 < nchunk) {
-      const bf16* src = sblk[(g + 1) >> 2].Wf + (long long)((g + 1) & 3) * FFN_SLOT_ELEMS + wave * (8 * 512) + lane * 8;
-      bf16* dst = ring + ((g + 1) & 1) * FFN_SLOT_ELEMS + wave * (8 * 512);
+      const e16* src = sblk[(g + 1) >> 2].Wf + (long long)((g + 1) & 3) * FFN_SLOT_ELEMS + wave * (8 * 512) + lane * 8;
+      e16* dst = ring + ((g + 1) & 1) * FFN_SLOT_ELEMS + wave * (8 * 512);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
     }
-    const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
-    bf16x8 af[2][4];
+    const e16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+    e16x8 af[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const e16x8*>(sl + k * 512);
 #pragma unroll
     for (int gq = 0; gq < 8; ++gq) {                   // group gq = fragments 4 gq .. + 4: k-step gq >> 1, tiles 4 (gq & 1) .. + 4
       if (gq < 7) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const e16x8*>(sl + ((gq + 1) * 4 + k) * 512);
       }
-      const bf16x8 xb = xf[4 * c + (gq >> 1)];
+      const e16x8 xb = xf[4 * c + (gq >> 1)];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if constexpr (KIND == PROJ_VT || KIND == PROJ_VFRAG) acc[4 * (gq & 1) + k] = mfma32(xb, af[gq & 1][k], acc[4 * (gq & 1) + k]);
@@ -255,23 +255,23 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
     if (m0w < a.M) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        bf16* img = pb.dst + ((long long)(seq * 4 + (t >> 1)) * a.kv_nstep + step) * 8192 + lane * 8;
+        e16* img = pb.dst + ((long long)(seq * 4 + (t >> 1)) * a.kv_nstep + step) * 8192 + lane * 8;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          bf16x8 fr;
+          e16x8 fr;
           if constexpr (KIND == PROJ_KFRAG) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
               const f32x4 bb = *reinterpret_cast<const f32x4*>(sbias + 32 * t + 16 * u + 8 * h + 4 * q);
 #pragma unroll
-              for (int j = 0; j < 4; ++j) fr[4 * q + j] = (bf16)(acc[t][8 * u + 4 * q + j] + bb[j]);
+              for (int j = 0; j < 4; ++j) fr[4 * q + j] = (e16)(acc[t][8 * u + 4 * q + j] + bb[j]);
             }
-            *reinterpret_cast<bf16x8*>(img + (kt2 * 4 + 2 * (t & 1) + u) * 512) = fr;
+            *reinterpret_cast<e16x8*>(img + (kt2 * 4 + 2 * (t & 1) + u) * 512) = fr;
           } else {
             const float bv = sbias[32 * t + r];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fr[j] = (bf16)(acc[t][8 * u + j] + bv);
-            *reinterpret_cast<bf16x8*>(img + 4096 + ((kt2 * 2 + u) * 2 + (t & 1)) * 512) = fr;
+            for (int j = 0; j < 8; ++j) fr[j] = (e16)(acc[t][8 * u + j] + bv);
+            *reinterpret_cast<e16x8*>(img + 4096 + ((kt2 * 2 + u) * 2 + (t & 1)) * 512) = fr;
           }
         }
       }
@@ -295,12 +295,12 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
     for (int t = 0; t < 8; ++t) {
       const int f = 32 * t + r;
       const float bv = sbias[f];
-      bf16* row = pb.dst + ((long long)(seq * 4 + (f >> 6)) * 64 + (f & 63)) * a.Spad;
+      e16* row = pb.dst + ((long long)(seq * 4 + (f >> 6)) * 64 + (f & 63)) * a.Spad;
       if (vec) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-          const bf16x4 lo = pack4(acc[t][8 * p] + bv, acc[t][8 * p + 1] + bv, acc[t][8 * p + 2] + bv, acc[t][8 * p + 3] + bv);          // token group q = 2 p
-          const bf16x4 hi = pack4(acc[t][8 * p + 4] + bv, acc[t][8 * p + 5] + bv, acc[t][8 * p + 6] + bv, acc[t][8 * p + 7] + bv);      // q = 2 p + 1
+          const e16x4 lo = pack4e(acc[t][8 * p] + bv, acc[t][8 * p + 1] + bv, acc[t][8 * p + 2] + bv, acc[t][8 * p + 3] + bv);          // token group q = 2 p
+          const e16x4 hi = pack4e(acc[t][8 * p + 4] + bv, acc[t][8 * p + 5] + bv, acc[t][8 * p + 6] + bv, acc[t][8 * p + 7] + bv);      // q = 2 p + 1
           const u32x2 la = __builtin_bit_cast(u32x2, lo), lb = __builtin_bit_cast(u32x2, hi);
           // lower half keeps its q = 2 p group and takes the upper half's; the upper half takes the lower's q = 2 p + 1 and keeps its own
           const auto s0 = __builtin_amdgcn_permlane32_swap(la[0], lb[0], false, false);
@@ -309,10 +309,10 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
           *reinterpret_cast<u32x4*>(row + pos0 + 16 * p + 8 * h) = o;
         }
       } else if (quad) {
-        bf16* base = pb.dst + ((long long)(f >> 6) * 64 + (f & 63)) * a.Spad;
+        e16* base = pb.dst + ((long long)(f >> 6) * 64 + (f & 63)) * a.Spad;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<bf16x4*>(base + qoff[q]) = pack4(acc[t][4 * q] + bv, acc[t][4 * q + 1] + bv, acc[t][4 * q + 2] + bv, acc[t][4 * q + 3] + bv);
+          *reinterpret_cast<e16x4*>(base + qoff[q]) = pack4e(acc[t][4 * q] + bv, acc[t][4 * q + 1] + bv, acc[t][4 * q + 2] + bv, acc[t][4 * q + 3] + bv);
       } else {
         // (any other sequence length, or the ragged last tile)
         float vals[16];
@@ -328,35 +328,35 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
               float v = vals[0];
 #pragma unroll
               for (int i = 1; i < 16; ++i) v = (i == 4 * q + j) ? vals[i] : v;
-              pb.dst[((long long)(sq * 4 + (f >> 6)) * 64 + (f & 63)) * a.Spad + ps] = (bf16)v;
+              pb.dst[((long long)(sq * 4 + (f >> 6)) * 64 + (f & 63)) * a.Spad + ps] = (e16)v;
             }
           }
       }
     }
   } else if constexpr (KIND == PROJ_ROW) {
-    bf16* yp = pb.dst + (long long)m * pb.ldd + 8 * h;
+    e16* yp = pb.dst + (long long)m * pb.ldd + 8 * h;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        bf16x8 o;
+        e16x8 o;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const f32x4 bb = *reinterpret_cast<const f32x4*>(sbias + 32 * t + 16 * u + 8 * h + 4 * q);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { float v = acc[t][8 * u + 4 * q + j] + bb[j]; if (pb.relu) v = fmaxf(v, 0.f); o[4 * q + j] = (bf16)v; }
+          for (int j = 0; j < 4; ++j) { float v = acc[t][8 * u + 4 * q + j] + bb[j]; if (pb.relu) v = fmaxf(v, 0.f); o[4 * q + j] = (e16)v; }
         }
-        if (m < a.M) *reinterpret_cast<bf16x8*>(yp + 16 * (2 * t + u)) = o;
+        if (m < a.M) *reinterpret_cast<e16x8*>(yp + 16 * (2 * t + u)) = o;
       }
   } else {
     // LN: the residual row arrives in pieces of the accumulators' own layout
     const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
-    const bf16* rp = a.R + (long long)rrow * 256 + 8 * h;
+    const e16* rp = a.R + (long long)rrow * 256 + 8 * h;
     // (an LN block is the last block of its launch -- launch_proj256 checks -- so the X fragments are dead and the residual's 16
     // fragments take their registers: one round trip for the whole row)
-    bf16x8 rf[16];
+    e16x8 rf[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) rf[s] = *reinterpret_cast<const bf16x8*>(rp + 16 * s);
+    for (int s = 0; s < 16; ++s) rf[s] = *reinterpret_cast<const e16x8*>(rp + 16 * s);
     float s1 = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -382,20 +382,20 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
       for (int i = 0; i < 16; ++i) { const float d = acc[t][i] - mean; s2 += d * d; }
     s2 += xhalf(s2);
     const float rstd = rsqrtf(s2 * (1.f / 256.f) + 1e-5f);
-    bf16* yp = pb.dst + (long long)m * pb.ldd + 8 * h;
+    e16* yp = pb.dst + (long long)m * pb.ldd + 8 * h;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        bf16x8 o;
+        e16x8 o;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int f0 = 32 * t + 16 * u + 8 * h + 4 * q;
           const f32x4 gg = *reinterpret_cast<const f32x4*>(sbias + 256 + f0), be = *reinterpret_cast<const f32x4*>(sbias + 512 + f0);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[4 * q + j] = (bf16)((acc[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);
+          for (int j = 0; j < 4; ++j) o[4 * q + j] = (e16)((acc[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);
         }
-        if (m < a.M) *reinterpret_cast<bf16x8*>(yp + 16 * (2 * t + u)) = o;
+        if (m < a.M) *reinterpret_cast<e16x8*>(yp + 16 * (2 * t + u)) = o;
       }
   }
 }
@@ -403,7 +403,7 @@ __device__ __forceinline__ void proj_block(const ProjArgs& a, const ProjBlock pb
 template <bool LNK>      // LNK: the launch is ONE LayerNorm block (its own instantiation: the X fragments die with the K loop)
 __global__ __launch_bounds__(256, 2) void k_proj256(ProjArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FFN_SLOT_ELEMS * 2 + 2 * 768 * 4 + PROJ_MAX_BLOCKS * sizeof(ProjBlock)];
-  bf16* ring = reinterpret_cast<bf16*>(smem);
+  e16* ring = reinterpret_cast<e16*>(smem);
   float* sbias = reinterpret_cast<float*>(smem + 2 * FFN_SLOT_ELEMS * 2);             // bias (| gamma | beta), two copies alternating by block
   ProjBlock* sblk = reinterpret_cast<ProjBlock*>(smem + 2 * FFN_SLOT_ELEMS * 2 + 2 * 768 * 4);      // the block list, indexable at run time (a by-value kernel argument is not)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5;
@@ -415,17 +415,17 @@ __global__ __launch_bounds__(256, 2) void k_proj256(ProjArgs a) {
     for (int i = 0; i < PROJ_MAX_BLOCKS; ++i) sblk[i] = a.blk[i];
   }
   {
-    const bf16* src = a.blk[0].Wf + wave * (8 * 512) + lane * 8;
-    bf16* dst = ring + wave * (8 * 512);
+    const e16* src = a.blk[0].Wf + wave * (8 * 512) + lane * 8;
+    e16* dst = ring + wave * (8 * 512);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
   }
-  bf16x8 xf[16];
+  e16x8 xf[16];
   {
-    const bf16* xp = a.X + (long long)mc * a.ldx + 8 * h;
+    const e16* xp = a.X + (long long)mc * a.ldx + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const e16x8*>(xp + 16 * s);
   }
   __syncthreads();                                       // sblk visible
   if constexpr (LNK) {
@@ -513,15 +513,15 @@ void pack_proj_weights(const float* W, bool permute_rows, uint16_t* dst, uint16_
 // plain pointers, hipcc folds every image's constant base (80 .. 147 KiB) into each access's constant part, finds it does not fit and keeps ONE address register per
 // distinct access -- with the head loop unrolled that was ~100 live address registers, the source of the kernel's 91 spills and of accumulator copies between MFMAs
 // (LABNOTES round 4).  The bases below pass through an empty asm, so each access is `ds_read_b128 v, base offset:imm`.
-typedef __attribute__((address_space(3))) const bf16x8* enc_lds_cp;
-typedef __attribute__((address_space(3))) bf16x8* enc_lds_p;
+typedef __attribute__((address_space(3))) const e16x8* enc_lds_cp;
+typedef __attribute__((address_space(3))) e16x8* enc_lds_p;
 #define ENC_RD8(base, off) (*(enc_lds_cp)(uintptr_t)((base) + (unsigned)(off)))
 #define ENC_WR8(base, off) (*(enc_lds_p)(uintptr_t)((base) + (unsigned)(off)))
 __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[ENC_LDS_BYTES];
-  bf16* ring = reinterpret_cast<bf16*>(smem + ENC_LDS_RING);
-  bf16* Kimg = reinterpret_cast<bf16*>(smem + ENC_LDS_K);        // [key tile 8][k-step 4][lane 64][8]
-  bf16* Vimg = reinterpret_cast<bf16*>(smem + ENC_LDS_V);        // [key tile 8][ks 2][dt 2][lane 64][8]
+  e16* ring = reinterpret_cast<e16*>(smem + ENC_LDS_RING);
+  e16* Kimg = reinterpret_cast<e16*>(smem + ENC_LDS_K);        // [key tile 8][k-step 4][lane 64][8]
+  e16* Vimg = reinterpret_cast<e16*>(smem + ENC_LDS_V);        // [key tile 8][ks 2][dt 2][lane 64][8]
   float* sbqkv = reinterpret_cast<float*>(smem + ENC_LDS_PAR);   // bqkv[768] | bo[256] | gamma[256] | beta[256] | b1[512] | b2[256]
   float* sbo = sbqkv + 768; float* sg = sbo + 256; float* sbe = sg + 256; float* sb1 = sbe + 256; float* sb2 = sb1 + 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
@@ -534,8 +534,8 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   asm volatile("" : "+v"(ringA), "+v"(ringB), "+v"(kimg_l), "+v"(vimg_l), "+v"(kimg_w), "+v"(vimg_w));
 #define ENC_SLOT(hc) (((hc) % ENC_NSLOT) == 4 ? ringB : ringA + ((hc) % ENC_NSLOT) * (ENC_HC_ELEMS * 2))
   auto issue = [&](int hc) {                             // half-chunk hc -> slot hc % 5: 16 one-KiB pieces, 2 per wave
-    const bf16* src = a.Wl + (long long)hc * ENC_HC_ELEMS + wave * (2 * 512) + lane * 8;
-    bf16* dst = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + wave * (2 * 512);
+    const e16* src = a.Wl + (long long)hc * ENC_HC_ELEMS + wave * (2 * 512) + lane * 8;
+    e16* dst = ring + (hc % ENC_NSLOT) * ENC_HC_ELEMS + wave * (2 * 512);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
@@ -557,11 +557,11 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   // 16 fragments of a half-chunk against B (or A) operands, four at a time, one group requested ahead of the MFMAs that use it
 #define ENC_HALF(sl, BODY)                                                                                             \
   {                                                                                                                    \
-    bf16x8 af[2][4];                                                                                                   \
+    e16x8 af[2][4];                                                                                                   \
     _Pragma("unroll") for (int k = 0; k < 4; ++k) af[0][k] = ENC_RD8(sl, k * 1024);                                   \
     _Pragma("unroll") for (int gq = 0; gq < 4; ++gq) {                                                                 \
       if (gq < 3) { _Pragma("unroll") for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = ENC_RD8(sl, ((gq + 1) * 4 + k) * 1024); }   \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k) { const bf16x8 fa = af[gq & 1][k]; BODY }                          \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) { const e16x8 fa = af[gq & 1][k]; BODY }                          \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                  \
   }
@@ -570,11 +570,11 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   // 4-fragment buffers -- with them hipcc parked 91 registers of the LayerNorm'ed tile in scratch once per sequence; the partner wave of the SIMD hides the shorter lead)
 #define ENC_HALF2(sl, BODY)                                                                                            \
   {                                                                                                                    \
-    bf16x8 af[2][2];                                                                                                   \
+    e16x8 af[2][2];                                                                                                   \
     _Pragma("unroll") for (int k = 0; k < 2; ++k) af[0][k] = ENC_RD8(sl, k * 1024);                                   \
     _Pragma("unroll") for (int g2 = 0; g2 < 8; ++g2) {                                                                 \
       if (g2 < 7) { _Pragma("unroll") for (int k = 0; k < 2; ++k) af[(g2 + 1) & 1][k] = ENC_RD8(sl, ((g2 + 1) * 2 + k) * 1024); }   \
-      _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) { const bf16x8 fa = af[g2 & 1][k2]; const int gq = g2 >> 1, k = 2 * (g2 & 1) + k2; (void)gq; (void)k; BODY }   \
+      _Pragma("unroll") for (int k2 = 0; k2 < 2; ++k2) { const e16x8 fa = af[g2 & 1][k2]; const int gq = g2 >> 1, k = 2 * (g2 & 1) + k2; (void)gq; (void)k; BODY }   \
       __builtin_amdgcn_sched_barrier(0);                                                                               \
     }                                                                                                                  \
   }
@@ -586,19 +586,19 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
   sb1[tid] = a.b1[tid];
 
   const float qscale = 0.125f * 1.4426950408889634f;     // 1 / sqrt(64) and the base-2 exponent, folded into Q
-  bf16x8 ofr[16];                                         // the four heads' normalised outputs as B fragments (k-step 4 head + ks)
+  e16x8 ofr[16];                                         // the four heads' normalised outputs as B fragments (k-step 4 head + ks)
   // ---- the wave's 32 tokens as B / A fragments, loaded ONCE and held through the four heads and the residual (rounds 2-3 re-read them per head -- 80 fragment-shaped
   // loads per wave, 32 rows x 32 bytes per instruction -- to save 64 registers during the attention; since the LDS accesses stopped costing ~100 address registers
   // (ENC_RD8 / ENC_WR8) there is room)
-  bf16x8 xf[16];
+  e16x8 xf[16];
   {
-    const bf16* xp = a.X + row * 256 + 8 * h;
+    const e16* xp = a.X + row * 256 + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const e16x8*>(xp + 16 * s);
   }
 #pragma unroll
   for (int hd = 0; hd < 4; ++hd) {
-    bf16x8 qf[4];
+    e16x8 qf[4];
     // ---- Q (part 0), K (part 1): token on the lane; V (part 2): feature on the lane.  A part = two half-chunks (k-steps 0..7, 8..15)
 #pragma unroll
     for (int part = 0; part < 3; ++part) {
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       if (part < 2) {
         // accumulator (tile dt, register i) of lane half h = feature 32 dt + 16 (i >> 3) + 8 h + (i & 7) of this head's 64:
         // fragment s = 2 dt + (i >> 3), element i & 7
-        bf16x8 fr[4];
+        e16x8 fr[4];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
               for (int j = 0; j < 4; ++j) {
                 float v = acc[dt][8 * u + 4 * q + j] + bb[j];
                 if (part == 0) v *= qscale;
-                fr[2 * dt + u][4 * q + j] = (bf16)v;
+                fr[2 * dt + u][4 * q + j] = (e16)v;
               }
             }
         if (part == 0) {
@@ -648,9 +648,9 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
           const float bv = sbqkv[512 + hd * 64 + 32 * dt + r];
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 fr;
+            e16x8 fr;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) fr[j] = (bf16)(acc[dt][8 * ks + j] + bv);
+            for (int j = 0; j < 8; ++j) fr[j] = (e16)(acc[dt][8 * ks + j] + bv);
             ENC_WR8(vimg_w, (ks * 2 + dt) * 1024) = fr;
           }
         }
@@ -700,9 +700,9 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 pf;
+          e16x8 pf;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[kt][8 * ks + j];
+          for (int j = 0; j < 8; ++j) pf[j] = (e16)sT[kt][8 * ks + j];
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
             o[dt] = mfma32(ENC_RD8(vimg_l, (((2 * kp + kt) * 2 + ks) * 2 + dt) * 1024), pf, o[dt]);
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ofr[4 * hd + 2 * dt + u][j] = (bf16)(o[dt][8 * u + j] * inv);
+        for (int j = 0; j < 8; ++j) ofr[4 * hd + 2 * dt + u][j] = (e16)(o[dt][8 * u + j] * inv);
   }
 
   // ---- fc_o over the four heads (half-chunks 24 .. 31: head hd = k-steps 4 hd .. + 4, two per half), bias + residual + LayerNorm
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       // fragment 4 gq + k of this half = k-step 2 hf2 + (gq >> 1) of the head, tile 4 (gq & 1) + k
       ENC_HALF2(sl, acc2[4 * (gq & 1) + k] = mfma32(fa, ofr[4 * hd + 2 * hf2 + (gq >> 1)], acc2[4 * (gq & 1) + k]);)
     }
-  // LayerNorm of (acc2 + bias + resid) -> xf (bf16 fragments); statistics in fp32.
+  // LayerNorm of (acc2 + bias + resid) -> xf (e16 fragments); statistics in fp32.
   // (The parameter vectors sit at the BOTTOM of this kernel's LDS: a ds_read reaches 64 KiB from its base register with its offset field.  In rounds 2-3 they sat
   // above the ring and the K / V images, at 0x24000: hipcc then materialised all 96 read addresses (0x25000 | lane part ...) in registers, kept them for the second
   // LayerNorm behind the feed-forward block and spilled them there -- the kernel's 91 spilled registers were addresses.)
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
       _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {                          \
         const int f0 = lnoff + 32 * t + 16 * u + 4 * q;                                                                      \
         const f32x4 gg = *reinterpret_cast<const f32x4*>(lnp_g + f0), be = *reinterpret_cast<const f32x4*>(lnp_be + f0);    \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (bf16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (e16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
       }                                                                                                                      \
       asm volatile("" : "+v"(lnoff) : "v"(xf[2 * t + 1]));                                                                   \
     }                                                                                                                        \
@@ -784,21 +784,21 @@ __global__ __launch_bounds__(512, 2) void k_enc_layer(EncLayerArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
     ENC_HALF2(sl, acc1 = mfma32(fa, xf[gq * 4 + k], acc1);)
-    bf16x8 hfr[2];
+    e16x8 hfr[2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + 32 * sc + 8 * q + 4 * h);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) hfr[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
+      for (int j = 0; j < 4; ++j) hfr[q >> 1][4 * (q & 1) + j] = (e16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
     }
     ENC_TOP(hc + 1);
     const unsigned sl2 = ENC_SLOT(hc + 1);
     ENC_HALF2(sl2, acc2[4 * (gq & 1) + k] = mfma32(fa, hfr[gq >> 1], acc2[4 * (gq & 1) + k]);)
   }
   ENC_RESID_LN(lnp_b2)
-  bf16* yp = a.Y + row * 256 + 8 * h;
+  e16* yp = a.Y + row * 256 + 8 * h;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) *reinterpret_cast<bf16x8*>(yp + 16 * s) = xf[s];
+  for (int s = 0; s < 16; ++s) *reinterpret_cast<e16x8*>(yp + 16 * s) = xf[s];
 #undef ENC_RESID_LN
 #undef ENC_HALF
 #undef ENC_HALF2
@@ -856,7 +856,7 @@ void pack_enc_layer_weights(const float* Wq, const float* Wk, const float* Wv, c
 // ================================================================================================
 __global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * FFN_SLOT_ELEMS * 2 + (256 * 3 + 512 + 256) * 4];
-  bf16* ring = reinterpret_cast<bf16*>(smem);
+  e16* ring = reinterpret_cast<e16*>(smem);
   float* sbo = reinterpret_cast<float*>(smem + 2 * FFN_SLOT_ELEMS * 2);      // bo[256] | gamma[256] | beta[256] | b1[512] | b2[256]
   float* sg = sbo + 256; float* sbe = sg + 256; float* sb1 = sbe + 256; float* sb2 = sb1 + 512;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
@@ -864,20 +864,20 @@ __global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
   const int mc = m < a.M ? m : a.M - 1;
   const int nstep = a.Wffn ? 20 : 4;
   auto issue = [&](int st) {                             // steps 0..3: fc_o chunks, 4..19: feed-forward chunks; 8 pieces per wave
-    const bf16* base = st < 4 ? a.Wo + (long long)st * FFN_SLOT_ELEMS : a.Wffn + (long long)(st - 4) * FFN_SLOT_ELEMS;
-    const bf16* src = base + wave * (8 * 512) + lane * 8;
-    bf16* dst = ring + (st & 1) * FFN_SLOT_ELEMS + wave * (8 * 512);
+    const e16* base = st < 4 ? a.Wo + (long long)st * FFN_SLOT_ELEMS : a.Wffn + (long long)(st - 4) * FFN_SLOT_ELEMS;
+    const e16* src = base + wave * (8 * 512) + lane * 8;
+    e16* dst = ring + (st & 1) * FFN_SLOT_ELEMS + wave * (8 * 512);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
   };
 #define PA_TOP(g) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); if ((g) + 1 < nstep) issue((g) + 1); } while (0)
   issue(0);
-  bf16x8 xf[16];
+  e16x8 xf[16];
   {
-    const bf16* xp = a.AO + (long long)mc * 256 + 8 * h;
+    const e16* xp = a.AO + (long long)mc * 256 + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const e16x8*>(xp + 16 * s);
   }
   sbo[tid] = a.bo[tid]; sg[tid] = a.gamma[tid]; sbe[tid] = a.beta[tid];
   if (a.Wffn) { sb1[tid] = a.b1[tid]; sb1[256 + tid] = a.b1[256 + tid]; sb2[tid] = a.b2[tid]; }
@@ -889,15 +889,15 @@ __global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     PA_TOP(c);
-    const bf16* sl = ring + (c & 1) * FFN_SLOT_ELEMS + lane * 8;
-    bf16x8 af[2][4];
+    const e16* sl = ring + (c & 1) * FFN_SLOT_ELEMS + lane * 8;
+    e16x8 af[2][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+    for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const e16x8*>(sl + k * 512);
 #pragma unroll
     for (int gq = 0; gq < 8; ++gq) {                     // group gq: k-step 4 c + (gq >> 1), tiles 4 (gq & 1) .. + 4
       if (gq < 7) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+        for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const e16x8*>(sl + ((gq + 1) * 4 + k) * 512);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], xf[4 * c + (gq >> 1)], acc2[4 * (gq & 1) + k]);
@@ -906,9 +906,9 @@ __global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
   }
   {
     const int rrow = a.r_mod > 0 ? mc % a.r_mod : mc;
-    const bf16* rp = a.R + (long long)rrow * 256 + 8 * h;
+    const e16* rp = a.R + (long long)rrow * 256 + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(rp + 16 * s);       // residual
+    for (int s = 0; s < 16; ++s) xf[s] = *reinterpret_cast<const e16x8*>(rp + 16 * s);       // residual
   }
 #define PA_RESID_LN(BIAS)                                                                                                    \
   {                                                                                                                          \
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
     _Pragma("unroll") for (int t = 0; t < 8; ++t) _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int q = 0; q < 2; ++q) {   \
       const int f0 = 32 * t + 16 * u + 8 * h + 4 * q;                                                                        \
       const f32x4 gg = *reinterpret_cast<const f32x4*>(sg + f0), be = *reinterpret_cast<const f32x4*>(sbe + f0);            \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (bf16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[2 * t + u][4 * q + j] = (e16)((acc2[t][8 * u + 4 * q + j] - mean) * rstd * gg[j] + be[j]);   \
     }                                                                                                                        \
   }
   PA_RESID_LN(sbo)
@@ -941,38 +941,38 @@ __global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
     for (int sc = 0; sc < FFN_NSUB; ++sc) {
       const int g = 4 + sc;
       PA_TOP(g);
-      const bf16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
+      const e16* sl = ring + (g & 1) * FFN_SLOT_ELEMS + lane * 8;
       f32x16 acc1;
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc1[i] = 0.f;
-      bf16x8 af[2][4];
+      e16x8 af[2][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + k * 512);
+      for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const e16x8*>(sl + k * 512);
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         if (gq < 3) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + ((gq + 1) * 4 + k) * 512);
+          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const e16x8*>(sl + ((gq + 1) * 4 + k) * 512);
         } else {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + k) * 512);
+          for (int k = 0; k < 4; ++k) af[0][k] = *reinterpret_cast<const e16x8*>(sl + (16 + k) * 512);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc1 = mfma32(af[gq & 1][k], xf[gq * 4 + k], acc1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      bf16x8 hf[2];
+      e16x8 hf[2];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + 32 * sc + 8 * q + 4 * h);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) hf[q >> 1][4 * (q & 1) + j] = (bf16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
+        for (int j = 0; j < 4; ++j) hf[q >> 1][4 * (q & 1) + j] = (e16)fmaxf(acc1[4 * q + j] + bb[j], 0.f);
       }
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         if (gq < 3) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const bf16x8*>(sl + (16 + (gq + 1) * 4 + k) * 512);
+          for (int k = 0; k < 4; ++k) af[(gq + 1) & 1][k] = *reinterpret_cast<const e16x8*>(sl + (16 + (gq + 1) * 4 + k) * 512);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc2[4 * (gq & 1) + k] = mfma32(af[gq & 1][k], hf[gq >> 1], acc2[4 * (gq & 1) + k]);
@@ -982,9 +982,9 @@ __global__ __launch_bounds__(256, 2) void k_post_attn(PostAttnArgs a) {
     PA_RESID_LN(sb2)
   }
   if (m < a.M) {
-    bf16* yp = a.Y + (long long)m * 256 + 8 * h;
+    e16* yp = a.Y + (long long)m * 256 + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 16; ++s) *reinterpret_cast<bf16x8*>(yp + 16 * s) = xf[s];
+    for (int s = 0; s < 16; ++s) *reinterpret_cast<e16x8*>(yp + 16 * s) = xf[s];
   }
 #undef PA_RESID_LN
 #undef PA_TOP
@@ -1008,27 +1008,27 @@ int launch_post_attn(const PostAttnArgs& a, hipStream_t st) {
 // arithmetic in the loop.  The arithmetic is k_attn's (query on the lane, online softmax in fp32, P^T from the accumulator
 // registers).  Workgroup = 4 waves x 32 queries; three ring slots, two steps in flight.            amt_apc.py:349-368
 // ================================================================================================
-#define AF_SLOT_ELEMS 8192              // bf16 elements per ring slot (16 KiB)
+#define AF_SLOT_ELEMS 8192              // e16 elements per ring slot (16 KiB)
 __global__ __launch_bounds__(256) void k_attn_frag(AttnFragArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[3 * AF_SLOT_ELEMS * 2];
-  bf16* ring = reinterpret_cast<bf16*>(smem);
+  e16* ring = reinterpret_cast<e16*>(smem);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int seq = blockIdx.y >> 2, head = blockIdx.y & 3;
   const int q0 = blockIdx.x * 128 + wave * 32;
   int qi = q0 + r; const bool qvalid = qi < a.Sq; if (!qvalid) qi = a.Sq - 1;
   const int nstep = a.Sk >> 6;
-  const bf16* img = a.KV + (long long)(seq * 4 + head) * nstep * AF_SLOT_ELEMS;
+  const e16* img = a.KV + (long long)(seq * 4 + head) * nstep * AF_SLOT_ELEMS;
   auto issue = [&](int st) {                             // step st -> slot st % 3: 16 one-KiB pieces, 4 per wave
-    const bf16* src = img + (long long)st * AF_SLOT_ELEMS + wave * (4 * 512) + lane * 8;
-    bf16* dst = ring + (st % 3) * AF_SLOT_ELEMS + wave * (4 * 512);
+    const e16* src = img + (long long)st * AF_SLOT_ELEMS + wave * (4 * 512) + lane * 8;
+    e16* dst = ring + (st % 3) * AF_SLOT_ELEMS + wave * (4 * 512);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 512), (lptr_t)(dst + i * 512), 16, 0, 0);
   };
-  const bf16* qp = a.Q + seq * a.q_seq_stride + (long long)qi * a.ldq + head * 64;
-  bf16x8 qf[4];
+  const e16* qp = a.Q + seq * a.q_seq_stride + (long long)qi * a.ldq + head * 64;
+  e16x8 qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16 + h * 8);
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const e16x8*>(qp + s * 16 + h * 8);
   issue(0);
   if (nstep > 1) issue(1);
   f32x16 o[2];
@@ -1043,14 +1043,14 @@ __global__ __launch_bounds__(256) void k_attn_frag(AttnFragArgs a) {
     if (st + 1 < nstep) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (st + 2 < nstep) issue(st + 2);                   // into the slot of step st - 1, which every wave has left (it passed this barrier)
-    const bf16* sl = ring + (st % 3) * AF_SLOT_ELEMS + lane * 8;
+    const e16* sl = ring + (st % 3) * AF_SLOT_ELEMS + lane * 8;
     f32x16 sT[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) sT[kt][i] = 0.f;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) sT[kt] = mfma32(*reinterpret_cast<const bf16x8*>(sl + (kt * 4 + s) * 512), qf[s], sT[kt]);
+      for (int s = 0; s < 4; ++s) sT[kt] = mfma32(*reinterpret_cast<const e16x8*>(sl + (kt * 4 + s) * 512), qf[s], sT[kt]);
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -1076,24 +1076,24 @@ __global__ __launch_bounds__(256) void k_attn_frag(AttnFragArgs a) {
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 pf;
+        e16x8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[kt][8 * ks + j];
+        for (int j = 0; j < 8; ++j) pf[j] = (e16)sT[kt][8 * ks + j];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          o[dt] = mfma32(*reinterpret_cast<const bf16x8*>(sl + 4096 + ((kt * 2 + ks) * 2 + dt) * 512), pf, o[dt]);
+          o[dt] = mfma32(*reinterpret_cast<const e16x8*>(sl + 4096 + ((kt * 2 + ks) * 2 + dt) * 512), pf, o[dt]);
       }
   }
   lrun += xhalf(lrun);
   const float inv = 1.f / lrun;
   if (qvalid) {
-    bf16* op = a.O + seq * a.o_seq_stride + (long long)(q0 + r) * a.ldo + head * 64;
+    e16* op = a.O + seq * a.o_seq_stride + (long long)(q0 + r) * a.ldo + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int d = dt * 32 + 8 * q + 4 * h;
-        *reinterpret_cast<bf16x4*>(op + d) = pack4(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
+        *reinterpret_cast<e16x4*>(op + d) = pack4e(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
       }
   }
 }

@@ -1,4 +1,4 @@
-// hFT-Transformer (AMT-APC) kernels for gfx950: token-major bf16 activations, fp32 accumulate,
+// hFT-Transformer (AMT-APC) kernels for gfx950: token-major e16 activations, fp32 accumulate,
 // v_mfma_f32_32x32x16_bf16 everywhere.  Reference ops: etude/models/amt_apc.py (cited per kernel).
 //
 // Orientation convention ("swapped"): for Y = X W^T we issue mfma(A = W rows, B = X rows) so the
@@ -15,8 +15,8 @@
 #include <cstdio>
 #include <vector>
 
-#define LDK 72  // LDS row stride (elements) of a 64-wide bf16 K-chunk: 144 B, 16-B aligned, conflict-free ds_read_b128
-#define EPP 136 // epilogue staging row stride (bf16 elements; 68 floats): 272 B = 17 x 16 B keeps rows 16-byte aligned, 128 features + pad
+#define LDK 72  // LDS row stride (elements) of a 64-wide e16 K-chunk: 144 B, 16-B aligned, conflict-free ds_read_b128
+#define EPP 136 // epilogue staging row stride (e16 elements; 68 floats): 272 B = 17 x 16 B keeps rows 16-byte aligned, 128 features + pad
 
 // ================================================================================================
 // k_linear: Y = X W^T + b  (+ReLU | + residual + LayerNorm)       amt_apc.py:342-344,371,386-389,250,256
@@ -38,7 +38,7 @@ __device__ __forceinline__ void lin_gload_w8(rsrc_t ws, const int (&wo)[8], int 
 #pragma unroll
   for (int i = 0; i < 8; ++i) wr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, wo[i], kc * 128, 0));
 }
-__device__ __forceinline__ void lin_lstore_xw(bf16* Xs, bf16* Ws, int tid, const u32x4 (&xr)[4], const u32x4 (&wr)[8]) {
+__device__ __forceinline__ void lin_lstore_xw(e16* Xs, e16* Ws, int tid, const u32x4 (&xr)[4], const u32x4 (&wr)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + i * 256, row = c >> 3, ch = c & 7;
@@ -57,14 +57,14 @@ __device__ __forceinline__ void lin_lstore_xw(bf16* Xs, bf16* Ws, int tid, const
 // 2 X + 4 W fragments for 8 MFMAs (0.75 KB of LDS per MFMA; a 32 x 256 per-wave layout needs 1.125 KB and
 // measured 2 % slower).
 template <bool NORMAL_ORIENT>
-__device__ __forceinline__ void lin_chunk_lds(const bf16* Xs, const bf16* Ws, int wm, int wn, int r, int h, f32x16 (&acc)[2][4]) {
+__device__ __forceinline__ void lin_chunk_lds(const e16* Xs, const e16* Ws, int wm, int wn, int r, int h, f32x16 (&acc)[2][4]) {
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    bf16x8 xf[2], wf[4];
+    e16x8 xf[2], wf[4];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const bf16x8*>(Xs + (wm * 64 + mt * 32 + r) * LDK + s * 16 + h * 8);
+    for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const e16x8*>(Xs + (wm * 64 + mt * 32 + r) * LDK + s * 16 + h * 8);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const bf16x8*>(Ws + (wn * 128 + nt * 32 + r) * LDK + s * 16 + h * 8);
+    for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const e16x8*>(Ws + (wn * 128 + nt * 32 + r) * LDK + s * 16 + h * 8);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   constexpr bool vt = MODE == 1;
   constexpr bool DEC = MODE >= 10;
   __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 256) * LDK * 2 + 3 * 256 * 4];
-  bf16* Xs = reinterpret_cast<bf16*>(smem);
+  e16* Xs = reinterpret_cast<e16*>(smem);
   float* sb = reinterpret_cast<float*>(smem + (128 + 256) * LDK * 2);   // bias | gamma | beta
   float* lnred = reinterpret_cast<float*>(smem + 4 * 32 * EPP * 2);      // [2][128] after the K loop (LN mode), behind the epilogue staging tiles
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   const int mtile = (slot / a.nby) * 8 + xcd;
   if (mtile * 128 >= a.M) return;
   const int m0 = mtile * 128, nb = slot % a.nby + a.nb0, n0 = nb * 256, z = blockIdx.z;
-  const bf16* W = a.W + (long long)z * a.wz + (long long)n0 * a.K;
+  const e16* W = a.W + (long long)z * a.wz + (long long)n0 * a.K;
   const float* bias = a.bias + (long long)z * a.bz + n0;
   sb[tid] = bias[tid];
   if (LN) { sb[256 + tid] = a.gamma[tid]; sb[512 + tid] = a.beta[tid]; }
@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   const int lane16 = lane * 16;
   const int wblk0 = __builtin_amdgcn_readfirstlane(wn) * 4 * kblocks;        // this wave's first fragment block (its 4 n-tiles are kblocks apart)
   const int xo = ((tid >> 3) * a.ldx + (tid & 7) * 8) * 2, xr32 = 32 * a.ldx * 2;
-  bf16* Xs1 = Xs + 128 * LDK;
+  bf16* const Xd = reinterpret_cast<bf16*>(smem);        // (the decoder modes compute in bf16 whatever the extractor's element type is)
+  bf16* Xs1 = Xd + 128 * LDK;
   lin_gload_x(xs, xo, xr32, 0, xa);
 #pragma unroll
   for (int sx = 0; sx < 4; ++sx)
@@ -187,26 +188,26 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
     for (int nt = 0; nt < 4; ++nt) wf[sx][nt] = lin_wfrag(ws, lane16, wblk0 + nt * kblocks + sx);
   lin_gload_x(xs, xo, xr32, nk > 1 ? 1 : 0, xb);
   __builtin_amdgcn_sched_barrier(0);
-  lin_lstore_x(Xs, tid, xa);
+  lin_lstore_x(Xd, tid, xa);
   if (nk > 2) lin_gload_x(xs, xo, xr32, 2, xa);
   __syncthreads();
   LIN_STAMP(1);
   for (int kc = 0; kc < nk; kc += 2) {
-    lin_chunk<vt>(Xs, wm, r, h, acc, wf, ws, lane16, wblk0 + (kc + 1) * 4, kblocks, true);       // kc + 1 < nk always (nk even)
+    lin_chunk<vt>(Xd, wm, r, h, acc, wf, ws, lane16, wblk0 + (kc + 1) * 4, kblocks, true);       // kc + 1 < nk always (nk even)
     lin_lstore_x(Xs1, tid, xb);
     if (kc + 3 < nk) lin_gload_x(xs, xo, xr32, kc + 3, xb);
     __syncthreads();
     if (kc == 0) LIN_STAMP(2);
     lin_chunk<vt>(Xs1, wm, r, h, acc, wf, ws, lane16, wblk0 + (kc + 2) * 4, kblocks, kc + 2 < nk);
     if (kc + 2 < nk) {
-      lin_lstore_x(Xs, tid, xa);
+      lin_lstore_x(Xd, tid, xa);
       if (kc + 4 < nk) lin_gload_x(xs, xo, xr32, kc + 4, xa);
     }
     __syncthreads();
     if (kc == 0) { LIN_STAMP(3); LIN_STAMP(4); }
   }
   } else {
-    bf16* Ws = Xs + 128 * LDK;
+    e16* Ws = Xs + 128 * LDK;
   // K loop, 64-deep chunks through one LDS buffer.  The activation rows come from HBM / the Infinity Cache with ~2-3 us of
   // latency under load while a chunk's 32 MFMAs per wave take 0.4 us, so X is requested TWO chunks ahead (two register
   // sets, alternating); the weight chunk (L2-resident) one ahead, and before the X request of the same step so that the
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   // (measured at K = 256: 53 % of the kernel).  Instead every wave transposes its 32-token x 128-feature half tile through
   // a private LDS region (the K-loop buffers are free now) and reads / writes global memory in full row segments, 16 bytes
   // per lane: 4 rows x 256 B per instruction.
-  bf16* stg = reinterpret_cast<bf16*>(smem) + wave * (32 * EPP);
+  e16* stg = reinterpret_cast<e16*>(smem) + wave * (32 * EPP);
   float* stf = reinterpret_cast<float*>(smem) + wave * (32 * (EPP / 2));
   const int er = lane >> 4, ec = lane & 15;          // row-contiguous view: row = 4*it + er, 16-byte chunk ec
   const int mw = m0 + wm * 64, nw = n0 + wn * 128;   // first token / feature of this wave's tile
@@ -404,14 +405,14 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
           for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
-              *reinterpret_cast<bf16x4*>(stg + r * 72 + mt * 32 + 8 * q + 4 * h) =
-                  pack4(acc[mt][nt][4 * q] + b, acc[mt][nt][4 * q + 1] + b, acc[mt][nt][4 * q + 2] + b, acc[mt][nt][4 * q + 3] + b);
+              *reinterpret_cast<e16x4*>(stg + r * 72 + mt * 32 + 8 * q + 4 * h) =
+                  pack4e(acc[mt][nt][4 * q] + b, acc[mt][nt][4 * q + 1] + b, acc[mt][nt][4 * q + 2] + b, acc[mt][nt][4 * q + 3] + b);
           __syncthreads();
           if (mb < a.M) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
               const int row = it * 8 + (lane >> 3), ch = lane & 7, fr = wn * 128 + nt * 32 + row;
-              bf16* dst = a.VT + (long long)z * a.vtz + ((long long)(seq * 4 + (fr >> 6)) * 64 + (fr & 63)) * a.Spad + pos0 + ch * 8;
+              e16* dst = a.VT + (long long)z * a.vtz + ((long long)(seq * 4 + (fr >> 6)) * 64 + (fr & 63)) * a.Spad + pos0 + ch * 8;
               *reinterpret_cast<u32x4*>(dst) = *reinterpret_cast<const u32x4*>(stg + row * 72 + ch * 8);
             }
           }
@@ -430,13 +431,13 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
             const int m = m0 + wm * 64 + mt * 32 + 8 * q + 4 * h;
             if (m < a.M) {
               const int seq = m / a.S, pos = m - seq * a.S;
-              bf16* dst = a.VT + (long long)z * a.vtz + ((long long)(seq * 4 + head) * 64 + d) * a.Spad + pos;
-              *reinterpret_cast<bf16x4*>(dst) = pack4(acc[mt][nt][4 * q] + b, acc[mt][nt][4 * q + 1] + b, acc[mt][nt][4 * q + 2] + b, acc[mt][nt][4 * q + 3] + b);
+              e16* dst = a.VT + (long long)z * a.vtz + ((long long)(seq * 4 + head) * 64 + d) * a.Spad + pos;
+              *reinterpret_cast<e16x4*>(dst) = pack4e(acc[mt][nt][4 * q] + b, acc[mt][nt][4 * q + 1] + b, acc[mt][nt][4 * q + 2] + b, acc[mt][nt][4 * q + 3] + b);
             }
           }
       }
     } else {
-      bf16* ybase = a.Y + (long long)z * a.yz + nw + ec * 8;
+      e16* ybase = a.Y + (long long)z * a.yz + nw + ec * 8;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
             float v0 = acc[mt][nt][4 * q + 0] + sb[f + 0], v1 = acc[mt][nt][4 * q + 1] + sb[f + 1];
             float v2 = acc[mt][nt][4 * q + 2] + sb[f + 2], v3 = acc[mt][nt][4 * q + 3] + sb[f + 3];
             if (a.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
-            *reinterpret_cast<bf16x4*>(stg + r * EPP + fl) = pack4(v0, v1, v2, v3);
+            *reinterpret_cast<e16x4*>(stg + r * EPP + fl) = pack4e(v0, v1, v2, v3);
           }
         __syncthreads();
 #pragma unroll
@@ -479,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int fl = nt * 32 + 8 * q + 4 * h, f = wn * 128 + fl;
-          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(stg + r * EPP + fl);
+          const e16x4 rv = *reinterpret_cast<const e16x4*>(stg + r * EPP + fl);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float v = acc[mt][nt][4 * q + j] + sb[f + j] + bf2f(rv[j]);
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
           float v[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = (acc[mt][nt][4 * q + j] - mean[mt]) * rstd * sb[256 + f + j] + sb[512 + f + j];
-          *reinterpret_cast<bf16x4*>(stg + r * EPP + fl) = pack4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<e16x4*>(stg + r * EPP + fl) = pack4e(v[0], v[1], v[2], v[3]);
         }
       __syncthreads();
 #pragma unroll
@@ -628,8 +629,8 @@ int launch_linear_ln(const LinArgs& a, hipStream_t st) {
 
 __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * LDK * 2 + 64 * LDV * 2];
-  bf16* Ks = reinterpret_cast<bf16*>(smem);
-  bf16* Vs = Ks + 64 * LDK;
+  e16* Ks = reinterpret_cast<e16*>(smem);
+  e16* Vs = Ks + 64 * LDK;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int nh = a.n_heads > 0 ? a.n_heads : 4;
   const int seq = blockIdx.y / nh, head = blockIdx.y - seq * nh;
@@ -649,13 +650,13 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   const int q0 = (int)blockIdx.x * 128 + wave * 32 - off;
   int qi = q0 + r; const bool qvalid = qi >= 0 && qi < Sq; qi = qi < 0 ? 0 : (qi < Sq ? qi : Sq - 1);
 
-  const bf16* qp = a.Q + qbase + (long long)qi * a.ldq + head * 64;
-  bf16x8 qf[4];
+  const e16* qp = a.Q + qbase + (long long)qi * a.ldq + head * 64;
+  e16x8 qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16 + h * 8);
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const e16x8*>(qp + s * 16 + h * 8);
 
-  const bf16* kbase = a.K + kbase_off + head * 64;
-  const bf16* vbase = a.VT + ((long long)(seq * nh + head) * 64) * a.Spad;
+  const e16* kbase = a.K + kbase_off + head * 64;
+  const e16* vbase = a.VT + ((long long)(seq * nh + head) * 64) * a.Spad;
 
   f32x16 o[2];
 #pragma unroll
@@ -701,7 +702,7 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
       for (int i = 0; i < 16; ++i) sT[kt][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * LDK + s * 16 + h * 8);
+        const e16x8 kf = *reinterpret_cast<const e16x8*>(Ks + (kt * 32 + r) * LDK + s * 16 + h * 8);
         sT[kt] = mfma32(kf, qf[s], sT[kt]);
       }
     }
@@ -746,15 +747,15 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
     // accumulator's own (permuted) order: element j <-> key 16ks + 8(j>>2) + 4h + (j&3)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      bf16x8 pf;
+      e16x8 pf;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[ks >> 1][8 * (ks & 1) + j];
+      for (int j = 0; j < 8; ++j) pf[j] = (e16)sT[ks >> 1][8 * (ks & 1) + j];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const bf16* vrow = Vs + (dt * 32 + r) * LDV + ks * 16 + 4 * h;
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vrow);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vrow + 8);
-        const bf16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        const e16* vrow = Vs + (dt * 32 + r) * LDV + ks * 16 + 4 * h;
+        const e16x4 lo = *reinterpret_cast<const e16x4*>(vrow);
+        const e16x4 hi = *reinterpret_cast<const e16x4*>(vrow + 8);
+        const e16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         o[dt] = mfma32(vf, pf, o[dt]);
       }
     }
@@ -764,13 +765,13 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
   lrun += xhalf(lrun);
   const float inv = 1.f / lrun;
   if (qvalid) {
-    bf16* op = a.O + obase + (long long)(q0 + r) * a.ldo + head * 64;
+    e16* op = a.O + obase + (long long)(q0 + r) * a.ldo + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int d = dt * 32 + 8 * q + 4 * h;
-        *reinterpret_cast<bf16x4*>(op + d) = pack4(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
+        *reinterpret_cast<e16x4*>(op + d) = pack4e(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
       }
   }
 }
@@ -800,9 +801,9 @@ int launch_attn(const AttnArgs& a, hipStream_t st) {
 
 __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[256 * LDE * 2 + (EFB + 80) * ELDX * 4 + 32 * ELDP * 2 + 256 * 4];
-  bf16* Wsm = reinterpret_cast<bf16*>(smem);
+  e16* Wsm = reinterpret_cast<e16*>(smem);
   float* Xsm = reinterpret_cast<float*>(smem + 256 * LDE * 2);
-  bf16* Psm = reinterpret_cast<bf16*>(smem + 256 * LDE * 2 + (EFB + 80) * ELDX * 4);
+  e16* Psm = reinterpret_cast<e16*>(smem + 256 * LDE * 2 + (EFB + 80) * ELDX * 4);
   float* bsm = reinterpret_cast<float*>(smem + 256 * LDE * 2 + (EFB + 80) * ELDX * 4 + 32 * ELDP * 2);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -850,24 +851,24 @@ __global__ __launch_bounds__(256) void k_embed(EmbedArgs a) {
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
-      bf16x8 xf;
+      e16x8 xf;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) xf[j] = (bf16)Xsm[(fl + s * 16 + h * 8 + j) * ELDX + r];
+      for (int j = 0; j < 8; ++j) xf[j] = (e16)Xsm[(fl + s * 16 + h * 8 + j) * ELDX + r];
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Wsm + (t * 32 + r) * LDE + s * 16 + h * 8);
+        const e16x8 wf = *reinterpret_cast<const e16x8*>(Wsm + (t * 32 + r) * LDE + s * 16 + h * 8);
         acc[t] = mfma32(wf, xf, acc[t]);
       }
     }
-    bf16* yrow = a.Y + ((long long)(wl * a.fc + fl0 + fl) * 256 + b0 + r) * 256;
+    e16* yrow = a.Y + ((long long)(wl * a.fc + fl0 + fl) * 256 + b0 + r) * 256;
 #pragma unroll
     for (int t = 0; t < 8; ++t)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f = t * 32 + 8 * q + 4 * h;
-        const bf16x4 p = *reinterpret_cast<const bf16x4*>(Psm + r * ELDP + f);
-        *reinterpret_cast<bf16x4*>(yrow + f) =
-            pack4((acc[t][4 * q + 0] + bsm[f + 0]) * 16.f + bf2f(p[0]), (acc[t][4 * q + 1] + bsm[f + 1]) * 16.f + bf2f(p[1]),
+        const e16x4 p = *reinterpret_cast<const e16x4*>(Psm + r * ELDP + f);
+        *reinterpret_cast<e16x4*>(yrow + f) =
+            pack4e((acc[t][4 * q + 0] + bsm[f + 0]) * 16.f + bf2f(p[0]), (acc[t][4 * q + 1] + bsm[f + 1]) * 16.f + bf2f(p[1]),
                   (acc[t][4 * q + 2] + bsm[f + 2]) * 16.f + bf2f(p[2]), (acc[t][4 * q + 3] + bsm[f + 3]) * 16.f + bf2f(p[3]));
       }
   }
@@ -891,8 +892,8 @@ int launch_embed(const EmbedArgs& a, hipStream_t st) {
 // ================================================================================================
 __global__ __launch_bounds__(256) void k_heads(HeadsArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[(128 + 160) * LDK * 2 + 160 * 4];
-  bf16* Xs = reinterpret_cast<bf16*>(smem);
-  bf16* Ws = Xs + 128 * LDK;
+  e16* Xs = reinterpret_cast<e16*>(smem);
+  e16* Ws = Xs + 128 * LDK;
   float* sb = reinterpret_cast<float*>(smem + (128 + 160) * LDK * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 128;
@@ -917,10 +918,10 @@ __global__ __launch_bounds__(256) void k_heads(HeadsArgs a) {
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + (wave * 32 + r) * LDK + s * 16 + h * 8);
+      const e16x8 xf = *reinterpret_cast<const e16x8*>(Xs + (wave * 32 + r) * LDK + s * 16 + h * 8);
 #pragma unroll
       for (int t = 0; t < 5; ++t) {
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + (t * 32 + r) * LDK + s * 16 + h * 8);
+        const e16x8 wf = *reinterpret_cast<const e16x8*>(Ws + (t * 32 + r) * LDK + s * 16 + h * 8);
         acc[t] = mfma32(wf, xf, acc[t]);
       }
     }
@@ -979,7 +980,7 @@ int launch_heads(const HeadsArgs& a, hipStream_t st) {
 // ================================================================================================
 // freq-major decoder state -> time-major time-decoder input, *sqrt(256) + pos_embedding_time
 //                                                                             amt_apc.py:203-205
-__global__ void k_freq2time(const bf16* __restrict__ src, bf16* __restrict__ dst, const float* __restrict__ pos,
+__global__ void k_freq2time(const e16* __restrict__ src, e16* __restrict__ dst, const float* __restrict__ pos,
                             int nw, int fc, int f0, int nf, int nn) {
   const long long total = (long long)nw * fc * nn * 32;           // 16-byte chunks
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -990,15 +991,15 @@ __global__ void k_freq2time(const bf16* __restrict__ src, bf16* __restrict__ dst
     const int note = (int)(row % nn);
     const long long fr = row / nn;
     const int fl = (int)(fr % fc), wl = (int)(fr / fc);
-    const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + row * 256 + ch * 8);
+    const e16x8 v = *reinterpret_cast<const e16x8*>(src + row * 256 + ch * 8);
     const float* pp = pos + (long long)(f0 + fl) * 256 + ch * 8;
-    bf16x8 o;
+    e16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (bf16)(bf2f(v[j]) * 16.f + pp[j]);
-    *reinterpret_cast<bf16x8*>(dst + (((long long)wl * nn + note) * nf + f0 + fl) * 256 + ch * 8) = o;
+    for (int j = 0; j < 8; ++j) o[j] = (e16)(bf2f(v[j]) * 16.f + pp[j]);
+    *reinterpret_cast<e16x8*>(dst + (((long long)wl * nn + note) * nf + f0 + fl) * 256 + ch * 8) = o;
   }
 }
-int launch_freq2time(const bf16* src, bf16* dst, const float* pos, int nw, int fc, int f0, int nf, int nn, hipStream_t st) {
+int launch_freq2time(const e16* src, e16* dst, const float* pos, int nw, int fc, int f0, int nf, int nn, hipStream_t st) {
   const long long total = (long long)nw * fc * nn * 32;
   ETD_LAUNCH_FILTER("k_freq2time");
   ProfScope ps("k_freq2time", st, 0, (double)total * 32);
@@ -1009,12 +1010,12 @@ int launch_freq2time(const bf16* src, bf16* dst, const float* pos, int nw, int f
 }
 
 // ================================================================================================
-__global__ void k_f32_to_bf16(const float* __restrict__ s, bf16* __restrict__ d, long long n) {
+__global__ void k_f32_to_bf16(const float* __restrict__ s, e16* __restrict__ d, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) d[i] = (bf16)s[i];
+  for (; i < n; i += stride) d[i] = (e16)s[i];
 }
-int launch_f32_to_bf16(const float* src, bf16* dst, long long n, hipStream_t st) {
+int launch_f32_to_bf16(const float* src, e16* dst, long long n, hipStream_t st) {
   if (n <= 0) return ETD_OK;
   long long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(k_f32_to_bf16, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n);

@@ -41,6 +41,9 @@ int launch_ln_rows_f32(const float* h, int M, int H, const float* g1, const floa
 // Y = epi(X W^T): X fp32 [M][K] (row stride ldx), W as packed planes; the DGemmArgs epilogue fields as for launch_dgemm (fp32 outputs / fp32 KV rows).
 // a.Wp = packed planes, a.w_log2 / a.x_log2 = the scales' logarithms.
 int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st);
+// the same for 2 .. 512 rows (weight-streaming shape: 32 x 32 tiles, K over four waves, K % 512 == 0), with an optional fused LayerNorm over K (a.ln_g / a.ln_b / a.ln_eps)
+bool gemm3_s_takes(const DGemmArgs& a, int epi);
+int launch_gemm3_s(const DGemmArgs& a, int epi, hipStream_t st);
 
 // softmax(Q K^T * scale) V per (sequence, head) on the same arithmetic, head_dim 64.  Rows of Q / K / V / O are fp32 with arbitrary row strides;
 // sequence s covers q rows [q_row0(s), + q_len(s)) and kv rows [kv_row0(s), + kv_len(s)).  Two addressing modes:

@@ -191,6 +191,123 @@ int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st) {
   return ETD_OK;
 }
 
+// ================================================================================================ k_gemm3_s
+// The same arithmetic for a handful of rows (2 .. 512: decode steps of a small batch, the last-position tail of a prefill): k_dgemm_s's shape -- 32 tokens x 32 features
+// per workgroup, K split over four waves, operand fragments straight from global memory / L2 to registers (the packed planes give a lane its 16 contiguous bytes per
+// k-step), partial tiles reduced through LDS in a fixed order; optional LayerNorm over K fused in front (the row statistics are computed per workgroup, as k_dgemm_s does).
+// What it replaces is that kernel's fp32 branch on v_mfma_f32_32x32x2_f32, whose K = 2048 chain alone took 31 us per launch at 54 rows.
+#define G3S_WAVES 4
+template <int EPI>
+__global__ __launch_bounds__(64 * G3S_WAVES) void k_gemm3_s(int p_M, int p_Npad, int p_K, const f16* __restrict__ p_Wp, const float* __restrict__ p_X, int p_ldx, float p_xs, float p_inv, DGemmArgs a) {
+  __shared__ __attribute__((aligned(16))) float red[G3S_WAVES - 1][16][64];
+  __shared__ float stat[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  // workgroup -> tile as in k_dgemm_s: the row tiles that stream the SAME weight tile take consecutive slots of ONE XCD (id = 8 * slot + xcd)
+  const int RT = (p_M + 31) / 32, FT = p_Npad / 32;
+  const int bid = blockIdx.x, wt = ((bid >> 3) / RT) * 8 + (bid & 7);
+  if (wt >= FT) return;
+  const int m0 = ((bid >> 3) % RT) * 32, n0 = wt * 32;
+  const bool ln = a.ln_g != nullptr;
+  if (ln) {
+    for (int rr = 0; rr < 32 / G3S_WAVES; ++rr) {
+      const int row = wave * (32 / G3S_WAVES) + rr;
+      int gm = m0 + row; gm = gm < p_M ? gm : p_M - 1;
+      const float* xp = p_X + (long long)gm * p_ldx;
+      float s = 0.f;
+      for (int k = lane * 4; k < p_K; k += 256) { const f32x4 v = *reinterpret_cast<const f32x4*>(xp + k); s = (((s + v[0]) + v[1]) + v[2]) + v[3]; }
+      s = wave_sum(s);
+      const float mean = s / (float)p_K;
+      float q = 0.f;
+      for (int k = lane * 4; k < p_K; k += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xp + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float dl = v[e] - mean; q = fmaf(dl, dl, q); }
+      }
+      q = wave_sum(q);
+      if (lane == 0) { stat[row] = mean; stat[32 + row] = 1.f / sqrtf(q / (float)p_K + a.ln_eps); }
+    }
+    __syncthreads();
+  }
+  int gm = m0 + r; gm = gm < p_M ? gm : p_M - 1;
+  const float mean = ln ? stat[r] : 0.f, rstd = ln ? stat[32 + r] : 1.f;
+  const float* xrow = p_X + (long long)gm * p_ldx + h * 8;
+  const int nchunk = p_K >> 5, n = n0 + r;
+  const f16* wrow = p_Wp + (size_t)(n >> 7) * nchunk * (2 * 128 * 32) + (n & 127) * 32 + h * 8;      // + chunk * 8192 + (k & 31) [+ 4096: lo plane]
+  const int kq = p_K / G3S_WAVES, kb = wave * kq, ke = kb + kq;
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int k = kb; k < ke; k += 128) {                    // 8 k-steps per round trip: 16 weight fragments + 16 x 16 B of activations in flight
+    f16x8 wh[8], wl[8]; f32x4 x0[8], x1[8];
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      const int kk = k + s8 * 16;
+      const f16* w = wrow + (size_t)(kk >> 5) * (2 * 128 * 32) + (kk & 31);
+      wh[s8] = *reinterpret_cast<const f16x8*>(w);
+      wl[s8] = *reinterpret_cast<const f16x8*>(w + 128 * 32);
+      x0[s8] = *reinterpret_cast<const f32x4*>(xrow + kk);
+      x1[s8] = *reinterpret_cast<const f32x4*>(xrow + kk + 4);
+    }
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8) {
+      if (ln) {
+        const int kk = k + s8 * 16 + h * 8;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.ln_g + kk), g1 = *reinterpret_cast<const f32x4*>(a.ln_g + kk + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.ln_b + kk), b1 = *reinterpret_cast<const f32x4*>(a.ln_b + kk + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x0[s8][j] = (x0[s8][j] - mean) * rstd * g0[j] + b0[j]; x1[s8][j] = (x1[s8][j] - mean) * rstd * g1[j] + b1[j]; }
+      }
+      f16x8 xh, xl;
+      split8(x0[s8], x1[s8], p_xs, xh, xl);
+      acc = mfma16h(wl[s8], xh, acc);
+      acc = mfma16h(wh[s8], xl, acc);
+      acc = mfma16h(wh[s8], xh, acc);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[wave - 1][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < G3S_WAVES - 1; ++w)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] += red[w][i][lane];
+  const int m = m0 + r;
+  if (m >= p_M) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] *= p_inv;
+  dgemm_epilogue<false, EPI>(a, acc, m, n0, h);
+}
+
+bool gemm3_s_takes(const DGemmArgs& a, int epi) {
+  return a.Wp && a.M >= 2 && a.M <= 512 && a.K % (128 * G3S_WAVES) == 0 && a.Npad % 128 == 0 && epi != DEPI_PARTIAL && !a.Xb && !a.Yb && !a.Qb && a.k_splits <= 1;
+}
+int launch_gemm3_s(const DGemmArgs& a, int epi, hipStream_t st) {
+  if (!gemm3_s_takes(a, epi) || !a.X || (a.ldx % 4) || ((uintptr_t)a.X & 15) || a.N > a.Npad) ETD_FAIL(ETD_EINVAL, "gemm3_s: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
+  if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "gemm3_s: QKV epilogue needs head_dim 64 and rotary_ndims 16");
+  if (epi == DEPI_RESID && (a.N % 4)) ETD_FAIL(ETD_EINVAL, "gemm3_s: resid needs N %% 4 == 0");
+  ETD_LAUNCH_FILTER("k_gemm3_s");
+  ProfScope ps("k_gemm3_s", st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * 4);
+  const int wtiles = a.Npad / 32;
+  const dim3 g((unsigned)(((wtiles + 7) / 8) * 8 * ((a.M + 31) / 32)));
+  const float xs = ldexpf(1.f, a.x_log2), inv = ldexpf(1.f, -(a.x_log2 + a.w_log2));
+#define G3S_LAUNCH(E) hipLaunchKernelGGL((k_gemm3_s<E>), g, dim3(64 * G3S_WAVES), 0, st, a.M, a.Npad, a.K, (const f16*)a.Wp, a.X, a.ldx, xs, inv, a)
+  switch (epi) {
+    case DEPI_BIAS: G3S_LAUNCH(DEPI_BIAS); break;
+    case DEPI_GELU: G3S_LAUNCH(DEPI_GELU); break;
+    case DEPI_RELU: G3S_LAUNCH(DEPI_RELU); break;
+    case DEPI_RESID: G3S_LAUNCH(DEPI_RESID); break;
+    case DEPI_LOGITS: G3S_LAUNCH(DEPI_LOGITS); break;
+    case DEPI_QKV: G3S_LAUNCH(DEPI_QKV); break;
+    default: ETD_FAIL(ETD_EINVAL, "gemm3_s: unsupported epilogue %d", epi);
+  }
+#undef G3S_LAUNCH
+  HIP_TRY(hipGetLastError());
+  return ETD_OK;
+}
+
 // ================================================================================================ fp32 LayerNorm rows
 // one wave per row; mean and biased variance over H as F.layer_norm computes them, (x - mean) / sqrt(var + eps) * g + b
 template <int NV>      // H = 256 NV
@@ -444,7 +561,8 @@ int launch_attn3(const Attn3Args& a, hipStream_t st) {
 
 // ================================================================================================ test hooks (include/etude_hip_debug.h)
 #include "../../include/etude_hip_debug.h"
-extern "C" int etd_debug_gemm3(const float* x_dev, int M, int K, const float* w_host, const float* bias_host, int N, float x_bound, int gelu, float* y_dev, void* stream) {
+extern "C" int etd_debug_gemm3(const float* x_dev, int M, int K, const float* w_host, const float* bias_host, int N, float x_bound, int gelu, float* y_dev,
+                               const float* ln_g_host, const float* ln_b_host, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!x_dev || !w_host || !y_dev || M < 1 || N < 1 || K < 32 || K % 32) ETD_FAIL(ETD_EINVAL, "debug_gemm3: bad arguments");
   const int Npad = (N + 127) / 128 * 128;
@@ -452,18 +570,22 @@ extern "C" int etd_debug_gemm3(const float* x_dev, int M, int K, const float* w_
   const int wl = g3_pack_weights_host(w_host, N, Npad, K, planes.data());
   std::vector<float> b(Npad, 0.f);
   if (bias_host) memcpy(b.data(), bias_host, (size_t)N * 4);
-  uint16_t* wp = nullptr; float* bd = nullptr;
+  uint16_t* wp = nullptr; float* bd = nullptr; float* lnd = nullptr;
   HIP_TRY(hipMalloc((void**)&wp, planes.size() * 2));
-  if (hipMalloc((void**)&bd, b.size() * 4) != hipSuccess) { (void)hipFree(wp); ETD_FAIL(ETD_EHIP, "debug_gemm3: hipMalloc"); }
+  if (hipMalloc((void**)&bd, b.size() * 4) != hipSuccess || hipMalloc((void**)&lnd, (size_t)2 * K * 4) != hipSuccess) { (void)hipFree(wp); (void)hipFree(bd); ETD_FAIL(ETD_EHIP, "debug_gemm3: hipMalloc"); }
   int rc = ETD_OK;
   if (hipMemcpy(wp, planes.data(), planes.size() * 2, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(bd, b.data(), b.size() * 4, hipMemcpyHostToDevice) != hipSuccess) rc = ETD_EHIP;
+  const bool ln = ln_g_host && ln_b_host;
+  if (rc == ETD_OK && ln && (hipMemcpy(lnd, ln_g_host, (size_t)K * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(lnd + K, ln_b_host, (size_t)K * 4, hipMemcpyHostToDevice) != hipSuccess)) rc = ETD_EHIP;
   if (rc == ETD_OK) {
     DGemmArgs a = {};
     a.X = x_dev; a.ldx = K; a.Wp = wp; a.w_log2 = wl; a.x_log2 = g3_scale_log2(x_bound); a.bias = bd; a.M = M; a.N = N; a.Npad = Npad; a.K = K; a.Y = y_dev; a.ldy = N;
-    rc = launch_gemm3(a, gelu ? DEPI_GELU : DEPI_BIAS, st);
+    if (ln) { a.ln_g = lnd; a.ln_b = lnd + K; a.ln_eps = 1e-5f; }       // (x_bound then bounds the LayerNorm OUTPUT; the fused LayerNorm exists in the small-M kernel only)
+    const int epi = gelu ? DEPI_GELU : DEPI_BIAS;
+    rc = gemm3_s_takes(a, epi) ? launch_gemm3_s(a, epi, st) : launch_gemm3(a, epi, st);
   }
   if (hipStreamSynchronize(st) != hipSuccess && rc == ETD_OK) { g_etd_err = "debug_gemm3: kernel failed"; rc = ETD_EHIP; }
-  (void)hipFree(wp); (void)hipFree(bd);
+  (void)hipFree(wp); (void)hipFree(bd); (void)hipFree(lnd);
   return rc;
 }
 extern "C" int etd_debug_attn3(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int n_seq, int n_heads, int Sq, int Sk, float q_bound, float k_bound, float v_bound,

@@ -155,7 +155,7 @@ extern "C" int etd_debug_linear(int M, int N, int K, int iters, void* stream, do
   hipLaunchKernelGGL(k_fill_bf16, dim3(1024), dim3(256), 0, st, X, (long long)M * K, 1u);
   hipLaunchKernelGGL(k_fill_bf16, dim3(1024), dim3(256), 0, st, W, (long long)N * K, 2u);      // (random values: the layout does not matter for timing)
   LinArgs a = {};
-  a.X = X; a.ldx = K; a.W = W; a.bias = b; a.M = M; a.N = N; a.K = K; a.Y = Y; a.ldy = N; a.vt_block = -1;
+  a.X = (const e16*)X; a.ldx = K; a.W = (const e16*)W; a.bias = b; a.M = M; a.N = N; a.K = K; a.Y = (e16*)Y; a.ldy = N; a.vt_block = -1;      // (timing only: 16-bit patterns of either type)
   int rc = launch_linear(a, 1, st);
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -196,8 +196,8 @@ extern "C" int etd_debug_kernel_loop(int which, int iters, void* stream) {
       HIP_TRY(hipMemcpyAsync(meta, hm.data(), hm.size() * 4, hipMemcpyHostToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));
       AttnArgs a = {};
-      a.Q = Q; a.ldq = H; a.q_seq_stride = (long long)S * H; a.K = K; a.ldk = H; a.k_seq_stride = (long long)S * H; a.VT = VT; a.Spad = Spad;
-      a.O = O; a.ldo = H; a.o_seq_stride = (long long)S * H; a.n_seq = n_seq; a.Sq = S; a.Sk = S; a.scale_log2e = 0.125f * 1.4426950408889634f; a.n_heads = nh;
+      a.Q = (const e16*)Q; a.ldq = H; a.q_seq_stride = (long long)S * H; a.K = (const e16*)K; a.ldk = H; a.k_seq_stride = (long long)S * H; a.VT = (const e16*)VT; a.Spad = Spad;
+      a.O = (e16*)O; a.ldo = H; a.o_seq_stride = (long long)S * H; a.n_seq = n_seq; a.Sq = S; a.Sk = S; a.scale_log2e = 0.125f * 1.4426950408889634f; a.n_heads = nh;
       if (which == 1) { a.seq_row0 = meta; a.seq_len = meta + n_seq; a.causal = 1; }
       for (int it = 0; it < iters && rc == ETD_OK; ++it) rc = launch_attn(a, st);
     }
@@ -213,7 +213,7 @@ extern "C" int etd_debug_kernel_loop(int which, int iters, void* stream) {
       HIP_TRY(hipMemcpyAsync(par, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st));
       HIP_TRY(hipStreamSynchronize(st));
       LinArgs a = {};
-      a.X = X; a.ldx = K; a.W = W; a.bias = par; a.M = M; a.N = N; a.K = K; a.Y = Y; a.ldy = N; a.vt_block = -1; a.R = R; a.ldr = N; a.gamma = par + N; a.beta = par + 2 * N;
+      a.X = (const e16*)X; a.ldx = K; a.W = (const e16*)W; a.bias = par; a.M = M; a.N = N; a.K = K; a.Y = (e16*)Y; a.ldy = N; a.vt_block = -1; a.R = (const e16*)R; a.ldr = N; a.gamma = par + N; a.beta = par + 2 * N;
       for (int it = 0; it < iters && rc == ETD_OK; ++it) rc = launch_linear_ln(a, st);
     }
   } else {

@@ -111,13 +111,15 @@ class AMTAPC_Extractor:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.config = config if config is not None else ExtractorConfig()
         c = self.config
-        # "bf16" (default): bf16 operands, fp32 accumulate -- the serving path.  "fp32": the parity mode (csrc/ext_fp32.hip), fp32 end
-        # to end like the reference (extractor.py runs the model in fp32), ~20x slower; also selectable with ETD_EXTRACTOR_PRECISION.
+        # "f16" (default; "bf16" is accepted as its older name): the 16-bit serving path -- IEEE-half operands (bf16 in a -DETD_EXT_BF16 build: `operand_dtype`),
+        # fp32 accumulate / LayerNorm / softmax / sigmoid.  "fp32": the exact-parity mode (csrc/ext_fp32.hip), fp32 activations and fp32-grade products like the
+        # reference (extractor.py runs the model in fp32), ~4x slower; also selectable with ETD_EXTRACTOR_PRECISION.
         import os
-        precision = precision or os.environ.get("ETD_EXTRACTOR_PRECISION", "bf16")
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
-        self.precision = precision
+        precision = precision or os.environ.get("ETD_EXTRACTOR_PRECISION", "f16")
+        if precision not in ("f16", "bf16", "fp32"):
+            raise ValueError("precision must be 'f16' (alias 'bf16') or 'fp32'")
+        self.precision = "fp32" if precision == "fp32" else "f16"
+        self.operand_dtype = torch.float32 if precision == "fp32" else (torch.float16 if _lib.lib().etd_extractor_operand_type() == 1 else torch.bfloat16)
         state = model_path if isinstance(model_path, dict) else load_extractor_state(model_path)
         cfg = _lib.ExtCfg(n_margin=c.input.margin_b, n_frame=c.input.num_frame, n_bin=c.feature.n_bins,
                           cnn_channel=c.model.cnn_channel, cnn_kernel=c.model.cnn_kernel, hid_dim=c.model.transformer_hid_dim,

@@ -93,10 +93,13 @@ typedef struct {
   float min_value;        /* -18.0: padding value of _transcript */
   int max_windows;        /* windows processed per internal batch (workspace size) */
   int chunk_frames;       /* frames per encoder/freq-decoder chunk (0 = default) */
-  int precision;          /* 0 = bf16 compute, fp32 accumulate / LayerNorm / softmax / sigmoid (default, the fast path);
-                             1 = fp32 parity mode: fp32 weights and activations, exact-fp32 products (csrc/ext_fp32.hip), one window
-                             at a time -- what the note-level parity tests run on */
+  int precision;          /* 0 = the 16-bit serving mode: IEEE-half operands (etd_extractor_operand_type), fp32 accumulate / LayerNorm / softmax /
+                             sigmoid (default, the fast path);
+                             1 = exact-parity mode: fp32 weights and activations, fp32-grade products (two-plane f16 splits on the matrix cores:
+                             csrc/gemm3.h, csrc/ext_fp32.hip), one window at a time -- what the note-level parity tests run on */
 } etd_ext_cfg;
+/* element type of the 16-bit serving mode's operands and activation buffers (debug taps): 1 = IEEE half (the default build), 0 = bf16 (-DETD_EXT_BF16) */
+int etd_extractor_operand_type(void);
 /* Weights: n named fp32 host tensors with the reference checkpoint's own keys ("encoder.*",
  * "decoder.*"); every key the model needs must be present with the right element count. */
 int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* names, const float* const* host_ptrs,

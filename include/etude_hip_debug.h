@@ -58,8 +58,11 @@ int etd_debug_decoder_force_pair(etd_dec*, int mode);
 int etd_debug_decoder_step_logits(etd_dec*, int on, float* out_host, int n_active, void* stream);
 
 /* test hooks of the fp32-grade f16-split kernels (csrc/gemm3.h; tests/test_gpu_gemm3.py):
- * y[M][N] = x[M][K] w[N][K]^T + bias (x, y device fp32 row-major; w, bias host; x_bound = bound of |x| for the plane scale; gelu != 0: erf-GELU epilogue) */
-int etd_debug_gemm3(const float* x_dev, int M, int K, const float* w_host, const float* bias_host, int N, float x_bound, int gelu, float* y_dev, void* stream);
+ * y[M][N] = x[M][K] w[N][K]^T + bias (x, y device fp32 row-major; w, bias host; x_bound = bound of |x| for the plane scale; gelu != 0: erf-GELU epilogue).
+ * 2 .. 512 rows with K % 512 == 0 take the weight-streaming kernel (k_gemm3_s), which can apply LayerNorm(x; ln_g, ln_b, eps 1e-5) over K first (host vectors or NULL;
+ * x_bound then bounds the LayerNorm output); everything else the 128 x 128 tile kernel (k_gemm3, no fused LayerNorm). */
+int etd_debug_gemm3(const float* x_dev, int M, int K, const float* w_host, const float* bias_host, int N, float x_bound, int gelu, float* y_dev,
+                    const float* ln_g_host, const float* ln_b_host, void* stream);
 /* o = softmax(q k^T / 8) v per (sequence, head), head_dim 64: q / o [n_seq][Sq][heads * 64], k / v [n_seq][Sk][heads * 64] device fp32; causal != 0: query t sees keys 0 .. t
  * through the RAGGED path (K / V then laid out as a KV cache [n_seq slots][heads][Sk][64], lens_host[n_seq] prompt lengths <= Sq == Sk, q / o rows packed prompt after prompt) */
 int etd_debug_attn3(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int n_seq, int n_heads, int Sq, int Sk, float q_bound, float k_bound, float v_bound,

@@ -11,6 +11,24 @@ TINY_DEC = dict(vocab_size=154, hidden_size=64, num_hidden_layers=2, num_attenti
 TINY_DEC_KW = dict(gain=2.0, p_eos=0.15)
 
 
+# ---- stated tolerances of the extractor's 16-bit serving mode against the fp32 reference (north_star: "extractor onset/frame logits within a stated fp tolerance").
+# Operands are IEEE half since round 5 (rounds 1-4, bf16 operands: 8e-2 max / 6e-3 mean on probabilities, 0.3 on velocity logits); measured values are printed by
+# close_to() (pytest -s) and recorded in profiles/r05_ext_f16.txt.  The exact-parity mode (precision "fp32") is held to 2e-4 in its own tests.
+# Measured with IEEE-half operands over every seed and shape the GPU suite uses: probabilities <= 1.94e-2 max (3-min clip: 1.19e-2) / <= 4.1e-4 mean, velocity logits 1.8e-2.
+EXT_P_TOL, EXT_P_MEAN, EXT_L_TOL = 3e-2, 1e-3, 0.06
+EXT_P_TOL_PAD = 3e-2          # HFT_Transformer wrapper, frames whose receptive field contains its -80 padding rows (bf16 operands needed 1e-1 there)
+
+
+def close_to(got, ref, tol, mean_tol=None, what=""):
+    """assert max |got - ref| < tol (and mean < mean_tol), printing what was measured"""
+    e = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    mx, mn = float(e.max()), float(e.mean())
+    print(f"[measured] {what}: max {mx:.3e} (tol {tol:.1e})" + (f", mean {mn:.3e} (tol {mean_tol:.1e})" if mean_tol else ""))
+    assert mx < tol, (what, mx, tol)
+    if mean_tol is not None:
+        assert mn < mean_tol, (what, mn, mean_tol)
+
+
 def torch_sd(sd):
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
 

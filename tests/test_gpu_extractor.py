@@ -1,10 +1,10 @@
 """HIP hFT-Transformer against the oracle / the reference's golden vectors, through the C ABI.
 
-Tolerance (stated per north_star): the HIP path computes in bf16 (fp32 accumulate, fp32 LayerNorm /
-softmax / sigmoid); the reference is fp32.  Measured on MI355X over the seeds used here: probabilities
-differ by <= 5.5e-2 (mean 3e-3), velocity logits by <= 0.15.  The tests allow 8e-2 max / 6e-3 mean on
-probabilities, 0.3 on logits, and require every velocity argmax to be a near-maximum of the ORACLE's
-logits (within 0.3)."""
+Tolerance (stated per north_star; the constants and the measured values live in tests/_util.py): the 16-bit serving mode computes with
+IEEE-half operands (fp32 accumulate, fp32 LayerNorm / softmax / sigmoid); the reference is fp32.  Measured on MI355X over the seeds used
+here: probabilities differ by <= 1.94e-2 (mean <= 4.1e-4), velocity logits by <= 1.8e-2 (rounds 1-4, bf16 operands: 5.5e-2 / 3e-3 / 0.15).
+The tests allow 3e-2 max / 1e-3 mean on probabilities, 0.06 on logits, and require every velocity argmax to be a near-maximum of the
+ORACLE's logits (within 0.06)."""
 import json
 
 import numpy as np
@@ -14,8 +14,9 @@ import torch
 from etude_amd import synth
 from etude_amd.config import ExtractorConfig
 
+from tests._util import EXT_L_TOL as L_TOL, EXT_P_MEAN as P_MEAN, EXT_P_TOL as P_TOL, close_to
+
 pytestmark = pytest.mark.gpu
-P_TOL, L_TOL, P_MEAN = 8e-2, 0.3, 6e-3
 
 
 @pytest.fixture(scope="module")
@@ -46,22 +47,22 @@ def test_full_size_window_against_reference_golden(dev, golden_dir):
     oA, fA, mA, vA, on, off, mpe, vel = [t.cpu().numpy() for t in ex.transcript_windows(x, want_A=True)]
     ex.debug_velocity_logits(None)
     for name, got in (("onset_B", on), ("offset_B", off), ("mpe_B", mpe)):
-        assert np.abs(got - g[name]).max() < P_TOL, name
-        assert np.abs(got - g[name]).mean() < P_MEAN, name
-    assert np.abs(oA - g["onset_A"].astype(np.float32)).max() < P_TOL
-    assert np.abs(mA - g["mpe_A"].astype(np.float32)).max() < P_TOL
-    assert np.abs(vl.cpu().numpy()[::64] - g["velocity_B_rows"]).max() < L_TOL
+        close_to(got, g[name], P_TOL, P_MEAN, "hft_full " + name)
+    close_to(oA, g["onset_A"].astype(np.float32), P_TOL, None, "hft_full onset_A")
+    close_to(mA, g["mpe_A"].astype(np.float32), P_TOL, None, "hft_full mpe_A")
+    close_to(vl.cpu().numpy()[::64], g["velocity_B_rows"], L_TOL, None, "hft_full velocity logits")
     clear = g["velocity_B_top2gap"].astype(np.float32) > 2 * L_TOL
     assert (vel == g["velocity_B_argmax"])[clear].all()
     assert (vel == g["velocity_B_argmax"]).mean() > 0.97
     assert on.min() >= 0 and on.max() <= 1 and np.isfinite(off).all()
 
 
-P_TOL_CAL, P_MEAN_CAL = 4e-2, 4e-3
+P_TOL_CAL, P_MEAN_CAL = 1e-2, 1e-3
 
 
-def test_full_size_window_calibrated_weights_bf16(dev, golden_dir):
-    """A second reference golden for the bf16 extractor, on a checkpoint whose FIRST encoder layer is well conditioned.  synth.extractor_state_dict feeds that
+def test_full_size_window_calibrated_weights_16bit(dev, golden_dir):
+    """(Numbers in this paragraph: rounds 1-4, bf16 operands.  With IEEE-half operands the same window sits at 4.3e-3 max, 0.06 % of the cells across 0.5,
+    velocity argmax agreement 0.998.)  A second reference golden for the 16-bit extractor, on a checkpoint whose FIRST encoder layer is well conditioned.  synth.extractor_state_dict feeds that
     layer x = 16 emb + pos with |x| ~ 75: its attention scores have sigma ~ 3 700 -- a hard argmax whose winner any rounding of X or K flips, which is what makes
     the 1.2 % rms the encoder taps show (tools/diag_rounding_budget.py reproduces it with emulated roundings on the oracle; a layer fed a LayerNorm output adds
     0.3 %).  synth.extractor_state_dict_cal scales the embedding so that layer 0's scores look like the other layers' (sigma ~ 3: a soft attention, the regime a
@@ -80,11 +81,11 @@ def test_full_size_window_calibrated_weights_bf16(dev, golden_dir):
         flips = max(flips, float(((got > 0.5) != (g[name] > 0.5)).mean()))
         assert err.max() < P_TOL_CAL and err.mean() < P_MEAN_CAL, (name, float(err.max()), float(err.mean()))
     agree = float((vel == g["velocity_B_argmax"]).mean())
-    print(f"bf16, calibrated checkpoint, one 512-frame window: max |p - reference| = {worst:.2e}, cells across 0.5: {flips:.5f}, velocity argmax agreement {agree:.4f}")
-    assert flips < 6e-3
+    print(f"16-bit mode, calibrated checkpoint, one 512-frame window: max |p - reference| = {worst:.2e}, cells across 0.5: {flips:.5f}, velocity argmax agreement {agree:.4f}")
+    assert flips < 1.5e-3
     assert np.abs(oA - g["onset_A"].astype(np.float32)).max() < P_TOL_CAL and np.abs(mA - g["mpe_A"].astype(np.float32)).max() < P_TOL_CAL
-    clear = g["velocity_B_top2gap"].astype(np.float32) > 0.3
-    assert (vel == g["velocity_B_argmax"])[clear].all() and agree > 0.98
+    clear = g["velocity_B_top2gap"].astype(np.float32) > 0.1
+    assert (vel == g["velocity_B_argmax"])[clear].all() and agree > 0.995
     ex.close()
 
 
@@ -98,7 +99,7 @@ def test_per_stage_taps_against_oracle(dev):
     hft.model_forward(sd, torch.from_numpy(x), d, taps)
     rows = {0: nf * 256, 3: nf * 256, 6: nf * 88, 7: 88 * nf, 10: 88 * nf}
     names = {0: "embed", 3: "enc2", 6: "dec2", 7: "time_in", 10: "time2"}
-    bufs = {s: torch.zeros((r, 256), dtype=torch.bfloat16, device=dev) for s, r in rows.items()}
+    bufs = {s: torch.zeros((r, 256), dtype=ex.operand_dtype, device=dev) for s, r in rows.items()}
     for s, b in bufs.items():
         ex.debug_tap(s, b)
     ex.transcript_windows(torch.from_numpy(x).to(dev))
@@ -107,8 +108,10 @@ def test_per_stage_taps_against_oracle(dev):
         ref = taps[names[s]].numpy().reshape(-1, 256)
         got = b.float().cpu().numpy()
         rel = np.abs(got - ref).max() / np.abs(ref).max()
-        assert rel < 0.12, (names[s], rel)                 # LayerNorm'ed activations, bf16 storage
-        assert np.abs(got - ref).mean() / np.abs(ref).mean() < 0.02, names[s]
+        relm = np.abs(got - ref).mean() / np.abs(ref).mean()
+        print(f"[measured] tap {names[s]}: max-abs error / max-abs value {rel:.3e}, mean error / mean value {relm:.3e}")
+        assert rel < 0.12, (names[s], rel)                 # LayerNorm'ed activations, 16-bit storage; the first encoder layer's hard-argmax attention
+        assert relm < 0.02, names[s]
 
 
 def test_transcript_ragged_matches_oracle_and_is_chunk_invariant(dev):
@@ -126,8 +129,7 @@ def test_transcript_ragged_matches_oracle_and_is_chunk_invariant(dev):
         assert len(got) == 8 and got[0].shape == (192, 88) and got[3].dtype == np.int8
         outs[tuple(kw.values())] = got
         for i in (0, 1, 2, 4, 5, 6):
-            assert np.abs(got[i] - ref[i]).max() < P_TOL, (kw, i)
-            assert np.abs(got[i] - ref[i]).mean() < P_MEAN, (kw, i)
+            close_to(got[i], ref[i], P_TOL, P_MEAN, f"ragged transcript {kw} output {i}")
         chosen = np.take_along_axis(ref_vl, got[7].astype(np.int64)[..., None], -1)[..., 0]
         assert (ref_vl.max(-1) - chosen).max() < L_TOL
         ex.close()
@@ -184,7 +186,7 @@ def test_extract_end_to_end_writes_reference_json(dev, tmp_path):
     # the device path on the same features agrees with the oracle within tolerance ...
     got = ex._transcript(feat)
     for i in (4, 5, 6):
-        assert np.abs(got[i] - o[i]).max() < P_TOL and np.abs(got[i] - o[i]).mean() < P_MEAN
+        close_to(got[i], o[i], P_TOL, P_MEAN, f"extract end to end output {i}")
     # ... and its own notes are exactly the reference algorithm applied to its own frame outputs
     ref_notes = mpe2note.notes_for_json(mpe2note.mpe2note(got[4], got[5], got[6], got[7], 0.5, 1.0, 0.5), 0.08)
     dev_feat = ex.wav2feature_tensor(wav, 44100)
@@ -210,7 +212,7 @@ def test_short_mono_16k_clip_single_partial_window(dev, tmp_path):
     sd, d = _oracle(nf, seed=4)
     o = hft.transcript(sd, feat, d)
     for i in (4, 5, 6):
-        assert np.abs(got[i] - o[i]).max() < P_TOL
+        close_to(got[i], o[i], P_TOL, None, f"short clip output {i}")
     dev_feat = ex.wav2feature_tensor(wav, 16000)
     assert np.abs(dev_feat.cpu().numpy() - feat).max() < 2e-3
     on, off, mp, ve = [t.cpu().numpy() for t in ex.transcript(dev_feat)]

@@ -19,7 +19,7 @@ from etude_amd import synth
 
 pytestmark = pytest.mark.gpu
 
-P_TOL, P_MEAN = 8e-2, 6e-3          # bf16 compute vs the fp32 reference (same bounds as tests/test_gpu_extractor.py)
+from tests._util import EXT_P_MEAN as P_MEAN, EXT_P_TOL as P_TOL, close_to      # the 16-bit serving mode vs the fp32 reference (the bounds of tests/test_gpu_extractor.py)
 HOP_S = 256 / 16000.0
 
 
@@ -99,7 +99,7 @@ def test_config1_single_clip_full_chain(dev, golden_dir, tmp_path):
         ref = g[name].astype(np.float32)
         e = np.abs(got[::8] - ref)
         worst = max(worst, float(e.max()))
-        assert e.max() < P_TOL and e.mean() < P_MEAN, (name, float(e.max()), float(e.mean()))
+        close_to(got[::8], ref, P_TOL, P_MEAN, "configs[1] 3-min clip " + name)
     vel_ref = g["velocity_B"]
     vel_agree = float((vel == vel_ref).mean())
     sat_ref = np.unpackbits(g["offset_B_sat"])[: off.size].reshape(off.shape).astype(bool)
@@ -116,11 +116,11 @@ def test_config1_single_clip_full_chain(dev, golden_dir, tmp_path):
     print(f"configs[1] extract: max frame error {worst:.3e}, velocity argmax agreement {vel_agree:.4f}, offset saturation agreement {sat_agree:.6f}; "
           f"notes written to extract.json (>= 0.08 s): {len(keep(got_notes))} vs {len(keep(ref_notes))} reference, recall {recall:.4f} precision {precision:.4f} (+-1 frame); "
           f"all raw notes incl. sub-80-ms fragments: {len(got_notes)} vs {len(ref_notes)}, recall {recall_all:.4f} precision {precision_all:.4f}")
-    # bf16 compute on SYNTHETIC weights: the frame outputs sit within 6e-2 of the reference, but seeded random weights give noise-like
-    # activations that hover around the 0.5 thresholds (49 k raw notes in 3 minutes), so a sizeable share of borderline notes flips;
-    # the fp32 parity mode below is the one held to >= 0.98 (measured here: 0.84 / 0.86 for the written notes, 0.956 raw)
-    assert recall >= 0.80 and precision >= 0.80 and recall_all >= 0.93
-    assert vel_agree > 0.97 and sat_agree > 0.999
+    # 16-bit compute on SYNTHETIC weights: seeded random weights give noise-like activations that hover around the 0.5 thresholds (49 k raw notes in 3
+    # minutes), so borderline notes flip with any rounding.  IEEE-half operands (round 5): frames within 1.2e-2, written notes 0.982 / 0.979, raw 0.993
+    # (bf16 operands, rounds 1-4: 6.6e-2, 0.84 / 0.86, 0.956).  The exact-parity mode below is held to >= 0.98 and measures 1.0000.
+    assert recall >= 0.95 and precision >= 0.95 and recall_all >= 0.985
+    assert vel_agree > 0.995 and sat_agree > 0.999
     # ---- fp32 parity mode on the same features: the reference's fp32 arithmetic on the device (csrc/ext_fp32.hip)
     ex32 = AMTAPC_Extractor(cfg, sd, "cuda", precision="fp32")
     on3, off3, mpe3, vel3 = [t.cpu().numpy() for t in ex32.transcript(fo)]
@@ -332,7 +332,7 @@ def test_config2_sixteen_window_batch(dev, golden_dir):
     assert on.shape == (16 * 512, 88) and vel.shape == (16 * 512, 88)
     for name, got in (("onset_B", on[:512]), ("offset_B", off[:512]), ("mpe_B", mpe[:512])):
         err = np.abs(got - g[name])
-        assert err.max() < P_TOL and err.mean() < 6e-3, (name, float(err.max()), float(err.mean()))
+        close_to(got, g[name], P_TOL, P_MEAN, "configs[2] window 0 " + name)
     for w in range(16):
         a = [t.cpu().numpy() for t in ex.transcript_windows(xd[w:w + 1])]
         sl = slice(w * 512, (w + 1) * 512)

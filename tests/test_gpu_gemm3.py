@@ -14,7 +14,7 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _gemm3(x, w, b, bound, gelu=False):
+def _gemm3(x, w, b, bound, gelu=False, ln=None):
     lib = _lib.lib()
     dev = _dev()
     xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
@@ -24,11 +24,13 @@ def _gemm3(x, w, b, bound, gelu=False):
     w = np.ascontiguousarray(w, np.float32)
     b = np.ascontiguousarray(b, np.float32)
     st = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.etd_debug_gemm3(xd.data_ptr(), M, K, w.ctypes.data, b.ctypes.data, N, float(bound), int(gelu), yd.data_ptr(), st), "etd_debug_gemm3")
+    g, be = (np.ascontiguousarray(v, np.float32) for v in ln) if ln is not None else (None, None)
+    _lib.check(lib.etd_debug_gemm3(xd.data_ptr(), M, K, w.ctypes.data, b.ctypes.data, N, float(bound), int(gelu), yd.data_ptr(),
+                                   g.ctypes.data if ln is not None else None, be.ctypes.data if ln is not None else None, st), "etd_debug_gemm3")
     return yd.cpu().numpy()
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1000, 131, 256), (515, 1536, 512), (2050, 512, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (1000, 131, 256), (515, 1536, 512), (2050, 512, 2048), (54, 1536, 512), (216, 512, 2048), (2, 154, 512)])
 def test_gemm3_has_the_error_of_an_fp32_product(M, N, K):
     rng = np.random.default_rng(M + N + K)
     x = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-3, 1, (M, 1)))).astype(np.float32)        # rows of very different magnitude
@@ -61,6 +63,25 @@ def test_gemm3_gelu_epilogue_and_a_loose_plane_bound():
     for bound in (np.abs(x).max(), 64.0 * np.abs(x).max()):      # a provable bound is looser than the data's own maximum: nothing may depend on that
         y = _gemm3(x, w, b, bound, gelu=True)
         assert np.abs(y - ref).max() <= 4e-6, (bound, np.abs(y - ref).max())
+
+
+def test_small_m_kernel_with_fused_layernorm():
+    """2 .. 512 rows take k_gemm3_s; its fused LayerNorm against float64 LayerNorm + product"""
+    rng = np.random.default_rng(21)
+    M, N, K = 100, 2048, 512
+    x = (rng.standard_normal((M, K)) * 3.0 + 0.5).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, K).astype(np.float32); be = (rng.standard_normal(K) * 0.1).astype(np.float32)
+    w = (rng.standard_normal((N, K)) * 0.04).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    x64 = x.astype(np.float64)
+    xn = (x64 - x64.mean(-1, keepdims=True)) / np.sqrt(x64.var(-1, keepdims=True) + 1e-5) * g + be
+    ref = xn @ w.astype(np.float64).T + b
+    bound = np.sqrt(K - 1) * np.abs(g).max() + np.abs(be).max()           # the provable bound the library uses (g3_bound_ln), ~8 x the data's own maximum
+    y = _gemm3(x, w, b, bound, ln=(g, be))
+    xn32 = torch.nn.functional.layer_norm(torch.from_numpy(x), (K,), torch.from_numpy(g), torch.from_numpy(be), 1e-5)
+    y32 = (xn32 @ torch.from_numpy(w).T + torch.from_numpy(b)).numpy()
+    e3, e32 = np.abs(y - ref).max(), np.abs(y32 - ref).max()
+    assert e3 <= max(2.0 * e32, 1e-6), (e3, e32)
 
 
 def _attn_ref(q, k, v, causal_lens=None):

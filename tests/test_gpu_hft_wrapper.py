@@ -12,8 +12,9 @@ import torch
 from etude_amd import synth
 from etude_amd.config import HFTConfig
 
+from tests._util import EXT_P_MEAN as P_MEAN, EXT_P_TOL as P_TOL, EXT_P_TOL_PAD as P_TOL_PAD, close_to
+
 pytestmark = pytest.mark.gpu
-P_TOL, P_TOL_PAD, P_MEAN = 8e-2, 1e-1, 6e-3
 
 
 @pytest.fixture(scope="module")
@@ -37,11 +38,10 @@ def test_transcript_stride_against_reference_golden(dev, golden_dir):
     assert out[0].shape == g["onset_B"].shape == (192, 88)        # 150 frames -> 3 half-windows of 64
     inner = slice(32, 118)                                         # frames >= 32 away from both clip ends (margin = 32 frames)
     for name, i in (("onset_B", 4), ("offset_B", 5), ("mpe_B", 6)):
-        assert np.abs(out[i] - g[name])[inner].max() < P_TOL, name
-        assert np.abs(out[i] - g[name]).max() < P_TOL_PAD, name
-        assert np.abs(out[i] - g[name]).mean() < P_MEAN, name
-    assert np.abs(out[0] - g["onset_A"].astype(np.float32)).max() < P_TOL_PAD
-    assert np.abs(out[2] - g["mpe_A"].astype(np.float32)).max() < P_TOL_PAD
+        close_to(out[i][inner], g[name][inner], P_TOL, None, "wrapper inner frames " + name)
+        close_to(out[i], g[name], P_TOL_PAD, P_MEAN, "wrapper all frames " + name)
+    close_to(out[0], g["onset_A"].astype(np.float32), P_TOL_PAD, None, "wrapper onset_A")
+    close_to(out[2], g["mpe_A"].astype(np.float32), P_TOL_PAD, None, "wrapper mpe_A")
     assert (out[7] == g["velocity_B"]).mean() > 0.9
 
 
@@ -55,7 +55,7 @@ def test_plain_transcript_against_oracle(dev):
     got = tr._transcript(feat)
     assert got[4].shape == want[4].shape == (256, 88)
     for i in (4, 5, 6):
-        assert np.abs(got[i] - want[i]).max() < P_TOL_PAD and np.abs(got[i] - want[i]).mean() < P_MEAN
+        close_to(got[i], want[i], P_TOL_PAD, P_MEAN, f"wrapper plain transcript output {i}")
 
 
 def test_constant_pad_front_end_matches_oracle(dev):

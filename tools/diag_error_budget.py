@@ -20,7 +20,7 @@ if __name__ == "__main__":
     names = ["embed", "enc0", "enc1", "enc2", "dec0", "dec1", "dec2", "time_in", "time0", "time1", "time2"]
     rows = [512 * 256] * 4 + [512 * 88] * 7
     res = {}
-    for prec, dt in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+    for prec, dt in (("fp32", torch.float32), ("f16", torch.float16)):
         ex = AMTAPC_Extractor(ExtractorConfig(), sd, "cuda", max_windows=1, precision=prec)
         bufs = [torch.zeros((r, 256), dtype=dt, device=dev) for r in rows]
         for s, b in enumerate(bufs):

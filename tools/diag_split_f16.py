@@ -79,7 +79,7 @@ def main():
     d = neox.NeoxDims()
     z = np.load(G / "decoder_ctx.npz")
     print("decoder_ctx.npz keys:", [k for k in z.files][:20])
-    modes = [("fp32 (oracle)", None, 1), ("f16 x3", torch.float16, 3), ("f16 x4", torch.float16, 4), ("f16 x3 unscaled", "f16ns", 3), ("bf16 x3", torch.bfloat16, 3), ("bf16 x4", torch.bfloat16, 4), ("f16 x1", torch.float16, 1)]
+    modes = [("fp32 (oracle)", None, 1), ("f16 x3", torch.float16, 3), ("f16 x4", torch.float16, 4), ("f16 x3 unscaled", "f16ns", 3), ("bf16 x3", torch.bfloat16, 3), ("bf16 x4", torch.bfloat16, 4), ("f16 x1", torch.float16, 1), ("f16 x1 unscaled", "f16ns1", 1), ("bf16 x1", torch.bfloat16, 1)]
     for wname, sdf in (("benchmark weights", lambda: synth.decoder_state_dict(1, {})), ("context weights", lambda: synth.decoder_state_dict_ctx(1))):
         sd = {k: torch.from_numpy(v) for k, v in sdf().items()}
         for T in (1024,):
@@ -88,7 +88,7 @@ def main():
             at = {k: torch.from_numpy(rng.integers(0, 3, T))[None] for k in ("pitch_overlap", "polyphony", "note_sustain", "rhythm_intensity")}
             ref = None
             for name, dt, terms in modes:
-                MODE.update(dtype=(torch.float16 if dt == "f16ns" else dt), terms=terms, scale=(dt != "f16ns"))
+                MODE.update(dtype=(torch.float16 if dt in ("f16ns", "f16ns1") else dt), terms=terms, scale=(dt not in ("f16ns", "f16ns1")))
                 lg, _ = neox.forward_logits(sd, d, ids, cls, at)
                 lg = lg[0].double().numpy()
                 if ref is None:
