@@ -55,11 +55,11 @@ import numpy as np  # noqa: E402
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md: the F16 forms take the same cycles)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 T_START = time.perf_counter()
 # cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r05_parity_mode.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
-# extract, the fp32 decode of its 27 jobs x all bars, and the bf16 decode of the same jobs
+# extract, the fp32 decode of its 27 jobs x all bars, and the 16-bit decode of the same jobs
 PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "8"))
 PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.2"))
 PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "1.5"))
@@ -217,9 +217,9 @@ def bar_divergence(ra, rb):
 
 def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_engines, time_left):
     """extras.parity_mode: what exact parity costs.  north_star's "identical token-id sequences under greedy decode" holds in the fp32 mode (the reference
-    runs fp32: etude_decoder.py:333); the headline is timed in bf16.  The SAME chain (extract .. notes) on the first `n_clips` clips of this rank with the fp32
+    runs fp32: etude_decoder.py:333); the headline is timed in the 16-bit serving mode (IEEE-half operands).  The SAME chain (extract .. notes) on the first `n_clips` clips of this rank with the fp32
     extractor and fp32 decoder engines (every dense contraction at fp32 grade on the f16 matrix cores: csrc/gemm3.h), ONE timed pass after a 2-bar warm-up pass;
-    then a few stamped steady-state bars for the roofline of the fp32 attention launches; then the bf16 decoder on the SAME condition bars (the fp32 extractor's)
+    then a few stamped steady-state bars for the roofline of the fp32 attention launches; then the 16-bit decoder on the SAME condition bars (the fp32 extractor's)
     for the per-bar divergence of the two decoders.  Whatever happens, every engine and the extractor are closed on the way out."""
     import torch
     from etude_amd import synth
@@ -291,7 +291,7 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_eng
             d.close()
         d32 = []
         pipe32.close(); pipe32 = None
-        # the bf16 decoder on the same condition bars: the headline's engines when they hold enough streams, else nothing (no new allocations this late)
+        # the 16-bit decoder on the same condition bars: the headline's engines when they hold enough streams, else nothing (no new allocations this late)
         if time_left() > 25.0 and bf16_engines and sum(d.max_streams for d in bf16_engines) >= n_jobs:
             pipe16 = ClipBatchPipeline([ex32], bf16_engines, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
             t4 = time.perf_counter()
@@ -299,11 +299,11 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_eng
             torch.cuda.synchronize(dev)
             t5 = time.perf_counter()
             same, comparable, jobs_same = bar_divergence(res32, res16)
-            out["bf16_same_conditions"] = {"decode_s": round(t5 - t4, 3), "decoder_tokens_per_s": round(sum(s["tokens"] for s in st16) / (t5 - t4), 1),
+            out["f16_same_conditions"] = {"decode_s": round(t5 - t4, 3), "decoder_tokens_per_s": round(sum(s["tokens"] for s in st16) / (t5 - t4), 1),
                                            "bars_identical": same, "bars_comparable": comparable, "bar_divergence_rate": round(1.0 - same / max(1, comparable), 5),
                                            "jobs_identical_end_to_end": jobs_same, "jobs": len(res32),
-                                           "note": "bf16 decoder engines of the headline on the fp32 extractor's condition bars; a bar is comparable while both histories are still equal"}
-            out["fp32_over_bf16_decode_time"] = round((t2 - t1) / (t5 - t4), 2)
+                                           "note": "the headline's 16-bit decoder engines (IEEE-half weights and KV cache; rounds 1-4: bf16, 8.5 % of the bars diverged) on the fp32 extractor's condition bars; a bar is comparable while both histories are still equal"}
+            out["fp32_over_f16_decode_time"] = round((t2 - t1) / (t5 - t4), 2)
         out["wall_s"] = round(time.perf_counter() - t_in, 2)
         return out
     finally:
@@ -570,11 +570,11 @@ def main():
         "metric": "audio-sec/s transcribed + decoder tokens/s, 3-min clip batch",
         "value": round(audio_s / elapsed, 3), "unit": "audio-s/s (each clip extracted, tokenized and decoded for every attribute tuple)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "strong" if args.clips == 0 else "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.clips == 0 else "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[4], the batch north_star names: {clips * world} x 3-min 44.1 kHz stereo clips ({clips} per rank), per clip the chain of infer.py "
                                 f"(extract wav->notes, volume contour, tokenizer on the synthetic tempo.json -> the clip's OWN condition bars: {int(np.mean(nbars))} bars of ~{xlen:.0f} ids), "
                                 f"greedy generate() for {clips}x{args.attr_grid} (clip, attribute tuple) jobs per rank with {args.bar_tokens} generated tokens per bar (Bar_EOS does not end a bar: "
-                                "synthetic weights carry no musical EOS statistics), overlap bin 2, decode_to_notes with the clip's volume map; bf16 compute / fp32 accumulate; seeded synthetic weights"
+                                "synthetic weights carry no musical EOS statistics), overlap bin 2, decode_to_notes with the clip's volume map; 16-bit operands / fp32 accumulate -- IEEE half (f16), which on MI355X has the storage, the layout and the MFMA rate of the bf16 that BASELINE.json's configs name and 3 more significant bits (extractor 5x closer to the fp32 reference, greedy bars 5x less divergent: profiles/r05_ext_f16.txt, r05_dec_f16.txt); seeded synthetic weights"
                                 + (f" -- ONLY THE FIRST {args.max_bars} BARS of every job are decoded (--max-bars: a profiling pass, not a throughput figure)" if args.max_bars else "")
                                 + (" -- CONDITION BARS REPLACED by the synthetic ~8-notes/bar song (--synthetic-bars, A/B)" if args.synthetic_bars else "")
                                 + (f" -- BATCH SHRUNK from {shrunk_from} to {clips} clips per rank to fit the harness budget of {args.budget_s:.0f}s (the full batch, one step: extras.batch64)" if shrunk_from else "")),
@@ -705,7 +705,7 @@ def main():
             torch.cuda.synchronize(dev)
             r1 = one.run(wavs[:1])
             extras["single_clip"] = {"workload": f"BASELINE configs[1]: one 3-min 44.1 kHz clip, extract (wav -> {r1['conditions'][0].notes.size} notes) + tokenize + greedy decode of "
-                                                 f"{len(r1['conditions'][0].bars)} bars x {args.bar_tokens} tokens + notes, attributes 1/1/1, bf16",
+                                                 f"{len(r1['conditions'][0].bars)} bars x {args.bar_tokens} tokens + notes, attributes 1/1/1, f16 operands",
                                      "extract_s": round(r1["t_extract"], 4), "decode_s": round(r1["t_decode"], 4), "notes_s": round(r1["t_notes"], 4),
                                      "wall_s": round(r1["t_extract"] + r1["t_decode"] + r1["t_notes"], 4),
                                      "audio_s_per_s": round(args.seconds / (r1["t_extract"] + r1["t_decode"] + r1["t_notes"]), 1),
@@ -824,7 +824,7 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     st = [dec.stats() for dec in decs]
     bytes_all = sum(s["kv_bytes"] + s["steps"] * s["weight_bytes_per_step"] for s in st)     # exact: every engine streams the weight set once per step
     gbs = bytes_all / dt / 1e9
-    out = {"workload": f"BASELINE configs[3]: {n_streams} streams on {engines} engine(s), bf16 weights+KV, ctx {ctx0 + 4}->{ctx0 + 4 + steps}, {steps} greedy steps, EOS suppressed",
+    out = {"workload": f"BASELINE configs[3]: {n_streams} streams on {engines} engine(s), f16 weights+KV, ctx {ctx0 + 4}->{ctx0 + 4 + steps}, {steps} greedy steps, EOS suppressed",
            "engines": engines, "tokens_per_s": round(n_streams * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 4),
            "alg_bytes_per_step": bytes_all / steps,
            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4)}}

@@ -21,17 +21,22 @@
 
 namespace {
 
+// fp32 -> the decoder's 16-bit operand type (dec_kernels.h: IEEE half by default, bf16 under -DETD_DEC_BF16), round to nearest even
+#if ETD_DEC_IS_F16
+inline uint16_t f2bf_h(float f) { const _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+#else
 inline uint16_t f2bf_h(float f) {
   uint32_t u; memcpy(&u, &f, 4);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
   return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
+#endif
 
 struct Lin { void* W = nullptr; float* b = nullptr; int N = 0, Npad = 0, K = 0;
-             void* Wf = nullptr;      // bf16 weights: a second copy in MFMA-fragment order for k_linear (the batched prefill); W stays row-major for the step kernels
+             void* Wf = nullptr;      // d16 weights: a second copy in MFMA-fragment order for k_linear (the batched prefill); W stays row-major for the step kernels
              void* Wp = nullptr; int w_log2 = 0; };   // fp32 weights: again as hi / lo f16 planes for k_gemm3 (csrc/gemm3.h; W stays fp32 for the weight-streaming kernels below 513 rows)
 struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
-               void* dense_hw = nullptr;   // bf16 [heads][H][64]: attention.dense regrouped per head for k_dstep_attn_down
+               void* dense_hw = nullptr;   // d16 [heads][H][64]: attention.dense regrouped per head for k_dstep_attn_down
                Lin cat;      // decode step: [dense_4h_to_h | attention.dense] along K, so mlp + attn come out of ONE GEMM
                void* mlp_frag = nullptr;   // batched prefill: up | (down | dense) as k_dmlp_fused's weight stream (H 512, I 2048)
                // fp32 mode on the f16 matrix cores: log2 of the plane scales of every GEMM / attention operand, from provable bounds (etd_decoder_create)
@@ -52,7 +57,7 @@ struct etd_dec {
   Lin head; int xf_log2 = 0;                     // (fp32 mode: plane scale of final_layer_norm's output)
   float *X1f = nullptr, *X2f = nullptr;          // fp32 mode, >= G3_MIN_ROWS rows: the two LayerNorm branches as fp32 rows
   float *t_q = nullptr, *t_ao = nullptr, *t_do = nullptr, *t_m1 = nullptr;   // fp32 mode: the last layer's tail on the prompts' last rows only ([S][H], [S][I])
-  void* head_frag = nullptr;                     // lm_head in MFMA-fragment order for k_dstep_head: [tile][k-step][lane][8] (bf16 weights, H == 512)
+  void* head_frag = nullptr;                     // lm_head in MFMA-fragment order for k_dstep_head: [tile][k-step][lane][8] (d16 weights, H == 512)
   float *rope_cos = nullptr, *rope_sin = nullptr;
   void *Kc = nullptr, *Vc = nullptr;             // [layer][slot][head][ctx][64]
   long long slot_stride = 0, layer_stride = 0;   // elements
@@ -64,8 +69,8 @@ struct etd_dec {
   float* tgt_proj = nullptr;                     // [slot][H]: attribute projection of the slot's target attributes (k_slot_proj)
   std::vector<int> last_slots;                   // host copy of what slots_dev holds
   float* qkv_raw = nullptr;                      // [3H] scratch row of the M == 1 QKV path
-  bf16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // bf16 activations of the bf16 pipeline (M > 1)
-  bf16* Qb = nullptr;                            // batched prefill: RoPE'd queries [M][H] of the MFMA attention (k_pattn reads K / V from the cache)
+  d16 *X1b = nullptr, *X2b = nullptr, *AOb = nullptr, *M1b = nullptr;   // d16 activations of the d16 pipeline (M > 1)
+  d16* Qb = nullptr;                            // batched prefill: RoPE'd queries [M][H] of the MFMA attention (k_pattn reads K / V from the cache)
   float* hlast = nullptr;                        // [S][H] gathered last rows of a batched prefill
   DSampleCfg* samp_dev = nullptr;                // sampling parameters (device-resident: captured graphs follow set_sampling)
   unsigned long long* rng_key = nullptr;         // [S] per-stream draw keys
@@ -74,7 +79,7 @@ struct etd_dec {
   // diagnostic (etd_debug_decoder_trace_*): per-row hashes of every decode-step kernel's outputs, one record per step
   unsigned* trace = nullptr; int* trace_step = nullptr; int trace_cap = 0; float* trace_pk = nullptr; float* trace_q = nullptr; float* trace_dbg = nullptr;   // trace_pk: layer 0's slabs of the LAST traced step
   int* row_cnt = nullptr;                        // [L][512] arrival counters of the in-launch row finish (DRowFin); zero between launches
-  bf16* Xcat = nullptr;                          // [512][I + H] bf16: GELU(up) | attention output, the K-concatenated input of that GEMM
+  d16* Xcat = nullptr;                          // [512][I + H] d16: GELU(up) | attention output, the K-concatenated input of that GEMM
   std::vector<int> stage;                        // host staging of a prefill batch (fallback when the pinned buffer is absent)
   // pinned host memory (hipHostMalloc): copies to / from it are true async DMAs -- a pageable source or destination costs a
   // staging pass and ~100 us per call at these sizes, all of it with this engine's queue empty (bar boundaries)
@@ -178,7 +183,7 @@ int load_vec(etd_dec* d, Loader& L, const std::string& name, int n, float** dst)
 // d->h.  Returns (in *hfinal) the buffer that holds the last layer's output (before the final LayerNorm).
 //
 // fp32 weights, or M == 1: fp32 activations, LayerNorm fused into the GEMM prologues (k_dgemm / k_dgemm_s / k_dgemv).
-// bf16 weights, M > 1:     k_ln_rows -> bf16 activations -> big-tile MFMA GEMM (k_linear decoder modes, M > 512, the
+// d16 weights, M > 1:     k_ln_rows -> d16 activations -> big-tile MFMA GEMM (k_linear decoder modes, M > 512, the
 //                          batched prefill) or the K-split skinny GEMM (M <= 512, the batched decode step).
 struct PrefillInfo { int n; const int* seq_row0; const int* seq_len; int max_len; double attn_flops; };
 // "Only each prompt's last position is needed" (begin_bars): the last layer then runs its attention, MLP and residual for
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(64) void k_trace_kv(const unsigned* Kc, const unsig
   const int slot = row_slot[row], pos = row_pos[row] < max_ctx ? row_pos[row] : max_ctx - 1;
   unsigned* out = trace + (long long)(*step % cap) * wps + off;
   for (int which = 0; which < 2; ++which) {
-    const unsigned* base = (which ? Vc : Kc) + (long long)slot * slot_stride_w + (long long)head * max_ctx * 32;      // 64 bf16 = 32 words per position
+    const unsigned* base = (which ? Vc : Kc) + (long long)slot * slot_stride_w + (long long)head * max_ctx * 32;      // 64 d16 = 32 words per position
     unsigned a_new = 0, a_all = 0;
     for (long long i = lane; i < (long long)(pos + 1) * 32; i += 64) {
       const unsigned w = base[i] * (2654435761u * (unsigned)(i + 1) | 1u);
@@ -328,13 +333,13 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
         // QKV with the token block stationary in registers and the weights streamed through LDS (csrc/dec_prefill.hip): 256-token workgroups that walk all 48 weight
         // tiles -- from ~192 workgroups up (below that k_linear's 128 x 256 tiles fill the chip better: 6 466 rows 24 us against 86)
         PQkvArgs pa = {};
-        pa.X = d->X1b; pa.ldx = d->H; pa.Wf = (const bf16*)w.qkv.Wf; pa.bias = w.qkv.b; pa.M = M; pa.N = w.qkv.N; pa.rows = rows;
-        pa.rope_cos = d->rope_cos; pa.rope_sin = d->rope_sin; pa.Qb = d->Qb; pa.Kc = (bf16*)Kl; pa.Vc = (bf16*)Vl; pa.slot_stride = d->slot_stride;
+        pa.X = d->X1b; pa.ldx = d->H; pa.Wf = (const d16*)w.qkv.Wf; pa.bias = w.qkv.b; pa.M = M; pa.N = w.qkv.N; pa.rows = rows;
+        pa.rope_cos = d->rope_cos; pa.rope_sin = d->rope_sin; pa.Qb = d->Qb; pa.Kc = (d16*)Kl; pa.Vc = (d16*)Vl; pa.slot_stride = d->slot_stride;
         pa.max_ctx = d->ctx; pa.n_heads = d->nh;
         ETD_TRY(launch_pqkv(pa, st));
       } else {
         LinArgs a = {};
-        a.X = (const e16*)d->X1b; a.ldx = d->H; a.W = (const e16*)w.qkv.Wf;     /* (LinArgs carries the extractor's element type; the decoder modes of k_linear read these as bf16) */ a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
+        a.X = (const e16*)d->X1b; a.ldx = d->H; a.W = (const e16*)w.qkv.Wf;     /* (LinArgs carries the extractor's element type; the decoder modes of k_linear read these as d16) */ a.bias = w.qkv.b; a.M = M; a.N = w.qkv.N; a.K = d->H; a.vt_block = -1; a.dec = q;
         ETD_TRY(launch_linear_dec(a, DEPI_QKV, st));
       }
       if (l == d->L - 1 && lo && mfma_attn && lo->n > 1 && lo->n <= DS_STEP_MAX_ROWS && d->H == 512 && (d->I + d->H) % (5 * 64 * 8) == 0 && !getenv("ETD_NO_LAST_ONLY")) {
@@ -392,7 +397,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       at.stamp = d->stamp_on ? d->stamp_dev : nullptr; at.stamp_par = l & 1;
       at.row_sp = d->row_sp; at.identity = d->rows_identity ? 1 : 0;
       const int ksd = d->I / 512;
-      at.dense_w = (const bf16*)w.dense_hw; at.dense_out = d->Pk + (size_t)ksd * M * d->H;
+      at.dense_w = (const d16*)w.dense_hw; at.dense_out = d->Pk + (size_t)ksd * M * d->H;
       at.dbg = (d->trace && l == 0) ? d->trace_dbg : nullptr;
       DGemmArgs dn = {};
       dn.Xb = d->Xcat; dn.ldx = d->I + d->H; dn.W = w.cat.W; dn.K = d->I + d->H; dn.M = M; dn.N = d->H; dn.Npad = d->H;
@@ -431,7 +436,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
     if (mfma_attn) {
       // ragged causal MFMA flash attention over the prompts of all streams at once, K / V straight from the cache rows (csrc/dec_prefill.hip)
       PAttnArgs t = {};
-      t.Q = d->Qb; t.ldq = d->H; t.Kc = (const bf16*)Kl; t.Vc = (const bf16*)Vl; t.slot_stride = d->slot_stride; t.max_ctx = d->ctx; t.n_heads = d->nh;
+      t.Q = d->Qb; t.ldq = d->H; t.Kc = (const d16*)Kl; t.Vc = (const d16*)Vl; t.slot_stride = d->slot_stride; t.max_ctx = d->ctx; t.n_heads = d->nh;
       t.O = d->Xcat + d->I; t.ldo = d->I + d->H; t.seq_row0 = pf->seq_row0; t.seq_len = pf->seq_len; t.row_slot = rows.slot;
       t.n_seq = pf->n; t.max_len = pf->max_len; t.scale_log2e = 0.125f * 1.4426950408889634f; t.flops_hint = pf->attn_flops;
       ETD_TRY(launch_pattn(t, st));
@@ -461,7 +466,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       // up + GELU, (down | dense), residual and the next layer's LayerNorms: one launch, the hidden layer never leaves the CU
       const Layer* nx = l + 1 < d->L ? &d->layers[l + 1] : nullptr;
       DMlpArgs ma = {};
-      ma.X2 = d->X2b; ma.AO = d->Xcat + d->I; ma.ldao = d->I + d->H; ma.hin = hin; ma.hout = hout; ma.Wm = (const bf16*)w.mlp_frag;
+      ma.X2 = d->X2b; ma.AO = d->Xcat + d->I; ma.ldao = d->I + d->H; ma.hin = hin; ma.hout = hout; ma.Wm = (const d16*)w.mlp_frag;
       ma.b_up = w.up.b; ma.b_cat = w.cat.b; ma.eps = d->cfg.layer_norm_eps; ma.M = M;
       if (nx) { ma.g1 = nx->ln1g; ma.b1 = nx->ln1b; ma.g2 = nx->ln2g; ma.b2 = nx->ln2b; ma.nx1 = d->X1b; ma.nx2 = d->X2b; }
       ETD_TRY(launch_dmlp_fused(ma, st));
@@ -677,6 +682,8 @@ int alloc_workspaces(etd_dec* d) {
 
 }  // namespace
 
+extern "C" int etd_decoder_operand_type(void) { return ETD_DEC_IS_F16; }
+
 extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                                   const int64_t* numels, int n, etd_dec** out) {
   if (!cfg || !names || !host_ptrs || !numels || !out) ETD_FAIL(ETD_EINVAL, "decoder_create: null argument");
@@ -811,7 +818,7 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
     d->xf_log2 = g3_scale_log2(g3_bound_ln(gf, bf_, H));
   }
   if (d->bf16w && H % 16 == 0) {
-    // the same bf16 values in the order one wave's A-operand loads want them: (tile t, k-step s, lane l) holds row
+    // the same d16 values in the order one wave's A-operand loads want them: (tile t, k-step s, lane l) holds row
     // 32 t + (l & 31), columns 16 s + 8 (l >> 5) .. +8 -- each load instruction then reads one contiguous 1 KiB block
     // instead of 32 B out of 32 different rows (the decode-step head kernel lives on one CU per 32 streams: its L1 traffic counts)
     const float* W = Ld.get("lm_head.weight", (int64_t)d->V * H);
@@ -1017,7 +1024,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   }
   d->rows_identity = true;
   for (int i = 0; i < n_active; ++i) if (slots[i] != i) { d->rows_identity = false; break; }
-  // bf16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
+  // d16 batched decode step on the fused kernels: [embed + LayerNorm] once per call, then per step 4 launches per layer
   // (QKV|up, attention, down|dense, residual + LayerNorm) and one head launch that also prepares the next step's rows
   const int vpad = (d->V + 31) / 32 * 32;
   // A single stream steps on the fused kernels too (round 3; ETD_FUSED_M1=0: the GEMV sequence of rounds 1-2): 25 launches per step instead of ~36 and the same
@@ -1056,7 +1063,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
       const Layer& w0 = d->layers[0];
       DHeadArgs hd = {};
       hd.hfin = hf; hd.M = n_active; hd.H = d->H; hd.V = d->V; hd.Vpad = vpad;
-      hd.lnf_g = d->lnfg; hd.lnf_b = d->lnfb; hd.eps = d->cfg.layer_norm_eps; hd.Whead = (const bf16*)d->head_frag;
+      hd.lnf_g = d->lnfg; hd.lnf_b = d->lnfb; hd.eps = d->cfg.layer_norm_eps; hd.Whead = (const d16*)d->head_frag;
       hd.row_slot = d->row_slot; hd.row_pos = d->row_pos; hd.row_active = d->row_active; hd.row_sp = d->row_sp;
       hd.cur_tok = d->cur_tok; hd.len = d->len; hd.done = d->done; hd.n_out = d->n_out; hd.out_tok = d->out_tok; hd.out_cap = d->out_cap;
       hd.eos = d->eos; hd.limit = d->limit; hd.tgt_attrs = d->tgt_attrs; hd.tgt_proj = d->tgt_proj; hd.tgt_cls = 2; hd.n_bins = d->cfg.num_attribute_bins;
@@ -1177,7 +1184,7 @@ extern "C" int etd_debug_decoder_force_pair(etd_dec* d, int mode) {
 }
 
 // test hook: after etd_debug_decoder_step_logits(d, 1, ...) every decode step stores its logits; out_host (may be null when switching)
-// receives the LAST step's [n_active][V] rows, fused bf16 step and unfused steps alike
+// receives the LAST step's [n_active][V] rows, fused d16 step and unfused steps alike
 extern "C" int etd_debug_decoder_step_logits(etd_dec* d, int on, float* out_host, int n_active, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (!d || n_active < 0 || n_active > d->S) ETD_FAIL(ETD_EINVAL, "step_logits: bad arguments");
@@ -1310,21 +1317,21 @@ extern "C" int etd_debug_decoder_checksum(etd_dec* d, unsigned long long* out, i
   return ETD_OK;
 }
 
-// diagnostic: out[(layer * S + slot) * ctx + pos] = 32-bit sum over the K and V words of that position (all heads), bf16 caches only
+// diagnostic: out[(layer * S + slot) * ctx + pos] = 32-bit sum over the K and V words of that position (all heads), d16 caches only
 __global__ void k_kv_rowsums(const unsigned* __restrict__ K, const unsigned* __restrict__ V, int L, int S, int nh, int ctx, unsigned* out) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= (long long)L * S * ctx) return;
   const int pos = (int)(i % ctx), slot = (int)((i / ctx) % S), l = (int)(i / ((long long)ctx * S));
   unsigned s = 0;
   for (int hd = 0; hd < nh; ++hd) {
-    const long long w0 = ((((long long)l * S + slot) * nh + hd) * ctx + pos) * 32;      // 64 bf16 = 32 words
+    const long long w0 = ((((long long)l * S + slot) * nh + hd) * ctx + pos) * 32;      // 64 d16 = 32 words
     for (int w = 0; w < 32; ++w) s += K[w0 + w] * (unsigned)(w + 1 + 64 * hd) + V[w0 + w] * (unsigned)(w + 33 + 64 * hd);
   }
   out[i] = s;
 }
 extern "C" int etd_debug_decoder_kv_rowsums(etd_dec* d, unsigned* out_host, long long cap, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!d || !out_host || !d->bf16w) ETD_FAIL(ETD_EINVAL, "kv_rowsums: bf16 handles only");
+  if (!d || !out_host || !d->bf16w) ETD_FAIL(ETD_EINVAL, "kv_rowsums: d16 handles only");
   const long long n = (long long)d->L * d->S * d->ctx;
   if (cap < n) ETD_FAIL(ETD_ENOMEM, "kv_rowsums: need room for %lld words", n);
   unsigned* dev = nullptr;
@@ -1336,7 +1343,7 @@ extern "C" int etd_debug_decoder_kv_rowsums(etd_dec* d, unsigned* out_host, long
   return ETD_OK;
 }
 
-// Step trace (tools/probe_trace.py): after trace_begin every decode step of the bf16 fused path records a hash of each row of each
+// Step trace (tools/probe_trace.py): after trace_begin every decode step of the d16 fused path records a hash of each row of each
 // kernel's outputs -- per layer Q, gelu(up), the 12 split-K slabs, the residual stream and the next LayerNorm rows; then the next
 // step's embeddings and tokens -- into a ring of cap_steps records.  words_per_step = (49 * layers + 2) * n_active.
 extern "C" int etd_debug_decoder_trace_begin(etd_dec* d, int cap_steps, void* stream) {
@@ -1370,7 +1377,7 @@ extern "C" int etd_debug_decoder_trace_slabs(etd_dec* d, float* out_host, long l
   HIP_TRY(hipStreamSynchronize(st));
   return ETD_OK;
 }
-// layer 0's queries [n_active][hidden] of the last traced step, and one (layer, slot, head)'s K and V cache rows [n_pos][64] (bf16 bit patterns)
+// layer 0's queries [n_active][hidden] of the last traced step, and one (layer, slot, head)'s K and V cache rows [n_pos][64] (d16 bit patterns)
 // the attention workgroups' per-lane softmax state of layer 0 in the last traced step: [heads][n_active][256][8]
 extern "C" int etd_debug_decoder_trace_lanes(etd_dec* d, float* out_host, long long cap_floats, int n_active, void* stream) {
   hipStream_t st = (hipStream_t)stream;

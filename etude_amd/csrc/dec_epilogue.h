@@ -4,7 +4,7 @@
 #include "dec_kernels.h"
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-// erf-GELU for the bf16 pipeline: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside bf16 rounding) -- one
+// erf-GELU for the d16 pipeline: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside d16 rounding) -- one
 // v_rcp, one v_exp and 7 FMAs instead of libm's two-branch erff, which costs more VALU time than the K = 512 MFMA loop
 // of the up projection it follows.  The fp32 parity mode keeps erff.
 __device__ __forceinline__ float gelu_fast(float x) {
@@ -43,10 +43,10 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
       }
     }
     if (a.Qb && part == 0) {
-      // batched prefill: bf16 row-major Q for the MFMA attention kernel (K / V: the cache rows below)
-      bf16* dp = a.Qb + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
+      // batched prefill: d16 row-major Q for the MFMA attention kernel (K / V: the cache rows below)
+      d16* dp = a.Qb + (long long)m * (a.n_heads * 64) + head * 64 + dbase;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(dp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<d16x4*>(dp + 8 * q + 4 * h) = pack4d(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
     }
     if (part == 0) {
       if (!a.Qb) {
@@ -58,9 +58,9 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
       const long long off = (long long)a.rows.slot[m] * a.slot_stride + ((long long)head * a.max_ctx + pos) * 64 + dbase;
       void* base = part == 1 ? a.Kc : a.Vc;
       if constexpr (WBF16) {
-        bf16* kp = reinterpret_cast<bf16*>(base) + off;
+        d16* kp = reinterpret_cast<d16*>(base) + off;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<bf16x4*>(kp + 8 * q + 4 * h) = pack4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<d16x4*>(kp + 8 * q + 4 * h) = pack4d(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
       } else {
         float* kp = reinterpret_cast<float*>(base) + off;
 #pragma unroll
@@ -85,8 +85,8 @@ __device__ __forceinline__ void dgemm_epilogue(const DGemmArgs& a, const f32x16&
         const f32x4 hi = *reinterpret_cast<const f32x4*>(a.hin + (long long)m * a.N + n);
         const f32x4 o = {(v[0] + ad[0]) + hi[0], (v[1] + ad[1]) + hi[1], (v[2] + ad[2]) + hi[2], (v[3] + ad[3]) + hi[3]};
         *reinterpret_cast<f32x4*>(a.hout + (long long)m * a.N + n) = o;
-      } else if (a.Yb) {     // bf16 destination (feeds the next bf16 GEMM)
-        *reinterpret_cast<bf16x4*>(a.Yb + (long long)m * a.ldy + n) = pack4(v[0], v[1], v[2], v[3]);
+      } else if (a.Yb) {     // d16 destination (feeds the next d16 GEMM)
+        *reinterpret_cast<d16x4*>(a.Yb + (long long)m * a.ldy + n) = pack4d(v[0], v[1], v[2], v[3]);
       } else if (n + 3 < a.N) {
         const f32x4 o = {v[0], v[1], v[2], v[3]};
         float* yp = a.Y + (long long)m * a.ldy + n;

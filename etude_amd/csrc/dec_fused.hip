@@ -1,4 +1,4 @@
-// Batched prefill of the EtudeDecoder, bf16: the MLP branch, attention.dense, the parallel residual and the NEXT layer's two
+// Batched prefill of the EtudeDecoder, d16: the MLP branch, attention.dense, the parallel residual and the NEXT layer's two
 // LayerNorms of a GPT-NeoX layer in ONE launch                      modeling_gpt_neox.py:239-245 (mlp), :250-272 (layer)
 //
 //   h_out = h_in + [W2 gelu(W1 x2 + b1) + Wd attn + (b2 + bd)],   x1' = LN1'(h_out),  x2' = LN2'(h_out)
@@ -33,7 +33,7 @@
 // distance is known; starting a launch's first round of workgroups staggered (s_sleep by blockIdx & 7) only added the idle time (round 4).
 //   * a wave owns 32 tokens; x2 enters once as the 32 B-operand fragments of v_mfma_f32_32x32x16_bf16 (128 registers);
 //   * the 2048-wide hidden layer exists 32 features at a time: acc1 = W1[32 rows] . x2 (32 chained MFMAs), bias + erf-GELU +
-//     bf16 rounding in registers; two v_permlane32_swap per k-step turn the accumulator's row order into the natural k order of a
+//     d16 rounding in registers; two v_permlane32_swap per k-step turn the accumulator's row order into the natural k order of a
 //     B fragment, so the second GEMM multiplies exactly the operands the unfused (down | dense) GEMM would have read from Xcat,
 //     in the same order: the result is BIT-IDENTICAL to the three-launch path (tests/test_gpu_decoder.py);
 //   * the token's 512 outputs are 16 accumulator tiles = 256 registers (the AGPR half of the wave's 512): one wave per SIMD,
@@ -50,7 +50,7 @@
 
 #include <cstdlib>
 #include <utility>
-#define PM_SLOT_ELEMS (32 * 1024)          // bf16 elements per ring slot: 64 fragments of 512 elements (64 KiB)
+#define PM_SLOT_ELEMS (32 * 1024)          // d16 elements per ring slot: 64 fragments of 512 elements (64 KiB)
 
 typedef const __attribute__((address_space(1))) void* pm_gptr_t;
 typedef __attribute__((address_space(3))) void* pm_lptr_t;
@@ -64,37 +64,37 @@ typedef __attribute__((address_space(3))) void* pm_lptr_t;
 // Register classes are explicit too: the 32 x2 / attention fragments are BORN in AGPRs (a global load may name an AccVGPR
 // destination) and are read from there as the MFMA's B operand; output tiles 0..7 live in AGPRs, 8..15 in VGPRs -- 256 + 241.
 // (Left to itself hipcc puts all 256 accumulator registers into AGPRs and shuttles the fragments through one AGPR quad.)
-template <int F> __device__ __forceinline__ void pm_rd(bf16x8& b, unsigned addr) {
+template <int F> __device__ __forceinline__ void pm_rd(d16x8& b, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(b) : "v"(addr), "n"(F * 1024));
 }
-template <int F0> __device__ __forceinline__ void pm_rd4(bf16x8 (&b)[4], unsigned addr) {
+template <int F0> __device__ __forceinline__ void pm_rd4(d16x8 (&b)[4], unsigned addr) {
   pm_rd<F0>(b[0], addr); pm_rd<F0 + 1>(b[1], addr); pm_rd<F0 + 2>(b[2], addr); pm_rd<F0 + 3>(b[3], addr);
 }
 template <int N> __device__ __forceinline__ void pm_wait_lds() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 // acc (VGPR) += A (VGPR) . B (AGPR)
-__device__ __forceinline__ void pm_mfma_v_a(f32x16& acc, const bf16x8& af, const bf16x8& bf) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(af), "a"(bf));
+__device__ __forceinline__ void pm_mfma_v_a(f32x16& acc, const d16x8& af, const d16x8& bf) {
+  asm volatile(ETD_MFMA16_DEC " %0, %1, %2, %0" : "+v"(acc) : "v"(af), "a"(bf));
 }
 // output tile T (AGPR for T < 8, VGPR above) += A (VGPR) . B (VGPR: the hidden fragment / AGPR: an attention fragment)
-template <int T, bool B_AGPR> __device__ __forceinline__ void pm_mfma_out(f32x16& acc, const bf16x8& af, const bf16x8& bf) {
+template <int T, bool B_AGPR> __device__ __forceinline__ void pm_mfma_out(f32x16& acc, const d16x8& af, const d16x8& bf) {
   if constexpr (T < 8) {
-    if constexpr (B_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(bf));
-    else                  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(bf));
+    if constexpr (B_AGPR) asm volatile(ETD_MFMA16_DEC " %0, %1, %2, %0" : "+a"(acc) : "v"(af), "a"(bf));
+    else                  asm volatile(ETD_MFMA16_DEC " %0, %1, %2, %0" : "+a"(acc) : "v"(af), "v"(bf));
   } else {
-    if constexpr (B_AGPR) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(af), "a"(bf));
-    else                  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(af), "v"(bf));
+    if constexpr (B_AGPR) asm volatile(ETD_MFMA16_DEC " %0, %1, %2, %0" : "+v"(acc) : "v"(af), "a"(bf));
+    else                  asm volatile(ETD_MFMA16_DEC " %0, %1, %2, %0" : "+v"(acc) : "v"(af), "v"(bf));
   }
 }
 // The NEXT chunk's 16 one-KiB LDS-DMA pieces of this wave are issued one per fragment group (two in the half chunks), behind the
 // group's MFMAs: issued as one burst at the chunk top they cost the wave ~100 clocks each with an idle MFMA pipe.
-struct PmNext { const bf16* src; bf16* dst; bool on; };
+struct PmNext { const d16* src; d16* dst; bool on; };
 template <int I> __device__ __forceinline__ void pm_dma(const PmNext& n) {
   // four pieces share one address computation: the instruction's immediate offset serves the global and the LDS address alike
   if (n.on) __builtin_amdgcn_global_load_lds((pm_gptr_t)(n.src + (I >> 2) * 2048), (pm_lptr_t)(n.dst + (I >> 2) * 2048), 16, (I & 3) * 1024, 0);
 }
 // fragments of group J of an MLP chunk [down(k - 1): 0 .. 31 | up(k): 32 .. 63]: groups 0 .. 7 = up, 8 .. 15 = down
 template <int J> struct PmMlpGroup { static constexpr int f0 = J < 8 ? 32 + 4 * J : 4 * (J - 8); };
-template <int J, int JEND> __device__ __forceinline__ void pm_roll(bf16x8 (&buf)[2][4], unsigned addr) {
+template <int J, int JEND> __device__ __forceinline__ void pm_roll(d16x8 (&buf)[2][4], unsigned addr) {
   // in front of group J: request group J + 1 (if the chunk has one), then wait until group J has landed
   if constexpr (J + 1 < JEND) { pm_rd4<PmMlpGroup<J + 1>::f0>(buf[(J + 1) & 1], addr); pm_wait_lds<4>(); }
   else pm_wait_lds<0>();
@@ -109,7 +109,7 @@ template <int J> __device__ __forceinline__ void pm_gelu2(f32x16& acc1, const fl
   }
 }
 // up group J (0 .. 7) of chunk 0 into accn (no GELU beside it: there is no previous chunk)
-template <int J> __device__ __forceinline__ void pm_up_group0(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, const bf16x8 (&xf)[32], const PmNext& nx) {
+template <int J> __device__ __forceinline__ void pm_up_group0(d16x8 (&buf)[2][4], unsigned addr, f32x16& accn, const d16x8 (&xf)[32], const PmNext& nx) {
   pm_roll<J, 8>(buf, addr);
 #pragma unroll
   for (int q = 0; q < 4; ++q) pm_mfma_v_a(accn, buf[J & 1][q], xf[4 * J + q]);
@@ -117,7 +117,7 @@ template <int J> __device__ __forceinline__ void pm_up_group0(bf16x8 (&buf)[2][4
   __builtin_amdgcn_sched_barrier(0);
 }
 // down group J (8 .. 15): k-step (J - 8) >> 2, tiles 4 ((J - 8) & 3) .. + 4
-template <int J, bool HALF> __device__ __forceinline__ void pm_down_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&hf)[2], const PmNext& nx) {
+template <int J, bool HALF> __device__ __forceinline__ void pm_down_group(d16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const d16x8 (&hf)[2], const PmNext& nx) {
   pm_roll<J, 16>(buf, addr);
   constexpr int g = J - 8, t0 = 4 * (g & 3);
   pm_mfma_out<t0 + 0, false>(acc2[t0 + 0], buf[J & 1][0], hf[g >> 2]);
@@ -128,7 +128,7 @@ template <int J, bool HALF> __device__ __forceinline__ void pm_down_group(bf16x8
   __builtin_amdgcn_sched_barrier(0);
 }
 // attention.dense group J (0 .. 15) of dense chunk DC: fragments 4 J .. + 4 = k-step 4 DC + (J >> 2), tiles 4 (J & 3) .. + 4
-template <int DC, int J> __device__ __forceinline__ void pm_dense_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], const PmNext& nx) {
+template <int DC, int J> __device__ __forceinline__ void pm_dense_group(d16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const d16x8 (&xf)[32], const PmNext& nx) {
   if constexpr (J + 1 < 16) { pm_rd4<4 * (J + 1)>(buf[(J + 1) & 1], addr); pm_wait_lds<4>(); }
   else pm_wait_lds<0>();
   constexpr int t0 = 4 * (J & 3), s = 4 * DC + (J >> 2);
@@ -139,7 +139,7 @@ template <int DC, int J> __device__ __forceinline__ void pm_dense_group(bf16x8 (
   pm_dma<J>(nx);
   __builtin_amdgcn_sched_barrier(0);
 }
-template <int DC, int... Js> __device__ __forceinline__ void pm_dense_chunk(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], const PmNext& nx,
+template <int DC, int... Js> __device__ __forceinline__ void pm_dense_chunk(d16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const d16x8 (&xf)[32], const PmNext& nx,
                                                                             std::integer_sequence<int, Js...>) {
   pm_rd4<0>(buf[0], addr);
   (pm_dense_group<DC, Js>(buf, addr, acc2, xf, nx), ...);
@@ -147,26 +147,26 @@ template <int DC, int... Js> __device__ __forceinline__ void pm_dense_chunk(bf16
 // the 32 GELU'd hidden features of a chunk as two natural-order B fragments: own rows are q = 2 ks -> hidden 16 ks + 4 h + (0..3)
 // and q = 2 ks + 1 -> 16 ks + 8 + 4 h + (0..3); a B fragment wants 16 ks + 8 h + (0..7): the lower lane half takes its partner's
 // q = 2 ks rows, the upper half its partner's q = 2 ks + 1
-__device__ __forceinline__ void pm_hidden_frags(const f32x16& acc1, bf16x8 (&hf)[2]) {
+__device__ __forceinline__ void pm_hidden_frags(const f32x16& acc1, d16x8 (&hf)[2]) {
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
-    const bf16x4 p0 = pack4(acc1[8 * ks], acc1[8 * ks + 1], acc1[8 * ks + 2], acc1[8 * ks + 3]);
-    const bf16x4 p1 = pack4(acc1[8 * ks + 4], acc1[8 * ks + 5], acc1[8 * ks + 6], acc1[8 * ks + 7]);
+    const d16x4 p0 = pack4d(acc1[8 * ks], acc1[8 * ks + 1], acc1[8 * ks + 2], acc1[8 * ks + 3]);
+    const d16x4 p1 = pack4d(acc1[8 * ks + 4], acc1[8 * ks + 5], acc1[8 * ks + 6], acc1[8 * ks + 7]);
     const u32x2 v0 = __builtin_bit_cast(u32x2, p0), v1 = __builtin_bit_cast(u32x2, p1);
     const auto s0 = __builtin_amdgcn_permlane32_swap(v0[0], v1[0], false, false);
     const auto s1 = __builtin_amdgcn_permlane32_swap(v0[1], v1[1], false, false);
     const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-    hf[ks] = __builtin_bit_cast(bf16x8, o);
+    hf[ks] = __builtin_bit_cast(d16x8, o);
   }
   // (VALU -> MFMA source wait states: the compiler does not know the asm below is an MFMA.  The fragments are operands of the nop so
   // that the arithmetic producing them cannot be scheduled behind it.)
   asm volatile("s_nop 4" : "+v"(hf[0]), "+v"(hf[1]) : : "memory");
 }
-template <int... Js> __device__ __forceinline__ void pm_up_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accn, const bf16x8 (&xf)[32], const PmNext& nx, std::integer_sequence<int, Js...>) {
+template <int... Js> __device__ __forceinline__ void pm_up_only(d16x8 (&buf)[2][4], unsigned addr, f32x16& accn, const d16x8 (&xf)[32], const PmNext& nx, std::integer_sequence<int, Js...>) {
   pm_rd4<PmMlpGroup<0>::f0>(buf[0], addr);
   (pm_up_group0<Js>(buf, addr, accn, xf, nx), ...);
 }
-template <int... Js> __device__ __forceinline__ void pm_down_only(bf16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const bf16x8 (&hf)[2], const PmNext& nx, std::integer_sequence<int, Js...>) {
+template <int... Js> __device__ __forceinline__ void pm_down_only(d16x8 (&buf)[2][4], unsigned addr, f32x16 (&acc2)[16], const d16x8 (&hf)[2], const PmNext& nx, std::integer_sequence<int, Js...>) {
   // chunk 64: only the down half exists -- groups 8 .. 15 with their own lead
   pm_rd4<PmMlpGroup<8>::f0>(buf[8 & 1], addr);
   (pm_down_group<8 + Js, true>(buf, addr, acc2, hf, nx), ...);
@@ -185,12 +185,12 @@ template <int... Js> __device__ __forceinline__ void pm_down_only(bf16x8 (&buf)[
 //   * four pieces share one address computation (the instruction's immediate offset serves the global and the LDS address alike);
 //   * the two up accumulators swap roles from chunk to chunk (no 16-register copy), and the first MFMA of a chain takes C = 0 (no zero fill).
 // acc (VGPR) = A (VGPR) . B (AGPR): the first MFMA of an up chain
-__device__ __forceinline__ void pm_mfma_v_a0(f32x16& acc, const bf16x8& af, const bf16x8& bf) {
-  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(acc) : "v"(af), "a"(bf));      // early clobber: the 16 result registers must not overlap the A operand
+__device__ __forceinline__ void pm_mfma_v_a0(f32x16& acc, const d16x8& af, const d16x8& bf) {
+  asm volatile(ETD_MFMA16_DEC " %0, %1, %2, 0" : "=&v"(acc) : "v"(af), "a"(bf));      // early clobber: the 16 result registers must not overlap the A operand
 }
 // group J of chunk [down(k - 1): groups 8 .. 15 | up(k): groups 0 .. 7]; GR >= 0: GELU of register GR of `g` (bias word at bias_addr + its offset); ND pieces from D0
 template <int J, int GR, int D0, int ND>
-__device__ __forceinline__ void pm_group(bf16x8 (&buf)[2][4], unsigned addr, f32x16& accu, f32x16 (&acc2)[16], const bf16x8 (&xf)[32], const bf16x8& hfk,
+__device__ __forceinline__ void pm_group(d16x8 (&buf)[2][4], unsigned addr, f32x16& accu, f32x16 (&acc2)[16], const d16x8 (&xf)[32], const d16x8& hfk,
                                          f32x16& g, unsigned bias_addr, const PmNext& nx) {
   constexpr bool UP = J < 8, GELU = GR >= 0, LAST = J == 15;
   constexpr int g8 = UP ? 0 : J - 8, t0 = 4 * (g8 & 3);
@@ -235,14 +235,14 @@ __device__ __forceinline__ void pm_group(bf16x8 (&buf)[2][4], unsigned addr, f32
   __builtin_amdgcn_sched_barrier(0);
 }
 // the GELU'd hidden features of k-step KS (registers 8 KS .. 8 KS + 7) as the natural-order B fragment (pm_hidden_frags, one k-step)
-template <int KS> __device__ __forceinline__ void pm_hidden_frag1(const f32x16& acc1, bf16x8& hfk) {
-  const bf16x4 p0 = pack4(acc1[8 * KS], acc1[8 * KS + 1], acc1[8 * KS + 2], acc1[8 * KS + 3]);
-  const bf16x4 p1 = pack4(acc1[8 * KS + 4], acc1[8 * KS + 5], acc1[8 * KS + 6], acc1[8 * KS + 7]);
+template <int KS> __device__ __forceinline__ void pm_hidden_frag1(const f32x16& acc1, d16x8& hfk) {
+  const d16x4 p0 = pack4d(acc1[8 * KS], acc1[8 * KS + 1], acc1[8 * KS + 2], acc1[8 * KS + 3]);
+  const d16x4 p1 = pack4d(acc1[8 * KS + 4], acc1[8 * KS + 5], acc1[8 * KS + 6], acc1[8 * KS + 7]);
   const u32x2 v0 = __builtin_bit_cast(u32x2, p0), v1 = __builtin_bit_cast(u32x2, p1);
   const auto s0 = __builtin_amdgcn_permlane32_swap(v0[0], v1[0], false, false);
   const auto s1 = __builtin_amdgcn_permlane32_swap(v0[1], v1[1], false, false);
   const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-  hfk = __builtin_bit_cast(bf16x8, o);
+  hfk = __builtin_bit_cast(d16x8, o);
   asm volatile("s_nop 4" : "+v"(hfk) : : "memory");      // (VALU -> MFMA source wait states: the compiler does not know the asm below is an MFMA)
 }
 // one chunk k in 1 .. 63.  prev = up(k - 1)'s accumulator (registers 0 .. 3 already GELU'd), cur = up(k)'s (written here; its registers 0 .. 3 leave GELU'd)
@@ -250,9 +250,9 @@ template <int KS> __device__ __forceinline__ void pm_hidden_frag1(const f32x16& 
 // x2's last use is group 7 -- instead of at the top of chunk 64, where the 32 fragment-shaped loads + their wait cost a wave ~8 k clocks with an idle MFMA pipe
 #define PM_LOADX(dst, ptr, S) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=a"(dst) : "v"(ptr), "n"(32 * (S)) : "memory")      /* fragment S of the lane's row: one base register, immediate offsets */
 template <bool AOL>
-__device__ __forceinline__ void pm_chunk(bf16x8 (&buf)[2][4], unsigned sa, f32x16& prev, f32x16& cur, f32x16 (&acc2)[16], bf16x8 (&xf)[32], bf16x8 (&hf)[2],
-                                         unsigned bias_prev, unsigned bias_cur, const PmNext& nx, const bf16* ao, long long ao_off) {
-  const bf16* ap = nullptr;
+__device__ __forceinline__ void pm_chunk(d16x8 (&buf)[2][4], unsigned sa, f32x16& prev, f32x16& cur, f32x16 (&acc2)[16], d16x8 (&xf)[32], d16x8 (&hf)[2],
+                                         unsigned bias_prev, unsigned bias_cur, const PmNext& nx, const d16* ao, long long ao_off) {
+  const d16* ap = nullptr;
   if constexpr (AOL) { ap = ao + ao_off; asm volatile("" : "+v"(ap)); }      // (formed here, not held through the 62 chunks before)
 #define PM_AOL(G) do { if constexpr (AOL) { PM_LOADX(xf[4 * (G)], ap, 4 * (G)); PM_LOADX(xf[4 * (G) + 1], ap, 4 * (G) + 1); PM_LOADX(xf[4 * (G) + 2], ap, 4 * (G) + 2); PM_LOADX(xf[4 * (G) + 3], ap, 4 * (G) + 3); } } while (0)
   pm_rd4<PmMlpGroup<0>::f0>(buf[0], sa);
@@ -297,7 +297,7 @@ __device__ unsigned long long g_pmlp_stamp[64 * 4 * 8];
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_dmlp_fused(DMlpArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PM_SLOT_ELEMS * 2 + 2048 * 4];
-  bf16* ring = reinterpret_cast<bf16*>(smem);
+  d16* ring = reinterpret_cast<d16*>(smem);
   float* sbu = reinterpret_cast<float*>(smem + 2 * PM_SLOT_ELEMS * 2);      // b_up[2048]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int m = blockIdx.x * 128 + wave * 32 + r;
@@ -310,8 +310,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 
   // ring slot (k & 1) <- stream chunk k: 64 one-KiB pieces, 16 per wave
   auto issue = [&](int k) {
-    const bf16* src = a.Wm + (long long)k * PM_SLOT_ELEMS + wave * (16 * 512) + lane * 8;
-    bf16* dst = ring + (k & 1) * PM_SLOT_ELEMS + wave * (16 * 512);
+    const d16* src = a.Wm + (long long)k * PM_SLOT_ELEMS + wave * (16 * 512) + lane * 8;
+    d16* dst = ring + (k & 1) * PM_SLOT_ELEMS + wave * (16 * 512);
 #pragma unroll
     for (int i = 0; i < 16; ++i)
       __builtin_amdgcn_global_load_lds((pm_gptr_t)(src + i * 512), (pm_lptr_t)(dst + i * 512), 16, 0, 0);
@@ -329,9 +329,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   issue(0);
   // the token tile as B fragments: lane (token r, half h) holds x2[token][16 s + 8 h .. + 8], s = 0 .. 31 -- loaded straight into
   // AGPRs; the compiler does not count these loads, PM_TOP(0)'s vmcnt(0) does
-  bf16x8 xf[32];
+  d16x8 xf[32];
   {
-    const bf16* xp = a.X2 + (long long)mc * 512 + 8 * h;
+    const d16* xp = a.X2 + (long long)mc * 512 + 8 * h;
 #define PM_X4(S) PM_LOADX(xf[S], xp, S); PM_LOADX(xf[(S) + 1], xp, (S) + 1); PM_LOADX(xf[(S) + 2], xp, (S) + 2); PM_LOADX(xf[(S) + 3], xp, (S) + 3)
     PM_X4(0); PM_X4(4); PM_X4(8); PM_X4(12); PM_X4(16); PM_X4(20); PM_X4(24); PM_X4(28);
 #undef PM_X4
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc2[t][i] = 0.f;
   f32x16 accA, accB;
-  bf16x8 buf[2][4], hf[2];
+  d16x8 buf[2][4], hf[2];
   using seq8 = std::make_integer_sequence<int, 8>;
   using seq16 = std::make_integer_sequence<int, 16>;
 #define PM_ZERO(x) _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) x[i_] = 0.f
@@ -519,12 +519,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   float qt;
   PM_FOLD(gs, qt);
   const float rstd = rsqrtf(qt / 512.f + a.eps);
-  // the two normalised rows, bf16: halves of 256 features = 512-byte segments through the same staging block ([32][264] bf16: the same 528-byte row pitch)
-  bf16* stb = reinterpret_cast<bf16*>(stg);
+  // the two normalised rows, d16: halves of 256 features = 512-byte segments through the same staging block ([32][264] d16: the same 528-byte row pitch)
+  d16* stb = reinterpret_cast<d16*>(stg);
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     const float* gam = spar + (which ? 1536 : 512); const float* bet = spar + (which ? 2048 : 1024);
-    bf16* dstp = which ? a.nx2 : a.nx1;
+    d16* dstp = which ? a.nx2 : a.nx1;
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -534,12 +534,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           const int t = 8 * hh + tt, f0 = 32 * t + 16 * u + 8 * h;
           const f32x4 ga = *reinterpret_cast<const f32x4*>(gam + f0), gb = *reinterpret_cast<const f32x4*>(gam + f0 + 4);
           const f32x4 ba = *reinterpret_cast<const f32x4*>(bet + f0), bb = *reinterpret_cast<const f32x4*>(bet + f0 + 4);
-          bf16x8 o;
+          d16x8 o;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            o[j] = (bf16)((acc2[t][8 * u + j] - mean) * rstd * ga[j] + ba[j]); o[4 + j] = (bf16)((acc2[t][8 * u + 4 + j] - mean) * rstd * gb[j] + bb[j]);
+            o[j] = (d16)((acc2[t][8 * u + j] - mean) * rstd * ga[j] + ba[j]); o[4 + j] = (d16)((acc2[t][8 * u + 4 + j] - mean) * rstd * gb[j] + bb[j]);
           }
-          *reinterpret_cast<bf16x8*>(stb + r * (2 * SROW) + 32 * tt + 16 * u + 8 * h) = o;
+          *reinterpret_cast<d16x8*>(stb + r * (2 * SROW) + 32 * tt + 16 * u + 8 * h) = o;
         }
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
@@ -573,7 +573,7 @@ int launch_dmlp_fused(const DMlpArgs& a, hipStream_t st) {
   return ETD_OK;
 }
 
-// Host side: dense_h_to_4h [2048][512] and the K-concatenated (dense_4h_to_h | attention.dense) [512][2560], both already bf16 in
+// Host side: dense_h_to_4h [2048][512] and the K-concatenated (dense_4h_to_h | attention.dense) [512][2560], both already d16 in
 // nn.Linear layout -> the kernel's stream: DMLP_NCHUNK chunks of 64 fragments x 64 lanes x 8 elements.
 //   chunk k = 0 .. 64:  fragments  0 .. 31 = down(k - 1): (k-step ks, tile t) at 16 ks + t (zeros for k = 0)
 //                       fragments 32 .. 63 = up(k): k-step s at 32 + s                     (zeros for k = 64)

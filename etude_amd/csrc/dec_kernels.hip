@@ -5,13 +5,13 @@
 // Two weight precisions share every kernel:
 //   * fp32 ("parity mode"): exact-fp32 products on v_mfma_f32_32x32x2_f32 (bit-identical to an fmaf
 //     chain), fp32 KV cache -- this is what the greedy token-id parity gate runs on;
-//   * bf16: v_mfma_f32_32x32x16_bf16 on bf16 weights and a bf16 KV cache (the HBM-bound serving mode).
+//   * d16: v_mfma_f32_32x32x16_bf16 on d16 weights and a d16 KV cache (the HBM-bound serving mode).
 // The residual stream, LayerNorm, RoPE, softmax and the logits are fp32 in both.
 #include "dec_kernels.h"
 #include "prof.h"
 
 #define DLD32 36   // fp32 LDS row stride (floats) for a 32-wide K chunk: 144 B
-#define DLD16 72   // bf16 LDS row stride (elements) for a 64-wide K chunk: 144 B
+#define DLD16 72   // d16 LDS row stride (elements) for a 64-wide K chunk: 144 B
 
 #include "dec_epilogue.h"
 
@@ -126,11 +126,11 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
       __syncthreads();
     }
   } else {
-    bf16* Xs = reinterpret_cast<bf16*>(smem);
-    bf16* Ws = Xs + 32 * DLD16;
-    const bf16* W = reinterpret_cast<const bf16*>(a.W) + (long long)n0 * a.K;
+    d16* Xs = reinterpret_cast<d16*>(smem);
+    d16* Ws = Xs + 32 * DLD16;
+    const d16* W = reinterpret_cast<const d16*>(a.W) + (long long)n0 * a.K;
     for (int k0 = 0; k0 < a.K; k0 += 64) {
-      {  // X: 32 rows x 8 chunks of 8 floats -> bf16
+      {  // X: 32 rows x 8 chunks of 8 floats -> d16
         const int row = tid >> 3, ch = tid & 7;
         int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
         const float* xp = a.X + (long long)gm * a.ldx + k0 + ch * 8;
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) { v0[j] = (v0[j] - mean) * rstd * g0[j] + b0[j]; v1[j] = (v1[j] - mean) * rstd * g1[j] + b1[j]; }
         }
-        bf16x8 o = {(bf16)v0[0], (bf16)v0[1], (bf16)v0[2], (bf16)v0[3], (bf16)v1[0], (bf16)v1[1], (bf16)v1[2], (bf16)v1[3]};
-        *reinterpret_cast<bf16x8*>(Xs + row * DLD16 + ch * 8) = o;
+        d16x8 o = {(d16)v0[0], (d16)v0[1], (d16)v0[2], (d16)v0[3], (d16)v1[0], (d16)v1[1], (d16)v1[2], (d16)v1[3]};
+        *reinterpret_cast<d16x8*>(Xs + row * DLD16 + ch * 8) = o;
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {  // W: 128 rows x 8 chunks of 16 B
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
       __syncthreads();
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + (wave * 32 + r) * DLD16 + s * 16 + h * 8);
-        const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Xs + r * DLD16 + s * 16 + h * 8);
+        const d16x8 wf = *reinterpret_cast<const d16x8*>(Ws + (wave * 32 + r) * DLD16 + s * 16 + h * 8);
+        const d16x8 xf = *reinterpret_cast<const d16x8*>(Xs + r * DLD16 + s * 16 + h * 8);
         acc = mfma32(wf, xf, acc);
       }
       __syncthreads();
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_dgemm(DGemmArgs a) {
 // K is split over the waves of a workgroup; each wave keeps 512 / DS_WAVES of k (32 fragment loads) in flight per round trip.
                      // Measured per 128-stream step: 8 waves 0.423 ms, 4 waves 0.404 ms, 2 waves 0.385 ms (fewer wave slots held, shorter LDS reduction)
 template <bool WBF16, int EPI>
-__global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, int p_ks, int p_K, const void* p_W, const bf16* p_Xb, int p_ldx, DGemmArgs a) {   // leading scalars: kernarg preload
+__global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, int p_ks, int p_K, const void* p_W, const d16* p_Xb, int p_ldx, DGemmArgs a) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   __shared__ float stat[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -221,28 +221,28 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, 
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
   if constexpr (WBF16) {
-    const bf16* wrow = reinterpret_cast<const bf16*>(p_W) + (long long)(n0 + r) * p_K;
+    const d16* wrow = reinterpret_cast<const d16*>(p_W) + (long long)(n0 + r) * p_K;
     if (p_Xb) {
-      const bf16* xbrow = p_Xb + (long long)gm * p_ldx;
+      const d16* xbrow = p_Xb + (long long)gm * p_ldx;
       int k = kb;
       constexpr int PW = 512 / DS_WAVES, PN = PW / 16;      // k covered per round trip by one wave: all its fragment loads in flight, then the MFMAs
       for (; k + PW <= ke; k += PW) {
-        bf16x8 wf[PN], xf[PN];
+        d16x8 wf[PN], xf[PN];
 #pragma unroll
         for (int s8 = 0; s8 < PN; ++s8) {
-          wf[s8] = *reinterpret_cast<const bf16x8*>(wrow + k + s8 * 16 + h * 8);
-          xf[s8] = *reinterpret_cast<const bf16x8*>(xbrow + k + s8 * 16 + h * 8);
+          wf[s8] = *reinterpret_cast<const d16x8*>(wrow + k + s8 * 16 + h * 8);
+          xf[s8] = *reinterpret_cast<const d16x8*>(xbrow + k + s8 * 16 + h * 8);
         }
         __builtin_amdgcn_sched_barrier(0);     // every load of the pass is issued before the first MFMA waits: ONE round trip
 #pragma unroll
         for (int s8 = 0; s8 < PN; ++s8) acc = mfma32(wf[s8], xf[s8], acc);
       }
       for (; k < ke; k += 64) {
-        bf16x8 wf[4], xf[4];
+        d16x8 wf[4], xf[4];
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
-          xf[s4] = *reinterpret_cast<const bf16x8*>(xbrow + k + s4 * 16 + h * 8);
+          wf[s4] = *reinterpret_cast<const d16x8*>(wrow + k + s4 * 16 + h * 8);
+          xf[s4] = *reinterpret_cast<const d16x8*>(xbrow + k + s4 * 16 + h * 8);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -251,10 +251,10 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, 
     } else {
 #pragma unroll 2
       for (int k = kb; k < ke; k += 64) {
-        bf16x8 wf[4]; f32x4 x0[4], x1[4];
+        d16x8 wf[4]; f32x4 x0[4], x1[4];
   #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4) {
-          wf[s4] = *reinterpret_cast<const bf16x8*>(wrow + k + s4 * 16 + h * 8);
+          wf[s4] = *reinterpret_cast<const d16x8*>(wrow + k + s4 * 16 + h * 8);
           x0[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8);
           x1[s4] = *reinterpret_cast<const f32x4*>(xrow + k + s4 * 16 + h * 8 + 4);
         }
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, 
   #pragma unroll
             for (int j = 0; j < 4; ++j) { x0[s4][j] = (x0[s4][j] - mean) * rstd * g0[j] + b0[j]; x1[s4][j] = (x1[s4][j] - mean) * rstd * g1[j] + b1[j]; }
           }
-          const bf16x8 xf = {(bf16)x0[s4][0], (bf16)x0[s4][1], (bf16)x0[s4][2], (bf16)x0[s4][3], (bf16)x1[s4][0], (bf16)x1[s4][1], (bf16)x1[s4][2], (bf16)x1[s4][3]};
+          const d16x8 xf = {(d16)x0[s4][0], (d16)x0[s4][1], (d16)x0[s4][2], (d16)x0[s4][3], (d16)x1[s4][0], (d16)x1[s4][1], (d16)x1[s4][2], (d16)x1[s4][3]};
           acc = mfma32(wf[s4], xf, acc);
         }
       }
@@ -320,11 +320,11 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dgemm_s(int p_M, int p_Npad, 
 // k_dstep_qkv_up: the two GEMMs of a decode step that only depend on the layer's LayerNorm rows -- the fused QKV
 // projection (X1b, +RoPE, KV append) and the MLP up projection (X2b, +GELU) -- in ONE launch: feature tiles
 // [0, split) belong to the first problem, the rest to the second.  Same 32x32 / 8-wave K-split body as k_dgemm_s
-// (bf16 inputs, K = hidden).  One dependent kernel boundary less per layer of a latency-bound chain.
+// (d16 inputs, K = hidden).  One dependent kernel boundary less per layer of a latency-bound chain.
 // ================================================================================================
 // Epilogue of one 32-feature x 32-token tile of the decode step's QKV|up GEMM: lane = token m, register i = feature n0 + acc_row(i, h).
 // QKV tiles ([head][q|k|v][64], modeling_gpt_neox.py:204-207): bias, partial RoPE on the first 16 dims of q / k, Q as fp32 rows, K / V appended
-// to the slot's cache rows; up tiles: bias + erf-GELU -> bf16 rows of Xcat.  Shared by k_dstep_qkv_up and k_dstep_qkv_up_mt (same operations in the
+// to the slot's cache rows; up tiles: bias + erf-GELU -> d16 rows of Xcat.  Shared by k_dstep_qkv_up and k_dstep_qkv_up_mt (same operations in the
 // same order: bit-identical results).
 __device__ __forceinline__ void qkv_up_tile_values(const f32x16& acc, const f32x4 (&bq)[4], bool isq, bool rope, const f32x4& rc, const f32x4& rs, float (&v)[16]) {
 #pragma unroll
@@ -351,13 +351,13 @@ __device__ __forceinline__ void qkv_up_store_tile(const f32x16& acc, const f32x4
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = acc[i] + bq[i >> 2][i & 3];
   if (!isq) {
-    // MLP up: erf-GELU, bf16 rows for the down projection
+    // MLP up: erf-GELU, d16 rows for the down projection
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
       const int n = n0 + 8 * q4 + 4 * h;
       if (n < up.N)
-        *reinterpret_cast<bf16x4*>(up.Yb + (long long)m * up.ldy + n) =
-            pack4(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
+        *reinterpret_cast<d16x4*>(up.Yb + (long long)m * up.ldy + n) =
+            pack4d(gelu_fast(v[4 * q4]), gelu_fast(v[4 * q4 + 1]), gelu_fast(v[4 * q4 + 2]), gelu_fast(v[4 * q4 + 3]));
     }
     return;
   }
@@ -374,14 +374,14 @@ __device__ __forceinline__ void qkv_up_store_tile(const f32x16& acc, const f32x4
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) { const f32x4 o = {v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]}; *reinterpret_cast<f32x4*>(qp + 8 * q4 + 4 * h) = o; }
   } else if (act && pos < q.max_ctx) {
-    bf16* kp = reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)slot * q.slot_stride + ((long long)head * q.max_ctx + pos) * 64 + dbase;
+    d16* kp = reinterpret_cast<d16*>(part == 1 ? q.Kc : q.Vc) + (long long)slot * q.slot_stride + ((long long)head * q.max_ctx + pos) * 64 + dbase;
 #pragma unroll
-    for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<bf16x4*>(kp + 8 * q4 + 4 * h) = pack4(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
+    for (int q4 = 0; q4 < 4; ++q4) *reinterpret_cast<d16x4*>(kp + 8 * q4 + 4 * h) = pack4d(v[4 * q4], v[4 * q4 + 1], v[4 * q4 + 2], v[4 * q4 + 3]);
   }
 }
 
-__global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K, int split, int p_ftiles, const void* p_Wq, const void* p_Wu, const bf16* p_Xq,
-                                                               const bf16* p_Xu, int p_ldxq, int p_ldxu, int p_rpt, DGemmArgs q, DGemmArgs up) {   // leading scalars: kernarg preload
+__global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K, int split, int p_ftiles, const void* p_Wq, const void* p_Wu, const d16* p_Xq,
+                                                               const d16* p_Xu, int p_ldxq, int p_ldxu, int p_rpt, DGemmArgs q, DGemmArgs up) {   // leading scalars: kernarg preload
   __shared__ __attribute__((aligned(16))) float red[DS_WAVES - 1][16][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int M = p_M, K = p_K;
@@ -410,20 +410,20 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) bq[q4] = *reinterpret_cast<const f32x4*>(bp + 8 * q4);
   }
-  const bf16* wrow = reinterpret_cast<const bf16*>(isq ? p_Wq : p_Wu) + (long long)(n0 + r) * K;
-  const bf16* xbase = isq ? p_Xq : p_Xu;
+  const d16* wrow = reinterpret_cast<const d16*>(isq ? p_Wq : p_Wu) + (long long)(n0 + r) * K;
+  const d16* xbase = isq ? p_Xq : p_Xu;
   const int ldx = isq ? p_ldxq : p_ldxu;
   const int kq = K / DS_WAVES, kb = wave * kq;
   constexpr int NS = 8 / DS_WAVES * 4;           // 16-wide k-steps per wave at K = 512 (launcher-checked: K == 64 * DS_WAVES * NS / 4)
-  bf16x8 wf[NS], xf[NS];
+  d16x8 wf[NS], xf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
 #ifdef ETD_ABL_QKVW
-    wf[s] = bf16x8{(bf16)(float)(((uintptr_t)(wrow + s)) & 7), 0, 0, 0, 0, 0, 0, 0};
+    wf[s] = d16x8{(d16)(float)(((uintptr_t)(wrow + s)) & 7), 0, 0, 0, 0, 0, 0, 0};
 #else
-    wf[s] = *reinterpret_cast<const bf16x8*>(wrow + kb + s * 16 + h * 8);
+    wf[s] = *reinterpret_cast<const d16x8*>(wrow + kb + s * 16 + h * 8);
 #endif
-    xf[s] = *reinterpret_cast<const bf16x8*>(xbase + (long long)gm * ldx + kb + s * 16 + h * 8);
+    xf[s] = *reinterpret_cast<const d16x8*>(xbase + (long long)gm * ldx + kb + s * 16 + h * 8);
   }
   for (int t = 0; t < p_rpt; ++t) {
     const int m0 = (rt0 + t) * 32;
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
     if (t + 1 < p_rpt && m0 + 32 < M) {
       int gn = m0 + 32 + r; gn = gn < M ? gn : M - 1;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xbase + (long long)gn * ldx + kb + s * 16 + h * 8);
+      for (int s = 0; s < NS; ++s) xf[s] = *reinterpret_cast<const d16x8*>(xbase + (long long)gn * ldx + kb + s * 16 + h * 8);
       pos = q.rows.pos[gn]; slot = q.rows.slot[gn]; act = q.rows.active[gn];
     }
     if (wave > 0) {
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
 //     conflict-free ds_read_b128 from 144-byte rows;
 //   * outputs leave as full row segments through the same LDS (below).
 // Bit-identical to the 32 x 32 form: a tile's sum is still (k 0 .. 255 chained) + (k 256 .. 511 chained), as that kernel's two K-half waves form it.
-#define QMT_PITCH 144                                    // bytes per LDS row of 64 bf16 (+16: conflict-free 16-byte fragment reads)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dstep_qkv_up_mt(int p_M, int split128, int p_ftiles128, const bf16* p_Wfq, const bf16* p_Wfu, const bf16* p_Xq, const bf16* p_Xu,
+#define QMT_PITCH 144                                    // bytes per LDS row of 64 d16 (+16: conflict-free 16-byte fragment reads)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dstep_qkv_up_mt(int p_M, int split128, int p_ftiles128, const d16* p_Wfq, const d16* p_Wfu, const d16* p_Xq, const d16* p_Xu,
                                                          int p_ldxq, int p_ldxu, DGemmArgs q, DGemmArgs up) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 128 * QMT_PITCH];      // K loop: two [128 rows][64 k] chunks of X; epilogue: four [64 rows][64 features] wave regions
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5, fh = wave & 1, rh = wave >> 1;
@@ -488,11 +488,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (ft >= p_ftiles128) return;
   const bool isq = ft < split128;
   const int mwg = ((bid >> 3) % RT) * 128, m0 = mwg + rh * 64, n0 = (isq ? ft : ft - split128) * 128 + fh * 64;
-  const bf16* wfrag = (isq ? p_Wfq : p_Wfu) + ((long long)(n0 / 32) * (K / 16) * 64 + lane) * 8;      // fragment (tile n0 / 32 + t, k-step s) at + ((t * 32 + s) * 64) * 8
-  const bf16* xbase = isq ? p_Xq : p_Xu;
+  const d16* wfrag = (isq ? p_Wfq : p_Wfu) + ((long long)(n0 / 32) * (K / 16) * 64 + lane) * 8;      // fragment (tile n0 / 32 + t, k-step s) at + ((t * 32 + s) * 64) * 8
+  const d16* xbase = isq ? p_Xq : p_Xu;
   const int ldx = isq ? p_ldxq : p_ldxu;
   // this thread's four 16-byte pieces of a chunk: piece p = tid + 256 i -> row p >> 3, 16-byte column p & 7
-  const bf16* xsrc[4]; int xdst[4];
+  const d16* xsrc[4]; int xdst[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int pce = tid + 256 * i, row = pce >> 3, c = pce & 7;
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[f][t][i] = 0.f;
   u32x4 xr[4];                                           // the next chunk's pieces on their way to LDS
-  bf16x8 wf[2][4][2];                                    // [buffer][k-step of the chunk][feature tile]
+  d16x8 wf[2][4][2];                                    // [buffer][k-step of the chunk][feature tile]
   auto xrequest = [&](int c) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) xr[i] = *reinterpret_cast<const u32x4*>(xsrc[i] + c * 64);
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-      for (int f = 0; f < 2; ++f) wf[b][s4][f] = *reinterpret_cast<const bf16x8*>(wfrag + (long long)((f * 32 + c * 4 + s4) * 64) * 8);
+      for (int f = 0; f < 2; ++f) wf[b][s4][f] = *reinterpret_cast<const d16x8*>(wfrag + (long long)((f * 32 + c * 4 + s4) * 64) * 8);
   };
   xrequest(0); wrequest(0, 0);
 #pragma unroll
@@ -546,9 +546,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (c + 1 < 8) { xrequest(c + 1); wrequest(c + 1, b ^ 1); }
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
-        bf16x8 xf[2];
+        d16x8 xf[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(xb + (rh * 64 + 32 * t + r) * QMT_PITCH + s4 * 32 + h * 16);
+        for (int t = 0; t < 2; ++t) xf[t] = *reinterpret_cast<const d16x8*>(xb + (rh * 64 + 32 * t + r) * QMT_PITCH + s4 * 32 + h * 16);
 #pragma unroll
         for (int f = 0; f < 2; ++f)
 #pragma unroll
@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   __syncthreads();                                       // the X buffers become the waves' output staging regions
-  // ---- epilogue.  With the token on the lane a direct store puts 8 (bf16) or 16 (fp32) bytes into each of 32 different rows per instruction: 1.5 M partial
+  // ---- epilogue.  With the token on the lane a direct store puts 8 (d16) or 16 (fp32) bytes into each of 32 different rows per instruction: 1.5 M partial
   // writes per 1 728-row launch, and THAT, not the operand traffic, set the 39 us of both tile shapes.  The wave's 64 features are exactly one (head, part) of the
   // fused QKV -- one 128-byte K / V cache row, one 256-byte run of a Q row -- or 128 bytes of an Xcat row: the values go through the wave's own LDS region
   // ([64 rows][64 features], row pitch + 16 B: conflict-free) and leave as full row segments, 8 lanes per 128 bytes.
@@ -592,14 +592,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   if (!isq || part != 0) {
-    // bf16 rows: Xcat (up) or the K / V cache row of (slot, head, position)
+    // d16 rows: Xcat (up) or the K / V cache row of (slot, head, position)
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4)
-          *reinterpret_cast<bf16x4*>(sw + (32 * t + r) * 144 + (32 * f + 8 * q4 + 4 * h) * 2) = pack4(vv[f][t][4 * q4], vv[f][t][4 * q4 + 1], vv[f][t][4 * q4 + 2], vv[f][t][4 * q4 + 3]);
+          *reinterpret_cast<d16x4*>(sw + (32 * t + r) * 144 + (32 * f + 8 * q4 + 4 * h) * 2) = pack4d(vv[f][t][4 * q4], vv[f][t][4 * q4 + 1], vv[f][t][4 * q4 + 2], vv[f][t][4 * q4 + 3]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (n0 + ec * 8 < up.N) *reinterpret_cast<u32x4*>(up.Yb + (long long)m * up.ldy + n0 + ec * 8) = val;
       } else {
         if (ac && ps < q.max_ctx)
-          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16*>(part == 1 ? q.Kc : q.Vc) + (long long)sl * q.slot_stride + ((long long)head * q.max_ctx + ps) * 64 + ec * 8) = val;
+          *reinterpret_cast<u32x4*>(reinterpret_cast<d16*>(part == 1 ? q.Kc : q.Vc) + (long long)sl * q.slot_stride + ((long long)head * q.max_ctx + ps) * 64 + ec * 8) = val;
       }
     }
   } else {
@@ -653,7 +653,7 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
   static const int mt_min = getenv("ETD_QKV_MT_MIN") ? atoi(getenv("ETD_QKV_MT_MIN")) : 256;
   if (mt_on && q.M >= mt_min && q.Npad % 128 == 0 && up.Npad % 128 == 0 && q.Wf && up.Wf) {
     const int split128 = q.Npad / 128, ft128 = split128 + up.Npad / 128, RT128 = (q.M + 127) / 128;
-    hipLaunchKernelGGL(k_dstep_qkv_up_mt, dim3((unsigned)(((ft128 + 7) / 8) * 8 * RT128)), dim3(256), 0, st, q.M, split128, ft128, (const bf16*)q.Wf, (const bf16*)up.Wf, q.Xb, up.Xb, q.ldx, up.ldx, q, up);
+    hipLaunchKernelGGL(k_dstep_qkv_up_mt, dim3((unsigned)(((ft128 + 7) / 8) * 8 * RT128)), dim3(256), 0, st, q.M, split128, ft128, (const d16*)q.Wf, (const d16*)up.Wf, q.Xb, up.Xb, q.ldx, up.ldx, q, up);
     HIP_TRY(hipGetLastError());
     return ETD_OK;
   }
@@ -773,10 +773,10 @@ __device__ long long g_head_stamp[8 * 16];
 #else
 #define HSTAMP(i) do { } while (0)
 #endif
-#define DH_LDX 520   // LayerNorm'ed rows in LDS: 512 + 8 bf16 (1040 B rows: conflict-free 16-byte fragment reads)
+#define DH_LDX 520   // LayerNorm'ed rows in LDS: 512 + 8 d16 (1040 B rows: conflict-free 16-byte fragment reads)
 #define DH_LDL 257   // logits rows in LDS (floats): up to 256 vocabulary entries + 1
 __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M, const int* p_row_slot, const int* p_row_active, const int* p_row_pos, DHeadArgs a) {   // leading scalars: kernarg preload
-  __shared__ __attribute__((aligned(16))) bf16 Xs[32 * DH_LDX];
+  __shared__ __attribute__((aligned(16))) d16 Xs[32 * DH_LDX];
   __shared__ float Ls[32 * DH_LDL];
   __shared__ float sps[8][256], sss[8][256];
   __shared__ int sis[8][256];
@@ -814,12 +814,12 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
   __builtin_amdgcn_sched_barrier(0);
   // the lm_head fragments of this wave's 32 vocabulary entries depend on nothing: all 32 requested here, behind the rows
   // above (loads return in order), and consumed after the LayerNorm -- left to the compiler they were 20 serial round trips
-  bf16x8 wf[32];
+  d16x8 wf[32];
   {
     const bool own = wave * 32 < a.Vpad;                // waves without a tile load one broadcast address (unconditional loads: no merge waits, next to no traffic)
-    const bf16* wfr = a.Whead + (own ? ((long long)wave * 32 * 64 + lane) * 8 : 0);       // fragment order: [tile][k-step][lane][8], 1 KiB per instruction
+    const d16* wfr = a.Whead + (own ? ((long long)wave * 32 * 64 + lane) * 8 : 0);       // fragment order: [tile][k-step][lane][8], 1 KiB per instruction
 #pragma unroll
-    for (int s4 = 0; s4 < 32; ++s4) wf[s4] = *reinterpret_cast<const bf16x8*>(wfr + s4 * 64 * 8);
+    for (int s4 = 0; s4 < 32; ++s4) wf[s4] = *reinterpret_cast<const d16x8*>(wfr + s4 * 64 * 8);
   }
   __builtin_amdgcn_sched_barrier(0);
   {
@@ -853,8 +853,8 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
         const int k = lane * 4 + half * 256;
         const f32x4 x = half ? hv1[j] : hv0[j];
         const f32x4 g = lg_[half], b = lb_[half];
-        *reinterpret_cast<bf16x4*>(Xs + rl * DH_LDX + k) =
-            pack4((x[0] - mean[j]) * rstd * g[0] + b[0], (x[1] - mean[j]) * rstd * g[1] + b[1], (x[2] - mean[j]) * rstd * g[2] + b[2], (x[3] - mean[j]) * rstd * g[3] + b[3]);
+        *reinterpret_cast<d16x4*>(Xs + rl * DH_LDX + k) =
+            pack4d((x[0] - mean[j]) * rstd * g[0] + b[0], (x[1] - mean[j]) * rstd * g[1] + b[1], (x[2] - mean[j]) * rstd * g[2] + b[2], (x[3] - mean[j]) * rstd * g[3] + b[3]);
       }
     }
   }
@@ -874,7 +874,7 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
   HSTAMP(1);
   // ---- logits: wave w < Vpad/32 owns features [32w, 32w+32)
   if (wave * 32 < a.Vpad) {
-    const bf16* xrow = Xs + r * DH_LDX;
+    const d16* xrow = Xs + r * DH_LDX;
     f32x16 tot;
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl) {
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
 #pragma unroll
       for (int s4 = 0; s4 < 4; ++s4) {
         const int k = sl * 64 + s4 * 16 + h * 8;
-        acc = mfma32(wf[sl * 4 + s4], *reinterpret_cast<const bf16x8*>(xrow + k), acc);
+        acc = mfma32(wf[sl * 4 + s4], *reinterpret_cast<const d16x8*>(xrow + k), acc);
       }
       if (sl == 0) tot = acc;
       else {
@@ -995,14 +995,14 @@ __global__ __launch_bounds__(512) void k_dstep_head(const float* p_hfin, int p_M
       { const f32x4 oa = {v[j][0], v[j][1], v[j][2], v[j][3]}, ob = {v[j][4], v[j][5], v[j][6], v[j][7]};
         *reinterpret_cast<f32x4*>(a.h + ro + k8) = oa; *reinterpret_cast<f32x4*>(a.h + ro + k8 + 4) = ob; }
       const float rstd = rsqrtf(q4[j] / (float)H + a.eps);
-      bf16x8 o1, o2;
+      d16x8 o1, o2;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        o1[e] = (bf16)((v[j][e] - mean[j]) * rstd * pg1[e >> 2][e & 3] + pb1[e >> 2][e & 3]);
-        o2[e] = (bf16)((v[j][e] - mean[j]) * rstd * pg2[e >> 2][e & 3] + pb2[e >> 2][e & 3]);
+        o1[e] = (d16)((v[j][e] - mean[j]) * rstd * pg1[e >> 2][e & 3] + pb1[e >> 2][e & 3]);
+        o2[e] = (d16)((v[j][e] - mean[j]) * rstd * pg2[e >> 2][e & 3] + pb2[e >> 2][e & 3]);
       }
-      *reinterpret_cast<bf16x8*>(a.x1 + ro + k8) = o1;
-      *reinterpret_cast<bf16x8*>(a.x2 + ro + k8) = o2;
+      *reinterpret_cast<d16x8*>(a.x1 + ro + k8) = o1;
+      *reinterpret_cast<d16x8*>(a.x2 + ro + k8) = o2;
     }
   }
   HSTAMP(4);
@@ -1069,12 +1069,12 @@ __global__ __launch_bounds__(256) void k_dgemv(DGemmArgs a) {
     for (int f = 0; f < 4; ++f) {
       float w[8];
       if constexpr (WBF16) {
-        const bf16x8 wv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16*>(a.W) + (long long)(nb + f) * a.K + k);
+        const d16x8 wv = *reinterpret_cast<const d16x8*>(reinterpret_cast<const d16*>(a.W) + (long long)(nb + f) * a.K + k);
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = bf2f(wv[j]);
-        // the MFMA paths round x to bf16 as well; keep the GEMV consistent with them
+        // the MFMA paths round x to d16 as well; keep the GEMV consistent with them
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc[f] = fmaf(w[j], bf2f((bf16)x0[j]), acc[f]); acc[f] = fmaf(w[4 + j], bf2f((bf16)x1[j]), acc[f]); }
+        for (int j = 0; j < 4; ++j) { acc[f] = fmaf(w[j], bf2f((d16)x0[j]), acc[f]); acc[f] = fmaf(w[4 + j], bf2f((d16)x1[j]), acc[f]); }
       } else {
         const float* wp = reinterpret_cast<const float*>(a.W) + (long long)(nb + f) * a.K + k;
         const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
@@ -1162,7 +1162,7 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
   if (path == 2 && epi == DEPI_QKV) {
     // GEMV writes the raw fused row into a.Y (caller-provided scratch [3H]); RoPE + Q/K/V scatter follow
     if (!a.Y) ETD_FAIL(ETD_EINVAL, "dgemm: M == 1 QKV path needs a scratch row in Y");
-    if (w_bf16) { dgemm_dispatch<true>(a, DEPI_BIAS, 2, st); hipLaunchKernelGGL(k_rope_scatter<bf16>, dim3(1), dim3(256), 0, st, a, a.Y); }
+    if (w_bf16) { dgemm_dispatch<true>(a, DEPI_BIAS, 2, st); hipLaunchKernelGGL(k_rope_scatter<d16>, dim3(1), dim3(256), 0, st, a, a.Y); }
     else { dgemm_dispatch<false>(a, DEPI_BIAS, 2, st); hipLaunchKernelGGL(k_rope_scatter<float>, dim3(1), dim3(256), 0, st, a, a.Y); }
   } else if (w_bf16) dgemm_dispatch<true>(a, epi, path, st);
   else dgemm_dispatch<false>(a, epi, path, st);
@@ -1174,7 +1174,7 @@ int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
 // k_dattn: causal attention of each row's query against its slot's KV cache [0, pos]
 //                                    modeling_gpt_neox.py:172-190 (softmax in fp32), :222-236
 // grid (M, heads); 4 waves split the key blocks; a wave-iteration covers 8 keys: lane = (key j = lane>>3,
-// 8-dim chunk c = lane&7), so K/V loads are fully coalesced 2 KB (fp32) / 1 KB (bf16) blocks.
+// 8-dim chunk c = lane&7), so K/V loads are fully coalesced 2 KB (fp32) / 1 KB (d16) blocks.
 // ================================================================================================
 // raw 8-element K/V pieces stay in their memory format in registers (so the loads remain in flight) and are widened at use
 template <typename KVT> struct Raw8;
@@ -1183,8 +1183,8 @@ template <> struct Raw8<float> {
   __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
   __device__ __forceinline__ float get(int j) const { return j < 4 ? a[j] : b[j - 4]; }
 };
-template <> struct Raw8<bf16> {
-  bf16x8 v;
+template <> struct Raw8<d16> {
+  d16x8 v;
   // K/V rows are read once per step and never again before they are overwritten in the caches by the next row's stream: the
   // nontemporal hint keeps them from evicting the weights (shared by all engines) from L2 / the Infinity Cache -- measured
   // -5.5 % per step with one engine and with four (tools/bench_engine_overlap.py)
@@ -1192,9 +1192,9 @@ template <> struct Raw8<bf16> {
 #define ETD_KV_NT 1
 #endif
 #if ETD_KV_NT
-  __device__ __forceinline__ void load(const bf16* p) { v = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p)); }
+  __device__ __forceinline__ void load(const d16* p) { v = __builtin_nontemporal_load(reinterpret_cast<const d16x8*>(p)); }
 #else
-  __device__ __forceinline__ void load(const bf16* p) { v = *reinterpret_cast<const bf16x8*>(p); }
+  __device__ __forceinline__ void load(const d16* p) { v = *reinterpret_cast<const d16x8*>(p); }
 #endif
   __device__ __forceinline__ float get(int j) const { return bf2f(v[j]); }
 };
@@ -1269,15 +1269,15 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
   for (int j = 0; j < 8; ++j) { const float d0 = v[j] - mean; q += d0 * d0; }
   q = wave_sum(q);
   const float rstd = rsqrtf(q / 512.f + f.eps);
-  bf16x8 o1, o2;
+  d16x8 o1, o2;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float n = (v[j] - mean) * rstd;
-    o1[j] = (bf16)(n * pg1[j >> 2][j & 3] + pb1[j >> 2][j & 3]);
-    o2[j] = (bf16)(n * pg2[j >> 2][j & 3] + pb2[j >> 2][j & 3]);
+    o1[j] = (d16)(n * pg1[j >> 2][j & 3] + pb1[j >> 2][j & 3]);
+    o2[j] = (d16)(n * pg2[j >> 2][j & 3] + pb2[j >> 2][j & 3]);
   }
-  *reinterpret_cast<bf16x8*>(f.x1 + ro + k) = o1;
-  *reinterpret_cast<bf16x8*>(f.x2 + ro + k) = o2;
+  *reinterpret_cast<d16x8*>(f.x1 + ro + k) = o1;
+  *reinterpret_cast<d16x8*>(f.x2 + ro + k) = o2;
 }
 #define D_ARRIVE(p) __hip_atomic_fetch_add((p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define D_CNT_RESET(p) __hip_atomic_store((p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -1285,14 +1285,14 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 // measurement builds ((history: 4ac2f57) tools/runs/r2_run18.sh): -DETD_ABL_DENSE / -DETD_ABL_GEMMW / -DETD_ABL_QKVW replace a weight stream by a
 // constant (wrong results on purpose) to see what that stream costs the OTHER engines' kernels
 #ifdef ETD_ABL_DENSE
-#define ABL_DENSE_LOAD(p) (bf16x8{(bf16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
+#define ABL_DENSE_LOAD(p) (d16x8{(d16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
 #else
-#define ABL_DENSE_LOAD(p) (*reinterpret_cast<const bf16x8*>(p))
+#define ABL_DENSE_LOAD(p) (*reinterpret_cast<const d16x8*>(p))
 #endif
 #ifdef ETD_ABL_GEMMW
-#define ABL_GEMMW_LOAD(p) (bf16x8{(bf16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
+#define ABL_GEMMW_LOAD(p) (d16x8{(d16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
 #else
-#define ABL_GEMMW_LOAD(p) (*reinterpret_cast<const bf16x8*>(p))
+#define ABL_GEMMW_LOAD(p) (*reinterpret_cast<const d16x8*>(p))
 #endif
 // cross-lane exchanges of the attention core: 0 = __shfl_xor (ds_bpermute_b32, LDS crossbar), 1 = lane_xor (DPP / permlane swaps)
 #ifndef ETD_AD_XCHG
@@ -1318,7 +1318,7 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 #define ETD_TRANS_SETTLE_LOOP(a_, b_) ((void)0)
 #endif
 #define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
-// DENSE: instead of storing the head's 64 outputs, multiply them (rounded to bf16, as the projection GEMM would read them)
+// DENSE: instead of storing the head's 64 outputs, multiply them (rounded to d16, as the projection GEMM would read them)
 // with this head's [512][64] slice of attention.dense and store the 512 partial sums as one more split-K slab for
 // k_resid_ln_rows -- the attention-output projection needs no launch of its own (k_dstep_attn_down below).
 //
@@ -1384,7 +1384,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   else { slot = a.rows.slot[m]; pos = a.rows.pos[m]; }
   const int ctx = (pos < p_max_ctx ? pos : p_max_ctx - 1) + 1;
   const int hidden = p_n_heads * 64;
-  // bf16 serving mode: scores pre-scaled by log2(e) and v_exp_f32 (exp2) -- softmax is base-invariant; the fp32
+  // d16 serving mode: scores pre-scaled by log2(e) and v_exp_f32 (exp2) -- softmax is base-invariant; the fp32
   // parity mode keeps the accurate expf like torch's softmax
   constexpr bool FAST = sizeof(KVT) == 2;
   const float qs = FAST ? p_scale * 1.4426950408889634f : p_scale;
@@ -1452,8 +1452,8 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   constexpr int FR = PAIR ? 64 / (2 * NW) : 64 / NW, FP = FR > 8 ? 8 : FR, NPASS = FR / FP;
   const int dwave = PAIR ? (int)(threadIdx.x >> 6) : wave;             // wave index among the waves that share the dense slice
   constexpr int DROWS = PAIR ? 512 / (2 * NW) : 512 / NW;              // dense rows (output features) per wave
-  bf16x8 dwv[DENSE ? FP : 1];
-  const bf16* dwb = nullptr;
+  d16x8 dwv[DENSE ? FP : 1];
+  const d16* dwb = nullptr;
   // measurement builds: ETD_AD_DENSE_LATE=1 requests the fragments AFTER the intra-wave merge, =2 requests them here but drains them before the merge
 #ifndef ETD_AD_DENSE_LATE
 #define ETD_AD_DENSE_LATE 0
@@ -1500,7 +1500,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   __syncthreads();
   if (wave == 0) {
     if constexpr (NW <= 4) {
-      // (the round-1 order of operations, kept bit for bit: NW = 4 is what the goldens of the bf16 mode were taken with)
+      // (the round-1 order of operations, kept bit for bit: NW = 4 is what the goldens of the d16 mode were taken with)
       if (j == 0) {
         float M2 = -INFINITY;
         for (int w = 0; w < NW; ++w) M2 = fmaxf(M2, red[w][c][0]);
@@ -1538,14 +1538,14 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
       const f32x4 x = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv}, y = {o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv};
       if constexpr (DENSE) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { osh[c * 8 + e] = (float)(bf16)x[e]; osh[c * 8 + 4 + e] = (float)(bf16)y[e]; }
+        for (int e = 0; e < 4; ++e) { osh[c * 8 + e] = (float)(d16)x[e]; osh[c * 8 + 4 + e] = (float)(d16)y[e]; }
       } else {
         float* op = a.O + (long long)m * hidden + head * 64 + c * 8;
         *reinterpret_cast<f32x4*>(op) = x;
         *reinterpret_cast<f32x4*>(op + 4) = y;
         if (a.Ob) {
-          const bf16x8 ob = {(bf16)x[0], (bf16)x[1], (bf16)x[2], (bf16)x[3], (bf16)y[0], (bf16)y[1], (bf16)y[2], (bf16)y[3]};
-          *reinterpret_cast<bf16x8*>(a.Ob + (long long)m * (a.ldob > 0 ? a.ldob : hidden) + head * 64 + c * 8) = ob;
+          const d16x8 ob = {(d16)x[0], (d16)x[1], (d16)x[2], (d16)x[3], (d16)y[0], (d16)y[1], (d16)y[2], (d16)y[3]};
+          *reinterpret_cast<d16x8*>(a.Ob + (long long)m * (a.ldob > 0 ? a.ldob : hidden) + head * 64 + c * 8) = ob;
         }
       }
     }
@@ -1678,7 +1678,7 @@ __global__ __launch_bounds__(256) void k_dattn(const int* p_row_sp, const float*
 // ================================================================================================
 // k_dstep_attn_down<NW>: one launch for the two things that depend on the QKV|up launch only
 //   * workgroups [0, p_gemm_wgs): the MLP down projection as split-K partial slabs.  A workgroup is NW / 2 independent
-//     2-wave units of k_dgemm_s's bf16 path (32x32 tile, one K slab of 512, K halved over the unit's two waves); the
+//     2-wave units of k_dgemm_s's d16 path (32x32 tile, one K slab of 512, K halved over the unit's two waves); the
 //     units of a workgroup are consecutive slots of one XCD, i.e. row tiles of the same weight tile where there are several.
 //   * the others: attention per (row, head), NW waves, with the head's slice of attention.dense applied in place (dattn_core<DENSE>).
 // k_resid_ln_rows then sums k_splits + n_heads slabs.  A decode-step layer is 3 launches instead of 4.
@@ -1707,14 +1707,14 @@ __device__ __forceinline__ void dstep_attn_down_body(const int* p_row_sp, const 
       const bool dup = m >= p_M;
       m = dup ? 2 * pr : m;
       float (&redh)[4][8][10] = *reinterpret_cast<float (*)[4][8][10]>(&red[4 * half][0][0]);
-      dattn_core<bf16, true, 4, false, true>(m, lid / P, redh, osh + 64 * half, sh + 512 * half, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a,
+      dattn_core<d16, true, 4, false, true>(m, lid / P, redh, osh + 64 * half, sh + 512 * half, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a,
                                              nullptr, osh + 64 * (half ^ 1), sh + 512 * (half ^ 1), dup);
       return;
     }
   }
   if ((int)blockIdx.x >= p_gemm_wgs) {
     const int lid = blockIdx.x - p_gemm_wgs;
-    dattn_core<bf16, true, NW, FIN>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a, &fin);
+    dattn_core<d16, true, NW, FIN>(lid % p_M, lid / p_M, red, osh, sh, p_row_sp, p_Q, p_Kc, p_Vc, p_slot_stride, p_max_ctx, p_n_heads, p_scale, p_identity, a, &fin);
     return;
   }
   // ---- GEMM role
@@ -1727,8 +1727,8 @@ __device__ __forceinline__ void dstep_attn_down_body(const int* p_row_sp, const 
   int gm = m0 + r; gm = gm < p_M ? gm : p_M - 1;
   const int Kz = 512;                                  // one slab = 512 input columns (checked by the launcher)
   const int kb = bz * Kz + wave * 256;
-  const bf16* wrow = reinterpret_cast<const bf16*>(g.W) + (long long)(n0 + r) * g.K + kb + h * 8;
-  const bf16* xrow = g.Xb + (long long)gm * g.ldx + kb + h * 8;
+  const d16* wrow = reinterpret_cast<const d16*>(g.W) + (long long)(n0 + r) * g.K + kb + h * 8;
+  const d16* xrow = g.Xb + (long long)gm * g.ldx + kb + h * 8;
   // (the same 16 MFMAs in the same order as k_dgemm_s, but fed in four passes of 4 k-steps: this role shares the launch -- and
   // so the register allocation -- with the attention role; four short round trips of a few dozen workgroups hide behind the
   // attention workgroups)
@@ -1738,9 +1738,9 @@ __device__ __forceinline__ void dstep_attn_down_body(const int* p_row_sp, const 
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
-    bf16x8 wf[4], xf[4];
+    d16x8 wf[4], xf[4];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) { wf[s4] = ABL_GEMMW_LOAD(wrow + (ps * 4 + s4) * 16); xf[s4] = *reinterpret_cast<const bf16x8*>(xrow + (ps * 4 + s4) * 16); }
+    for (int s4 = 0; s4 < 4; ++s4) { wf[s4] = ABL_GEMMW_LOAD(wrow + (ps * 4 + s4) * 16); xf[s4] = *reinterpret_cast<const d16x8*>(xrow + (ps * 4 + s4) * 16); }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) acc = mfma32(wf[s4], xf[s4], acc);
@@ -1865,7 +1865,7 @@ int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
   ProfScope ps(a.M > 512 ? "k_dattn_prefill" : "k_dattn", st, 0, a.bytes_hint);
   dim3 g(a.M, a.n_heads);
   const int ident = a.identity && a.row_sp && a.max_ctx >= 64 ? 1 : 0;
-  if (kv_bf16) hipLaunchKernelGGL(k_dattn<bf16>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, ident, a);
+  if (kv_bf16) hipLaunchKernelGGL(k_dattn<d16>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, ident, a);
   else hipLaunchKernelGGL(k_dattn<float>, g, dim3(256), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale, ident, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
@@ -1873,9 +1873,9 @@ int launch_dattn(const DAttnArgs& a, bool kv_bf16, hipStream_t st) {
 
 // ================================================================================================
 // LayerNorm of the residual stream for both parallel branches at once (input_layernorm and
-// post_attention_layernorm read the same h, modeling_gpt_neox.py:250-270); one wave per row, bf16 out.
+// post_attention_layernorm read the same h, modeling_gpt_neox.py:250-270); one wave per row, d16 out.
 __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ hsrc, int M, int H, const float* __restrict__ g1, const float* __restrict__ b1,
-                                                 const float* __restrict__ g2, const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
+                                                 const float* __restrict__ g2, const float* __restrict__ b2, float eps, d16* __restrict__ x1, d16* __restrict__ x2) {
   // one wave per row, the row is read ONCE (8 floats per lane per 512 columns, H <= 2048) and kept in registers:
   // a kernel this small is pure latency, so one global round trip instead of three is the whole optimisation
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1910,23 +1910,23 @@ __global__ __launch_bounds__(256) void k_ln_rows(const float* __restrict__ hsrc,
     if (k < H) {
       const f32x4 ga = *reinterpret_cast<const f32x4*>(g1 + k), gb = *reinterpret_cast<const f32x4*>(g1 + k + 4);
       const f32x4 ba = *reinterpret_cast<const f32x4*>(b1 + k), bb = *reinterpret_cast<const f32x4*>(b1 + k + 4);
-      bf16x8 o1;
+      d16x8 o1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { o1[j] = (bf16)((v[it][j] - mean) * rstd * ga[j] + ba[j]); o1[4 + j] = (bf16)((v[it][4 + j] - mean) * rstd * gb[j] + bb[j]); }
-      *reinterpret_cast<bf16x8*>(x1 + (long long)row * H + k) = o1;
+      for (int j = 0; j < 4; ++j) { o1[j] = (d16)((v[it][j] - mean) * rstd * ga[j] + ba[j]); o1[4 + j] = (d16)((v[it][4 + j] - mean) * rstd * gb[j] + bb[j]); }
+      *reinterpret_cast<d16x8*>(x1 + (long long)row * H + k) = o1;
       if (x2) {
         const f32x4 ha = *reinterpret_cast<const f32x4*>(g2 + k), hb = *reinterpret_cast<const f32x4*>(g2 + k + 4);
         const f32x4 ca = *reinterpret_cast<const f32x4*>(b2 + k), cb = *reinterpret_cast<const f32x4*>(b2 + k + 4);
-        bf16x8 o2;
+        d16x8 o2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o2[j] = (bf16)((v[it][j] - mean) * rstd * ha[j] + ca[j]); o2[4 + j] = (bf16)((v[it][4 + j] - mean) * rstd * hb[j] + cb[j]); }
-        *reinterpret_cast<bf16x8*>(x2 + (long long)row * H + k) = o2;
+        for (int j = 0; j < 4; ++j) { o2[j] = (d16)((v[it][j] - mean) * rstd * ha[j] + ca[j]); o2[4 + j] = (d16)((v[it][4 + j] - mean) * rstd * hb[j] + cb[j]); }
+        *reinterpret_cast<d16x8*>(x2 + (long long)row * H + k) = o2;
       }
     }
   }
 }
 int launch_ln_rows(const float* hsrc, int M, int H, const float* g1, const float* b1, const float* g2, const float* b2, float eps,
-                   bf16* x1, bf16* x2, hipStream_t st) {
+                   d16* x1, d16* x2, hipStream_t st) {
   if (M <= 0 || H % 8 || H > 2048) ETD_FAIL(ETD_EINVAL, "ln_rows: bad shape");
   ProfScope ps("k_ln_rows", st, 0, (double)M * H * (4 + (x2 ? 4 : 2)));
   hipLaunchKernelGGL(k_ln_rows, dim3((M + 3) / 4), dim3(256), 0, st, hsrc, M, H, g1, b1, g2, b2, eps, x1, x2);
@@ -1934,7 +1934,7 @@ int launch_ln_rows(const float* hsrc, int M, int H, const float* g1, const float
   return ETD_OK;
 }
 
-// hout = ((sum_z P[z] + bias) + add) + hin, then the next layer's two LayerNorms -> bf16.  One wave per row, single pass.
+// hout = ((sum_z P[z] + bias) + add) + hin, then the next layer's two LayerNorms -> d16.  One wave per row, single pass.
 #ifndef ETD_RL_ROWS
 #define ETD_RL_ROWS 4      // rows (= waves) per workgroup of the row kernel
 #endif
@@ -1942,7 +1942,7 @@ template <int KS>   // KS > 0: slab count known at compile time -> all slab load
 __global__ __launch_bounds__(64 * ETD_RL_ROWS) void k_resid_ln_rows(const float* __restrict__ P, int ks_rt, const float* __restrict__ bias, const float* __restrict__ add,
                                                        const float* __restrict__ hin, float* __restrict__ hout, int M, int H,
                                                        const float* __restrict__ g1, const float* __restrict__ b1, const float* __restrict__ g2,
-                                                       const float* __restrict__ b2, float eps, bf16* __restrict__ x1, bf16* __restrict__ x2) {
+                                                       const float* __restrict__ b2, float eps, d16* __restrict__ x1, d16* __restrict__ x2) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * ETD_RL_ROWS + (threadIdx.x >> 6);
   if (row >= M) return;
   SS_DECL(); SS(0);
@@ -2017,23 +2017,23 @@ __global__ __launch_bounds__(64 * ETD_RL_ROWS) void k_resid_ln_rows(const float*
   for (int it = 0; it < 4; ++it) {
     const int k = lane * 8 + it * 512;
     if (k < H) {
-      bf16x8 o1, o2;
+      d16x8 o1, o2;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float n = (v[it][j] - mean) * rstd;
         const float w1 = it == 0 ? pg1[j >> 2][j & 3] : g1[k + j], c1 = it == 0 ? pb1[j >> 2][j & 3] : b1[k + j];
         const float w2 = it == 0 ? pg2[j >> 2][j & 3] : g2[k + j], c2 = it == 0 ? pb2[j >> 2][j & 3] : b2[k + j];
-        o1[j] = (bf16)(n * w1 + c1);
-        o2[j] = (bf16)(n * w2 + c2);
+        o1[j] = (d16)(n * w1 + c1);
+        o2[j] = (d16)(n * w2 + c2);
       }
-      *reinterpret_cast<bf16x8*>(x1 + ro + k) = o1;
-      *reinterpret_cast<bf16x8*>(x2 + ro + k) = o2;
+      *reinterpret_cast<d16x8*>(x1 + ro + k) = o1;
+      *reinterpret_cast<d16x8*>(x2 + ro + k) = o2;
     }
   }
   SS(3); SS_FLUSH(3, 0);
 }
 int launch_resid_ln_rows(const float* P, int k_splits, const float* bias, const float* add, const float* hin, float* hout, int M, int H,
-                         const float* g1, const float* b1, const float* g2, const float* b2, float eps, bf16* x1, bf16* x2, hipStream_t st) {
+                         const float* g1, const float* b1, const float* g2, const float* b2, float eps, d16* x1, d16* x2, hipStream_t st) {
   if (M <= 0 || H % 8 || H > 2048 || k_splits < 1) ETD_FAIL(ETD_EINVAL, "resid_ln_rows: bad shape");
   ProfScope ps("k_resid_ln_rows", st, 0, (double)M * H * 4 * (k_splits + 3));
   if (k_splits == 5) hipLaunchKernelGGL(k_resid_ln_rows<5>, dim3((M + ETD_RL_ROWS - 1) / ETD_RL_ROWS), dim3(64 * ETD_RL_ROWS), 0, st, P, k_splits, bias, add, hin, hout, M, H, g1, b1, g2, b2, eps, x1, x2);

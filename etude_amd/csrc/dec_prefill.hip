@@ -1,4 +1,4 @@
-// Batched prefill of the EtudeDecoder, bf16: ragged causal flash attention over every prompt of a begin_bars pass, reading K and V
+// Batched prefill of the EtudeDecoder, d16: ragged causal flash attention over every prompt of a begin_bars pass, reading K and V
 // STRAIGHT FROM THE KV CACHE the QKV epilogue has just written                     modeling_gpt_neox.py:195-281, etude_decoder.py:291-297
 //
 // Rounds 1-3 ran the extractor's k_attn here, fed by two scratch copies the QKV epilogue wrote beside the cache rows: Kp (K again, row-major
@@ -24,8 +24,8 @@ typedef __attribute__((address_space(3))) pa_s16x4* pa_lds_s16x4;
 
 __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * PA_LDK * 2 + 64 * PA_LDV * 2];
-  bf16* Ks = reinterpret_cast<bf16*>(smem);
-  bf16* Vs = Ks + 64 * PA_LDK;
+  d16* Ks = reinterpret_cast<d16*>(smem);
+  d16* Vs = Ks + 64 * PA_LDK;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int nh = a.n_heads;
   const int seq = blockIdx.y / nh, head = blockIdx.y - seq * nh;
@@ -37,14 +37,14 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
   const int q0 = (int)blockIdx.x * 128 + wave * 32 - off;  // wave-uniform
   int qi = q0 + r; const bool qvalid = qi >= 0 && qi < S; qi = qi < 0 ? 0 : (qi < S ? qi : S - 1);
 
-  const bf16* qp = a.Q + (r0 + qi) * a.ldq + head * 64;
-  bf16x8 qf[4];
+  const d16* qp = a.Q + (r0 + qi) * a.ldq + head * 64;
+  d16x8 qf[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qp + s * 16 + h * 8);
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const d16x8*>(qp + s * 16 + h * 8);
 
   const long long cbase = (long long)slot * a.slot_stride + (long long)head * a.max_ctx * 64;
-  const bf16* kbase = a.Kc + cbase;
-  const bf16* vbase = a.Vc + cbase;
+  const d16* kbase = a.Kc + cbase;
+  const d16* vbase = a.Vc + cbase;
 
   f32x16 o[2];
 #pragma unroll
@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
   // transposing read of the V tile: lane (16-lane group g, q = bits 3:2, p = bits 1:0) supplies the address of key row (4 h + q), columns 16 (g & 1) + 4 p .. + 4;
   // it receives keys 4 h .. 4 h + 3 of column d = lane & 31
   const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
-  const bf16* vtr = Vs + (4 * h + tq) * PA_LDV + 16 * tg + 4 * tp;
+  const d16* vtr = Vs + (4 * h + tq) * PA_LDV + 16 * tg + 4 * tp;
   tile_gload(0);
   for (int jt = 0; jt < ntile; ++jt) {
     const int kv0 = jt * 64;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
         for (int i = 0; i < 16; ++i) sT[kt][i] = 0.f;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-          const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + r) * PA_LDK + s * 16 + h * 8);
+          const d16x8 kf = *reinterpret_cast<const d16x8*>(Ks + (kt * 32 + r) * PA_LDK + s * 16 + h * 8);
           sT[kt] = mfma32(kf, qf[s], sT[kt]);
         }
       }
@@ -130,15 +130,15 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
       // O^T[d][query] += V^T[d][key] P^T[key][query]; k-step ks covers keys 16 ks .. + 15 in the accumulator's own order: element j <-> key 16 ks + 8 (j >> 2) + 4 h + (j & 3)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        bf16x8 pf;
+        d16x8 pf;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (bf16)sT[ks >> 1][8 * (ks & 1) + j];
+        for (int j = 0; j < 8; ++j) pf[j] = (d16)sT[ks >> 1][8 * (ks & 1) + j];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const pa_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4)(vtr + (ks * 16) * PA_LDV + dt * 32));
           const pa_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((pa_lds_s16x4)(vtr + (ks * 16 + 8) * PA_LDV + dt * 32));
           const __attribute__((ext_vector_type(8))) short v8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-          o[dt] = mfma32(__builtin_bit_cast(bf16x8, v8), pf, o[dt]);
+          o[dt] = mfma32(__builtin_bit_cast(d16x8, v8), pf, o[dt]);
         }
       }
     }
@@ -148,13 +148,13 @@ __global__ __launch_bounds__(256) void k_pattn(PAttnArgs a) {
   lrun += xhalf(lrun);
   const float inv = 1.f / lrun;
   if (qvalid) {
-    bf16* op = a.O + (r0 + q0 + r) * a.ldo + head * 64;
+    d16* op = a.O + (r0 + q0 + r) * a.ldo + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int d = dt * 32 + 8 * q + 4 * h;
-        *reinterpret_cast<bf16x4*>(op + d) = pack4(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
+        *reinterpret_cast<d16x4*>(op + d) = pack4d(o[dt][4 * q] * inv, o[dt][4 * q + 1] * inv, o[dt][4 * q + 2] * inv, o[dt][4 * q + 3] * inv);
       }
   }
 }
@@ -180,33 +180,33 @@ int launch_pattn(const PAttnArgs& a, hipStream_t st) {
 // registers (32 B-operand fragments = 128 registers, loaded once), the 1.5 MiB weight matrix streams through LDS in 32-feature tiles of 32 KiB (fragment order:
 // an LDS-DMA piece is a plain copy, a fragment read a conflict-free ds_read_b128) shared by the workgroup's EIGHT waves -- 256 tokens per weight byte pulled from
 // L2, two waves per SIMD -- and each tile is one chain of 32 MFMAs into 16 accumulator registers.  Two tiles are one (head, q | k | v) block of 64 features: bias,
-// rotary embedding (lane-local: the pair (d, d + 8) sits in one lane) and bf16 rounding on the token-on-lane accumulators, a transpose through the wave's own LDS
+// rotary embedding (lane-local: the pair (d, d + 8) sits in one lane) and d16 rounding on the token-on-lane accumulators, a transpose through the wave's own LDS
 // block, and the rows leave as 128-byte segments: Q to the attention kernel's scratch, K / V to their cache rows -- 3 KB per prompt row, nothing else.
 // The arithmetic is k_linear<QKV>'s (same MFMA, same k order, same epilogue formulas): bit-identical cache rows and queries (tools/bench_prefill.py --digest).
 // Ring: two 32 KiB slots; tile t + 1 is requested at the top of tile t, behind the barrier that says every wave is done with tile t - 1's slot, and is waited
 // for -- vmcnt(0), a whole tile of MFMAs later -- at the top of tile t + 1.  The row stores of a finished block are issued at the top of the NEXT tile, ahead
 // of its 32 MFMAs, so that wait never waits for a store either.
 // ================================================================================================
-#define PQ_EPP 136                       // staging row stride (bf16 elements): 272 B
+#define PQ_EPP 136                       // staging row stride (d16 elements): 272 B
 #define PQ_TILE_ELEMS (32 * 512)         // one 32-feature tile of the fragment-ordered weights: 32 k-steps x 1 KiB
 typedef const __attribute__((address_space(1))) void* pq_gptr_t;
 typedef __attribute__((address_space(3))) void* pq_lptr_t;
 
 __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PQ_TILE_ELEMS * 2 + 8 * 32 * PQ_EPP * 2 + 1536 * 4];
-  bf16* ring = reinterpret_cast<bf16*>(smem);
-  bf16* stg_all = reinterpret_cast<bf16*>(smem + 2 * PQ_TILE_ELEMS * 2);
+  d16* ring = reinterpret_cast<d16*>(smem);
+  d16* stg_all = reinterpret_cast<d16*>(smem + 2 * PQ_TILE_ELEMS * 2);
   float* sb = reinterpret_cast<float*>(smem + 2 * PQ_TILE_ELEMS * 2 + 8 * 32 * PQ_EPP * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-  bf16* stg = stg_all + wave * (32 * PQ_EPP);
+  d16* stg = stg_all + wave * (32 * PQ_EPP);
   const int NT = a.N >> 5;                                   // 48 tiles
   const int mw = blockIdx.x * 256 + wave * 32;               // the wave's first token
   const int m = mw + r, mc = m < a.M ? m : a.M - 1;
 
   // tile t -> slot t & 1: 32 one-KiB pieces, 4 per wave
   auto issue = [&](int t) {
-    const bf16* src = a.Wf + (long long)t * PQ_TILE_ELEMS + wave * (4 * 512) + lane * 8;
-    bf16* dst = ring + (t & 1) * PQ_TILE_ELEMS + wave * (4 * 512);
+    const d16* src = a.Wf + (long long)t * PQ_TILE_ELEMS + wave * (4 * 512) + lane * 8;
+    d16* dst = ring + (t & 1) * PQ_TILE_ELEMS + wave * (4 * 512);
     // (one address, four immediate offsets: the offset field serves the global and the LDS address alike)
     __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 1024, 0);
@@ -216,11 +216,11 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
   issue(0);
   for (int i = tid; i < a.N; i += 512) sb[i] = a.bias[i];
   // the wave's 32 tokens as B fragments: lane (token r, half h) holds x[token][16 s + 8 h .. + 8]
-  bf16x8 xf[32];
+  d16x8 xf[32];
   {
-    const bf16* xp = a.X + (long long)mc * a.ldx + 8 * h;
+    const d16* xp = a.X + (long long)mc * a.ldx + 8 * h;
 #pragma unroll
-    for (int s = 0; s < 32; ++s) xf[s] = *reinterpret_cast<const bf16x8*>(xp + 16 * s);
+    for (int s = 0; s < 32; ++s) xf[s] = *reinterpret_cast<const d16x8*>(xp + 16 * s);
   }
   // rotary factors of this lane's token: dims 4 h .. 4 h + 3 (pair partner d + 8 = register i + 4)
   const int pos_l = a.rows.pos[mc];
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
   // the rows of block u (features 64 u .. + 64: head u / 3, part u % 3) from the staging block to global memory
   auto store_block = [&](int u) {
     const int head = u / 3, part = u - head * 3;
-    bf16* cbase = (part == 1 ? a.Kc : a.Vc) + (long long)head * a.max_ctx * 64;
+    d16* cbase = (part == 1 ? a.Kc : a.Vc) + (long long)head * a.max_ctx * 64;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const u32x4 val = *reinterpret_cast<const u32x4*>(stg + (it * 8 + er8) * PQ_EPP + ec8 * 8);
@@ -258,8 +258,8 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(buf[2]) : "v"(sl), "n"((F0) * 1024 + 2048));                     \
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(buf[3]) : "v"(sl), "n"((F0) * 1024 + 3072));                     \
   } while (0)
-#define PQ_MFMA(c, af, bfr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(af), "v"(bfr))
-#define PQ_MFMA0(c, af, bfr) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(c) : "v"(af), "v"(bfr))
+#define PQ_MFMA(c, af, bfr) asm volatile(ETD_MFMA16_DEC " %0, %1, %2, %0" : "+v"(c) : "v"(af), "v"(bfr))
+#define PQ_MFMA0(c, af, bfr) asm volatile(ETD_MFMA16_DEC " %0, %1, %2, 0" : "=&v"(c) : "v"(af), "v"(bfr))
 #define PQ_GROUP(c, G)                                                                                                   \
   do {                                                                                                                   \
     if constexpr ((G) < 7) { PQ_RD4(wf[((G) + 1) & 1], ((G) + 1) * 4); asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); } \
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
     if ((t) + 1 < NT) issue((t) + 1);                                                                                    \
     if ((t) >= 2 && !((t) & 1)) store_block(((t) - 2) >> 1);                                                              \
     const unsigned sl = ring_l + ((t) & 1) * (PQ_TILE_ELEMS * 2);                                                        \
-    bf16x8 wf[2][4];                                                                                                     \
+    d16x8 wf[2][4];                                                                                                     \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            /* (the staging reads of store_block are compiler-counted; start the hand count from zero) */ \
     __builtin_amdgcn_sched_barrier(0);                                                                                   \
     PQ_RD4(wf[0], 0);                                                                                                    \
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
     PQ_TILE(c1, 2 * u + 1);
     asm volatile("s_nop 15\n\ts_nop 15" : "+v"(c1) : : "memory");      // (MFMA -> VALU wait states behind the asm MFMAs; c0's ended a whole tile ago)
     {
-      // block u complete: bias, rotary embedding on Q / K, bf16, transpose through the wave's staging block
+      // block u complete: bias, rotary embedding on Q / K, d16, transpose through the wave's staging block
       const int part = u % 3;
       float v[2][16];
 #pragma unroll
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
       for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<bf16x4*>(stg + r * PQ_EPP + nn * 32 + 8 * q + 4 * h) = pack4(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
+          *reinterpret_cast<d16x4*>(stg + r * PQ_EPP + nn * 32 + 8 * q + 4 * h) = pack4d(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
     }
   }
 #undef PQ_TILE

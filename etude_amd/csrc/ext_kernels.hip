@@ -80,7 +80,7 @@ __device__ __forceinline__ void lin_gload_x(rsrc_t xs, int xo, int row32_bytes, 
 #pragma unroll
   for (int i = 0; i < 4; ++i) xr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xs, xo, kc * 128 + i * row32_bytes, 0));
 }
-__device__ __forceinline__ void lin_lstore_x(bf16* Xs, int tid, const u32x4 (&xr)[4]) {
+__device__ __forceinline__ void lin_lstore_x(d16* Xs, int tid, const u32x4 (&xr)[4]) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = tid + i * 256, row = c >> 3, ch = c & 7;
@@ -90,8 +90,8 @@ __device__ __forceinline__ void lin_lstore_x(bf16* Xs, int tid, const u32x4 (&xr
 // Weights come in MFMA-FRAGMENT ORDER (pack_wfrag below / etd host loaders): block (n-tile t of 32 features, k-step s of 16)
 // is 1 KiB, lane l holding row 32 t + (l & 31), columns 16 s + 8 (l >> 5) .. +8.  One load instruction per fragment reads
 // one contiguous KiB straight into the operand registers: the weights never touch LDS (they were 2/3 of its traffic).
-__device__ __forceinline__ bf16x8 lin_wfrag(rsrc_t ws, int lane16, int blk) {
-  return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ws, lane16, blk * 1024, 0));
+__device__ __forceinline__ d16x8 lin_wfrag(rsrc_t ws, int lane16, int blk) {
+  return __builtin_bit_cast(d16x8, __builtin_amdgcn_raw_buffer_load_b128(ws, lane16, blk * 1024, 0));
 }
 
 // MODE 0: row-major store (+ReLU); MODE 1: V^T store (feature on the lane); MODE 2: residual + LayerNorm;
@@ -100,19 +100,19 @@ __device__ __forceinline__ bf16x8 lin_wfrag(rsrc_t ws, int lane16, int blk) {
 // from LDS and holds 4 W fragments in registers for 8 MFMAs.
 // One 64-deep chunk: k-step s multiplies with wf[s][*], then re-requests those registers for the NEXT chunk's k-step s.
 template <bool NORMAL_ORIENT>
-__device__ __forceinline__ void lin_chunk(const bf16* Xs, int wm, int r, int h, f32x16 (&acc)[2][4], bf16x8 (&wf)[4][4],
+__device__ __forceinline__ void lin_chunk(const d16* Xs, int wm, int r, int h, f32x16 (&acc)[2][4], d16x8 (&wf)[4][4],
                                           rsrc_t ws, int lane16, int wblk_next, int kblocks, bool more) {
-  const bf16* xp = Xs + (wm * 64 + r) * LDK + h * 8;
-  bf16x8 xf[2][2];
+  const d16* xp = Xs + (wm * 64 + r) * LDK + h * 8;
+  d16x8 xf[2][2];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) xf[0][mt] = *reinterpret_cast<const bf16x8*>(xp + mt * 32 * LDK);
+  for (int mt = 0; mt < 2; ++mt) xf[0][mt] = *reinterpret_cast<const d16x8*>(xp + mt * 32 * LDK);
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     // the next k-step's X fragments are requested before this k-step's MFMAs (a k-step is 8 MFMAs = 256 clk; an LDS read
     // takes about that long to come back, and with the weights out of LDS nothing else hides it)
     if (s < 3) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) xf[(s + 1) & 1][mt] = *reinterpret_cast<const bf16x8*>(xp + mt * 32 * LDK + (s + 1) * 16);
+      for (int mt = 0; mt < 2; ++mt) xf[(s + 1) & 1][mt] = *reinterpret_cast<const d16x8*>(xp + mt * 32 * LDK + (s + 1) * 16);
     }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   // vmcnt retires in order, so the wait for a W fragment never forces the younger X requests.
   LIN_STAMP(0);
   u32x4 xa[4], xb[4];
-  bf16x8 wf[4][4];
+  d16x8 wf[4][4];
   const int nk = (a.dbg & 2) ? 0 : a.K >> 6;       // even: K % 128 == 0 is checked by the launchers
   const int kblocks = a.K >> 4;                    // 16-deep k-steps per feature row block
   const rsrc_t xs = lin_rsrc(a.X + (long long)m0 * a.ldx, ((long long)(a.M - m0) * a.ldx) * 2);
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
   const int lane16 = lane * 16;
   const int wblk0 = __builtin_amdgcn_readfirstlane(wn) * 4 * kblocks;        // this wave's first fragment block (its 4 n-tiles are kblocks apart)
   const int xo = ((tid >> 3) * a.ldx + (tid & 7) * 8) * 2, xr32 = 32 * a.ldx * 2;
-  bf16* const Xd = reinterpret_cast<bf16*>(smem);        // (the decoder modes compute in bf16 whatever the extractor's element type is)
-  bf16* Xs1 = Xd + 128 * LDK;
+  d16* const Xd = reinterpret_cast<d16*>(smem);        // (the decoder modes compute in d16 whatever the extractor's element type is)
+  d16* Xs1 = Xd + 128 * LDK;
   lin_gload_x(xs, xo, xr32, 0, xa);
 #pragma unroll
   for (int sx = 0; sx < 4; ++sx)
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int fl = nt * 32 + 8 * q + 4 * h, f = wn * 128 + fl;
-            *reinterpret_cast<bf16x4*>(stg + r * EPP + fl) =
-                pack4(gelu_fast(acc[mt][nt][4 * q] + sb[f]), gelu_fast(acc[mt][nt][4 * q + 1] + sb[f + 1]),
+            *reinterpret_cast<d16x4*>(stg + r * EPP + fl) =
+                pack4d(gelu_fast(acc[mt][nt][4 * q] + sb[f]), gelu_fast(acc[mt][nt][4 * q + 1] + sb[f + 1]),
                       gelu_fast(acc[mt][nt][4 * q + 2] + sb[f + 2]), gelu_fast(acc[mt][nt][4 * q + 3] + sb[f + 3]));
           }
         __syncthreads();
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
             for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
               for (int q = 0; q < 4; ++q)
-                *reinterpret_cast<bf16x4*>(stg + r * EPP + nn * 32 + 8 * q + 4 * h) = pack4(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
+                *reinterpret_cast<d16x4*>(stg + r * EPP + nn * 32 + 8 * q + 4 * h) = pack4d(v[nn][4 * q], v[nn][4 * q + 1], v[nn][4 * q + 2], v[nn][4 * q + 3]);
             __syncthreads();
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
                 if (part == 0) *reinterpret_cast<u32x4*>(g.Qb + (long long)m * (g.n_heads * 64) + head * 64 + ec8 * 8) = val;
                 else {
                   if (ract[it] && rpos[it] < g.max_ctx) {
-                    bf16* cp = reinterpret_cast<bf16*>(part == 1 ? g.Kc : g.Vc) + (long long)rslot[it] * g.slot_stride + ((long long)head * g.max_ctx + rpos[it]) * 64 + ec8 * 8;
+                    d16* cp = reinterpret_cast<d16*>(part == 1 ? g.Kc : g.Vc) + (long long)rslot[it] * g.slot_stride + ((long long)head * g.max_ctx + rpos[it]) * 64 + ec8 * 8;
                     *reinterpret_cast<u32x4*>(cp) = val;
                   }
                 }
@@ -588,7 +588,7 @@ int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
 }
 int launch_linear_dec(const LinArgs& a, int dec_epi, hipStream_t st) {
   if (a.K % 128 || a.N % 256 || a.M <= 0 || !a.bias) ETD_FAIL(ETD_EINVAL, "linear_dec: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
-  if (dec_epi == DEPI_GELU && (!a.dec.Yb || a.dec.ldy % 8 || ((uintptr_t)a.dec.Yb & 15))) ETD_FAIL(ETD_EINVAL, "linear_dec: GELU needs 16-byte aligned bf16 rows");
+  if (dec_epi == DEPI_GELU && (!a.dec.Yb || a.dec.ldy % 8 || ((uintptr_t)a.dec.Yb & 15))) ETD_FAIL(ETD_EINVAL, "linear_dec: GELU needs 16-byte aligned d16 rows");
   if (dec_epi == DEPI_RESID && (!a.dec.hin || !a.dec.hout || a.dec.N % 4)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad residual arguments");
   if (dec_epi == DEPI_QKV && a.dec.Qb && (a.dec.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "linear_dec: bad QKV arguments");
   ETD_LAUNCH_FILTER("k_linear_dec");

@@ -219,7 +219,7 @@ extern "C" int etd_debug_kernel_loop(int which, int iters, void* stream) {
   } else {
     const int M = 18432, H = 512;
     float* h = (float*)get((size_t)M * H * 4); float* par = (float*)get(4 * H * 4);
-    bf16 *x1 = (bf16*)get((size_t)M * H * 2), *x2 = (bf16*)get((size_t)M * H * 2);
+    d16 *x1 = (d16*)get((size_t)M * H * 2), *x2 = (d16*)get((size_t)M * H * 2);
     if (!h || !par || !x1 || !x2) rc = ETD_ENOMEM;
     if (rc == ETD_OK) {
       fill(h, (size_t)M * H * 2, 7u);            // (random bf16 pairs read as floats: finite, any magnitude)

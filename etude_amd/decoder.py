@@ -97,9 +97,12 @@ class EtudeDecoder:
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.config = config
+        # "fp32" (default: the reference's token ids) or the 16-bit serving mode "f16" ("bf16" is accepted as its older name: the operands are IEEE half since round 5,
+        # bf16 in a -DETD_DEC_BF16 build -- `etd_decoder_operand_type`)
         precision = precision or os.environ.get("ETD_DECODER_PRECISION", "fp32")
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' (token-parity mode) or 'bf16'")
+        if precision not in ("fp32", "f16", "bf16"):
+            raise ValueError("precision must be 'fp32' (token-parity mode) or 'f16' (alias 'bf16': the 16-bit serving mode)")
+        precision = "fp32" if precision == "fp32" else "bf16"        # (internal name of the serving mode: kept for the C ABI's precision = 1)
         self.precision = precision
         self.max_streams = int(max_streams)
         # KV positions per stream.  A bar touches prompt + limit - 1 positions, and the prompt (after the truncation rule of

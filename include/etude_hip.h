@@ -154,11 +154,15 @@ typedef struct {
   float rotary_pct, rope_theta, layer_norm_eps;
   int max_streams;        /* concurrent token streams (KV slots) */
   int max_ctx;            /* KV positions per stream */
-  int precision;          /* 0 = fp32 weights/activations (token-parity mode), 1 = bf16 weights */
+  int precision;          /* 0 = exact-parity mode: fp32 weights, activations and KV cache, fp32-grade products (csrc/gemm3.h) -- the reference's token ids;
+                             1 = the 16-bit serving mode: IEEE-half weights, LayerNorm rows and KV cache (etd_decoder_operand_type), fp32 residual stream /
+                             accumulators / softmax / logits */
   int max_prefill_rows;   /* prompt rows one etd_decoder_begin_bars call may carry (0 = max(max_ctx, max_streams)) */
 } etd_dec_cfg;
 int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
                        const int64_t* numels, int n, etd_dec** out);
+/* element type of the 16-bit serving mode (weights, KV cache, debug peeks): 1 = IEEE half (the default build), 0 = bf16 (-DETD_DEC_BF16) */
+int etd_decoder_operand_type(void);
 void etd_decoder_destroy(etd_dec*);
 /* A second engine over the SAME weights: own KV cache, workspaces and stream state (same cfg), the weight buffers of `src`
  * (or of the handle `src` was cloned from) are shared, not copied -- concurrent engines then stream one weight set through

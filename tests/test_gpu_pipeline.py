@@ -113,7 +113,7 @@ def test_bench_line_small_configuration():
               "roofline", "cpu_baseline", "extras", "tokens_sha256_rank0"):
         assert k in d, k
     _no_errors(d)
-    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["scaling"] == "strong" and d["dtype"] == "bf16" and d["vs_baseline"] is None
+    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["scaling"] == "strong" and d["dtype"] == "f16" and d["vs_baseline"] is None
     assert d["config"]["batch_clips"] == 2 and d["jobs_gathered"] == 6
     r = d["roofline"]
     assert r["kernel"] == "k_dstep_attn_down" and r["bound"] == "hbm" and r["peak"] == 8000.0 and 0 < r["frac"] <= 1.0
