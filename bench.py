@@ -199,6 +199,13 @@ def cpu_baseline(bars, seconds_budget: float = 25.0, clip_seconds: float = 180.0
             "extract_audio_s_per_s": round(nwin * 8.192 / t_ext, 4),
             "decoder_tokens_per_s": round(bar_tokens / t_bar, 2), "decoder_cores": dthreads}
 
+def default_engines(n_jobs: int, world: int = 1) -> int:
+    """decoder engines for `n_jobs` jobs on one rank when --engines is not given: whatever measured fastest (round 5, profiles/r05_engines.txt: 64 clips on one GPU 567 /
+    574 / 588 / 581 audio-s/s with 1 / 2 / 3 / 4 engines, same token digest): three chains of launches overlap each other's small kernels and bar boundaries while a
+    launch still covers most of the chip; small per-rank batches (216 jobs at N = 8) stay on four (the latency-bound regime)"""
+    return 3 if (n_jobs >= 1024 or (world == 1 and n_jobs >= 512)) else 4
+
+
 def bar_divergence(ra, rb):
     """per-bar comparison of two result lists [(flat ids, bar lengths)] of the same jobs (tests/test_gpu_full_configs.py: a bar can only be compared
     while the two histories are still equal): -> (bars identical, comparable bars, jobs identical end to end)"""
@@ -338,11 +345,10 @@ def main():
                     help="extractor instances that transcribe different clips at the same time (own stream + host thread each); 0 = three beside one decoder engine, "
                          "two beside four (hardware queues).  Measured on the 64-clip extract stage: 2 -> 4 850, 3 -> 5 040, 4 -> 5 080 audio-s/s")
     ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "0")),
-                    help="decoder engines (own HIP stream + KV cache each, driven from host threads); 0 = by the jobs per rank: ONE engine holding every job as a stream "
-                         "from 1024 jobs up (and from 512 on a single GPU) -- 1728 rows per decode-step launch at N = 1: the HBM-bound attention launches then never overlap "
-                         "each other and each runs at its own ~0.7 of the HBM peak -- and four engines below (216 jobs per rank at N = 8: the latency-bound regime, where "
-                         "four chains of short kernels overlap).  Measured, audio-s/s with 1 / 2 / 4 engines: 64 clips 513 / 516 / 526, 32 clips 491 / 515 / 526, 16 clips "
-                         "459 / 502 / 506, 8 clips 419 / 433 / 457 (tools/runs3/r3_run12.sh): four engines always carry 2-7 %% more, at a quarter of the HBM per attention launch")
+                    help="decoder engines (own HIP stream + KV cache each, driven from host threads); 0 = by the jobs per rank, whatever measured fastest: THREE engines "
+                         "(576 streams each) from 1024 jobs up (and from 512 on a single GPU), four below (216 jobs per rank at N = 8: the latency-bound regime, where four "
+                         "chains of short kernels overlap).  Measured on the round-5 tree, 64 clips, audio-s/s with 1 / 2 / 3 / 4 engines: 567 / 574 / 588 / 581 "
+                         "(profiles/r05_engines.txt); the roofline of concurrent engines is reported on the UNION of their attention launches (roofline.frac)")
     ap.add_argument("--max-streams", type=int, default=2048, help="streams per engine (the fused decode step takes up to 2048 rows per launch)")
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS does not end a bar)")
     ap.add_argument("--synthetic-bars", action="store_true", help="rounds 1-2 workload: ~8-notes/bar synthetic condition bars instead of the clip's own (A/B only)")
@@ -406,7 +412,7 @@ def main():
     cfg = ExtractorConfig()
     wb = int(os.environ.get("ETD_WB", "4"))
     n_jobs0 = (args.clips if args.clips > 0 else args.batch_clips // world) * args.attr_grid
-    one_engine = (args.engines == 1) or (args.engines == 0 and (n_jobs0 >= 1024 or (world == 1 and n_jobs0 >= 512)))
+    one_engine = args.engines == 1
     n_ext = args.ext_engines if args.ext_engines > 0 else (3 if one_engine else 2)
     exs = [AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=wb) for _ in range(n_ext)]
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
@@ -415,7 +421,7 @@ def main():
 
     def build_engines(n_clips):
         n_jobs = n_clips * len(grid)
-        want = args.engines if args.engines > 0 else (1 if (n_jobs >= 1024 or (world == 1 and n_jobs >= 512)) else 4)
+        want = args.engines if args.engines > 0 else default_engines(n_jobs, world)      # by measurement, not by the look of a per-launch figure
         n_eng = max(1, min(want, n_jobs))
         per_eng = min(args.max_streams, (n_jobs + n_eng - 1) // n_eng)
         # one batched-prefill pass carries up to 256 k prompt rows (~500 prompts at the 512-token truncation): a bar boundary of 1728 streams is then
@@ -588,6 +594,7 @@ def main():
         "notes_stage_s_per_step": round(t_notes / args.steps, 4),
         "decoder_tokens_per_step": n_tok / args.steps, "notes_per_clip": float(np.mean([cd.notes.size for cd in conds])),
         "cover_notes_per_job": float(np.mean([n.size for n in state["notes"]])), "jobs_gathered": gathered_jobs, "tokens_sha256_rank0": tok_digest, "tokens_sha256_all": tok_digest_all,
+        "build_id": _lib.lib().etd_build_id().decode(),
     }
 
     time_left = lambda: args.budget_s - since_process_start()                       # noqa: E731  (the ONE JSON line matters more than its optional parts)
@@ -614,13 +621,35 @@ def main():
         launches = sum(s["stamped_launches"] for s in st)
         secs = sum(s["stamped_seconds"] for s in st)
         byts = sum(s["stamped_alg_bytes"] for s in st)
+        # concurrent engines share the HBM: a launch of one engine then reads its bytes at a fraction of the peak by construction, and the statistic that says how well
+        # the memory system is used is bytes of ALL launches / the time during which ANY of them was running -- the union of the per-launch (start, end) stamps of
+        # every engine (one device clock).  With one engine the union is the sum and both figures coincide.
+        logs = [d.stamp_log() for d in decs]
+        iv = np.concatenate([l for l in logs if len(l)]) if any(len(l) for l in logs) else np.zeros((0, 2), np.uint64)
+        union_s = 0.0
+        if len(iv):
+            iv = iv[np.argsort(iv[:, 0])].astype(np.int64)
+            cur_s, cur_e = int(iv[0, 0]), int(iv[0, 1])
+            tot = 0
+            for a_, b_ in iv[1:]:
+                if a_ > cur_e:
+                    tot += cur_e - cur_s; cur_s, cur_e = int(a_), int(b_)
+                elif b_ > cur_e:
+                    cur_e = int(b_)
+            tot += cur_e - cur_s
+            union_s = tot * 1e-8
         if launches > 0 and secs > 0:
-            ach = byts / secs / 1e9
+            per_launch = byts / secs / 1e9
+            # (a log holds the first 131 072 launches of an engine: should a run exceed that, the union covers the logged share and so do the bytes)
+            ach = byts * (len(iv) / launches) / union_s / 1e9 if union_s > 0 else per_launch
             roof.update(achieved=round(ach, 1), frac=round(ach / PEAK_HBM_GBS, 4), launches=int(launches), avg_launch_ms=round(1e3 * secs / launches, 5),
-                        alg_bytes_per_launch=byts / launches,
-                        frac_source=("device stamps (etd_decoder_stamp): s_memrealtime of the first workgroup's start and the last workgroup's end of EVERY k_dstep_attn_down launch "
+                        alg_bytes_per_launch=byts / launches, engines=len(decs), launches_in_union=int(len(iv)),
+                        frac_per_launch=round(per_launch / PEAK_HBM_GBS, 4), union_busy_s=round(union_s, 4), sum_of_spans_s=round(secs, 4),
+                        frac_source=("device stamps (etd_decoder_stamp / etd_decoder_stamp_log): s_memrealtime of the first workgroup's start and the last workgroup's end of EVERY k_dstep_attn_down launch "
                                      f"of one extra decode stage over the same jobs (bars {skip_bars} .. {(stamp_bars or int(np.mean(nbars))) - 1}: the steady-state prompt size, 96 % of a job's bars) with all {len(decs)} "
-                                     "engine(s) running, i.e. the kernel's own span in the timed configuration -- what a rocprofv3 kernel trace of this command averages; "
+                                     "engine(s) running.  frac = algorithmic bytes of all stamped launches / the UNION of their (start, end) intervals across engines (one device clock) / peak: what the "
+                                     "memory system delivers while any attention launch runs; frac_per_launch = the same bytes / the SUM of the spans (a launch that shares the HBM with another engine's "
+                                     "reads its bytes at a fraction of the peak by construction; with one engine the two coincide -- and that figure is what a rocprofv3 kernel trace averages); "
                                      "algorithmic bytes = K+V rows of every (row, head) context + the down / dense weights a launch streams, counted exactly by the library"))
     result["roofline"] = roof
     tp = ROOT / "profiles" / "traffic.json"
@@ -629,11 +658,17 @@ def main():
             tj = json.loads(tp.read_text())
             sj = tj.get("k_dstep_attn_down_steady")
             if sj and roof.get("alg_bytes_per_launch"):
-                # PMC bytes of the SAME attention form at the SAME contexts as the stamped launches (steady-state bars), so traffic / alg_bytes_per_launch reads directly
-                roof["traffic"] = sj["bytes_per_launch"]
-                roof["traffic_over_algorithmic"] = round(sj["bytes_per_launch"] / roof["alg_bytes_per_launch"], 4)
-                roof["traffic_source"] = ("static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of " + sj["form"] + " over the steady-state "
-                                          "bars (4..7) of separate 8-bar profiling passes of this command, committed with the tree; NOT measured in this run")
+                # PMC bytes of the SAME attention form at the SAME rows per launch and contexts as the stamped launches (steady-state bars), so traffic / alg_bytes_per_launch
+                # reads directly; a table measured on another launch shape (other engine count / batch) is not this run's traffic and is left out
+                if sj.get("rows_per_launch") == per_eng and sj.get("engines") == len(decs):
+                    roof["traffic"] = sj["bytes_per_launch"]
+                    roof["traffic_over_algorithmic"] = round(sj["bytes_per_launch"] / roof["alg_bytes_per_launch"], 4)
+                    roof["traffic_source"] = ("static: profiles/traffic.json -- rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE per launch of " + sj["form"] + f" ({sj['engines']} engine(s) x "
+                                              f"{sj['rows_per_launch']} rows, library build {sj.get('build_id', '?')}) over the steady-state bars (4..7) of separate 8-bar profiling passes of this "
+                                              "command, committed with the tree; NOT measured in this run")
+                else:
+                    roof["traffic_source"] = (f"none: profiles/traffic.json holds {sj.get('engines', '?')} engine(s) x {sj.get('rows_per_launch', '?')} rows per launch, this run "
+                                              f"{len(decs)} x {per_eng} (tools/profile.sh measures the default layout)")
         except Exception:
             pass
     # the whole decode stage as ONE figure that needs no per-kernel timing: SURVEY 8(d)'s step bytes (weights once per engine-step + K/V of

@@ -149,6 +149,7 @@ SIGNATURES = {
     "etd_decoder_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_void_p]),
     "etd_decoder_stats_reset": (C.c_int, [C.c_void_p, C.c_void_p]),
     "etd_decoder_stamp": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "etd_decoder_stamp_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(C.c_longlong), C.c_void_p]),
     "etd_debug_decoder_force_pair": (C.c_int, [C.c_void_p, C.c_int]),
     "etd_debug_decoder_step_logits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "etd_debug_decoder_checksum": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_int, C.c_void_p]),

@@ -25,8 +25,38 @@ if os.environ.get("ETD_KERNARG_PRELOAD", "1") != "0":
 # VGPRs and back around each VALU use (online-softmax rescale, epilogues): 2 209 v_accvgpr moves across the library, 256 of them per key tile in the prefill
 # attention.  With the VGPR form there are none, the kernels need 15-40 % fewer registers (k_attn 200 -> 134, k_embed 424 -> 250) and the arithmetic is unchanged.
 # (k_dmlp_fused places its operands by asm constraints and is not affected.)  ETD_MFMA_VGPR_FORM=0 turns it off.
+def _llvm_flag_ok(flag: str) -> bool:
+    """Does this hipcc's LLVM know the (hidden) -mllvm option?  One trivial gfx950 compile, the answer cached next to the objects (keyed by the compiler binary's
+    mtime): a toolchain without it would otherwise abort the whole build with 'Unknown command line argument'."""
+    import json
+    import tempfile
+    try:
+        hipcc = next(c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc") if c and (Path(c).exists() or c == "hipcc"))
+        key = f"{hipcc}:{Path(hipcc).stat().st_mtime_ns if Path(hipcc).exists() else 0}:{flag}"
+        cache = OBJ / "flag_probe.json"
+        known = json.loads(cache.read_text()) if cache.exists() else {}
+        if key in known:
+            return bool(known[key])
+        with tempfile.TemporaryDirectory() as td:
+            src = Path(td) / "p.hip"
+            src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(float* p) { p[0] = 1.f; }\n")
+            r = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-mllvm", flag, "-c", str(src), "-o", str(Path(td) / "p.o")],
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        ok = r.returncode == 0
+        OBJ.mkdir(exist_ok=True)
+        known[key] = ok
+        cache.write_text(json.dumps(known))
+        return ok
+    except Exception:      # noqa: BLE001  (no compiler here at all: let the build itself report that)
+        return True
+
+
 if os.environ.get("ETD_MFMA_VGPR_FORM", "1") != "0":
-    FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+    if _llvm_flag_ok("-amdgpu-mfma-vgpr-form"):
+        FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]      # (part of every file's flag set, hence of the build id: builds with and without it never mix)
+    else:
+        print("etude_amd.build: this hipcc does not know -mllvm -amdgpu-mfma-vgpr-form; building without it (MFMA accumulators in AGPRs: correct, 15-40 % more registers)",
+              file=sys.stderr)
 FLAGS += os.environ.get("ETD_EXTRA_FLAGS", "").split()      # diagnostic builds (e.g. -DETD_HEAD_STAMP, -DETD_LIN_STAMP)
 # -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
 

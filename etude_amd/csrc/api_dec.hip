@@ -44,7 +44,7 @@ struct Layer { float *ln1g, *ln1b, *ln2g, *ln2b; Lin qkv, dense, up, down;
 
 }  // namespace
 
-#define ETD_STAMP_WORDS (8 + 2 * 64)      // u64 words of the device-side span accumulator of k_dstep_attn_down (layout: dec_kernels.hip)
+#define ETD_STAMP_WORDS (ETD_STAMP_HDR + 2 * ETD_STAMP_LOGCAP)      // u64 words of the device-side span accumulator + launch log of the attention launches (layout: dec_kernels.h)
 struct etd_dec {
   etd_dec_cfg cfg;
   std::vector<void*> allocs;
@@ -1137,9 +1137,9 @@ extern "C" int etd_decoder_stats(etd_dec* d, double* out, int n, void* stream) {
   if (!d || !out || n < 1) ETD_FAIL(ETD_EINVAL, "decoder_stats: bad arguments");
   unsigned long long sum_ticks = 0, n_stamped = 0;
   if (d->stamp_dev) {
-    std::vector<unsigned long long> sp(ETD_STAMP_WORDS);
+    std::vector<unsigned long long> sp(ETD_STAMP_HDR);
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemcpy(sp.data(), d->stamp_dev, ETD_STAMP_WORDS * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sp.data(), d->stamp_dev, ETD_STAMP_HDR * 8, hipMemcpyDeviceToHost));
     sum_ticks = sp[0]; n_stamped = sp[1];
     for (int bank = 0; bank < 2; ++bank) {              // the launch(es) no later launch has folded in yet
       unsigned long long e = 0;
@@ -1155,12 +1155,32 @@ extern "C" int etd_decoder_stats(etd_dec* d, double* out, int n, void* stream) {
   return ETD_OK;
 }
 
+// (start, end) of every stamped attention launch since the last reset, in 100 MHz ticks of the device's s_memrealtime (ONE clock for every queue of the chip: the
+// logs of several engines can be merged); out_pairs [cap][2]; *n = launches written (the log keeps the first ETD_STAMP_LOGCAP)
+extern "C" int etd_decoder_stamp_log(etd_dec* d, unsigned long long* out_pairs, long long cap, long long* n, void* stream) {
+  if (!d || !out_pairs || cap < 1 || !n) ETD_FAIL(ETD_EINVAL, "decoder_stamp_log: bad arguments");
+  *n = 0;
+  if (!d->stamp_dev) return ETD_OK;
+  std::vector<unsigned long long> sp(ETD_STAMP_WORDS);
+  HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  HIP_TRY(hipMemcpy(sp.data(), d->stamp_dev, ETD_STAMP_WORDS * 8, hipMemcpyDeviceToHost));
+  long long k = (long long)std::min<unsigned long long>(sp[1], ETD_STAMP_LOGCAP), w = 0;
+  for (long long i = 0; i < k && w < cap; ++i, ++w) { out_pairs[2 * w] = sp[ETD_STAMP_HDR + 2 * i]; out_pairs[2 * w + 1] = sp[ETD_STAMP_HDR + 2 * i + 1]; }
+  for (int bank = 0; bank < 2 && w < cap; ++bank) {     // the launch(es) no later launch has folded in yet
+    unsigned long long e = 0;
+    for (int i = 0; i < 64; ++i) e = std::max(e, sp[8 + 64 * bank + i]);
+    if (sp[2 + bank] != 0 && e > sp[2 + bank]) { out_pairs[2 * w] = sp[2 + bank]; out_pairs[2 * w + 1] = e; ++w; }
+  }
+  *n = w;
+  return ETD_OK;
+}
+
 extern "C" int etd_decoder_stats_reset(etd_dec* d, void* stream) {
   if (!d) ETD_FAIL(ETD_EINVAL, "decoder_stats_reset: null handle");
   d->stat_steps = d->stat_row_steps = d->stat_kv_bytes = d->stat_attn_launches = d->stat_stamp_bytes = 0;
   if (d->stamp_dev) {
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    HIP_TRY(hipMemset(d->stamp_dev, 0, ETD_STAMP_WORDS * 8));
+    HIP_TRY(hipMemset(d->stamp_dev, 0, ETD_STAMP_HDR * 8));          // (the log behind the header is indexed by the launch count, which restarts at zero)
   }
   return ETD_OK;
 }

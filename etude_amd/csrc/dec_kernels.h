@@ -41,6 +41,11 @@ struct DecRows {
 // bar): results do not depend on which slot or engine a job lands on.
 struct DSampleCfg { float inv_temp; float top_p; unsigned long long seed; };
 
+// device-side span stamps of the attention launches (etd_decoder_stamp): u64 words [0] sum of spans, [1] launches folded in, [2 + bank] start, [8 + 64 bank + i] end slots,
+// then ETD_STAMP_LOGCAP (start, end) pairs of the folded launches in order -- the union of several engines' launches is formed from those on the host
+#define ETD_STAMP_HDR (8 + 2 * 64)
+#define ETD_STAMP_LOGCAP 131072
+
 enum { DEPI_BIAS = 0, DEPI_GELU = 1, DEPI_RESID = 2, DEPI_LOGITS = 3, DEPI_QKV = 4, DEPI_PARTIAL = 5, DEPI_RELU = 6 /* k_gemm3 only */ };
 
 struct DGemmArgs {

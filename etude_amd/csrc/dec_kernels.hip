@@ -1650,7 +1650,11 @@ __device__ __forceinline__ void attn_stamp_begin(unsigned long long* stp, int pa
     for (int o = 32; o > 0; o >>= 1) { const unsigned long long x = __shfl_xor(e, o, 64); e = x > e ? x : e; }
     if (lane == 0) {
       const unsigned long long s0 = atomicExch(stp + 2 + prev, 0ull);
-      if (s0 != 0 && e > s0) { atomicAdd(stp, e - s0); atomicAdd(stp + 1, 1ull); }
+      if (s0 != 0 && e > s0) {
+        atomicAdd(stp, e - s0);
+        const unsigned long long n = atomicAdd(stp + 1, 1ull);
+        if (n < ETD_STAMP_LOGCAP) { stp[ETD_STAMP_HDR + 2 * n] = s0; stp[ETD_STAMP_HDR + 2 * n + 1] = e; }      // the launch's own (start, end), for unions across engines
+      }
       atomicExch(stp + 2 + bank, now);
     }
   }

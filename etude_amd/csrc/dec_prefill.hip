@@ -163,8 +163,9 @@ int launch_pattn(const PAttnArgs& a, hipStream_t st) {
   if (a.n_seq <= 0 || a.max_len <= 0 || a.n_heads <= 0 || !a.Q || !a.Kc || !a.Vc || !a.O || !a.seq_row0 || !a.seq_len || !a.row_slot || a.max_len > a.max_ctx ||
       (a.ldq % 8) || (a.ldo % 4) || (((uintptr_t)a.Q | (uintptr_t)a.Kc | (uintptr_t)a.Vc) & 15) || ((uintptr_t)a.O & 7))
     ETD_FAIL(ETD_EINVAL, "pattn: bad arguments");
-  ETD_LAUNCH_FILTER("k_attn_causal");
-  ProfScope ps("k_attn_causal", st, a.flops_hint, ((double)a.n_seq * 4.0 * a.max_len * 64 * a.n_heads) * 2);
+  ETD_LAUNCH_FILTER("k_pattn");
+  // bytes: Q read + O written once per row, K / V cache rows read once per (prompt, head) from HBM (the re-reads by later query tiles are L2 hits)
+  ProfScope ps("k_pattn", st, a.flops_hint, ((double)a.n_seq * 4.0 * a.max_len * 64 * a.n_heads) * 2);
   dim3 g((a.max_len + 127) / 128, a.n_seq * a.n_heads);
   hipLaunchKernelGGL(k_pattn, g, dim3(256), 0, st, a);
   HIP_TRY(hipGetLastError());
@@ -321,8 +322,8 @@ int launch_pqkv(const PQkvArgs& a, hipStream_t st) {
   if (a.M <= 0 || a.N != 1536 || a.ldx < 512 || (a.ldx % 8) || !a.X || !a.Wf || !a.bias || !a.Qb || !a.Kc || !a.Vc || !a.rows.pos || !a.rows.slot || !a.rows.active ||
       !a.rope_cos || !a.rope_sin || a.n_heads != 8 || (((uintptr_t)a.X | (uintptr_t)a.Wf | (uintptr_t)a.Qb | (uintptr_t)a.Kc | (uintptr_t)a.Vc) & 15) || (a.slot_stride % 8))
     ETD_FAIL(ETD_EINVAL, "pqkv: bad arguments");
-  ETD_LAUNCH_FILTER("k_linear_dec");
-  ProfScope ps("k_linear_dec", st, 2.0 * a.M * a.N * 512.0, ((double)a.M * 512 + (double)a.N * 512 + 3.0 * a.M * 512) * 2);
+  ETD_LAUNCH_FILTER("k_pqkv");
+  ProfScope ps("k_pqkv", st, 2.0 * a.M * a.N * 512.0, ((double)a.M * 512 + (double)a.N * 512 + 3.0 * a.M * 512) * 2);
   hipLaunchKernelGGL(k_pqkv, dim3((a.M + 255) / 256), dim3(512), 0, st, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;

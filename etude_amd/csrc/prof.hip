@@ -28,7 +28,7 @@ bool prof_enabled() { return g_on; }
 bool launch_skipped(const char* name) {
   static const char* only = getenv("ETD_EXT_ONLY");
   if (!only || !*only) return false;
-  if (!strcmp(name, "k_linear_dec") || !strcmp(name, "k_attn_causal")) return false;     // the decoder's batched prefill, never the Extract stage
+  if (!strcmp(name, "k_linear_dec") || !strcmp(name, "k_attn_causal") || !strcmp(name, "k_pqkv") || !strcmp(name, "k_pattn")) return false;     // the decoder's batched prefill, never the Extract stage
   const size_t n = strlen(name);
   for (const char* p = only; *p;) {
     const char* q = strchr(p, ',');

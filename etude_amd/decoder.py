@@ -346,6 +346,14 @@ class EtudeDecoder:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().etd_decoder_stamp(self._h, 1 if on else 0, int(skip_steps), self._stream()), "etd_decoder_stamp")
 
+    def stamp_log(self) -> np.ndarray:
+        """(start, end) of every stamped attention launch since the last stats_reset, uint64 [n, 2] in 100 MHz device ticks (one clock for the whole chip)"""
+        buf = np.zeros((131072 + 2, 2), np.uint64)
+        n = C.c_longlong()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().etd_decoder_stamp_log(self._h, buf.ctypes.data, buf.shape[0], C.byref(n), self._stream()), "etd_decoder_stamp_log")
+        return buf[: n.value]
+
     def debug_step_logits(self, on: bool, n_active: int = 0) -> Optional[np.ndarray]:
         """Test hook: switch the per-step logit store on / off; with n_active > 0 also return the LAST step's logits [n_active, V]."""
         out = np.zeros((n_active, self.config.vocab_size), np.float32) if n_active > 0 else None

@@ -243,6 +243,10 @@ double etd_decoder_step_bytes(const etd_dec*, int n_streams, int ctx);
 int etd_decoder_stats(etd_dec*, double* out, int n, void* stream);
 int etd_decoder_stats_reset(etd_dec*, void* stream);
 int etd_decoder_stamp(etd_dec*, int on, int skip_steps, void* stream);
+/* (start, end) of every stamped attention launch since the last reset, in 100 MHz ticks of the device's s_memrealtime -- ONE clock for every queue of the chip, so the
+ * logs of several engines can be merged into the union of the times an attention launch was running (bench.py: the roofline of concurrent engines is bytes of all
+ * launches / that union, not a per-launch fraction).  out_pairs [cap][2]; *n = launches written (the log keeps the first 131 072 per handle). */
+int etd_decoder_stamp_log(etd_dec*, unsigned long long* out_pairs, long long cap, long long* n, void* stream);
 /* ---- TinyREMITokenizer glue on either side of the decoder (host code, no GPU) ----
  * etd_tok_create      TinyREMITokenizer.__init__ / _create_measures      etude/data/tokenizer.py:24-41,166-229
  * etd_tok_encode      encode (+ _assign_notes, grace-note linking)        :231-252, :78-116, :265-297

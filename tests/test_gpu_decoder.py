@@ -1,8 +1,8 @@
 """HIP EtudeDecoder against the reference's golden logits / greedy token ids, through the C ABI.
 
-fp32 mode (exact-fp32 MFMA) is the parity gate: logits within 1e-4, greedy ids IDENTICAL.
-bf16 mode: logits within 5e-2; its ids are also compared (they match on these goldens) but the
-contract for bf16 is only the logit tolerance."""
+fp32 mode (fp32 weights, activations and KV cache; products at fp32 grade on the f16 matrix cores, csrc/gemm3.h) is the parity gate: logits within 1e-4, greedy ids IDENTICAL.
+16-bit serving mode ("bf16" in the API; IEEE-half operands since round 5): logits within 1e-2 (measured <= 3.3e-3); its ids are also compared
+(they match on these goldens) but the contract for that mode is only the logit tolerance."""
 import numpy as np
 import pytest
 import torch
@@ -34,7 +34,7 @@ def _decoder(precision, seed=1, max_streams=1, **kw):
                         precision=precision, max_streams=max_streams, **kw)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-4), ("bf16", 1e-2)])
 def test_prompt_logits_against_reference(dev, golden_dir, precision, tol):
     g = np.load(golden_dir / "decoder_full.npz")
     dec = _decoder(precision)

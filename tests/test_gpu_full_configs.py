@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 
 from tests._util import EXT_P_MEAN as P_MEAN, EXT_P_TOL as P_TOL, close_to      # the 16-bit serving mode vs the fp32 reference (the bounds of tests/test_gpu_extractor.py)
 HOP_S = 256 / 16000.0
+TOL16 = 1e-2                         # the decoder's 16-bit serving mode: logits vs the fp32 oracle (tests/test_gpu_decoder_parity.py: TOL)
 
 
 @pytest.fixture(scope="module")
@@ -206,11 +207,12 @@ def test_config3_128_streams_at_4k_context(dev):
     # ---- oracle: greedy continuation of the two prompts (positions 3500 .. 3500 + n: far beyond max_position_embeddings = 1024,
     # where HF's rotary embedding is computed on the fly, modeling_gpt_neox.py:72-107)
     n_chk = 12
-    want, want_lg = [], []
+    want, want_lg, prompt_lg = [], [], []
     for ids, cls, a4 in base:
         at = {"pitch_overlap": torch.from_numpy(a4[0])[None], "polyphony": torch.from_numpy(a4[1])[None],
               "note_sustain": torch.from_numpy(a4[2])[None], "rhythm_intensity": torch.from_numpy(a4[3])[None]}
         lg, kv = neox.forward_logits(sd, nd, torch.from_numpy(ids)[None], torch.from_numpy(cls)[None], at)
+        prompt_lg.append(lg[0].numpy().copy())
         seq = []
         for _ in range(n_chk + 1):
             nxt = int(torch.argmax(lg[:, -1, :], -1))
@@ -228,6 +230,12 @@ def test_config3_128_streams_at_4k_context(dev):
     # ---- bf16, 128 streams (64 copies of each prompt, interleaved), 64 steps through the captured decode step: streams
     # with equal prompts must produce equal tokens whatever slot they sit in, and the start agrees with the fp32 ids
     d16 = EtudeDecoder(dcfg, sd_np, "cuda", precision="bf16", max_streams=128, max_ctx=4096)
+    # the 16-bit contract is stated on logits: the batched prefill (MFMA attention from the cache rows, 55 key tiles per query) at T = 3 500 against the oracle, every 50th position
+    for k, (ids, cls, a4) in enumerate(base):
+        lg16 = d16.prefill_logits(ids, cls, a4)
+        err = float(np.abs(lg16[::50] - prompt_lg[k][::50]).max())
+        print(f"configs[3]: 16-bit prefill logits of prompt {k} at T = {ctx0}: max error {err:.3e} (tol {TOL16:.0e})")
+        assert err < TOL16, (k, err)
     got16 = _raw_generate(d16, [base[s % 2] for s in range(128)], tgt, steps)
     d16.close()
     for s in range(2, 128):
@@ -242,7 +250,7 @@ def test_config3_128_streams_at_4k_context(dev):
             lgk = want_lg[k * (n_chk + 1) + agree[k]]
             gap = float(lgk[want[k][agree[k]]] - lgk[int(got16[k][agree[k]])])
             print(f"  prompt {k}: bf16 token {int(got16[k][agree[k]])} vs {want[k][agree[k]]} at step {agree[k]}: reference logit gap {gap:.4f}")
-            assert 0.0 <= gap < 0.1, (k, agree[k], gap)
+            assert 0.0 <= gap < 2 * TOL16, (k, agree[k], gap)
 
 
 def test_generate_kv_window_bound_with_large_overlap_ratio(dev):

@@ -158,6 +158,22 @@ def test_traffic_table_is_keyed_by_the_names_the_bench_profiler_uses():
     assert not any("<" in k for k in t)
 
 
+def test_traffic_table_was_measured_on_the_launch_shape_the_bench_stamps():
+    """roofline.traffic is static (profiles/traffic.json, PMC passes of tools/profile.sh): it must describe the launches the bench stamps -- the default engine
+    layout of the 64-clip batch (rows per launch), the attention form that layout takes -- and say which library build it was measured on.  bench.py leaves
+    `traffic` null when the shapes differ; this test makes a stale table fail the suite instead of going unnoticed."""
+    import json
+    from pathlib import Path
+    import bench
+    sj = json.loads((Path(__file__).resolve().parent.parent / "profiles" / "traffic.json").read_text())["k_dstep_attn_down_steady"]
+    n_jobs = 64 * 27
+    eng = bench.default_engines(n_jobs, 1)
+    assert sj["engines"] == eng and sj["rows_per_launch"] == (n_jobs + eng - 1) // eng, (sj.get("engines"), sj.get("rows_per_launch"))
+    assert sj["form"].startswith("k_dstep_attn_down<8, false, true>")          # >= 32 rows at contexts 192 .. 1024: the paired-rows form (api_dec.hip)
+    assert isinstance(sj.get("build_id"), str) and len(sj["build_id"]) == 32
+    assert 0.9 < sj["bytes_per_launch"] / (sj["rows_per_launch"] * 8 * 537 * 256.0 + 2.6e6) < 1.3      # ~ the algorithmic bytes of such a launch (K + V of ~537 positions per (row, head))
+
+
 def _bench(args, env_extra):
     import os, subprocess, sys
     from pathlib import Path

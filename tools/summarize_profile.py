@@ -116,8 +116,15 @@ def main():
         nf, f = pmc_steady(os.path.join(root, "prof_fetch"), "FETCH_SIZE", form)
         nw, w = pmc_steady(os.path.join(root, "prof_write"), "WRITE_SIZE", form)
         if nf and nw:
+            cfgl = {}
+            try:
+                cfgl = json.load(open(os.path.join(root, "prof_fetch.json")))
+            except Exception:      # noqa: BLE001
+                pass
             out["k_dstep_attn_down_steady"] = {"form": form, "launches": min(nf, nw), "fetch_bytes_per_launch": 2.0 * f * 1024, "write_bytes_per_launch": w * 1024,
                                                "bytes_per_launch": 2.0 * f * 1024 + w * 1024,
+                                               "rows_per_launch": cfgl.get("config", {}).get("decoder_streams_per_engine"), "engines": cfgl.get("config", {}).get("decoder_engines"),
+                                               "build_id": cfgl.get("build_id"),
                                                "what": "second half of the form's launches in dispatch order = bars 4..7 of the 8-bar PMC passes: prompts at the 512-token truncation, "
                                                        "the contexts of the stamped launches"}
             print(f"== {form}, steady-state half of the PMC run: {nf} launches, {(2.0 * f * 1024 + w * 1024) / 1e6:.1f} MB per launch")
