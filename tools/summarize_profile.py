@@ -15,6 +15,12 @@ from collections import defaultdict
 
 
 def short(name):
+    # rocprofv3 leaves names with _Float16 pointer arguments mangled (its demangler does not know DF16_): _Z<len><name>... -> <name>; template instances of such
+    # kernels (_Z<len><name>I...E) lose their arguments here, which only merges instances
+    m = re.match(r"_Z(\d+)", name)
+    if m:
+        n = int(m.group(1)); st = m.end()
+        name = name[st:st + n]
     name = re.sub(r"\(.*", "", name)
     m = re.search(r"(k_[a-z0-9_]+)(?:<([^>]*)>)?", name)
     if m:
