@@ -40,6 +40,28 @@ def kernel_trace(d):
     return rows
 
 
+def union_of(d, kernel_prefix):
+    """(launches, sum of durations, union of the dispatch intervals) in seconds of one kernel over every queue of the trace: concurrent engines' launches overlap, and
+    what the memory system delivers is bytes / the time during which ANY of them ran (bench.py: roofline.frac), not a per-launch figure"""
+    iv = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if short(r.get("Kernel_Name", "")).startswith(kernel_prefix):
+                    iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    if not iv:
+        return 0, 0.0, 0.0
+    iv.sort()
+    tot = 0; cs, ce = iv[0]
+    for a, b in iv[1:]:
+        if a > ce:
+            tot += ce - cs; cs, ce = a, b
+        elif b > ce:
+            ce = b
+    tot += ce - cs
+    return len(iv), sum(b - a for a, b in iv) * 1e-9, tot * 1e-9
+
+
 def pmc(d, counter):
     rows = defaultdict(lambda: [0, 0.0])
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -75,6 +97,16 @@ def main():
     print("== kernel trace (prof_trace): kernel, launches, total_ms, avg_us, share")
     for k, (n, us) in sorted(kt.items(), key=lambda kv: -kv[1][1])[:30]:
         print(f"{k:40s} {n:9d} {us/1e3:12.3f} {us/n:10.2f} {100*us/tot:6.2f}%")
+    try:
+        n_u, sum_u, uni_u = union_of(os.path.join(root, "prof_trace"), "k_dstep_attn_down<8, false, true>")
+        if n_u:
+            line = json.load(open(os.path.join(root, "prof_trace.json")))
+            apl = line["roofline"]["alg_bytes_per_launch"]
+            print(f"== k_dstep_attn_down<8, false, true> in the kernel trace (whole run, every queue): {n_u} launches, sum of durations {sum_u:.3f} s, UNION of the dispatch intervals {uni_u:.3f} s "
+                  f"(x {sum_u / uni_u:.2f} overlap); at the stamped launches' {apl / 1e6:.1f} MB per launch: per launch {apl * n_u / sum_u / 8e12:.3f} of 8 TB/s, on the union {apl * n_u / uni_u / 8e12:.3f} "
+                  "(the ramp-up bars of every stage read less than that per launch: the bench's own figures count bytes exactly)")
+    except Exception as e:      # noqa: BLE001
+        print("(no union of the attention launches:", e, ")")
     fe = pmc(os.path.join(root, "prof_fetch"), "FETCH_SIZE")
     wr = pmc(os.path.join(root, "prof_write"), "WRITE_SIZE")
     traffic = {}
