@@ -206,6 +206,25 @@ def default_engines(n_jobs: int, world: int = 1) -> int:
     return 3 if (n_jobs >= 1024 or (world == 1 and n_jobs >= 512)) else 4
 
 
+def union_seconds(pairs, tick_s: float = 1e-8) -> float:
+    """length of the union of [start, end) intervals given in device ticks (uint64 [n, 2], any order): the time during which at least one of them was running"""
+    iv = np.asarray(pairs)
+    if iv.size == 0:
+        return 0.0
+    iv = iv.reshape(-1, 2)
+    iv = iv[np.argsort(iv[:, 0], kind="stable")].astype(np.int64)
+    cur_s, cur_e = int(iv[0, 0]), int(iv[0, 1])
+    tot = 0
+    for a_, b_ in iv[1:]:
+        if a_ > cur_e:
+            tot += cur_e - cur_s
+            cur_s, cur_e = int(a_), int(b_)
+        elif b_ > cur_e:
+            cur_e = int(b_)
+    tot += cur_e - cur_s
+    return tot * tick_s
+
+
 def bar_divergence(ra, rb):
     """per-bar comparison of two result lists [(flat ids, bar lengths)] of the same jobs (tests/test_gpu_full_configs.py: a bar can only be compared
     while the two histories are still equal): -> (bars identical, comparable bars, jobs identical end to end)"""
@@ -626,18 +645,7 @@ def main():
         # every engine (one device clock).  With one engine the union is the sum and both figures coincide.
         logs = [d.stamp_log() for d in decs]
         iv = np.concatenate([l for l in logs if len(l)]) if any(len(l) for l in logs) else np.zeros((0, 2), np.uint64)
-        union_s = 0.0
-        if len(iv):
-            iv = iv[np.argsort(iv[:, 0])].astype(np.int64)
-            cur_s, cur_e = int(iv[0, 0]), int(iv[0, 1])
-            tot = 0
-            for a_, b_ in iv[1:]:
-                if a_ > cur_e:
-                    tot += cur_e - cur_s; cur_s, cur_e = int(a_), int(b_)
-                elif b_ > cur_e:
-                    cur_e = int(b_)
-            tot += cur_e - cur_s
-            union_s = tot * 1e-8
+        union_s = union_seconds(iv)
         if launches > 0 and secs > 0:
             per_launch = byts / secs / 1e9
             # (a log holds the first 131 072 launches of an engine: should a run exceed that, the union covers the logged share and so do the bytes)

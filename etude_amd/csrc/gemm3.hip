@@ -617,3 +617,21 @@ extern "C" int etd_debug_attn3(const float* q_dev, const float* k_dev, const flo
   if (meta) (void)hipFree(meta);
   return rc;
 }
+
+// host-only test hook: the load-time bounds the plane scales come from (tests/test_host_logic.py checks that they bound)
+extern "C" int etd_debug_g3_bounds(const float* W, const float* c, int N, int K, const float* g, const float* b, float elem_bound, float* out4, int32_t* log2_out4) {
+  if (!W || !g || !b || !out4 || !log2_out4 || N < 1 || K < 1) ETD_FAIL(ETD_EINVAL, "debug_g3_bounds: bad arguments");
+  out4[0] = g3_bound_ln(g, b, K);
+  out4[1] = g3_bound_linear_of_ln(W, c, N, K, g, b);
+  out4[2] = g3_bound_linear(W, c, N, K, elem_bound);
+  std::vector<uint16_t> planes(g3_packed_elems((N + 127) / 128 * 128, (K + 31) / 32 * 32));
+  out4[3] = 0.f;
+  for (int i = 0; i < 3; ++i) log2_out4[i] = g3_scale_log2(out4[i]);
+  log2_out4[3] = (K % 32 == 0) ? g3_pack_weights_host(W, N, (N + 127) / 128 * 128, K, planes.data()) : 0;
+  if (K % 32 == 0) {        // largest plane magnitude actually stored: must sit in [2^14, 2^15)
+    float mx = 0.f;
+    for (size_t i = 0; i < planes.size(); ++i) { f16 h; memcpy(&h, &planes[i], 2); const float v = fabsf((float)h); mx = v > mx ? v : mx; }
+    out4[3] = mx;
+  }
+  return ETD_OK;
+}

@@ -68,6 +68,10 @@ int etd_debug_gemm3(const float* x_dev, int M, int K, const float* w_host, const
 int etd_debug_attn3(const float* q_dev, const float* k_dev, const float* v_dev, float* o_dev, int n_seq, int n_heads, int Sq, int Sk, float q_bound, float k_bound, float v_bound,
                     int causal, const int32_t* lens_host, void* stream);
 
+/* host-only test hook: the load-time bounds behind the plane scales of csrc/gemm3.h -- out4 = { bound of LayerNorm(.; g, b) over K features, bound of W LN(.) + c,
+ * bound of W x + c for |x| <= elem_bound, largest |value| in the packed f16 planes of W }, log2_out4 = the scale logarithms chosen for the three bounds and for W */
+int etd_debug_g3_bounds(const float* W, const float* c, int N, int K, const float* g, const float* b, float elem_bound, float* out4, int32_t* log2_out4);
+
 #ifdef __cplusplus
 }
 #endif

@@ -215,3 +215,67 @@ def test_config_structs_carry_their_size():
     assert lib.etd_debug_assemble_prompt(C.byref(sc), *args) == 0 and T.value == 2 * 4 * 2 + 3 + 1
     sc.struct_bytes -= 8
     assert lib.etd_debug_assemble_prompt(C.byref(sc), *args) == -22 and b"etd_sched_cfg" in lib.etd_last_error()
+
+
+def test_union_of_launch_intervals():
+    """bench.py's roofline for concurrent engines = bytes / the union of their attention launches' (start, end) intervals (device ticks of 10 ns)"""
+    import numpy as np
+    import bench
+    assert bench.union_seconds(np.zeros((0, 2), np.uint64)) == 0.0
+    one = np.asarray([[100, 200], [200, 300], [350, 400]], np.uint64)            # one engine: back to back and a gap -> the sum
+    assert abs(bench.union_seconds(one) - 250e-8) < 1e-15
+    three = np.asarray([[100, 200], [150, 260], [120, 130], [400, 500], [450, 460], [499, 520]], np.uint64)   # overlapping, nested, unsorted input
+    assert abs(bench.union_seconds(three[::-1]) - (160 + 120) * 1e-8) < 1e-15
+    big = np.asarray([[2 ** 62, 2 ** 62 + 10]], np.uint64)                        # s_memrealtime values are large
+    assert abs(bench.union_seconds(big) - 10e-8) < 1e-15
+
+
+def test_default_engine_layout():
+    import bench
+    assert bench.default_engines(64 * 27, 1) == 3 and bench.default_engines(8 * 27, 8) == 4 and bench.default_engines(8 * 27, 1) == 4
+    assert bench.default_engines(32 * 27, 2) == 4 and bench.default_engines(64 * 27, 8) == 3
+
+
+def test_device_clip_synthesis_follows_config2_construction():
+    """synth.clip_audio_device (bench.py's 64 clips, seeds 0..63) is synth.clip_audio's construction with device noise: same tonal part, peak 0.5, deterministic per seed"""
+    import numpy as np
+    from etude_amd import synth
+    a = synth.clip_audio_device(5, seconds=1.0, device="cpu").numpy()
+    b = synth.clip_audio_device(5, seconds=1.0, device="cpu").numpy()
+    c = synth.clip_audio_device(6, seconds=1.0, device="cpu").numpy()
+    ref = synth.clip_audio(5, seconds=1.0)
+    assert a.shape == ref.shape == (2, 44100) and a.dtype == np.float32
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert abs(float(np.abs(a).max()) - 0.5) < 1e-6
+    assert np.corrcoef(a[0], ref[0])[0, 1] > 0.98 and np.corrcoef(a[1], ref[1])[0, 1] > 0.98       # same sinusoids; the -30 dB noise differs (device generator)
+
+
+def test_plane_scale_bounds_do_bound():
+    """csrc/gemm3.h: an fp32 operand x is carried as f16 planes of s x with |s x| < 2^15 by a PROVABLE bound of |x| -- checked here on adversarial LayerNorm inputs
+    (one-hot and two-level rows reach the sqrt(n - 1) extreme of a normalised coordinate) and random ones, through the library's own bound functions."""
+    import ctypes as C
+    import numpy as np
+    from etude_amd import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(0)
+    N, K = 96, 256
+    W = (rng.standard_normal((N, K)) * 0.07).astype(np.float32); c = rng.standard_normal(N).astype(np.float32)
+    g = rng.uniform(0.2, 3.0, K).astype(np.float32) * rng.choice([-1, 1], K).astype(np.float32); b = (rng.standard_normal(K) * 0.5).astype(np.float32)
+    out = np.zeros(4, np.float32); lg = np.zeros(4, np.int32)
+    _lib.check(lib.etd_debug_g3_bounds(W.ctypes.data, c.ctypes.data, N, K, g.ctypes.data, b.ctypes.data, C.c_float(7.5), out.ctypes.data, lg.ctypes.data), "g3_bounds")
+    rows = [rng.standard_normal(K) * rng.uniform(1e-3, 1e3) for _ in range(200)]
+    for k in range(0, K, 17):
+        e = np.zeros(K); e[k] = 1.0; rows.append(e); rows.append(-e * 1e4)                  # one coordinate carries everything: |z_k| = sqrt(K - 1)
+    rows.append(np.r_[np.ones(K // 2), -np.ones(K - K // 2)] * 3.0)
+    x = np.stack(rows).astype(np.float64)
+    z = (x - x.mean(-1, keepdims=True)) / np.sqrt(x.var(-1, keepdims=True) + 1e-5)
+    y = z * g + b
+    assert np.abs(y).max() <= out[0] * (1 + 1e-6), (np.abs(y).max(), out[0])
+    assert np.abs(y).max() > 0.5 * out[0]                                                      # ... and the bound is tight, not vacuous
+    u = y @ W.astype(np.float64).T + c
+    assert np.abs(u).max() <= out[1] * (1 + 1e-6), (np.abs(u).max(), out[1])
+    xe = rng.uniform(-7.5, 7.5, (300, K)); xe[0] = 7.5 * np.sign(W[0])
+    assert np.abs(xe @ W.astype(np.float64).T + c).max() <= out[2] * (1 + 1e-6)
+    for i in range(3):
+        assert out[i] * 2.0 ** lg[i] < 2 ** 15 and out[i] * 2.0 ** lg[i] >= 2 ** 13.9           # scaled bound inside f16's range with less than a bit to spare
+    assert 2 ** 14 <= out[3] < 2 ** 15 and abs(np.abs(W).max() * 2.0 ** lg[3] - out[3]) <= 8    # the weight planes' own maximum (f16 rounding of the top value)
