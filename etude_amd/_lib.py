@@ -77,6 +77,7 @@ SIGNATURES = {
     "etd_build_id": (C.c_char_p, []),
     "etd_extractor_operand_type": (C.c_int, []),
     "etd_decoder_operand_type": (C.c_int, []),
+    "etd_has_experiments": (C.c_int, []),
     "etd_prof_enable": (C.c_int, [C.c_int]),
     "etd_prof_reset": (C.c_int, []),
     "etd_prof_collect": (C.c_int, []),

@@ -408,7 +408,11 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
       // ((history: 4ac2f57) tools/runs/r2_run21/24/27.sh): a step of one engine 0.197 -> 0.185 ms, four engines stepping 9.9 -> 10.1 engine-steps/ms,
       // but the JOB 569-575 -> 567 audio-s/s (the attention workgroups live 19 instead of 15.5 us and hold 128 registers per
       // wave while the other engines' prefill GEMMs want the same CUs).  Off by default.
+#ifdef ETD_EXPERIMENTS
       static const bool rowfin = getenv("ETD_ROWFIN") && atoi(getenv("ETD_ROWFIN")) > 0;
+#else
+      constexpr bool rowfin = false;          // (measured dead end: built with -DETD_EXPERIMENTS only)
+#endif
       if (rowfin && ksd + d->nh == 12 && M <= DS_STEP_MAX_ROWS) {
         DRowFin fin = {};
         fin.cnt = d->row_cnt + (size_t)l * DS_STEP_MAX_ROWS; fin.target = d->nh + 16 * ksd; fin.P = d->Pk; fin.nslab = 12;
@@ -682,6 +686,16 @@ int alloc_workspaces(etd_dec* d) {
 
 }  // namespace
 
+// 1 when the library was built with -DETD_EXPERIMENTS: the measured dead ends (in-launch row finish, 8 / 16-wave attention workgroups, k_post_attn) are compiled in
+// and their environment switches are live; the shipped build has one path per precision and ignores those switches
+extern "C" int etd_has_experiments(void) {
+#ifdef ETD_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 extern "C" int etd_decoder_operand_type(void) { return ETD_DEC_IS_F16; }
 
 extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const float* const* host_ptrs,
@@ -952,7 +966,11 @@ extern "C" int etd_decoder_begin_bars(etd_dec* d, int n, const int32_t* slots, c
   }
   // the row-finish counters (ETD_ROWFIN=1) are zero between launches by construction (the last arriver resets its word); a launch
   // that died half way would leave them poisoned for good, so every bar starts from zero anyway (16 KiB, on the stream)
+#ifdef ETD_EXPERIMENTS
   static const bool rowfin_on = getenv("ETD_ROWFIN") && atoi(getenv("ETD_ROWFIN")) > 0;
+#else
+  constexpr bool rowfin_on = false;
+#endif
   if (rowfin_on && d->row_cnt) HIP_TRY(hipMemsetAsync(d->row_cnt, 0, (size_t)d->L * DS_STEP_MAX_ROWS * sizeof(int), st));
   Staged sg; float* hf = nullptr;
   bool compact = false;

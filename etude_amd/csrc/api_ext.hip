@@ -396,7 +396,12 @@ bool frag_attn() { static const bool on = !getenv("ETD_NO_FRAG_ATTN") && !getenv
 // ETD_POST_ATTN=1: fc_o + LayerNorm + feed-forward block of the decoder layers as ONE launch (k_post_attn).  Measured equal in time to the
 // two launches it replaces (0.319 vs 0.309 ms per window: its mid-kernel LayerNorm costs what the saved HBM round trip gains), so the
 // two-launch sequence stays the default
+// (a measured dead end: compiled with -DETD_EXPERIMENTS only)
+#ifdef ETD_EXPERIMENTS
 bool fused_post() { static const bool on = getenv("ETD_POST_ATTN") && atoi(getenv("ETD_POST_ATTN")) != 0 && !getenv("ETD_NO_FUSED_PROJ") && !getenv("ETD_NO_FUSED_FFN"); return on; }
+#else
+constexpr bool fused_post() { return false; }
+#endif
 
 ProjBlock pblock(const e16* Wf, const float* bias, int kind, e16* dst, int ldd, int relu = 0) {
   ProjBlock b = {}; b.Wf = Wf; b.bias = bias; b.kind = kind; b.relu = relu; b.dst = dst; b.ldd = ldd; return b;

@@ -41,17 +41,7 @@ extern "C" int etd_debug_step_stamps(long long* dev_buf, unsigned long long cap_
 #define SS_DECL() do { } while (0)
 #define SS(i) do { } while (0)
 #define SS_LANDED() do { } while (0)
-#ifdef ETD_STEP_FENCE       /* measurement build: an agent-scope fence behind the last stores of every per-layer step kernel (1: both, 2: release, 3: acquire) */
-#if ETD_STEP_FENCE == 2
-#define SS_FLUSH(kid, role) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
-#elif ETD_STEP_FENCE == 3
-#define SS_FLUSH(kid, role) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
-#else
-#define SS_FLUSH(kid, role) __threadfence()
-#endif
-#else
 #define SS_FLUSH(kid, role) do { } while (0)
-#endif
 #endif
 
 // ================================================================================================
@@ -418,11 +408,7 @@ __global__ __launch_bounds__(64 * DS_WAVES) void k_dstep_qkv_up(int p_M, int p_K
   d16x8 wf[NS], xf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-#ifdef ETD_ABL_QKVW
-    wf[s] = d16x8{(d16)(float)(((uintptr_t)(wrow + s)) & 7), 0, 0, 0, 0, 0, 0, 0};
-#else
     wf[s] = *reinterpret_cast<const d16x8*>(wrow + kb + s * 16 + h * 8);
-#endif
     xf[s] = *reinterpret_cast<const d16x8*>(xbase + (long long)gm * ldx + kb + s * 16 + h * 8);
   }
   for (int t = 0; t < p_rpt; ++t) {
@@ -1188,14 +1174,7 @@ template <> struct Raw8<d16> {
   // K/V rows are read once per step and never again before they are overwritten in the caches by the next row's stream: the
   // nontemporal hint keeps them from evicting the weights (shared by all engines) from L2 / the Infinity Cache -- measured
   // -5.5 % per step with one engine and with four (tools/bench_engine_overlap.py)
-#ifndef ETD_KV_NT
-#define ETD_KV_NT 1
-#endif
-#if ETD_KV_NT
   __device__ __forceinline__ void load(const d16* p) { v = __builtin_nontemporal_load(reinterpret_cast<const d16x8*>(p)); }
-#else
-  __device__ __forceinline__ void load(const d16* p) { v = *reinterpret_cast<const d16x8*>(p); }
-#endif
   __device__ __forceinline__ float get(int j) const { return bf2f(v[j]); }
 };
 
@@ -1284,39 +1263,13 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 
 // measurement builds ((history: 4ac2f57) tools/runs/r2_run18.sh): -DETD_ABL_DENSE / -DETD_ABL_GEMMW / -DETD_ABL_QKVW replace a weight stream by a
 // constant (wrong results on purpose) to see what that stream costs the OTHER engines' kernels
-#ifdef ETD_ABL_DENSE
-#define ABL_DENSE_LOAD(p) (d16x8{(d16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
-#else
 #define ABL_DENSE_LOAD(p) (*reinterpret_cast<const d16x8*>(p))
-#endif
-#ifdef ETD_ABL_GEMMW
-#define ABL_GEMMW_LOAD(p) (d16x8{(d16)(float)(((uintptr_t)(p)) & 7), 0, 0, 0, 0, 0, 0, 0})
-#else
 #define ABL_GEMMW_LOAD(p) (*reinterpret_cast<const d16x8*>(p))
-#endif
 // cross-lane exchanges of the attention core: 0 = __shfl_xor (ds_bpermute_b32, LDS crossbar), 1 = lane_xor (DPP / permlane swaps)
-#ifndef ETD_AD_XCHG
-#define ETD_AD_XCHG 0
-#endif
-#if ETD_AD_XCHG
-#define ETD_XCH(v, O) lane_xor<O>(v)
-#else
 #define ETD_XCH(v, O) __shfl_xor(v, O, 64)
-#endif
 // measurement builds: ETD_AD_TRANS_NOP=1 puts 16 wait states between the merge's v_exp_f32 results and their first use, = 2 also in the key loop
-#ifndef ETD_AD_TRANS_NOP
-#define ETD_AD_TRANS_NOP 0
-#endif
-#if ETD_AD_TRANS_NOP
-#define ETD_TRANS_SETTLE(a_, b_) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a_), "+v"(b_))
-#else
 #define ETD_TRANS_SETTLE(a_, b_) ((void)0)
-#endif
-#if ETD_AD_TRANS_NOP > 1
-#define ETD_TRANS_SETTLE_LOOP(a_, b_) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(a_), "+v"(b_))
-#else
 #define ETD_TRANS_SETTLE_LOOP(a_, b_) ((void)0)
-#endif
 #define EXPF(x) (FAST ? __builtin_amdgcn_exp2f(x) : expf(x))
 // DENSE: instead of storing the head's 64 outputs, multiply them (rounded to d16, as the projection GEMM would read them)
 // with this head's [512][64] slice of attention.dense and store the 512 partial sums as one more split-K slab for
@@ -1335,9 +1288,6 @@ __device__ __forceinline__ void row_finish(const DRowFin& f, const int row_in, c
 // tests/test_isa_guard.py keeps the form out of the library.
 // (-DETD_AD_CROSSED_PK=1 rebuilds the failing form: tools/probe_trace.py and tests/test_gpu_reproducibility.py then fail again)
 __device__ __forceinline__ float merge_sum(float a, float b, float c, float d) {
-#if defined(ETD_AD_CROSSED_PK) && ETD_AD_CROSSED_PK
-  return a * b + c * d;
-#endif
   float t, u, r;
   asm volatile("v_mul_f32 %0, %1, %2" : "=v"(t) : "v"(a), "v"(b));
   asm volatile("v_mul_f32 %0, %1, %2" : "=v"(u) : "v"(c), "v"(d));
@@ -1354,11 +1304,7 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
                                            const int* p_row_sp, const float* p_Q, const void* p_Kc, const void* p_Vc, long long p_slot_stride,
                                            int p_max_ctx, int p_n_heads, float p_scale, int p_identity, const DAttnArgs& a, const DRowFin* fin = nullptr,
                                            const float* osh_other = nullptr, float* outsh_other = nullptr, bool dup = false) {
-#if defined(ETD_AD_UNIFORM) && ETD_AD_UNIFORM
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane >> 3, c = lane & 7;      // (measurement build: the key loop's trip count is then provably wave-uniform)
-#else
   const int tid = PAIR ? (int)(threadIdx.x & (64 * NW - 1)) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane >> 3, c = lane & 7;
-#endif
   SS_DECL(); SS(0);
   constexpr int G2 = 8 * NW;         // offset of a wave's second 8-key group inside an iteration
   constexpr int KI = 16 * NW;        // keys per workgroup iteration
@@ -1374,13 +1320,8 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
     const int ka = wave * 8 + j, kbb = ka + G2;                        // < 16 NW <= max_ctx (checked by the launcher)
     kA.load(kb0 + (long long)ka * 64 + c * 8); kB.load(kb0 + (long long)kbb * 64 + c * 8);
     wA.load(vb0 + (long long)ka * 64 + c * 8); wB.load(vb0 + (long long)kbb * 64 + c * 8);
-#if ETD_KV_NT
     slot = m; pos = __builtin_nontemporal_load(p_row_sp + 2 * m + 1);
   } else if (p_row_sp) { const i32x2 sp = __builtin_nontemporal_load(reinterpret_cast<const i32x2*>(p_row_sp + 2 * m)); slot = sp[0]; pos = sp[1]; }   // one 8-byte load
-#else
-    slot = m; pos = p_row_sp[2 * m + 1];
-  } else if (p_row_sp) { const i32x2 sp = *reinterpret_cast<const i32x2*>(p_row_sp + 2 * m); slot = sp[0]; pos = sp[1]; }
-#endif
   else { slot = a.rows.slot[m]; pos = a.rows.pos[m]; }
   const int ctx = (pos < p_max_ctx ? pos : p_max_ctx - 1) + 1;
   const int hidden = p_n_heads * 64;
@@ -1455,19 +1396,10 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   d16x8 dwv[DENSE ? FP : 1];
   const d16* dwb = nullptr;
   // measurement builds: ETD_AD_DENSE_LATE=1 requests the fragments AFTER the intra-wave merge, =2 requests them here but drains them before the merge
-#ifndef ETD_AD_DENSE_LATE
-#define ETD_AD_DENSE_LATE 0
-#endif
   if constexpr (DENSE) {
     dwb = a.dense_w + (long long)head * (512 * 64) + (long long)(dwave * DROWS + (lane >> 3)) * 64 + (lane & 7) * 8;
-#if ETD_AD_DENSE_LATE != 1
 #pragma unroll
     for (int it = 0; it < FP; ++it) dwv[it] = ABL_DENSE_LOAD(dwb + it * 8 * 64);
-#endif
-#if ETD_AD_DENSE_LATE == 2
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-#endif
   }
   // merge the 8 key slots of this wave (lanes differing in bits 3..5), then the NW waves through LDS
 #define ETD_MERGE_STAGE(off)                                                                                                \
@@ -1485,13 +1417,6 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
   if (dp) { dp[0] = lr; dp[1] = mr; dp[2] = o[0]; }
   ETD_MERGE_STAGES()
   if (dp) { dp[5] = lr; dp[7] = o[0]; }
-#if ETD_AD_DENSE_LATE == 1
-  if constexpr (DENSE) {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int it = 0; it < FP; ++it) dwv[it] = ABL_DENSE_LOAD(dwb + it * 8 * 64);
-  }
-#endif
   if (j == 0) {
     red[wave][c][0] = mr; red[wave][c][1] = lr;
 #pragma unroll
@@ -1607,9 +1532,6 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
       __syncthreads();
       SS(5); SS_FLUSH(2, 0);
       if (wave != 0) return;
-#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 1
-      return;
-#endif
 #ifdef ETD_STEP_STAMP
       ss_t[0] = ss_t[5]; ss_t[3] = ss_t[4] = ss_t[5] = 0;
 #endif
@@ -1621,10 +1543,6 @@ __device__ __forceinline__ void dattn_core(const int m, const int head, float (&
       if (old != fin->target - 1) { SS_FLUSH(4, 0); return; }
 #else
       if (old != fin->target - 1) return;
-#endif
-#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 2
-      if (lane == 0) D_CNT_RESET(fin->cnt + m);
-      return;
 #endif
       row_finish(*fin, m, a.M, lane);
       if (lane == 0) D_CNT_RESET(fin->cnt + m);
@@ -1775,19 +1693,9 @@ __device__ __forceinline__ void dstep_attn_down_body(const int* p_row_sp, const 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SS(2); SS_FLUSH(2, 1);
     // both lane halves of a row have drained their stores before the row's lane adds: the wait above is wave-wide
-#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 1
-    return;
-#endif
-#ifdef ETD_FIN_TEST_SLOWGEMM      /* test build: the units of odd feature tiles arrive ~40 us late, so that THEY are the last arrivers and finish the rows */
-    if ((n0 >> 5) & 1) for (int i = 0; i < 10; ++i) __builtin_amdgcn_s_sleep(127);
-#endif
     int old = -1;
     if (h == 0 && m < p_M) old = D_ARRIVE(fin.cnt + m);
     unsigned long long last = __ballot(old == fin.target - 1);
-#if defined(ETD_FIN_ABL) && ETD_FIN_ABL == 2
-    if (last) { if (old == fin.target - 1) D_CNT_RESET(fin.cnt + m); }
-    return;
-#endif
     while (last) {
       const int rl = __builtin_ctzll(last);
       last &= last - 1;
@@ -1826,12 +1734,22 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(FIN ? E
 // (row, head)'s whole context at once does NOT shorten the launch: its ~8 us of fixed cost are not the key loop's round trips.  Nor are
 // they the second pass of dense-weight fragments in the tail: with all 16 requested before the merge (100 registers, 4 waves per SIMD)
 // one engine steps in 0.199 instead of 0.198 ms and four engines reach 9.97-10.03 engine-steps per ms either way ((history: 4ac2f57) tools/runs/r2_run12.sh).
+// The shipped library holds ONE form per case: 4-wave one-row workgroups and the 8-wave paired-rows form (both without the in-launch row finish).  The 8 / 16-wave
+// one-row forms (ETD_AD_WAVES) and the row finish (ETD_ROWFIN, DRowFin) are measured dead ends kept for the record: built only with -DETD_EXPERIMENTS
+// (ETD_EXTRA_FLAGS=-DETD_EXPERIMENTS python -m etude_amd.build --force), which `etd_has_experiments()` reports.
 static int ad_waves(int M) {
-  static const int env = getenv("ETD_AD_WAVES") ? atoi(getenv("ETD_AD_WAVES")) : 0;
   (void)M;
+#ifdef ETD_EXPERIMENTS
+  static const int env = getenv("ETD_AD_WAVES") ? atoi(getenv("ETD_AD_WAVES")) : 0;
   return (env == 8 || env == 16) ? env : 4;
+#else
+  return 4;
+#endif
 }
 int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin* fin, hipStream_t st) {
+#ifndef ETD_EXPERIMENTS
+  if (fin) ETD_FAIL(ETD_EINVAL, "dstep_attn_down: the in-launch row finish is built with -DETD_EXPERIMENTS only");
+#endif
   if (fin && (!fin->cnt || fin->target != a.n_heads + 16 * g.k_splits || fin->nslab != 12 || g.k_splits + a.n_heads != 12 || fin->P != g.Y ||
               a.dense_out != g.Y + (size_t)g.k_splits * a.M * 512 || !fin->bias || !fin->hin || !fin->hout || fin->hin == fin->hout || (fin->x1 && (!fin->x2 || !fin->g1 || !fin->b1 || !fin->g2 || !fin->b2))))
     ETD_FAIL(ETD_EINVAL, "dstep_attn_down: bad row-finish arguments");
@@ -1857,8 +1775,12 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
     hipLaunchKernelGGL((k_dstep_attn_down<8, false, true>), dim3(gemm_wgs + ((a.M + 1) / 2) * a.n_heads), dim3(512), 0, st, a.row_sp, a.Q, a.Kc, a.Vc, a.slot_stride, a.max_ctx, a.n_heads, a.scale,
                        a.identity ? 1 : 0, gemm_wgs, a.M, a, g, f0);
   } else
+#ifdef ETD_EXPERIMENTS
   if (fin) { if (nw == 16) ETD_AD_LAUNCH(16, true); else if (nw == 8) ETD_AD_LAUNCH(8, true); else ETD_AD_LAUNCH(4, true); }
   else if (nw == 16) ETD_AD_LAUNCH(16, false); else if (nw == 8) ETD_AD_LAUNCH(8, false); else ETD_AD_LAUNCH(4, false);
+#else
+  ETD_AD_LAUNCH(4, false);
+#endif
 #undef ETD_AD_LAUNCH
   HIP_TRY(hipGetLastError());
   return ETD_OK;

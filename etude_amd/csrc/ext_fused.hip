@@ -847,6 +847,7 @@ void pack_enc_layer_weights(const float* Wq, const float* Wk, const float* Wv, c
 }
 
 
+#ifdef ETD_EXPERIMENTS      // k_post_attn: a measured dead end (equal in time to the two launches it replaces, 103 spilled registers), kept for the record
 // ================================================================================================
 // k_post_attn: everything of a layer that follows its attention, for layers whose attention runs as its own launch (the
 // frequency decoder's self- and cross-attention blocks, the time decoder):
@@ -1000,6 +1001,9 @@ int launch_post_attn(const PostAttnArgs& a, hipStream_t st) {
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
+#else
+int launch_post_attn(const PostAttnArgs&, hipStream_t) { ETD_FAIL(ETD_EINVAL, "k_post_attn is built with -DETD_EXPERIMENTS only"); }
+#endif      // ETD_EXPERIMENTS
 
 // ================================================================================================
 // k_attn_frag: softmax(Q K^T / 8) V per (sequence, head) with K and V arriving as MFMA-fragment images (k_proj256's KFRAG /

@@ -175,7 +175,7 @@ struct PostAttnArgs {
   const float* bo; const float* gamma; const float* beta; const float* b1; const float* b2;
   e16* Y; int M;
 };
-int launch_post_attn(const PostAttnArgs& a, hipStream_t st);
+int launch_post_attn(const PostAttnArgs& a, hipStream_t st);      // (-DETD_EXPERIMENTS builds only)
 
 // ---- attention over K / V fragment images (csrc/ext_fused.hip: k_attn_frag); 4 heads x 64
 struct AttnFragArgs {

@@ -163,6 +163,8 @@ int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* names, const f
                        const int64_t* numels, int n, etd_dec** out);
 /* element type of the 16-bit serving mode (weights, KV cache, debug peeks): 1 = IEEE half (the default build), 0 = bf16 (-DETD_DEC_BF16) */
 int etd_decoder_operand_type(void);
+/* 1 when built with -DETD_EXPERIMENTS (measured dead ends compiled in, their environment switches live); the shipped build returns 0 and has one path per precision */
+int etd_has_experiments(void);
 void etd_decoder_destroy(etd_dec*);
 /* A second engine over the SAME weights: own KV cache, workspaces and stream state (same cfg), the weight buffers of `src`
  * (or of the handle `src` was cloned from) are shared, not copied -- concurrent engines then stream one weight set through

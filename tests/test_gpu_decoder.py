@@ -270,7 +270,11 @@ def test_row_finish_opt_in_is_bit_identical(dev):
     """ETD_ROWFIN=1 folds k_resid_ln_rows into the attention launch (the last contributor of a row sums its split-K slabs, adds the
     residual and normalises it for the next layer -- an in-launch hand-off through write-through stores, an agent-scope counter
     and sc1 loads).  Same additions in the same order: the greedy token streams of two engines stepping concurrently must be the
-    same bytes as with the separate row kernel.  (The switch is read once per process, hence the child processes.)"""
+    same bytes as with the separate row kernel.  (The switch is read once per process, hence the child processes.)
+    The row finish is a measured dead end (LABNOTES round 2): since round 5 it is compiled with -DETD_EXPERIMENTS only, and this test runs on such a build only."""
+    from etude_amd import _lib
+    if not _lib.lib().etd_has_experiments():
+        pytest.skip("the shipped library has no in-launch row finish (ETD_EXTRA_FLAGS=-DETD_EXPERIMENTS python -m etude_amd.build --force builds it)")
     import os
     import subprocess
     import sys
