@@ -225,6 +225,51 @@ def union_seconds(pairs, tick_s: float = 1e-8) -> float:
     return tot * tick_s
 
 
+def n8_share_extras(args, dev, exs, wavs, grid, vocab, headline_value):
+    """extras.n8_share: what ONE rank of the N = 8 run does -- 8 of the batch's clips x 27 tuples = 216 jobs on four engines of 54 streams (`default_engines`), one
+    timed pass after a 2-bar warm-up pass -- measured here on the one GPU of an N = 1 run, so that the line carries the scaling expectation (8 x this figure against the
+    N = 1 value) whether or not a node is available to the driver.  The driver computes the measured efficiency itself from its own N = 1, 2, 4, 8 runs."""
+    import torch
+    from etude_amd import synth
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    from etude_amd.pipeline import ClipBatchPipeline, synthetic_tempo
+    n_clips = 8
+    n_jobs = n_clips * len(grid)
+    n_eng = default_engines(n_jobs, 8)
+    per_eng = (n_jobs + n_eng - 1) // n_eng
+    decs = []; pipe = None
+    try:
+        decs = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng,
+                             max_prefill_rows=min(262144, per_eng * 520))]
+        decs += [decs[0].clone() for _ in range(n_eng - 1)]
+        pipe = ClipBatchPipeline(exs[:2], decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+        sub = wavs[:n_clips]
+        conds = pipe.extract_stage(sub)
+        pipe.decode_stage(conds, max_bars=2)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        r = pipe.run(sub)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        v = args.seconds * n_clips / dt
+        return {"workload": f"one rank's share of the N = 8 run on this GPU: {n_clips} clips x {len(grid)} tuples = {n_jobs} jobs, {n_eng} engines x {per_eng} streams, the whole chain, one pass",
+                "s_per_step": round(dt, 3), "audio_s_per_s": round(v, 2), "extract_s": round(r["t_extract"], 3), "decode_s": round(r["t_decode"], 3),
+                "projected_n8_audio_s_per_s": round(8 * v, 1), "projected_n8_over_n1": round(8 * v / headline_value, 2),
+                "note": "projection = 8 x this figure (ranks share nothing but the final gather of token ids); the small per-rank batch is latency-bound (25 dependent launches per "
+                        "decode step at 54 rows), which is why 8 ranks are projected at less than 8 x the N = 1 value"}
+    finally:
+        for d in reversed(decs):
+            try:
+                d.close()
+            except Exception:      # noqa: BLE001
+                pass
+        if pipe is not None:
+            try:
+                pipe.close()
+            except Exception:      # noqa: BLE001
+                pass
+
+
 def bar_divergence(ra, rb):
     """per-bar comparison of two result lists [(flat ids, bar lengths)] of the same jobs (tests/test_gpu_full_configs.py: a bar can only be compared
     while the two histories are still equal): -> (bars identical, comparable bars, jobs identical end to end)"""
@@ -370,6 +415,7 @@ def main():
                          "(profiles/r05_engines.txt); the roofline of concurrent engines is reported on the UNION of their attention launches (roofline.frac)")
     ap.add_argument("--max-streams", type=int, default=2048, help="streams per engine (the fused decode step takes up to 2048 rows per launch)")
     ap.add_argument("--prefill-rows", type=int, default=int(os.environ.get("ETD_PREFILL_ROWS", "0")), help="prompt rows one batched-prefill pass of an engine may carry (0 = the default rule)")
+    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("ETD_STAGGER_MS", "0")), help="engine i starts its decode stage i x this many ms after engine 0 (A/B: phase-offset engines)")
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS does not end a bar)")
     ap.add_argument("--synthetic-bars", action="store_true", help="rounds 1-2 workload: ~8-notes/bar synthetic condition bars instead of the clip's own (A/B only)")
     ap.add_argument("--max-bars", type=int, default=0, help="diagnostics / profiling passes only: decode just the first N bars of every job (stated in config.workload)")
@@ -462,7 +508,7 @@ def main():
 
     decs, n_jobs, per_eng = build_engines(clips)
     wavs = make_wavs(clips)
-    pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+    pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens, **({"stagger_s": args.stagger_ms * 1e-3} if args.stagger_ms > 0 else {}))
     log(f"setup done: {clips} clip(s) on this rank, {n_jobs} decode jobs on {len(decs)} engine(s) x {per_eng} streams")
 
     def synthetic_conditions(conds):
@@ -779,6 +825,13 @@ def main():
                 extras["parity_mode"] = parity_mode_extras(args, dev, wavs, grid, vocab, pick[0], pick[1], decs, lambda: time_left() - CPU_RESERVE_S)
             except Exception as e:      # extras must never take the headline down
                 extras["parity_mode"] = {"error": repr(e)}
+
+    # ---- extras.n8_share: the per-rank batch of the N = 8 run, measured on this GPU (the scaling expectation the N = 1 line carries)
+    if not args.no_extras and rank == 0 and world == 1 and clips >= 8 and time_left() > CPU_RESERVE_S + 25.0:
+        try:
+            result.setdefault("extras", {})["n8_share"] = n8_share_extras(args, dev, exs, wavs, grid, vocab, result["value"])
+        except Exception as e:      # extras must never take the headline down
+            result.setdefault("extras", {})["n8_share"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and late(6.0):
         result["cpu_baseline"] = {"skipped": "the run is within 6 s of its harness budget"}

@@ -75,8 +75,8 @@ int g3_scale_log2(float bound) {
 // of 32: the four planes of a chunk (X hi / lo converted from fp32 on the way in, W hi / lo copied from the packed stream) sit in 40 KiB of LDS as 80-byte rows (16
 // consecutive rows start on 16 different 16-byte bank groups: conflict-free ds_read_b128 fragments); the next chunk's global loads are in flight behind the chunk's 24
 // MFMAs; two or three workgroups per CU cover each other's barriers.
-#define G3_LDR 40                 // f16 elements per LDS row (32 k + 8 pad)
-#define G3_PLANE (128 * G3_LDR)   // elements per plane
+// KC = k per chunk (32; 64 is kept as a template instance for -DG3_KC_MAX=64 measurement builds).  LDS rows are KC + 8 elements (80 / 144 bytes: conflict-free ds_read_b128).
+template <int KC> struct G3Geom { static constexpr int LDR = KC + 8, PLANE = 128 * LDR, NB = KC / 32; };
 
 __device__ __forceinline__ f32x16 mfma16h(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
@@ -91,23 +91,124 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, float s
   }
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void k_gemm3(const float* __restrict__ p_X, int p_ldx, const f16* __restrict__ p_Wp, int p_M, int p_K, float p_xs, float p_inv, DGemmArgs a) {
-  __shared__ __attribute__((aligned(16))) f16 sm[4 * G3_PLANE];        // X hi | X lo | W hi | W lo
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * 128, nt = blockIdx.y, nchunk = p_K >> 5;
-  const int srow = tid >> 1, sh = tid & 1;                             // staging role: row, 16-element half of the 32-wide chunk
-  int gm = m0 + srow; gm = gm < p_M ? gm : p_M - 1;
-  const float* xp = p_X + (long long)gm * p_ldx + sh * 16;
-  const f16* wp = p_Wp + (size_t)nt * nchunk * (2 * 128 * 32) + tid * 16;
-  f32x4 xr[4]; u32x4 whr[2], wlr[2];
-  auto gload = [&](int kc) {
-    const float* x = xp + kc * 32;
+// 4 fp32 values -> hi / lo f16
+__device__ __forceinline__ void split4(const f32x4& v, float s, f16x4& hi, f16x4& lo) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const f32x4*>(x + 4 * j);
-    const f16* w = wp + (size_t)kc * (2 * 128 * 32);
-    whr[0] = *reinterpret_cast<const u32x4*>(w); whr[1] = *reinterpret_cast<const u32x4*>(w + 8);
-    wlr[0] = *reinterpret_cast<const u32x4*>(w + 128 * 32); wlr[1] = *reinterpret_cast<const u32x4*>(w + 128 * 32 + 8);
+  for (int j = 0; j < 4; ++j) { const float t = v[j] * s; const f16 x = (f16)t; hi[j] = x; lo[j] = (f16)(t - (float)x); }
+}
+
+// ---- the epilogue of one wave's 32-token x 64-feature block, rows first: the accumulator has the TOKEN on the lane, so a direct store writes 16 bytes into 32 different rows per
+// instruction and the memory pipeline handles one row segment at a time (measured on the first version of this kernel: the K loop could be emptied of its MFMAs without
+// the kernel getting faster).  The block goes through a wave-private LDS tile ([32][68] floats, the K-loop planes are free by then) and leaves as 256-byte row segments, four
+// rows per instruction: bias / GELU / ReLU / RoPE on the registers before the transpose, residual reads and the Q / KV-cache scatter on the rows after it.
+template <int EPI>
+__device__ __forceinline__ void g3_store_block(const DGemmArgs& a, const f32x16 (&acc)[2], float inv, float* stg, int m_base, int p_M, int nb, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const int m = m_base + r;
+  int head = 0, part = 0;
+  if constexpr (EPI == DEPI_QKV) { head = nb / 192; part = (nb - head * 192) >> 6; }
+  int pos_l = 0;
+  if constexpr (EPI == DEPI_QKV) pos_l = a.rows.pos[m < p_M ? m : p_M - 1];
+#pragma unroll
+  for (int tf = 0; tf < 2; ++tf) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = nb + tf * 32 + acc_row(i, h);
+      v[i] = acc[tf][i] * inv;
+      if (EPI != DEPI_LOGITS) v[i] += a.bias[n];          // (bias is padded to Npad)
+      if (EPI == DEPI_GELU) v[i] = gelu_erf(v[i]);
+      if (EPI == DEPI_RELU) v[i] = fmaxf(v[i], 0.f);
+    }
+    if constexpr (EPI == DEPI_QKV) {
+      if (part < 2 && tf == 0) {
+        // partial RoPE on dims [0, 16): pair (d, d + 8) = registers (i, i + 4), i < 4, d = i + 4 h        modeling_gpt_neox.py:111-151
+        const float* cs = a.rope_cos + (long long)pos_l * a.rot_half;
+        const float* sn = a.rope_sin + (long long)pos_l * a.rot_half;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float c = cs[i + 4 * h], sgn = sn[i + 4 * h];
+          const float x1 = v[i], x2 = v[i + 4];
+          v[i] = x1 * c - x2 * sgn;
+          v[i + 4] = x2 * c + x1 * sgn;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 o = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      *reinterpret_cast<f32x4*>(stg + r * 68 + tf * 32 + 8 * q + 4 * h) = o;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int er = lane >> 4, ec = lane & 15;          // row-contiguous view: row = 4 it + er, 16-byte chunk ec (features 4 ec .. + 3 of the 64)
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int row = it * 4 + er, mr = m_base + row;
+    const f32x4 val = *reinterpret_cast<const f32x4*>(stg + row * 68 + ec * 4);
+    if (mr >= p_M) continue;
+    const int n = nb + ec * 4;
+    if constexpr (EPI == DEPI_QKV) {
+      if (part == 0) {
+        *reinterpret_cast<f32x4*>(a.Q + (long long)mr * (a.n_heads * 64) + head * 64 + ec * 4) = val;
+      } else {
+        const int pos = a.rows.pos[mr];
+        if (a.rows.active[mr] && pos < a.max_ctx) {
+          float* base = reinterpret_cast<float*>(part == 1 ? a.Kc : a.Vc);
+          *reinterpret_cast<f32x4*>(base + (long long)a.rows.slot[mr] * a.slot_stride + ((long long)head * a.max_ctx + pos) * 64 + ec * 4) = val;
+        }
+      }
+    } else if constexpr (EPI == DEPI_RESID) {
+      if (n < a.N) {
+        const long long off = (long long)mr * a.N + n;
+        f32x4 ad = {0.f, 0.f, 0.f, 0.f};
+        if (a.add) ad = *reinterpret_cast<const f32x4*>(a.add + off);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(a.hin + off);
+        const f32x4 o = {(val[0] + ad[0]) + hi[0], (val[1] + ad[1]) + hi[1], (val[2] + ad[2]) + hi[2], (val[3] + ad[3]) + hi[3]};
+        *reinterpret_cast<f32x4*>(a.hout + off) = o;
+      }
+    } else {
+      float* yp = a.Y + (long long)mr * a.ldy + n;
+      if (n + 3 < a.N && (a.ldy & 3) == 0) *reinterpret_cast<f32x4*>(yp) = val;
+      else { for (int j = 0; j < 4; ++j) if (n + j < a.N) yp[j] = val[j]; }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();                  // the tile is rewritten by the next block
+}
+
+// G3_ABL (measurement builds, ETD_FLAGS_GEMM3=-DG3_ABL=n; results are then wrong on purpose): 2 = no global loads inside the K loop, 4 = no MFMAs, 5 = no LDS stores
+// inside the K loop, 6 = no epilogue stores
+#ifndef G3_ABL
+#define G3_ABL 0
+#endif
+template <int EPI, int KC>
+__global__ __launch_bounds__(256, 2) void k_gemm3(const float* __restrict__ p_X, int p_ldx, const f16* __restrict__ p_Wp, int p_M, int p_K, float p_xs, float p_inv, DGemmArgs a) {
+  using G = G3Geom<KC>;
+  constexpr int LDR = G::LDR, PLANE = G::PLANE, NB = G::NB;
+  __shared__ __attribute__((aligned(16))) f16 sm[4 * PLANE];        // X hi | X lo | W hi | W lo (>= 40 KiB: the epilogue's four [32][68] fp32 tiles fit)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 128, nt = blockIdx.y, nchunk = p_K / KC, nblk32 = p_K >> 5;
+  // X staging: a load instruction covers FULL 128-byte row segments (8 lanes per row, 8 rows per wave, rows 32 apart per instruction) -- two lanes per row made every
+  // instruction touch 32 different cache lines, and the CU's address path, not the bytes, was the limit
+  const int xrow = tid >> 3, xc = tid & 7;
+  const float* xp[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { int gm = m0 + xrow + 32 * i; gm = gm < p_M ? gm : p_M - 1; xp[i] = p_X + (long long)gm * p_ldx + xc * 4; }
+  // W staging: the packed planes are contiguous per (tile, 32-block): 16 bytes per lane, 1 KiB per wave instruction
+  const int srow = tid >> 1, sh = tid & 1;
+  const f16* wp = p_Wp + (size_t)nt * nblk32 * (2 * 128 * 32) + tid * 16;
+  f32x4 xr[NB][4]; u32x4 whr[NB][2], wlr[NB][2];
+  auto gload = [&](int kc) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xr[b][i] = *reinterpret_cast<const f32x4*>(xp[i] + kc * KC + b * 32);
+      const f16* w = wp + (size_t)(kc * NB + b) * (2 * 128 * 32);
+      whr[b][0] = *reinterpret_cast<const u32x4*>(w); whr[b][1] = *reinterpret_cast<const u32x4*>(w + 8);
+      wlr[b][0] = *reinterpret_cast<const u32x4*>(w + 128 * 32); wlr[b][1] = *reinterpret_cast<const u32x4*>(w + 128 * 32 + 8);
+    }
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -116,54 +217,62 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const float* __restrict__ p_X,
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-  f16* Xh = sm; f16* Xl = sm + G3_PLANE; f16* Wh = sm + 2 * G3_PLANE; f16* Wl = sm + 3 * G3_PLANE;
-  const int so = srow * G3_LDR + sh * 16;
-  const int fw = ((wave >> 1) * 64 + r) * G3_LDR + h * 8, fx = ((wave & 1) * 64 + r) * G3_LDR + h * 8;
+  f16* Xh = sm; f16* Xl = sm + PLANE; f16* Wh = sm + 2 * PLANE; f16* Wl = sm + 3 * PLANE;
+  const int so = srow * LDR + sh * 16, xo = xrow * LDR + xc * 4;
+  const int fw = ((wave >> 1) * 64 + r) * LDR + h * 8, fx = ((wave & 1) * 64 + r) * LDR + h * 8;
   gload(0);
   for (int kc = 0; kc < nchunk; ++kc) {
-    {
-      f16x8 hi, lo;
-      split8(xr[0], xr[1], p_xs, hi, lo);
-      *reinterpret_cast<f16x8*>(Xh + so) = hi; *reinterpret_cast<f16x8*>(Xl + so) = lo;
-      split8(xr[2], xr[3], p_xs, hi, lo);
-      *reinterpret_cast<f16x8*>(Xh + so + 8) = hi; *reinterpret_cast<f16x8*>(Xl + so + 8) = lo;
-      *reinterpret_cast<u32x4*>(Wh + so) = whr[0]; *reinterpret_cast<u32x4*>(Wh + so + 8) = whr[1];
-      *reinterpret_cast<u32x4*>(Wl + so) = wlr[0]; *reinterpret_cast<u32x4*>(Wl + so + 8) = wlr[1];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+#if G3_ABL == 5
+      if (kc > 0) continue;
+#endif
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f16x4 hi, lo;
+        split4(xr[b][i], p_xs, hi, lo);
+        *reinterpret_cast<f16x4*>(Xh + xo + 32 * i * LDR + b * 32) = hi; *reinterpret_cast<f16x4*>(Xl + xo + 32 * i * LDR + b * 32) = lo;
+      }
+      *reinterpret_cast<u32x4*>(Wh + so + b * 32) = whr[b][0]; *reinterpret_cast<u32x4*>(Wh + so + b * 32 + 8) = whr[b][1];
+      *reinterpret_cast<u32x4*>(Wl + so + b * 32) = wlr[b][0]; *reinterpret_cast<u32x4*>(Wl + so + b * 32 + 8) = wlr[b][1];
     }
     __syncthreads();
+#if G3_ABL != 2
     if (kc + 1 < nchunk) gload(kc + 1);
+#endif
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KC / 16; ++ks) {
       f16x8 wh[2], wl[2], xh[2], xl[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        wh[t] = *reinterpret_cast<const f16x8*>(Wh + fw + t * 32 * G3_LDR + ks * 16);
-        wl[t] = *reinterpret_cast<const f16x8*>(Wl + fw + t * 32 * G3_LDR + ks * 16);
-        xh[t] = *reinterpret_cast<const f16x8*>(Xh + fx + t * 32 * G3_LDR + ks * 16);
-        xl[t] = *reinterpret_cast<const f16x8*>(Xl + fx + t * 32 * G3_LDR + ks * 16);
+        wh[t] = *reinterpret_cast<const f16x8*>(Wh + fw + t * 32 * LDR + ks * 16);
+        wl[t] = *reinterpret_cast<const f16x8*>(Wl + fw + t * 32 * LDR + ks * 16);
+        xh[t] = *reinterpret_cast<const f16x8*>(Xh + fx + t * 32 * LDR + ks * 16);
+        xl[t] = *reinterpret_cast<const f16x8*>(Xl + fx + t * 32 * LDR + ks * 16);
       }
 #pragma unroll
       for (int tf = 0; tf < 2; ++tf)
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
+#if G3_ABL == 4
+          acc[tf][tt][0] += (float)wl[tf][0] * (float)xh[tt][0] + (float)wh[tf][1] * (float)xl[tt][1];
+#else
           acc[tf][tt] = mfma16h(wl[tf], xh[tt], acc[tf][tt]);
           acc[tf][tt] = mfma16h(wh[tf], xl[tt], acc[tf][tt]);
           acc[tf][tt] = mfma16h(wh[tf], xh[tt], acc[tf][tt]);
+#endif
         }
     }
     __syncthreads();
   }
+#if G3_ABL == 6
+  if (acc[0][0][0] != 1.2345e30f) return;
+#endif
+  float* stg = reinterpret_cast<float*>(sm) + wave * (32 * 68);
 #pragma unroll
   for (int tt = 0; tt < 2; ++tt) {
-    const int m = m0 + (wave & 1) * 64 + tt * 32 + r;
-    if (m >= p_M) continue;
-#pragma unroll
-    for (int tf = 0; tf < 2; ++tf) {
-      f32x16 c = acc[tf][tt];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) c[e] *= p_inv;
-      dgemm_epilogue<false, EPI>(a, c, m, nt * 128 + (wave >> 1) * 64 + tf * 32, h);
-    }
+    const f32x16 blk[2] = {acc[0][tt], acc[1][tt]};
+    g3_store_block<EPI>(a, blk, p_inv, stg, m0 + (wave & 1) * 64 + tt * 32, p_M, nt * 128 + (wave >> 1) * 64, lane);
   }
 }
 
@@ -176,7 +285,14 @@ int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st) {
   ProfScope ps(a.M >= 8192 ? "k_gemm3" : "k_gemm3_step", st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * 4 + (double)a.M * a.K * 4);
   const dim3 g((a.M + 127) / 128, a.Npad / 128);
   const float xs = ldexpf(1.f, a.x_log2), inv = ldexpf(1.f, -(a.x_log2 + a.w_log2));
-#define G3_LAUNCH(E) hipLaunchKernelGGL((k_gemm3<E>), g, dim3(256), 0, st, a.X, a.ldx, (const f16*)a.Wp, a.M, a.K, xs, inv, a)
+// K per chunk: 32 (40 KiB of LDS, 154 registers: three workgroups per CU) measured 10 % faster than 64 (72 KiB, two per CU) on every shape of tools/bench_gemm3.py:
+// what bounds this kernel is the dependent chain load -> split -> LDS -> barrier -> fragments -> MFMA of a workgroup, covered by the other workgroups of the CU, not a pipe
+#ifndef G3_KC_MAX
+#define G3_KC_MAX 32
+#endif
+  const bool k64 = G3_KC_MAX >= 64 && a.K % 64 == 0;
+#define G3_LAUNCH(E) do { if (k64) hipLaunchKernelGGL((k_gemm3<E, 64>), g, dim3(256), 0, st, a.X, a.ldx, (const f16*)a.Wp, a.M, a.K, xs, inv, a); \
+                          else hipLaunchKernelGGL((k_gemm3<E, 32>), g, dim3(256), 0, st, a.X, a.ldx, (const f16*)a.Wp, a.M, a.K, xs, inv, a); } while (0)
   switch (epi) {
     case DEPI_BIAS: G3_LAUNCH(DEPI_BIAS); break;
     case DEPI_GELU: G3_LAUNCH(DEPI_GELU); break;
