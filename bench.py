@@ -414,8 +414,6 @@ def main():
                          "chains of short kernels overlap).  Measured on the round-5 tree, 64 clips, audio-s/s with 1 / 2 / 3 / 4 engines: 567 / 574 / 588 / 581 "
                          "(profiles/r05_engines.txt); the roofline of concurrent engines is reported on the UNION of their attention launches (roofline.frac)")
     ap.add_argument("--max-streams", type=int, default=2048, help="streams per engine (the fused decode step takes up to 2048 rows per launch)")
-    ap.add_argument("--prefill-rows", type=int, default=int(os.environ.get("ETD_PREFILL_ROWS", "0")), help="prompt rows one batched-prefill pass of an engine may carry (0 = the default rule)")
-    ap.add_argument("--stagger-ms", type=float, default=float(os.environ.get("ETD_STAGGER_MS", "0")), help="engine i starts its decode stage i x this many ms after engine 0 (A/B: phase-offset engines)")
     ap.add_argument("--bar-tokens", type=int, default=48, help="tokens generated per bar (Bar_EOS does not end a bar)")
     ap.add_argument("--synthetic-bars", action="store_true", help="rounds 1-2 workload: ~8-notes/bar synthetic condition bars instead of the clip's own (A/B only)")
     ap.add_argument("--max-bars", type=int, default=0, help="diagnostics / profiling passes only: decode just the first N bars of every job (stated in config.workload)")
@@ -492,7 +490,7 @@ def main():
         per_eng = min(args.max_streams, (n_jobs + n_eng - 1) // n_eng)
         # one batched-prefill pass carries up to 256 k prompt rows (~500 prompts at the 512-token truncation): a bar boundary of 1728 streams is then
         # four passes, and the host assembles / stages pass k + 1 while the GPU runs pass k (one 886 k-row pass left the queue empty for ~6 ms per bar)
-        decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng, max_prefill_rows=args.prefill_rows or min(262144, per_eng * 520))]
+        decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng, max_prefill_rows=min(262144, per_eng * 520))]
         decs += [decs[0].clone() for _ in range(n_eng - 1)]            # engines share one weight set (own KV caches and state)
         return decs, n_jobs, per_eng
 
@@ -508,7 +506,7 @@ def main():
 
     decs, n_jobs, per_eng = build_engines(clips)
     wavs = make_wavs(clips)
-    pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens, **({"stagger_s": args.stagger_ms * 1e-3} if args.stagger_ms > 0 else {}))
+    pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
     log(f"setup done: {clips} clip(s) on this rank, {n_jobs} decode jobs on {len(decs)} engine(s) x {per_eng} streams")
 
     def synthetic_conditions(conds):
