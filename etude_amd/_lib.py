@@ -116,6 +116,8 @@ SIGNATURES = {
     "etd_mpe2note_dev_destroy": (None, [C.c_void_p]),
     "etd_mpe2note_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_float,
                                    C.c_int, C.c_int, C.c_int, C.POINTER(Note), C.c_longlong, C.POINTER(C.c_longlong), C.c_void_p]),
+    "etd_mpe2note_dev_modes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_float, C.c_float, C.c_float,
+                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Note), C.c_longlong, C.POINTER(C.c_longlong), C.c_void_p]),
     "etd_tok_create": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "etd_tok_destroy": (None, [C.c_void_p]),
     "etd_tok_num_measures": (C.c_int, [C.c_void_p]),

@@ -38,6 +38,7 @@ struct M2nArgs {
   const float* onset; const float* offset; const float* mpe; const int8_t* vel;
   long long T; int n_note;
   float thr_on, thr_off, thr_mpe; double hop_sec; int note_min;
+  int mode_velocity, mode_offset;            // ETD_M2N_VEL_* / ETD_M2N_* (etude_hip.h): extractor.py:256-258, 386-408
   int* pk_loc0; int* pk_loc1; double* pk_time0; double* pk_time1; int* nb; etd_note* notes; int* cnt; long long Tcap;
 };
 
@@ -161,8 +162,10 @@ __global__ __launch_bounds__(TPB) void k_m2n_pitch(M2nArgs a) {
       if (!flag_off && !flag_mpe) off_val = t_next;
       else if (flag_off && !flag_mpe) off_val = t_off;
       else if (!flag_off && flag_mpe) off_val = t_mpe;
-      else off_val = (loc_off <= loc_mpe) ? t_off : t_mpe;   // mode_offset = "shorter"
-      emit = vel > 0;                                        // mode_velocity = "ignore_zero"
+      else if (a.mode_offset == ETD_M2N_OFFSET) off_val = t_off;                                   // (a) always the offset peak      extractor.py:387-389
+      else if (a.mode_offset == ETD_M2N_LONGER) off_val = (loc_off >= loc_mpe) ? t_off : t_mpe;    // (b) the later of the two        :390-395
+      else off_val = (loc_off <= loc_mpe) ? t_off : t_mpe;                                         // (c) "shorter", the default      :396-401
+      emit = a.mode_velocity == ETD_M2N_VEL_ORG || vel > 0;                                        // "ignore_zero" drops velocity 0  :402-406
       nt.onset = on_t[k]; nt.offset = off_val; nt.pitch = j + a.note_min; nt.velocity = vel;
     }
     const int slot = ordered_slot(emit, wsum, &base);
@@ -233,8 +236,16 @@ static int m2n_reserve(etd_m2n* h, long long T) {
 extern "C" int etd_mpe2note_dev(etd_m2n* h, const float* onset_dev, const float* offset_dev, const float* mpe_dev, const int8_t* vel_dev,
                                 long long T, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr, int note_min,
                                 etd_note* out, long long cap, long long* n_out, void* stream) {
+  return etd_mpe2note_dev_modes(h, onset_dev, offset_dev, mpe_dev, vel_dev, T, thred_onset, thred_offset, thred_mpe, hop_sample, sr, note_min,
+                                ETD_M2N_VEL_IGNORE_ZERO, ETD_M2N_SHORTER, out, cap, n_out, stream);
+}
+
+extern "C" int etd_mpe2note_dev_modes(etd_m2n* h, const float* onset_dev, const float* offset_dev, const float* mpe_dev, const int8_t* vel_dev,
+                                      long long T, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr, int note_min,
+                                      int mode_velocity, int mode_offset, etd_note* out, long long cap, long long* n_out, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  if (!h || !onset_dev || !offset_dev || !mpe_dev || !vel_dev || T < 0 || T > 0x7ffffff0LL || !n_out || hop_sample < 1 || sr < 1)
+  if (!h || !onset_dev || !offset_dev || !mpe_dev || !vel_dev || T < 0 || T > 0x7ffffff0LL || !n_out || hop_sample < 1 || sr < 1 ||
+      (mode_velocity != ETD_M2N_VEL_IGNORE_ZERO && mode_velocity != ETD_M2N_VEL_ORG) || mode_offset < ETD_M2N_SHORTER || mode_offset > ETD_M2N_OFFSET)
     ETD_FAIL(ETD_EINVAL, "mpe2note_dev: bad args");
   *n_out = 0;
   if (T == 0) return ETD_OK;
@@ -242,6 +253,7 @@ extern "C" int etd_mpe2note_dev(etd_m2n* h, const float* onset_dev, const float*
   M2nArgs a;
   a.onset = onset_dev; a.offset = offset_dev; a.mpe = mpe_dev; a.vel = vel_dev; a.T = T; a.n_note = h->n_note;
   a.thr_on = thred_onset; a.thr_off = thred_offset; a.thr_mpe = thred_mpe; a.hop_sec = (double)hop_sample / (double)sr; a.note_min = note_min;
+  a.mode_velocity = mode_velocity; a.mode_offset = mode_offset;
   a.pk_loc0 = h->pk_loc[0]; a.pk_loc1 = h->pk_loc[1]; a.pk_time0 = h->pk_time[0]; a.pk_time1 = h->pk_time[1];
   a.nb = h->nb; a.notes = h->notes; a.cnt = h->cnt; a.Tcap = h->Tcap;
   {

@@ -195,9 +195,9 @@ class AMTAPC_Extractor:
             return buf[: n.value]
 
     def mpe2note_device(self, onset: torch.Tensor, offset: torch.Tensor, mpe: torch.Tensor, velocity: torch.Tensor,
-                        thred_onset=0.5, thred_offset=0.5, thred_mpe=0.5) -> np.ndarray:
+                        thred_onset=0.5, thred_offset=0.5, thred_mpe=0.5, mode_velocity="ignore_zero", mode_offset="shorter") -> np.ndarray:
         """extractor.py:256-418 on the device arrays `transcript` returned (fp32 [T, n_note] x3, int8 [T, n_note]); only the
-        notes cross PCIe.  Same structured array, bit for bit, as `_mpe2note_array` on the host copies."""
+        notes cross PCIe.  Same structured array, bit for bit, as `_mpe2note_array` on the host copies, for every mode of the reference."""
         lib = _lib.lib()
         for t, dt in ((onset, torch.float32), (offset, torch.float32), (mpe, torch.float32), (velocity, torch.int8)):
             if not t.is_cuda or t.dtype != dt or not t.is_contiguous() or t.shape != onset.shape:
@@ -214,9 +214,10 @@ class AMTAPC_Extractor:
             buf = np.empty(cap, dtype=NOTE_DTYPE)
             n = C.c_longlong()
             with torch.cuda.device(self.device):
-                rc = lib.etd_mpe2note_dev(self._m2n, onset.data_ptr(), offset.data_ptr(), mpe.data_ptr(), velocity.data_ptr(), T,
-                                          thred_onset, thred_offset, thred_mpe, f.hop_sample, f.sr, self.config.midi.note_min,
-                                          C.cast(buf.ctypes.data, C.POINTER(_lib.Note)), cap, C.byref(n), st)
+                rc = lib.etd_mpe2note_dev_modes(self._m2n, onset.data_ptr(), offset.data_ptr(), mpe.data_ptr(), velocity.data_ptr(), T,
+                                                thred_onset, thred_offset, thred_mpe, f.hop_sample, f.sr, self.config.midi.note_min,
+                                                self._M2N_VEL[mode_velocity], self._M2N_OFF[mode_offset],
+                                                C.cast(buf.ctypes.data, C.POINTER(_lib.Note)), cap, C.byref(n), st)
             if rc == -12 and n.value > cap:
                 cap = int(n.value)
                 continue

@@ -128,8 +128,8 @@ int etd_mpe2note(const float* onset, const float* offset, const float* mpe, cons
                  int note_min, etd_note* out, long long cap, long long* n_out);
 /* The same with the reference's two mode switches (extractor.py:256-258): mode_velocity "ignore_zero" (default) drops notes whose
  * velocity argmax is 0, "org" keeps them; mode_offset picks, when both an offset peak and an mpe drop exist, the earlier one
- * ("shorter", default), the later one ("longer") or always the offset peak ("offset") (:386-404).  Host only: the device path
- * (etd_mpe2note_dev) implements the defaults, which is all the reference's callers use. */
+ * ("shorter", default), the later one ("longer") or always the offset peak ("offset") (:386-404).  The device path has the same
+ * switches (etd_mpe2note_dev_modes); etd_mpe2note / etd_mpe2note_dev are the defaults, which is all the reference's callers use. */
 enum { ETD_M2N_VEL_IGNORE_ZERO = 0, ETD_M2N_VEL_ORG = 1 };
 enum { ETD_M2N_SHORTER = 0, ETD_M2N_LONGER = 1, ETD_M2N_OFFSET = 2 };
 int etd_mpe2note_modes(const float* onset, const float* offset, const float* mpe, const int8_t* velocity, long long T, int n_note,
@@ -144,6 +144,9 @@ void etd_mpe2note_dev_destroy(etd_m2n*);
 int etd_mpe2note_dev(etd_m2n*, const float* onset_dev, const float* offset_dev, const float* mpe_dev, const int8_t* vel_dev,
                      long long T, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr, int note_min,
                      etd_note* out_host, long long cap, long long* n_out, void* stream);
+int etd_mpe2note_dev_modes(etd_m2n*, const float* onset_dev, const float* offset_dev, const float* mpe_dev, const int8_t* vel_dev,
+                           long long T, float thred_onset, float thred_offset, float thred_mpe, int hop_sample, int sr, int note_min,
+                           int mode_velocity, int mode_offset, etd_note* out_host, long long cap, long long* n_out, void* stream);
 
 /* ------------------------------------------------------------------ decoder (EtudeDecoder / GPT-NeoX) */
 typedef struct etd_dec etd_dec;

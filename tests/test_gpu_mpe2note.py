@@ -104,3 +104,53 @@ def test_device_mpe2note_empty_and_capacity(handle):
     rc = lib.etd_mpe2note_dev(handle, on.data_ptr(), z.data_ptr(), z.data_ptr(), vel.data_ptr(), 8, 0.5, 0.5, 0.5, 256, 16000, 21, None, 0,
                               C.byref(n), None)
     assert rc == -12 and n.value == 1            # ETD_ENOMEM reports the room needed
+
+
+_VEL = {"ignore_zero": 0, "org": 1}
+_OFF = {"shorter": 0, "longer": 1, "offset": 2}
+
+
+def _dev_notes_modes(h, on, off, mpe, vel, thr, mode_velocity, mode_offset, note_min=21):
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    t = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (on.astype(np.float32), off.astype(np.float32), mpe.astype(np.float32), vel.astype(np.int8))]
+    T = on.shape[0]
+    cap = max(16, T * on.shape[1])
+    buf = (_lib.Note * cap)()
+    n = C.c_longlong()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.etd_mpe2note_dev_modes(h, t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), T, thr[0], thr[1], thr[2],
+                                          256, 16000, note_min, _VEL[mode_velocity], _OFF[mode_offset], buf, cap, C.byref(n), st), "etd_mpe2note_dev_modes")
+    return [{"pitch": buf[i].pitch, "onset": buf[i].onset, "offset": buf[i].offset, "velocity": buf[i].velocity} for i in range(n.value)]
+
+
+def test_device_mpe2note_mode_switches_match_reference_golden(handle, golden_dir):
+    """mode_velocity "org" / "ignore_zero" and mode_offset "shorter" / "longer" / "offset" (extractor.py:256-258, 386-408) on the device: the reference's own
+    fixtures (tests/golden/mpe2note_modes.json: 18 cases), and against the host entry on random plateau-rich frames for every combination"""
+    g = json.loads((golden_dir / "mpe2note_modes.json").read_text())
+    done = 0
+    for c in g["cases"]:
+        i = g["inputs"][c["input"]]
+        on, off, mpe = (np.asarray(i[k], np.float32) for k in ("onset", "offset", "mpe"))
+        vel = np.asarray(i["velocity"], np.int8)
+        if on.shape[1] > 88:
+            continue
+        got = _dev_notes_modes(handle, _pad88(on), _pad88(off), _pad88(mpe), _pad88(vel), i["thr"], c["mode_velocity"], c["mode_offset"])
+        assert got == c["notes"], (c["input"], c["mode_velocity"], c["mode_offset"])
+        done += 1
+    assert done >= 12
+    lib = _lib.lib()
+    rng = np.random.default_rng(23)
+    T = 900
+    q = lambda: (rng.integers(0, 4, (T, 88)) / 3).astype(np.float32)      # noqa: E731
+    on, off, mpe = q(), q(), q()
+    vel = (rng.integers(0, 3, (T, 88)) * rng.integers(0, 50, (T, 88))).astype(np.int8)
+    for mv in _VEL:
+        for mo in _OFF:
+            cap = T * 88
+            buf = (_lib.Note * cap)()
+            n = C.c_longlong()
+            _lib.check(lib.etd_mpe2note_modes(on.ctypes.data, off.ctypes.data, mpe.ctypes.data, vel.ctypes.data, T, 88, 0.5, 0.5, 0.5, 256, 16000, 21,
+                                              _VEL[mv], _OFF[mo], buf, cap, C.byref(n)), "etd_mpe2note_modes")
+            host = [{"pitch": buf[k].pitch, "onset": buf[k].onset, "offset": buf[k].offset, "velocity": buf[k].velocity} for k in range(n.value)]
+            assert _dev_notes_modes(handle, on, off, mpe, vel, (0.5, 0.5, 0.5), mv, mo) == host, (mv, mo)
