@@ -4,10 +4,14 @@
 #include "dec_kernels.h"
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
-// erf-GELU for the d16 pipeline: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside d16 rounding) -- one
-// v_rcp, one v_exp and 7 FMAs instead of libm's two-branch erff, which costs more VALU time than the K = 512 MFMA loop
-// of the up projection it follows.  The fp32 parity mode keeps erff.
+// erf-GELU for the d16 pipeline, priced by ISSUE time: beside the MFMAs of a one-wave-per-SIMD kernel every VALU instruction costs its 4 clocks (a transcendental 8)
+// and an MFMA gap hides only ~24 of them (LABNOTES round 4: k_dmlp_fused's chunks are issue-bound, sixteen GELUs per chunk).  x * Phi(x) with
+// Phi(u) - 1/2 = u q(u^2), u = clamp(x, +-3.875), q a degree-6 minimax polynomial pinned to q(c^2) = 1 / (2 c) so that both tails are exact (0 and x):
+// 10 plain VALU instructions = 40 clocks instead of 15 + two transcendentals = 76; |error| <= 6.8e-5 max(1, |x|) over all x (tools/fit_gelu.py), a
+// quarter of the d16 rounding of the value it produces.  -DETD_GELU_AS keeps the round-2 form (erf by Abramowitz & Stegun 7.1.26, 1.5e-7) for A/B runs;
+// the fp32 parity mode keeps erff.
 __device__ __forceinline__ float gelu_fast(float x) {
+#ifdef ETD_GELU_AS
   const float z = fabsf(x) * 0.70710678118654752440f;
   const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
   float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -15,6 +19,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
   const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
   const float er = fmaf(-p * t, e, 1.f);                  // erf(|x| / sqrt 2)
   return 0.5f * x * (1.f + copysignf(er, x));
+#else
+  const float u = __builtin_amdgcn_fmed3f(x, -3.875f, 3.875f);
+  const float s = u * u;
+  float q = fmaf(3.1433767589e-08f, s, -2.0315644633e-06f);
+  q = fmaf(q, s, 5.6378066802e-05f); q = fmaf(q, s, -8.9401804144e-04f); q = fmaf(q, s, 9.1527355835e-03f);
+  q = fmaf(q, s, -6.5392248333e-02f); q = fmaf(q, s, 3.9845609665e-01f);
+  return x * fmaf(q, u, 0.5f);
+#endif
 }
 
 // ---- shared epilogue: lane = token m, registers = features nb + acc_row(i, h)

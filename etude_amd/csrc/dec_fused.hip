@@ -206,6 +206,8 @@ __device__ __forceinline__ void pm_group(d16x8 (&buf)[2][4], unsigned addr, f32x
     else pm_mfma_out<t0 + (q), false>(acc2[t0 + (q)], buf[J & 1][q], hfk);                                                      \
   } while (0)
   PM_MFMA(0);
+  // gelu_fast (dec_epilogue.h) by hand, the same operations in the same order, one half behind each of the group's first two MFMAs
+#ifdef ETD_GELU_AS
   float x0 = 0.f, tt = 0.f, ee = 0.f;
   if constexpr (GELU) {
     // the bias word has landed (nothing younger than group J + 1's fragments is outstanding); bb is an operand of the wait so that no use of it moves above
@@ -226,6 +228,28 @@ __device__ __forceinline__ void pm_group(d16x8 (&buf)[2][4], unsigned addr, f32x
     PM_PIN(r0);
     g[GR < 0 ? 0 : GR] = r0;
   }
+#else
+  float x0 = 0.f, uu = 0.f, ss = 0.f, qq = 0.f;
+  if constexpr (GELU) {
+    // the bias word has landed (nothing younger than group J + 1's fragments is outstanding); bb is an operand of the wait so that no use of it moves above
+    if constexpr (!LAST) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(bb) : : "memory"); else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bb) : : "memory");
+    x0 = g[GR < 0 ? 0 : GR] + bb;
+    uu = __builtin_amdgcn_fmed3f(x0, -3.875f, 3.875f);
+    ss = uu * uu;
+    qq = fmaf(3.1433767589e-08f, ss, -2.0315644633e-06f);
+    qq = fmaf(qq, ss, 5.6378066802e-05f);
+    PM_PIN(x0); PM_PIN(uu); PM_PIN(ss); PM_PIN(qq);
+  }
+  PM_MFMA(1);
+  if constexpr (GELU) {
+    PM_PIN(x0); PM_PIN(uu); PM_PIN(ss); PM_PIN(qq);
+    qq = fmaf(qq, ss, -8.9401804144e-04f); qq = fmaf(qq, ss, 9.1527355835e-03f);
+    qq = fmaf(qq, ss, -6.5392248333e-02f); qq = fmaf(qq, ss, 3.9845609665e-01f);
+    float r0 = x0 * fmaf(qq, uu, 0.5f);
+    PM_PIN(r0);
+    g[GR < 0 ? 0 : GR] = r0;
+  }
+#endif
   PM_MFMA(2);
   if constexpr (ND >= 1) pm_dma<D0>(nx);
   PM_MFMA(3);
