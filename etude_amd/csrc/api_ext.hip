@@ -209,12 +209,16 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
   if (!cfg || !names || !host_ptrs || !numels || !out) ETD_FAIL(ETD_EINVAL, "extractor_create: null argument");
   if (cfg->struct_bytes != (int)sizeof(etd_ext_cfg)) ETD_FAIL(ETD_EINVAL, "extractor_create: etd_ext_cfg of %d bytes, this library (ABI %d) expects %d -- caller built against another etude_hip.h", cfg->struct_bytes, ETD_ABI_VERSION, (int)sizeof(etd_ext_cfg));
   const etd_ext_cfg& c = *cfg;
-  // The kernels are specialised for the reference's default architecture (schema.py:103-112).
-  if (c.hid_dim != 256 || c.n_heads != 4 || c.pf_dim != 512 || c.n_bin != 256 || c.n_margin != 32 || c.cnn_channel != 4 ||
-      c.cnn_kernel != 5 || c.n_layers_enc != 3 || c.n_layers_dec != 3 || c.n_velocity != 128)
-    ETD_FAIL(ETD_EINVAL, "extractor_create: unsupported architecture (kernels are built for hid 256 / 4 heads / pf 512 / 256 bins / margin 32 / cnn 4x5 / 3+3 layers / 128 velocities)");
-  if (c.n_frame < 32 || c.n_frame % 32 || c.n_note < 4 || c.n_note % 4 || c.n_note > 128 || c.max_windows < 1)
-    ETD_FAIL(ETD_EINVAL, "extractor_create: need n_frame %% 32 == 0, n_note %% 4 == 0 and <= 128, max_windows >= 1");
+  // The 16-bit serving kernels are specialised for the reference's default architecture (schema.py:103-112); the exact-parity engine (precision 1, csrc/ext_fp32.hip)
+  // takes every architecture with head_dim 64 and checks its own limits.
+  const bool dflt_arch = c.hid_dim == 256 && c.n_heads == 4 && c.pf_dim == 512 && c.n_bin == 256 && c.n_margin == 32 && c.cnn_channel == 4 && c.cnn_kernel == 5 &&
+                         c.n_layers_enc == 3 && c.n_layers_dec == 3 && c.n_velocity == 128;
+  if (c.precision == 0 && !dflt_arch)
+    ETD_FAIL(ETD_EINVAL, "extractor_create: unsupported architecture for the 16-bit serving mode (its kernels are built for hid 256 / 4 heads / pf 512 / 256 bins / margin 32 / cnn 4x5 / 3+3 layers / 128 velocities); "
+                         "precision = 1 selects the general engine, which takes any architecture with head_dim 64");
+  if (c.precision == 0 && (c.n_frame < 32 || c.n_frame % 32 || c.n_note < 4 || c.n_note % 4 || c.n_note > 128))
+    ETD_FAIL(ETD_EINVAL, "extractor_create: the 16-bit serving mode needs n_frame %% 32 == 0, n_note %% 4 == 0 and <= 128");
+  if (c.n_frame < 1 || c.n_note < 1 || c.max_windows < 1) ETD_FAIL(ETD_EINVAL, "extractor_create: need n_frame >= 1, n_note >= 1, max_windows >= 1");
   etd_ext* e = new etd_ext();
   e->cfg = c; e->nf = c.n_frame; e->nn = c.n_note; e->margin = c.n_margin; e->wb = c.max_windows;
   e->fc = c.chunk_frames > 0 ? c.chunk_frames : c.n_frame;   // measured: whole-window launches beat MALL-sized chunks (2.9 vs 4.4 ms/window)
@@ -368,18 +372,20 @@ extern "C" int etd_extractor_debug_tap(etd_ext* e, int stage, void* dst_dev) {
 }
 
 extern "C" double etd_extractor_window_flops(const etd_ext* e) {
-  // lin(t,i,o)=2tio; attn(N,q,k)=4*N*q*k*256 (4 heads x 64)
-  const double nf = e->nf, nb = 256, nn = e->nn, H = 256, PF = 512;
+  // lin(t,i,o)=2tio; attn(N,q,k)=4*N*q*k*hid (n_heads x 64)
+  const etd_ext_cfg& c = e->cfg;
+  const double nf = e->nf, nb = c.n_bin, nn = e->nn, H = c.hid_dim, PF = c.pf_dim, LE = c.n_layers_enc, LD = c.n_layers_dec;
+  const double P = 2 * c.n_margin + 1 - (c.cnn_kernel - 1), nhead = c.n_velocity + 3;
   auto lin = [](double t, double i, double o) { return 2 * t * i * o; };
-  auto attn = [](double N, double q, double k) { return 4 * N * q * k * 256; };
+  auto attn = [H](double N, double q, double k) { return 4 * N * q * k * H; };
   const double te = nf * nb, tq = nf * nn;
   double enc_layer = 4 * lin(te, H, H) + attn(nf, nb, nb) + lin(te, H, PF) + lin(te, PF, H);
-  double conv = 2 * te * 4 * 61 * 5, embed = lin(te, 244, H);
+  double conv = 2 * te * c.cnn_channel * P * c.cnn_kernel, embed = lin(te, c.cnn_channel * P, H);
   double d0 = lin(tq, H, H) + 2 * lin(te, H, H) + attn(nf, nn, nb) + lin(tq, H, H) + lin(tq, H, PF) + lin(tq, PF, H);
   double dn = d0 + 4 * lin(tq, H, H) + attn(nf, nn, nn);
-  double heads = lin(tq, H, 131);
+  double heads = lin(tq, H, nhead);
   double time_layer = 4 * lin(tq, H, H) + attn(nn, nf, nf) + lin(tq, H, PF) + lin(tq, PF, H);
-  return conv + embed + 3 * enc_layer + d0 + 2 * dn + heads + 3 * time_layer + heads;
+  return conv + embed + LE * enc_layer + d0 + (LD - 1) * dn + heads + LD * time_layer + heads;
 }
 
 namespace {
@@ -640,7 +646,7 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
   h.X = e->TI; h.W = e->head_time.W; h.bias = e->head_time.b; h.M = Mt; h.time_layout = 1; h.nf = nf; h.nn = nn;
   h.out_off = out_row0 * nn;
   h.onset = B.on; h.offset = B.off; h.mpe = B.mpe; h.vel = B.vel;
-  h.vel_logit = e->dbg_vel ? e->dbg_vel + out_row0 * nn * 128 : nullptr;
+  h.vel_logit = e->dbg_vel;            // (the kernel's output index already carries out_off)
   ETD_TRY(launch_heads(h, st));
   return ETD_OK;
 }
@@ -661,7 +667,7 @@ extern "C" int etd_transcript(etd_ext* e, const float* feat_dev, long long T, fl
                               int8_t* vel_B, float* onset_A, float* offset_A, float* mpe_A, int8_t* vel_A, void* stream) {
   if (!e || !feat_dev || T <= 0 || !onset_B || !offset_B || !mpe_B || !vel_B) ETD_FAIL(ETD_EINVAL, "transcript: bad args");
   EmbedArgs s = {};
-  s.src = feat_dev; s.feat_mode = 1; s.T = T; s.s_t = 256; s.s_bin = 1; s.s_win = 0;
+  s.src = feat_dev; s.feat_mode = 1; s.T = T; s.s_t = e->cfg.n_bin; s.s_bin = 1; s.s_win = 0;
   const int nwin = (int)((T + e->nf - 1) / e->nf);
   return run_all(e, s, nwin, Outs{onset_B, offset_B, mpe_B, vel_B}, Outs{onset_A, offset_A, mpe_A, vel_A}, (hipStream_t)stream);
 }
@@ -671,6 +677,6 @@ extern "C" int etd_transcript_windows(etd_ext* e, const float* spec_dev, int B, 
   if (!e || !spec_dev || B <= 0 || !onset_B || !offset_B || !mpe_B || !vel_B) ETD_FAIL(ETD_EINVAL, "transcript_windows: bad args");
   EmbedArgs s = {};
   const long long nin = e->nf + 2 * e->margin;
-  s.src = spec_dev; s.feat_mode = 0; s.s_win = 256 * nin; s.s_bin = nin; s.s_t = 1;
+  s.src = spec_dev; s.feat_mode = 0; s.s_win = (long long)e->cfg.n_bin * nin; s.s_bin = nin; s.s_t = 1;
   return run_all(e, s, B, Outs{onset_B, offset_B, mpe_B, vel_B}, Outs{onset_A, offset_A, mpe_A, vel_A}, (hipStream_t)stream);
 }

@@ -1,5 +1,8 @@
 // fp32 parity mode of the Extract stage -- see ext_fp32.h.  Reference ops: etude/models/amt_apc.py (cited per kernel).
-// The plain, unfused op sequence of the reference with fp32 activations (row-major [token][256]) and fp32-grade products: every linear and both attention
+// This is also the GENERAL engine: it takes every architecture the reference can build from its config (etude/config/schema.py:100-112, extractor.py:78-113)
+// with head_dim 64 -- hid_dim = 64 n_heads <= 512, pf_dim % 32 == 0, n_bin % 32 == 0, any margin <= 64, any conv channels / kernel, any layer counts, any
+// n_velocity; the 16-bit serving kernels (api_ext.hip) are specialised for the default one.
+// The plain, unfused op sequence of the reference with fp32 activations (row-major [token][hid]) and fp32-grade products: every linear and both attention
 // products run on the f16 matrix cores as two-plane splits of their fp32 operands, three MFMAs per product tile (csrc/gemm3.h: the error of an fp32 fmaf
 // chain at 5 x its rate); LayerNorm, softmax, sigmoid and the head argmax are fp32 VALU code.  Every operand's plane scale comes from a provable bound
 // computed here at load time (LayerNorm parameters and weight-row norms), so no f16 plane can overflow.
@@ -25,10 +28,13 @@ inline float in_bound(const InB& i) { return i.g ? g3_bound_ln(i.g, i.b, i.n) : 
 struct Ext32 {
   etd_ext_cfg cfg;
   int nf = 0, nn = 0, margin = 0;
+  int H = 256, PF = 512, NB = 256, NH = 4, taps = 65, LE = 3, LD = 3, NVEL = 128, HLD = 256;     // hid, pf, bins, heads, 2 margin + 1, layer counts, velocities, head logits row pitch
+  bool dflt = true;                                                    // the reference's default architecture: the specialised forms of the small kernels
+  float emb_scale = 16.f;                                              // sqrt(hid_dim)  amt_apc.py:66,101,204
   std::vector<void*> allocs;
-  float *Wf = nullptr, *bfold = nullptr, *pos_freq_enc = nullptr;      // folded conv+linear [256][65], bias [256], [256 bins][256]
-  Enc32 enc[3], tim[3];
-  Dec32 dec[3];
+  float *Wf = nullptr, *bfold = nullptr, *pos_freq_enc = nullptr;      // folded conv+linear [hid][taps], bias [hid], [bins][hid]
+  std::vector<Enc32> enc, tim;
+  std::vector<Dec32> dec;
   float *q0 = nullptr, *trg0 = nullptr, *pos_time = nullptr;
   Lin32 head_time, head_freq;
   // one window of workspaces
@@ -86,25 +92,26 @@ int load_stack(Ext32* e, const WeightMap& w, const std::vector<std::string>& pfx
   return ETD_OK;
 }
 int load_ln(Ext32* e, const WeightMap& w, const std::string& p, float** g, float** b) {
-  const float* gw = wget(w, p + ".weight", 256);
-  const float* bw = wget(w, p + ".bias", 256);
+  const float* gw = wget(w, p + ".weight", e->H);
+  const float* bw = wget(w, p + ".bias", e->H);
   if (!gw || !bw) return ETD_EINVAL;
-  ETD_TRY(up(e, g, gw, 256));
-  ETD_TRY(up(e, b, bw, 256));
+  ETD_TRY(up(e, g, gw, e->H));
+  ETD_TRY(up(e, b, bw, e->H));
   return ETD_OK;
 }
 // one EncoderLayer (amt_apc.py:236-259); `in` = what is known about its input; *out = its output (the layer's own LayerNorm)
 int load_enc(Ext32* e, const WeightMap& w, const std::string& p, const InB& in, Enc32* l, InB* out) {
-  const float* gw = wget(w, p + ".layer_norm.weight", 256);
-  const float* bw = wget(w, p + ".layer_norm.bias", 256);
+  const int H = e->H, PF = e->PF;
+  const float* gw = wget(w, p + ".layer_norm.weight", H);
+  const float* bw = wget(w, p + ".layer_norm.bias", H);
   if (!gw || !bw) return ETD_EINVAL;
-  const InB ln{gw, bw, 256, 0.f};
+  const InB ln{gw, bw, H, 0.f};
   std::vector<float> ob;
-  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, in, &l->qkv, &ob));
+  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {H, H, H}, H, in, &l->qkv, &ob));
   l->q_log2 = g3_scale_log2(ob[0]); l->k_log2 = g3_scale_log2(ob[1]); l->v_log2 = g3_scale_log2(ob[2]);
-  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, InB{nullptr, nullptr, 256, ob[2]}, &l->o));          // attention output: a convex combination of V rows
-  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, ln, &l->f1, &ob));
-  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, InB{nullptr, nullptr, 512, ob[0]}, &l->f2));    // ReLU does not grow anything
+  ETD_TRY(load_stack(e, w, {p + ".self_attention.fc_o"}, {H}, H, InB{nullptr, nullptr, H, ob[2]}, &l->o));          // attention output: a convex combination of V rows
+  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {PF}, H, ln, &l->f1, &ob));
+  ETD_TRY(load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {H}, PF, InB{nullptr, nullptr, PF, ob[0]}, &l->f2));    // ReLU does not grow anything
   *out = ln;
   return load_ln(e, w, p + ".layer_norm", &l->g, &l->be);
 }
@@ -140,6 +147,35 @@ __global__ __launch_bounds__(256) void k32_embed(EmbedArgs a, const float* __res
   }
 }
 
+// the same map for any architecture: hid features over the block's threads, taps <= 129, folded weights read through L1 (the default architecture keeps k32_embed)
+__global__ __launch_bounds__(256) void k32_embed_g(EmbedArgs a, const float* __restrict__ Wf, const float* __restrict__ bf, const float* __restrict__ pos, float* __restrict__ Y,
+                                                   int H, int NB, int taps, float scale) {
+  __shared__ float xs[32][130];
+  const int f = blockIdx.x, b0 = blockIdx.y * 32, w = a.w0;
+  for (int c = threadIdx.x; c < 32 * taps; c += 256) {
+    const int bin = c / taps, t = c - bin * taps;
+    const int tt = f + t;
+    float v;
+    if (a.feat_mode) {
+      const long long g = (long long)w * a.nf + tt - a.margin;
+      v = (g >= 0 && g < a.T) ? a.src[g * a.s_t + (long long)(b0 + bin) * a.s_bin] : a.pad_value;
+    } else {
+      v = a.src[(long long)w * a.s_win + (long long)(b0 + bin) * a.s_bin + (long long)tt * a.s_t];
+    }
+    xs[bin][t] = v;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < H; o += 256) {
+    const float* wr = Wf + (long long)o * taps;
+    const float bo = bf[o];
+    for (int bin = 0; bin < 32; ++bin) {
+      float acc = 0.f;
+      for (int t = 0; t < taps; ++t) acc = fmaf(wr[t], xs[bin][t], acc);
+      Y[((long long)f * NB + b0 + bin) * H + o] = (acc + bo) * scale + pos[(long long)(b0 + bin) * H + o];
+    }
+  }
+}
+
 // Y = LayerNorm(A + R) * g + b over 256 features, one wave per row; R row = r_mod > 0 ? m % r_mod : m      amt_apc.py:250,256
 __global__ __launch_bounds__(256) void k32_add_ln(const float* __restrict__ A, const float* __restrict__ R, int r_mod, const float* __restrict__ g,
                                                   const float* __restrict__ b, float* __restrict__ Y, int M) {
@@ -166,15 +202,38 @@ __global__ __launch_bounds__(256) void k32_add_ln(const float* __restrict__ A, c
   *reinterpret_cast<f32x4*>(Y + (long long)m * 256 + lane * 4) = o;
 }
 
-// logits [M][ld] (0..127 velocity, 128 onset, 129 offset, 130 mpe) -> sigmoid (fp32) / argmax (lowest index on ties)
+// the same for hid = 64 NV features (NV <= 8): lane l holds features l + 64 j
+__global__ __launch_bounds__(256) void k32_add_ln_g(const float* __restrict__ A, const float* __restrict__ R, int r_mod, const float* __restrict__ g,
+                                                    const float* __restrict__ b, float* __restrict__ Y, int M, int H) {
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  const int rr = r_mod > 0 ? m % r_mod : m, nv = H >> 6;
+  float v[8];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = j < nv ? R[(long long)rr * H + lane + 64 * j] + A[(long long)m * H + lane + 64 * j] : 0.f;
+    s += v[j];
+  }
+  s = wave_sum(s);
+  const float mean = s / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (j < nv) { const float d = v[j] - mean; q = fmaf(d, d, q); }
+  q = wave_sum(q);
+  const float rstd = 1.f / sqrtf(q / (float)H + 1e-5f);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) if (j < nv) Y[(long long)m * H + lane + 64 * j] = (v[j] - mean) * rstd * g[lane + 64 * j] + b[lane + 64 * j];
+}
+
+// logits [M][ld] (0 .. nv - 1 velocity, nv onset, nv + 1 offset, nv + 2 mpe) -> sigmoid (fp32) / argmax (lowest index on ties)
 //                                                                amt_apc.py:186-189,217-220 + extractor.py:242,248
-__global__ __launch_bounds__(256) void k32_heads_epi(const float* __restrict__ L, int ld, HeadsArgs a) {
+__global__ __launch_bounds__(256) void k32_heads_epi(const float* __restrict__ L, int ld, HeadsArgs a, int nv) {
   const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= a.M) return;
   const float* lg = L + (long long)m * ld;
-  const float v0 = lg[lane], v1 = lg[lane + 64];
-  float best = v0; int bi = lane;
-  if (v1 > best) { best = v1; bi = lane + 64; }
+  float best = -INFINITY; int bi = 0x7fffffff;
+  for (int i = lane; i < nv; i += 64) { const float v = lg[i]; if (v > best || bi == 0x7fffffff) { best = v; bi = i; } }      // ascending i: the lowest index of a lane's maximum
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const float ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
@@ -191,26 +250,27 @@ __global__ __launch_bounds__(256) void k32_heads_epi(const float* __restrict__ L
   oidx += a.out_off;
   if (lane == 0) {
     a.vel[oidx] = (int8_t)bi;
-    a.onset[oidx] = 1.f / (1.f + expf(-lg[128]));
-    a.offset[oidx] = 1.f / (1.f + expf(-lg[129]));
-    a.mpe[oidx] = 1.f / (1.f + expf(-lg[130]));
+    a.onset[oidx] = 1.f / (1.f + expf(-lg[nv]));
+    a.offset[oidx] = 1.f / (1.f + expf(-lg[nv + 1]));
+    a.mpe[oidx] = 1.f / (1.f + expf(-lg[nv + 2]));
   }
-  if (a.vel_logit) { a.vel_logit[oidx * 128 + lane] = v0; a.vel_logit[oidx * 128 + lane + 64] = v1; }
+  if (a.vel_logit) for (int i = lane; i < nv; i += 64) a.vel_logit[oidx * nv + i] = lg[i];
 }
 
-// freq-major [(f*nn + note)][256] -> time-major [(note*nf + f)][256] = x*16 + pos_embedding_time[f]     amt_apc.py:203-205
-__global__ void k32_freq2time(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ pos, int nf, int nn) {
-  const long long total = (long long)nf * nn * 64;
+// freq-major [(f*nn + note)][hid] -> time-major [(note*nf + f)][hid] = x*sqrt(hid) + pos_embedding_time[f]     amt_apc.py:203-205
+__global__ void k32_freq2time(const float* __restrict__ src, float* __restrict__ dst, const float* __restrict__ pos, int nf, int nn, int H, float scale) {
+  const int cpr = H >> 2;                               // 16-byte chunks per row
+  const long long total = (long long)nf * nn * cpr;
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (; i < total; i += stride) {
-    const int ch = (int)(i & 63);
-    const long long row = i >> 6;
+    const int ch = (int)(i % cpr);
+    const long long row = i / cpr;
     const int note = (int)(row % nn), f = (int)(row / nn);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * 256 + ch * 4);
-    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (long long)f * 256 + ch * 4);
-    const f32x4 o = {v[0] * 16.f + p[0], v[1] * 16.f + p[1], v[2] * 16.f + p[2], v[3] * 16.f + p[3]};
-    *reinterpret_cast<f32x4*>(dst + ((long long)note * nf + f) * 256 + ch * 4) = o;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + row * H + ch * 4);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (long long)f * H + ch * 4);
+    const f32x4 o = {v[0] * scale + p[0], v[1] * scale + p[1], v[2] * scale + p[2], v[3] * scale + p[3]};
+    *reinterpret_cast<f32x4*>(dst + ((long long)note * nf + f) * H + ch * 4) = o;
   }
 }
 
@@ -220,148 +280,165 @@ int gemm32(const float* X, int ldx, const Lin32& w, int M, float* Y, int ldy, hi
   a.X = X; a.ldx = ldx; a.Wp = w.Wp; a.w_log2 = w.w_log2; a.x_log2 = w.x_log2; a.bias = w.b; a.M = M; a.N = w.N; a.Npad = w.Npad; a.K = w.K; a.Y = Y; a.ldy = ldy;
   return launch_gemm3(a, epi, st);
 }
-int add_ln(const float* A, const float* R, int r_mod, const float* g, const float* b, float* Y, int M, hipStream_t st) {
-  hipLaunchKernelGGL(k32_add_ln, dim3((M + 3) / 4), dim3(256), 0, st, A, R, r_mod, g, b, Y, M);
+int add_ln(const Ext32* e, const float* A, const float* R, int r_mod, const float* g, const float* b, float* Y, int M, hipStream_t st) {
+  if (e->H == 256) hipLaunchKernelGGL(k32_add_ln, dim3((M + 3) / 4), dim3(256), 0, st, A, R, r_mod, g, b, Y, M);
+  else hipLaunchKernelGGL(k32_add_ln_g, dim3((M + 3) / 4), dim3(256), 0, st, A, R, r_mod, g, b, Y, M, e->H);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }
-// softmax(Q K^T / sqrt(64)) V per (sequence, head), head_dim 64, 4 heads                              amt_apc.py:349-368
-int attn32(const float* Q, int ldq, long long q_seq, const float* K, int ldk, long long k_seq, const float* V, int ldv, long long v_seq,
+// softmax(Q K^T / sqrt(64)) V per (sequence, head), head_dim 64                                        amt_apc.py:349-368
+int attn32(const Ext32* e, const float* Q, int ldq, long long q_seq, const float* K, int ldk, long long k_seq, const float* V, int ldv, long long v_seq,
            float* O, int ldo, long long o_seq, int n_seq, int Sq, int Sk, int q_log2, int k_log2, int v_log2, hipStream_t st) {
   Attn3Args a = {};
   a.Q = Q; a.ldq = ldq; a.q_seq = q_seq; a.K = K; a.ldk = ldk; a.k_seq = k_seq; a.V = V; a.ldv = ldv; a.v_seq = v_seq; a.O = O; a.ldo = ldo; a.o_seq = o_seq;
-  a.n_seq = n_seq; a.n_heads = 4; a.Sq = Sq; a.Sk = Sk; a.scale = 0.125f; a.q_log2 = q_log2; a.k_log2 = k_log2; a.v_log2 = v_log2;
-  a.flops_hint = 4.0 * n_seq * (double)Sq * Sk * 256;
+  a.n_seq = n_seq; a.n_heads = e->NH; a.Sq = Sq; a.Sk = Sk; a.scale = 0.125f; a.q_log2 = q_log2; a.k_log2 = k_log2; a.v_log2 = v_log2;
+  a.flops_hint = 4.0 * n_seq * (double)Sq * Sk * e->H;
   return launch_attn3(a, st);
 }
 // x = LN(x + MHA(x)); x = LN(x + FFN(x)), one shared LayerNorm                                          amt_apc.py:244-259
 int enc_layer32(Ext32* e, const Enc32& w, float* X, int M, int n_seq, int S, hipStream_t st) {
-  ETD_TRY(gemm32(X, 256, w.qkv, M, e->QKV, 768, st));
-  ETD_TRY(attn32(e->QKV, 768, (long long)S * 768, e->QKV + 256, 768, (long long)S * 768, e->QKV + 512, 768, (long long)S * 768,
-                 e->AO, 256, (long long)S * 256, n_seq, S, S, w.q_log2, w.k_log2, w.v_log2, st));
-  ETD_TRY(gemm32(e->AO, 256, w.o, M, e->T, 256, st));
-  ETD_TRY(add_ln(e->T, X, 0, w.g, w.be, e->X1, M, st));
-  ETD_TRY(gemm32(e->X1, 256, w.f1, M, e->HF, 512, st, DEPI_RELU));      // fc_1 + ReLU (amt_apc.py:389) in the epilogue
-  ETD_TRY(gemm32(e->HF, 512, w.f2, M, e->T, 256, st));
-  ETD_TRY(add_ln(e->T, e->X1, 0, w.g, w.be, X, M, st));
+  const int H = e->H, PF = e->PF;
+  ETD_TRY(gemm32(X, H, w.qkv, M, e->QKV, 3 * H, st));
+  ETD_TRY(attn32(e, e->QKV, 3 * H, (long long)S * 3 * H, e->QKV + H, 3 * H, (long long)S * 3 * H, e->QKV + 2 * H, 3 * H, (long long)S * 3 * H,
+                 e->AO, H, (long long)S * H, n_seq, S, S, w.q_log2, w.k_log2, w.v_log2, st));
+  ETD_TRY(gemm32(e->AO, H, w.o, M, e->T, H, st));
+  ETD_TRY(add_ln(e, e->T, X, 0, w.g, w.be, e->X1, M, st));
+  ETD_TRY(gemm32(e->X1, H, w.f1, M, e->HF, PF, st, DEPI_RELU));      // fc_1 + ReLU (amt_apc.py:389) in the epilogue
+  ETD_TRY(gemm32(e->HF, PF, w.f2, M, e->T, H, st));
+  ETD_TRY(add_ln(e, e->T, e->X1, 0, w.g, w.be, X, M, st));
   return ETD_OK;
 }
 
-int tap32(void* const* tap, int stage, const float* src, size_t rows, bool first, hipStream_t st) {
-  if (first && tap && tap[stage]) HIP_TRY(hipMemcpyAsync(tap[stage], src, rows * 256 * 4, hipMemcpyDeviceToDevice, st));
+// test hook: stage 0 embedding, 1 .. 3 encoder layers, 4 .. 6 frequency-decoder layers, 7 time-decoder input, 8 .. 10 time-decoder layers (the first three of each kind)
+int tap32(const Ext32* e, void* const* tap, int stage, int layer, const float* src, size_t rows, bool first, hipStream_t st) {
+  if (layer > 2) return ETD_OK;
+  if (first && tap && tap[stage + layer]) HIP_TRY(hipMemcpyAsync(tap[stage + layer], src, rows * e->H * 4, hipMemcpyDeviceToDevice, st));
   return ETD_OK;
 }
 
 }  // namespace
 
 int ext32_create(const etd_ext_cfg& c, const WeightMap& w, Ext32** out) {
+  if (c.hid_dim < 64 || c.hid_dim % 64 || c.hid_dim > 512 || c.n_heads * 64 != c.hid_dim || c.pf_dim < 32 || c.pf_dim % 32 || c.n_bin < 32 || c.n_bin % 32 ||
+      c.n_margin < 0 || c.n_margin > 64 || c.cnn_channel < 1 || c.cnn_kernel < 1 || c.cnn_kernel > 2 * c.n_margin + 1 || c.n_layers_enc < 1 || c.n_layers_dec < 1 ||
+      c.n_velocity < 1 || c.n_velocity > 128)
+    ETD_FAIL(ETD_EINVAL, "extractor_create: the general engine needs hid_dim = 64 * n_heads <= 512, pf_dim %% 32 == 0, n_bin %% 32 == 0, n_margin <= 64, cnn_kernel <= 2 * n_margin + 1, "
+                         "n_layers_enc / n_layers_dec >= 1 and n_velocity <= 128 (an int8 argmax, extractor.py:248)");
   Ext32* e = new Ext32();
   e->cfg = c; e->nf = c.n_frame; e->nn = c.n_note; e->margin = c.n_margin;
+  e->H = c.hid_dim; e->PF = c.pf_dim; e->NB = c.n_bin; e->NH = c.n_heads; e->taps = 2 * c.n_margin + 1; e->LE = c.n_layers_enc; e->LD = c.n_layers_dec; e->NVEL = c.n_velocity;
+  e->HLD = (c.n_velocity + 3 + 127) / 128 * 128;
+  e->dflt = c.hid_dim == 256 && c.n_bin == 256 && c.n_margin == 32;
+  e->emb_scale = sqrtf((float)c.hid_dim);
+  e->enc.resize(e->LE); e->tim.resize(e->LD); e->dec.resize(e->LD);
+  const int H = e->H, PF = e->PF, NB = e->NB, taps = e->taps, CH = c.cnn_channel, CK = c.cnn_kernel, P = taps - CK + 1;      // P conv outputs per channel: cnn_dim = CH * P  (amt_apc.py:62-64)
   auto fail = [&](int rc) { ext32_destroy(e); return rc; };
   float x0_bound = 0.f;
   {
-    const float* cw = wget(w, "encoder.conv.weight", 4 * 5);
-    const float* cb = wget(w, "encoder.conv.bias", 4);
-    const float* tw = wget(w, "encoder.tok_embedding_freq.weight", 256 * 244);
-    const float* tb = wget(w, "encoder.tok_embedding_freq.bias", 256);
-    const float* pe = wget(w, "encoder.pos_embedding_freq.weight", 256 * 256);
+    const float* cw = wget(w, "encoder.conv.weight", (int64_t)CH * CK);
+    const float* cb = wget(w, "encoder.conv.bias", CH);
+    const float* tw = wget(w, "encoder.tok_embedding_freq.weight", (int64_t)H * CH * P);
+    const float* tb = wget(w, "encoder.tok_embedding_freq.bias", H);
+    const float* pe = wget(w, "encoder.pos_embedding_freq.weight", (int64_t)NB * H);
     if (!cw || !cb || !tw || !tb || !pe) return fail(ETD_EINVAL);
-    std::vector<float> Wf(256 * 65), bf(256);
-    for (int o = 0; o < 256; ++o) {
-      double fold[65] = {0};
+    // Conv2d(1, CH, (1, CK)) then Linear(CH * P, hid) over the unfolded taps = ONE [hid][taps] map, folded in double       amt_apc.py:79-99
+    std::vector<float> Wf((size_t)H * taps), bf(H);
+    std::vector<double> fold(taps);
+    for (int o = 0; o < H; ++o) {
+      std::fill(fold.begin(), fold.end(), 0.0);
       double bacc = tb[o];
-      for (int ch = 0; ch < 4; ++ch)
-        for (int p = 0; p < 61; ++p) {
-          const double wv = tw[o * 244 + ch * 61 + p];
+      for (int ch = 0; ch < CH; ++ch)
+        for (int p = 0; p < P; ++p) {
+          const double wv = tw[(size_t)o * CH * P + (size_t)ch * P + p];
           bacc += wv * cb[ch];
-          for (int k = 0; k < 5; ++k) fold[p + k] += wv * cw[ch * 5 + k];
+          for (int k = 0; k < CK; ++k) fold[p + k] += wv * cw[ch * CK + k];
         }
-      for (int t = 0; t < 65; ++t) Wf[o * 65 + t] = (float)fold[t];
+      for (int t = 0; t < taps; ++t) Wf[(size_t)o * taps + t] = (float)fold[t];
       bf[o] = (float)bacc;
     }
     int rc = up(e, &e->Wf, Wf.data(), Wf.size()); if (rc) return fail(rc);
-    rc = up(e, &e->bfold, bf.data(), 256); if (rc) return fail(rc);
-    rc = up(e, &e->pos_freq_enc, pe, 256 * 256); if (rc) return fail(rc);
-    // bound of the embedding (acc + b) * 16 + pos for log-mel features in [-F, F]: log(mel + 1e-8) >= -18.4, and |audio| <= 1 keeps it below 15; the padding value
+    rc = up(e, &e->bfold, bf.data(), H); if (rc) return fail(rc);
+    rc = up(e, &e->pos_freq_enc, pe, (size_t)NB * H); if (rc) return fail(rc);
+    // bound of the embedding (acc + b) * sqrt(hid) + pos for log-mel features in [-F, F]: log(mel + 1e-8) >= -18.4, and |audio| <= 1 keeps it below 15; the padding value
     // of the HFT_Transformer wrapper is -80
     const float F = fmaxf(fabsf(c.min_value), 32.f);
     float pmax = 0.f;
-    for (int i = 0; i < 256 * 256; ++i) pmax = fmaxf(pmax, fabsf(pe[i]));
-    x0_bound = 16.f * g3_bound_linear(Wf.data(), bf.data(), 256, 65, F) + pmax;
+    for (size_t i = 0; i < (size_t)NB * H; ++i) pmax = fmaxf(pmax, fabsf(pe[i]));
+    x0_bound = e->emb_scale * g3_bound_linear(Wf.data(), bf.data(), H, taps, F) + pmax;
   }
-  InB cur{nullptr, nullptr, 256, x0_bound};
-  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "encoder.layers_freq." + std::to_string(i), cur, &e->enc[i], &cur); if (rc) return fail(rc); }
+  InB cur{nullptr, nullptr, H, x0_bound};
+  for (int i = 0; i < e->LE; ++i) { int rc = load_enc(e, w, "encoder.layers_freq." + std::to_string(i), cur, &e->enc[i], &cur); if (rc) return fail(rc); }
   const InB enc_out = cur;
   const int nn = e->nn;
-  const float* pe_d = wget(w, "decoder.pos_embedding_freq.weight", (int64_t)nn * 256);
-  const float* pt = wget(w, "decoder.pos_embedding_time.weight", (int64_t)e->nf * 256);
+  const float* pe_d = wget(w, "decoder.pos_embedding_freq.weight", (int64_t)nn * H);
+  const float* pt = wget(w, "decoder.pos_embedding_time.weight", (int64_t)e->nf * H);
   if (!pe_d || !pt) return fail(ETD_EINVAL);
   float q0_bound = 0.f;
   {
-    const float* qw = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.weight", 256 * 256);
-    const float* qb = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.bias", 256);
+    const float* qw = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.weight", (int64_t)H * H);
+    const float* qb = wget(w, "decoder.layer_zero_freq.encoder_attention.fc_q.bias", H);
     if (!qw || !qb) return fail(ETD_EINVAL);
-    std::vector<float> q0((size_t)nn * 256);          // layer-zero queries are input independent: fc_q(pos_embedding_freq)   amt_apc.py:168-175
+    std::vector<float> q0((size_t)nn * H);          // layer-zero queries are input independent: fc_q(pos_embedding_freq)   amt_apc.py:168-175
     for (int r = 0; r < nn; ++r)
-      for (int o = 0; o < 256; ++o) {
+      for (int o = 0; o < H; ++o) {
         float s = 0.f;                                 // fp32 dot products in k order, + bias: what F.linear computes up to summation order
-        for (int k = 0; k < 256; ++k) s = fmaf(pe_d[r * 256 + k], qw[o * 256 + k], s);
-        q0[(size_t)r * 256 + o] = s + qb[o];
+        for (int k = 0; k < H; ++k) s = fmaf(pe_d[(size_t)r * H + k], qw[(size_t)o * H + k], s);
+        q0[(size_t)r * H + o] = s + qb[o];
         q0_bound = fmaxf(q0_bound, fabsf(s + qb[o]));
       }
     int rc = up(e, &e->q0, q0.data(), q0.size()); if (rc) return fail(rc);
-    rc = up(e, &e->trg0, pe_d, (size_t)nn * 256); if (rc) return fail(rc);
-    rc = up(e, &e->pos_time, pt, (size_t)e->nf * 256); if (rc) return fail(rc);
+    rc = up(e, &e->trg0, pe_d, (size_t)nn * H); if (rc) return fail(rc);
+    rc = up(e, &e->pos_time, pt, (size_t)e->nf * H); if (rc) return fail(rc);
   }
-  // frequency decoder (amt_apc.py:261-320): layer 0 = cross attention of the constant note queries + FFN; layers 1-2 = self attention, cross attention, FFN; one LayerNorm per layer
-  InB dcur{};     // layers 1-2: the previous layer's LayerNorm output
-  for (int i = 0; i < 3; ++i) {
+  // frequency decoder (amt_apc.py:261-320): layer 0 = cross attention of the constant note queries + FFN; the others = self attention, cross attention, FFN; one LayerNorm per layer
+  InB dcur{};     // layers 1 ..: the previous layer's LayerNorm output
+  for (int i = 0; i < e->LD; ++i) {
     const std::string p = i == 0 ? std::string("decoder.layer_zero_freq") : "decoder.layers_freq." + std::to_string(i - 1);
     Dec32& d = e->dec[i];
     d.has_self = i > 0;
-    const float* gw = wget(w, p + ".layer_norm.weight", 256);
-    const float* bw = wget(w, p + ".layer_norm.bias", 256);
+    const float* gw = wget(w, p + ".layer_norm.weight", H);
+    const float* bw = wget(w, p + ".layer_norm.bias", H);
     if (!gw || !bw) return fail(ETD_EINVAL);
-    const InB ln{gw, bw, 256, 0.f};
+    const InB ln{gw, bw, H, 0.f};
     std::vector<float> ob;
     int rc;
     if (d.has_self) {
-      rc = load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {256, 256, 256}, 256, dcur, &d.qkv_s, &ob); if (rc) return fail(rc);
+      rc = load_stack(e, w, {p + ".self_attention.fc_q", p + ".self_attention.fc_k", p + ".self_attention.fc_v"}, {H, H, H}, H, dcur, &d.qkv_s, &ob); if (rc) return fail(rc);
       d.qs_log2 = g3_scale_log2(ob[0]); d.ks_log2 = g3_scale_log2(ob[1]); d.vs_log2 = g3_scale_log2(ob[2]);
-      rc = load_stack(e, w, {p + ".self_attention.fc_o"}, {256}, 256, InB{nullptr, nullptr, 256, ob[2]}, &d.o_s); if (rc) return fail(rc);
+      rc = load_stack(e, w, {p + ".self_attention.fc_o"}, {H}, H, InB{nullptr, nullptr, H, ob[2]}, &d.o_s); if (rc) return fail(rc);
     }
-    // cross-attention queries: layer 0 the precomputed q0 (no GEMM at run time: the Lin32 is loaded for its bias / shape only), layers 1-2 fc_q of the self-attention block's LayerNorm output
-    rc = load_stack(e, w, {p + ".encoder_attention.fc_q"}, {256}, 256, d.has_self ? ln : InB{nullptr, nullptr, 256, 1.f}, &d.q_c, &ob); if (rc) return fail(rc);
+    // cross-attention queries: layer 0 the precomputed q0 (no GEMM at run time: the Lin32 is loaded for its bias / shape only), the others fc_q of the self-attention block's LayerNorm output
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_q"}, {H}, H, d.has_self ? ln : InB{nullptr, nullptr, H, 1.f}, &d.q_c, &ob); if (rc) return fail(rc);
     d.qc_log2 = g3_scale_log2(d.has_self ? ob[0] : q0_bound);
-    rc = load_stack(e, w, {p + ".encoder_attention.fc_k", p + ".encoder_attention.fc_v"}, {256, 256}, 256, enc_out, &d.kv_c, &ob); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_k", p + ".encoder_attention.fc_v"}, {H, H}, H, enc_out, &d.kv_c, &ob); if (rc) return fail(rc);
     d.kc_log2 = g3_scale_log2(ob[0]); d.vc_log2 = g3_scale_log2(ob[1]);
-    rc = load_stack(e, w, {p + ".encoder_attention.fc_o"}, {256}, 256, InB{nullptr, nullptr, 256, ob[1]}, &d.o_c); if (rc) return fail(rc);
-    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {512}, 256, ln, &d.f1, &ob); if (rc) return fail(rc);
-    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {256}, 512, InB{nullptr, nullptr, 512, ob[0]}, &d.f2); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".encoder_attention.fc_o"}, {H}, H, InB{nullptr, nullptr, H, ob[1]}, &d.o_c); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_1"}, {PF}, H, ln, &d.f1, &ob); if (rc) return fail(rc);
+    rc = load_stack(e, w, {p + ".positionwise_feedforward.fc_2"}, {H}, PF, InB{nullptr, nullptr, PF, ob[0]}, &d.f2); if (rc) return fail(rc);
     rc = load_ln(e, w, p + ".layer_norm", &d.g, &d.be); if (rc) return fail(rc);
     dcur = ln;
   }
   {
-    int rc = load_stack(e, w, {"decoder.fc_velocity_freq", "decoder.fc_onset_freq", "decoder.fc_offset_freq", "decoder.fc_mpe_freq"}, {128, 1, 1, 1}, 256, dcur, &e->head_freq);
+    int rc = load_stack(e, w, {"decoder.fc_velocity_freq", "decoder.fc_onset_freq", "decoder.fc_offset_freq", "decoder.fc_mpe_freq"}, {e->NVEL, 1, 1, 1}, H, dcur, &e->head_freq);
     if (rc) return fail(rc);
   }
-  // time decoder (amt_apc.py:203-220): its input is freq-decoder output * 16 + pos_embedding_time
+  // time decoder (amt_apc.py:203-220): its input is freq-decoder output * sqrt(hid) + pos_embedding_time
   float ptmax = 0.f;
-  for (size_t i = 0; i < (size_t)e->nf * 256; ++i) ptmax = fmaxf(ptmax, fabsf(pt[i]));
-  cur = InB{nullptr, nullptr, 256, 16.f * in_bound(dcur) + ptmax};
-  for (int i = 0; i < 3; ++i) { int rc = load_enc(e, w, "decoder.layers_time." + std::to_string(i), cur, &e->tim[i], &cur); if (rc) return fail(rc); }
+  for (size_t i = 0; i < (size_t)e->nf * H; ++i) ptmax = fmaxf(ptmax, fabsf(pt[i]));
+  cur = InB{nullptr, nullptr, H, e->emb_scale * in_bound(dcur) + ptmax};
+  for (int i = 0; i < e->LD; ++i) { int rc = load_enc(e, w, "decoder.layers_time." + std::to_string(i), cur, &e->tim[i], &cur); if (rc) return fail(rc); }
   {
-    int rc = load_stack(e, w, {"decoder.fc_velocity_time", "decoder.fc_onset_time", "decoder.fc_offset_time", "decoder.fc_mpe_time"}, {128, 1, 1, 1}, 256, cur, &e->head_time);
+    int rc = load_stack(e, w, {"decoder.fc_velocity_time", "decoder.fc_onset_time", "decoder.fc_offset_time", "decoder.fc_mpe_time"}, {e->NVEL, 1, 1, 1}, H, cur, &e->head_time);
     if (rc) return fail(rc);
   }
-  const size_t Me = (size_t)e->nf * 256, Mq = (size_t)e->nf * e->nn;
+  const size_t Me = (size_t)e->nf * NB, Mq = (size_t)e->nf * e->nn, Mx = Me > Mq ? Me : Mq;
   e->Me = Me; e->Mq = Mq;
   int rc = 0;
-  rc = rc ? rc : e->alloc(&e->X, Me * 256); rc = rc ? rc : e->alloc(&e->X1, Me * 256); rc = rc ? rc : e->alloc(&e->QKV, Me * 768);
-  rc = rc ? rc : e->alloc(&e->AO, Me * 256); rc = rc ? rc : e->alloc(&e->HF, Me * 512); rc = rc ? rc : e->alloc(&e->T, Me * 256);
-  rc = rc ? rc : e->alloc(&e->KV, 3 * Me * 512);
-  rc = rc ? rc : e->alloc(&e->D0, Mq * 256); rc = rc ? rc : e->alloc(&e->D1, Mq * 256); rc = rc ? rc : e->alloc(&e->D2, Mq * 256);
-  rc = rc ? rc : e->alloc(&e->Qd, Mq * 256); rc = rc ? rc : e->alloc(&e->TI, Mq * 256); rc = rc ? rc : e->alloc(&e->HL, Mq * 256);
+  rc = rc ? rc : e->alloc(&e->X, Me * H); rc = rc ? rc : e->alloc(&e->X1, Mx * H); rc = rc ? rc : e->alloc(&e->QKV, Mx * 3 * H);
+  rc = rc ? rc : e->alloc(&e->AO, Mx * H); rc = rc ? rc : e->alloc(&e->HF, Mx * PF); rc = rc ? rc : e->alloc(&e->T, Mx * H);
+  rc = rc ? rc : e->alloc(&e->KV, (size_t)e->LD * Me * 2 * H);
+  rc = rc ? rc : e->alloc(&e->D0, Mq * H); rc = rc ? rc : e->alloc(&e->D1, Mq * H); rc = rc ? rc : e->alloc(&e->D2, Mq * H);
+  rc = rc ? rc : e->alloc(&e->Qd, Mq * H); rc = rc ? rc : e->alloc(&e->TI, Mq * H); rc = rc ? rc : e->alloc(&e->HL, Mq * (size_t)e->HLD);
   if (rc) return fail(rc);
   *out = e;
   return ETD_OK;
@@ -374,70 +451,71 @@ void ext32_destroy(Ext32* e) {
 }
 
 int ext32_run(Ext32* e, const EmbedArgs& src, int n_windows, Outs32 B, Outs32 A, void* const* tap, float* dbg_vel, hipStream_t st) {
-  const int nf = e->nf, nn = e->nn, Me = nf * 256, Mq = nf * nn;
+  const int nf = e->nf, nn = e->nn, H = e->H, PF = e->PF, NB = e->NB, Me = nf * NB, Mq = nf * nn;
   const bool wantA = A.on && A.off && A.mpe && A.vel;
   for (int w = 0; w < n_windows; ++w) {
     const bool first = w == 0;
     // ---- encoder                                                                                      amt_apc.py:74-120
     EmbedArgs ea = src;
     ea.w0 = w; ea.nf = nf; ea.margin = e->margin; ea.pad_value = e->cfg.min_value;
-    hipLaunchKernelGGL(k32_embed, dim3(nf, 8), dim3(256), 0, st, ea, e->Wf, e->bfold, e->pos_freq_enc, e->X);
+    if (e->dflt) hipLaunchKernelGGL(k32_embed, dim3(nf, 8), dim3(256), 0, st, ea, e->Wf, e->bfold, e->pos_freq_enc, e->X);
+    else hipLaunchKernelGGL(k32_embed_g, dim3(nf, NB / 32), dim3(256), 0, st, ea, e->Wf, e->bfold, e->pos_freq_enc, e->X, H, NB, e->taps, e->emb_scale);
     HIP_TRY(hipGetLastError());
-    ETD_TRY(tap32(tap, 0, e->X, Me, first, st));
-    for (int l = 0; l < 3; ++l) {
-      ETD_TRY(enc_layer32(e, e->enc[l], e->X, Me, nf, 256, st));
-      ETD_TRY(tap32(tap, 1 + l, e->X, Me, first, st));
+    ETD_TRY(tap32(e, tap, 0, 0, e->X, Me, first, st));
+    for (int l = 0; l < e->LE; ++l) {
+      ETD_TRY(enc_layer32(e, e->enc[l], e->X, Me, nf, NB, st));
+      ETD_TRY(tap32(e, tap, 1, l, e->X, Me, first, st));
     }
-    // ---- frequency decoder: 88 note queries per frame against the frame's 256 encoder tokens             amt_apc.py:168-177,261-320
+    // ---- frequency decoder: n_note queries per frame against the frame's n_bin encoder tokens              amt_apc.py:168-177,261-320
     float *D0 = e->D0, *D1 = e->D1, *D2 = e->D2;
-    for (int l = 0; l < 3; ++l) {
+    for (int l = 0; l < e->LD; ++l) {
       const Dec32& d = e->dec[l];
-      float* KVl = e->KV + (size_t)l * Me * 512;
-      ETD_TRY(gemm32(e->X, 256, d.kv_c, Me, KVl, 512, st));
+      float* KVl = e->KV + (size_t)l * Me * 2 * H;
+      ETD_TRY(gemm32(e->X, H, d.kv_c, Me, KVl, 2 * H, st));
       const float* cross_in = D0; int r_mod = 0;
       if (l == 0) { cross_in = e->trg0; r_mod = nn; }
       if (d.has_self) {
-        ETD_TRY(gemm32(D0, 256, d.qkv_s, Mq, e->QKV, 768, st));
-        ETD_TRY(attn32(e->QKV, 768, (long long)nn * 768, e->QKV + 256, 768, (long long)nn * 768, e->QKV + 512, 768, (long long)nn * 768,
-                       e->AO, 256, (long long)nn * 256, nf, nn, nn, d.qs_log2, d.ks_log2, d.vs_log2, st));
-        ETD_TRY(gemm32(e->AO, 256, d.o_s, Mq, e->T, 256, st));
-        ETD_TRY(add_ln(e->T, D0, 0, d.g, d.be, D1, Mq, st));
+        ETD_TRY(gemm32(D0, H, d.qkv_s, Mq, e->QKV, 3 * H, st));
+        ETD_TRY(attn32(e, e->QKV, 3 * H, (long long)nn * 3 * H, e->QKV + H, 3 * H, (long long)nn * 3 * H, e->QKV + 2 * H, 3 * H, (long long)nn * 3 * H,
+                       e->AO, H, (long long)nn * H, nf, nn, nn, d.qs_log2, d.ks_log2, d.vs_log2, st));
+        ETD_TRY(gemm32(e->AO, H, d.o_s, Mq, e->T, H, st));
+        ETD_TRY(add_ln(e, e->T, D0, 0, d.g, d.be, D1, Mq, st));
         cross_in = D1;
       }
       const float* Qp; long long q_seq;
       if (l == 0) { Qp = e->q0; q_seq = 0; }
-      else { ETD_TRY(gemm32(cross_in, 256, d.q_c, Mq, e->Qd, 256, st)); Qp = e->Qd; q_seq = (long long)nn * 256; }
-      ETD_TRY(attn32(Qp, 256, q_seq, KVl, 512, 256LL * 512, KVl + 256, 512, 256LL * 512, e->AO, 256, (long long)nn * 256, nf, nn, 256, d.qc_log2, d.kc_log2, d.vc_log2, st));
-      ETD_TRY(gemm32(e->AO, 256, d.o_c, Mq, e->T, 256, st));
-      ETD_TRY(add_ln(e->T, cross_in, r_mod, d.g, d.be, D2, Mq, st));
-      ETD_TRY(gemm32(D2, 256, d.f1, Mq, e->HF, 512, st, DEPI_RELU));
-      ETD_TRY(gemm32(e->HF, 512, d.f2, Mq, e->T, 256, st));
-      ETD_TRY(add_ln(e->T, D2, 0, d.g, d.be, D0, Mq, st));
-      ETD_TRY(tap32(tap, 4 + l, D0, Mq, first, st));
+      else { ETD_TRY(gemm32(cross_in, H, d.q_c, Mq, e->Qd, H, st)); Qp = e->Qd; q_seq = (long long)nn * H; }
+      ETD_TRY(attn32(e, Qp, H, q_seq, KVl, 2 * H, (long long)NB * 2 * H, KVl + H, 2 * H, (long long)NB * 2 * H, e->AO, H, (long long)nn * H, nf, nn, NB, d.qc_log2, d.kc_log2, d.vc_log2, st));
+      ETD_TRY(gemm32(e->AO, H, d.o_c, Mq, e->T, H, st));
+      ETD_TRY(add_ln(e, e->T, cross_in, r_mod, d.g, d.be, D2, Mq, st));
+      ETD_TRY(gemm32(D2, H, d.f1, Mq, e->HF, PF, st, DEPI_RELU));
+      ETD_TRY(gemm32(e->HF, PF, d.f2, Mq, e->T, H, st));
+      ETD_TRY(add_ln(e, e->T, D2, 0, d.g, d.be, D0, Mq, st));
+      ETD_TRY(tap32(e, tap, 4, l, D0, Mq, first, st));
     }
     const long long out_row0 = (long long)w * nf;
     if (wantA) {
-      ETD_TRY(gemm32(D0, 256, e->head_freq, Mq, e->HL, 256, st));
+      ETD_TRY(gemm32(D0, H, e->head_freq, Mq, e->HL, e->HLD, st));
       HeadsArgs h = {};
       h.M = Mq; h.time_layout = 0; h.nf = nf; h.nn = nn; h.out_off = out_row0 * nn;
       h.onset = A.on; h.offset = A.off; h.mpe = A.mpe; h.vel = A.vel;
-      hipLaunchKernelGGL(k32_heads_epi, dim3((Mq + 3) / 4), dim3(256), 0, st, e->HL, 256, h);
+      hipLaunchKernelGGL(k32_heads_epi, dim3((Mq + 3) / 4), dim3(256), 0, st, e->HL, e->HLD, h, e->NVEL);
       HIP_TRY(hipGetLastError());
     }
     // ---- time decoder: nn sequences of nf frames                                                       amt_apc.py:203-220
-    hipLaunchKernelGGL(k32_freq2time, dim3(2048), dim3(256), 0, st, D0, e->TI, e->pos_time, nf, nn);
+    hipLaunchKernelGGL(k32_freq2time, dim3(2048), dim3(256), 0, st, D0, e->TI, e->pos_time, nf, nn, H, e->emb_scale);
     HIP_TRY(hipGetLastError());
-    ETD_TRY(tap32(tap, 7, e->TI, Mq, first, st));
-    for (int l = 0; l < 3; ++l) {
+    ETD_TRY(tap32(e, tap, 7, 0, e->TI, Mq, first, st));
+    for (int l = 0; l < e->LD; ++l) {
       ETD_TRY(enc_layer32(e, e->tim[l], e->TI, Mq, nn, nf, st));
-      ETD_TRY(tap32(tap, 8 + l, e->TI, Mq, first, st));
+      ETD_TRY(tap32(e, tap, 8, l, e->TI, Mq, first, st));
     }
-    ETD_TRY(gemm32(e->TI, 256, e->head_time, Mq, e->HL, 256, st));
+    ETD_TRY(gemm32(e->TI, H, e->head_time, Mq, e->HL, e->HLD, st));
     HeadsArgs h = {};
     h.M = Mq; h.time_layout = 1; h.nf = nf; h.nn = nn; h.out_off = out_row0 * nn;
     h.onset = B.on; h.offset = B.off; h.mpe = B.mpe; h.vel = B.vel;
-    h.vel_logit = dbg_vel ? dbg_vel + out_row0 * nn * 128 : nullptr;
-    hipLaunchKernelGGL(k32_heads_epi, dim3((Mq + 3) / 4), dim3(256), 0, st, e->HL, 256, h);
+    h.vel_logit = dbg_vel;               // (the kernel's output index already carries out_off)
+    hipLaunchKernelGGL(k32_heads_epi, dim3((Mq + 3) / 4), dim3(256), 0, st, e->HL, e->HLD, h, e->NVEL);
     HIP_TRY(hipGetLastError());
   }
   return ETD_OK;

@@ -114,8 +114,13 @@ class AMTAPC_Extractor:
         # "f16" (default; "bf16" is accepted as its older name): the 16-bit serving path -- IEEE-half operands (bf16 in a -DETD_EXT_BF16 build: `operand_dtype`),
         # fp32 accumulate / LayerNorm / softmax / sigmoid.  "fp32": the exact-parity mode (csrc/ext_fp32.hip), fp32 activations and fp32-grade products like the
         # reference (extractor.py runs the model in fp32), ~4x slower; also selectable with ETD_EXTRACTOR_PRECISION.
+        # The 16-bit kernels are built for the reference's default architecture (etude/config/schema.py:100-112); any other architecture the reference can build
+        # with head_dim 64 runs on the fp32 engine, which is general: that is the default precision for it (an explicit "f16" is refused by the library).
         import os
-        precision = precision or os.environ.get("ETD_EXTRACTOR_PRECISION", "f16")
+        m = c.model
+        default_arch = (m.transformer_hid_dim, m.encoder_n_head, m.transformer_pf_dim, c.feature.n_bins, c.input.margin_b, m.cnn_channel, m.cnn_kernel,
+                        m.encoder_n_layer, m.decoder_n_layer, c.midi.num_velocity) == (256, 4, 512, 256, 32, 4, 5, 3, 3, 128)
+        precision = precision or os.environ.get("ETD_EXTRACTOR_PRECISION") or ("f16" if default_arch else "fp32")
         if precision not in ("f16", "bf16", "fp32"):
             raise ValueError("precision must be 'f16' (alias 'bf16') or 'fp32'")
         self.precision = "fp32" if precision == "fp32" else "f16"

@@ -96,7 +96,11 @@ typedef struct {
   int precision;          /* 0 = the 16-bit serving mode: IEEE-half operands (etd_extractor_operand_type), fp32 accumulate / LayerNorm / softmax /
                              sigmoid (default, the fast path);
                              1 = exact-parity mode: fp32 weights and activations, fp32-grade products (two-plane f16 splits on the matrix cores:
-                             csrc/gemm3.h, csrc/ext_fp32.hip), one window at a time -- what the note-level parity tests run on */
+                             csrc/gemm3.h, csrc/ext_fp32.hip), one window at a time -- what the note-level parity tests run on.
+                             Architectures (etude/config/schema.py:100-112): mode 0 is built for the reference's default one (hid 256 / 4 heads / pf 512 /
+                             256 bins / margin 32 / conv 4 x 5 / 3 + 3 layers / 128 velocities, n_frame % 32 == 0, n_note % 4 == 0 <= 128) and refuses any
+                             other; mode 1 takes hid_dim = 64 * n_heads <= 512, pf_dim % 32 == 0, n_bin % 32 == 0, n_margin <= 64,
+                             cnn_kernel <= 2 * n_margin + 1, any layer / note / frame counts, n_velocity <= 128 */
 } etd_ext_cfg;
 /* element type of the 16-bit serving mode's operands and activation buffers (debug taps): 1 = IEEE half (the default build), 0 = bf16 (-DETD_EXT_BF16) */
 int etd_extractor_operand_type(void);

@@ -156,8 +156,10 @@ def test_unsupported_architecture_fails_loudly(dev):
     from etude_amd import _lib
     from etude_amd.extractor import AMTAPC_Extractor
     cfg = ExtractorConfig()
-    cfg.model.transformer_hid_dim = 128
+    cfg.model.transformer_hid_dim = 128          # 4 heads of 32: neither engine has that (other architectures with head_dim 64: tests/test_gpu_extractor_archs.py)
     with pytest.raises(_lib.EtudeHipError, match="unsupported architecture"):
+        AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), "cuda", precision="f16")
+    with pytest.raises(_lib.EtudeHipError, match="general engine needs"):
         AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), "cuda")
     cfg = ExtractorConfig()
     sd = synth.extractor_state_dict(0)
