@@ -238,6 +238,7 @@ static DGemmArgs g3_args(const float* X, int ldx, const Lin& w, int x_log2, int 
 // ---- fp32 mode, >= G3_MIN_ROWS rows: the layer as LayerNorm rows -> QKV (+RoPE, KV append) -> attention -> dense -> up + GELU -> down + residual with every
 // contraction on the f16 matrix cores at fp32 grade (csrc/gemm3.h).  Prefill: ragged causal attention over the prompts straight from the fp32 cache rows the QKV
 // epilogue has just written, and the last layer's tail only for each prompt's last position; decode step: k_dattn<float> per (row, head).
+static int gemm3_auto(const DGemmArgs& a, int epi, hipStream_t st) { return gemm3_s_takes(a, epi) ? launch_gemm3_s(a, epi, st) : launch_gemm3(a, epi, st); }
 int forward_body_x3(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf, const LastOnly* lo, bool* compact) {
   float* hin = d->h; float* hout = d->h2;
   const int H = d->H;
@@ -249,7 +250,7 @@ int forward_body_x3(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipS
     DGemmArgs q = g3_args(d->X1f, H, w.qkv, w.x1_log2, M);
     q.rows = rows; q.rope_cos = d->rope_cos; q.rope_sin = d->rope_sin; q.rot_half = 8; q.Q = d->Q;
     q.Kc = Kl; q.Vc = Vl; q.slot_stride = d->slot_stride; q.max_ctx = d->ctx; q.n_heads = d->nh;
-    ETD_TRY(launch_gemm3(q, DEPI_QKV, st));
+    ETD_TRY(gemm3_auto(q, DEPI_QKV, st));
     if (l == d->L - 1 && lo && pf && lo->n >= 1 && lo->n < G3_MIN_ROWS && lo->n <= d->S) {
       // last layer: every position's K / V is in the cache now; attention, MLP and residual are needed for the prompts' last rows only
       const int n = lo->n;
@@ -284,11 +285,11 @@ int forward_body_x3(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipS
       ETD_TRY(launch_dattn(at, false, st));
     }
     DGemmArgs de = g3_args(d->AO, H, w.dense, w.v_log2, M); de.Y = d->DO; de.ldy = H;      // (attention output: a convex combination of V rows)
-    ETD_TRY(launch_gemm3(de, DEPI_BIAS, st));
+    ETD_TRY(gemm3_auto(de, DEPI_BIAS, st));
     DGemmArgs up = g3_args(d->X2f, H, w.up, w.x2_log2, M); up.Y = d->M1; up.ldy = d->I;
-    ETD_TRY(launch_gemm3(up, DEPI_GELU, st));
+    ETD_TRY(gemm3_auto(up, DEPI_GELU, st));
     DGemmArgs dn = g3_args(d->M1, d->I, w.down, w.m_log2, M); dn.add = d->DO; dn.hin = hin; dn.hout = hout;
-    ETD_TRY(launch_gemm3(dn, DEPI_RESID, st));
+    ETD_TRY(gemm3_auto(dn, DEPI_RESID, st));
     float* t = hin; hin = hout; hout = t;
   }
   *hfinal = hin;

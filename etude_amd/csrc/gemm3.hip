@@ -397,8 +397,15 @@ __global__ __launch_bounds__(64 * G3S_WAVES) void k_gemm3_s(int p_M, int p_Npad,
   dgemm_epilogue<false, EPI>(a, acc, m, n0, h);
 }
 
+// Which kernel: the 32 x 32-tile kernel up to 512 rows, and up to 2 048 rows when the output is at most 512 wide -- there k_gemm3's 128 x 128 tiles are a handful of
+// workgroups walking the whole K one after the other (measured, tools/bench_gemm3.py step: attention.dense 21.8 -> 12.1 us at 576 rows, 22.3 -> 20.3 at 1 728; the
+// K = 2 048 down projection 70.9 -> 29.5 and 71.7 -> 54.7; QKV and up, 1 536 / 2 048 wide, are faster on the tiles from 576 rows up).  ETD_G3S_MAX_ROWS overrides the row limit.
+static int g3s_max_rows(int npad) {
+  static const int v = getenv("ETD_G3S_MAX_ROWS") ? atoi(getenv("ETD_G3S_MAX_ROWS")) : 0;
+  return v > 0 ? v : (npad <= 512 ? 2048 : 512);
+}
 bool gemm3_s_takes(const DGemmArgs& a, int epi) {
-  return a.Wp && a.M >= 2 && a.M <= 512 && a.K % (128 * G3S_WAVES) == 0 && a.Npad % 128 == 0 && epi != DEPI_PARTIAL && !a.Xb && !a.Yb && !a.Qb && a.k_splits <= 1;
+  return a.Wp && a.M >= 2 && a.M <= g3s_max_rows(a.Npad) && a.K % (128 * G3S_WAVES) == 0 && a.Npad % 128 == 0 && epi != DEPI_PARTIAL && !a.Xb && !a.Yb && !a.Qb && a.k_splits <= 1;
 }
 int launch_gemm3_s(const DGemmArgs& a, int epi, hipStream_t st) {
   if (!gemm3_s_takes(a, epi) || !a.X || (a.ldx % 4) || ((uintptr_t)a.X & 15) || a.N > a.Npad) ETD_FAIL(ETD_EINVAL, "gemm3_s: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);

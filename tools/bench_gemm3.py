@@ -20,7 +20,11 @@ def main():
     st = torch.cuda.current_stream(dev).cuda_stream
     shapes = [("dec qkv", 131072, 1536, 512), ("dec dense", 131072, 512, 512), ("dec up", 131072, 2048, 512), ("dec down", 131072, 512, 2048),
               ("ext qkv", 131072, 768, 256), ("ext o", 131072, 256, 256), ("ext f1", 131072, 512, 256), ("ext f2", 131072, 256, 512),
-              ("step qkv", 1728, 1536, 512), ("step down", 1728, 512, 2048), ("small qkv", 54, 1536, 512), ("small down", 54, 512, 2048)]
+              ("step qkv", 1728, 1536, 512), ("step dense", 1728, 512, 512), ("step up", 1728, 2048, 512), ("step down", 1728, 512, 2048),
+              ("step qkv", 576, 1536, 512), ("step dense", 576, 512, 512), ("step up", 576, 2048, 512), ("step down", 576, 512, 2048),
+              ("small qkv", 54, 1536, 512), ("small down", 54, 512, 2048)]
+    if len(sys.argv) > 1 and sys.argv[1] == "step":
+        shapes = [s_ for s_ in shapes if s_[0].startswith("step")]
     rng = np.random.default_rng(0)
     for name, M, N, K in shapes:
         x = torch.randn((M, K), dtype=torch.float32, device=dev)
