@@ -189,7 +189,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const float* __restrict__ p_X,
   constexpr int LDR = G::LDR, PLANE = G::PLANE, NB = G::NB;
   __shared__ __attribute__((aligned(16))) f16 sm[4 * PLANE];        // X hi | X lo | W hi | W lo (>= 40 KiB: the epilogue's four [32][68] fp32 tiles fit)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * 128, nt = blockIdx.y, nchunk = p_K / KC, nblk32 = p_K >> 5;
+  // workgroup -> tile, XCD-aware: consecutive workgroup ids go round the 8 XCDs, each with its own L2.  The NT column tiles of a row tile read the same 128 x K block of
+  // X: they take CONSECUTIVE slots of ONE XCD (id = 8 * slot + xcd; slot = row-tile group * NT + column tile), so that the block comes from HBM once and from that L2
+  // NT - 1 times -- with (row tile, column tile) = (blockIdx.x, blockIdx.y) the column tiles of a row tile ran 1 024 workgroups apart and X was read NT times from HBM
+  const int NT = (int)gridDim.y, RT = (p_M + 127) >> 7;
+  const int wid = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, slot = wid >> 3;
+  const int nt = slot % NT, rt = (slot / NT) * 8 + (wid & 7);
+  if (rt >= RT) return;
+  const int m0 = rt * 128, nchunk = p_K / KC, nblk32 = p_K >> 5;
   // X staging: a load instruction covers FULL 128-byte row segments (8 lanes per row, 8 rows per wave, rows 32 apart per instruction) -- two lanes per row made every
   // instruction touch 32 different cache lines, and the CU's address path, not the bytes, was the limit
   const int xrow = tid >> 3, xc = tid & 7;
@@ -283,7 +290,7 @@ int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st) {
   if (a.ln_g || a.Xb || a.Yb || a.Qb || a.k_splits > 1) ETD_FAIL(ETD_EINVAL, "gemm3: fp32 operands only (no fused LayerNorm, bf16 buffers or split-K)");
   ETD_LAUNCH_FILTER("k_gemm3");
   ProfScope ps(a.M >= 8192 ? "k_gemm3" : "k_gemm3_step", st, 2.0 * a.M * a.N * a.K, (double)a.Npad * a.K * 4 + (double)a.M * a.K * 4);
-  const dim3 g((a.M + 127) / 128, a.Npad / 128);
+  const dim3 g((unsigned)((((a.M + 127) / 128 + 7) / 8) * 8), a.Npad / 128);      // row tiles rounded up to a multiple of 8 (one per XCD): see the kernel's workgroup -> tile map
   const float xs = ldexpf(1.f, a.x_log2), inv = ldexpf(1.f, -(a.x_log2 + a.w_log2));
 // K per chunk: 32 (40 KiB of LDS, 154 registers: three workgroups per CU) measured 10 % faster than 64 (72 KiB, two per CU) on every shape of tools/bench_gemm3.py:
 // what bounds this kernel is the dependent chain load -> split -> LDS -> barrier -> fragments -> MFMA of a workgroup, covered by the other workgroups of the CU, not a pipe
