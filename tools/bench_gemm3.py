@@ -25,6 +25,8 @@ def main():
               ("small qkv", 54, 1536, 512), ("small down", 54, 512, 2048)]
     if len(sys.argv) > 1 and sys.argv[1] == "step":
         shapes = [s_ for s_ in shapes if s_[0].startswith("step")]
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        shapes = [s_ for s_ in shapes if s_[0].startswith("dec")]
     rng = np.random.default_rng(0)
     for name, M, N, K in shapes:
         x = torch.randn((M, K), dtype=torch.float32, device=dev)
