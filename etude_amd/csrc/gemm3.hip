@@ -199,13 +199,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const float* __restrict__ p_X,
   const int m0 = rt * 128, nchunk = p_K / KC, nblk32 = p_K >> 5;
   // X staging: a load instruction covers FULL 128-byte row segments (8 lanes per row, 8 rows per wave, rows 32 apart per instruction) -- two lanes per row made every
   // instruction touch 32 different cache lines, and the CU's address path, not the bytes, was the limit
-  const int xrow = tid >> 3, xc = tid & 7;
+  // (row order: the four rows a 32-lane half of a store covers are 4 apart -- with 80-byte LDS rows they then start on bank offsets 0 / 64 / 128 / 192 of the 256-byte
+  // bank cycle and the 8-byte hi / lo stores of the split are conflict-free; consecutive rows overlapped 48 bytes: a third of the LDS pipe's cycles were conflicts)
+  const int xt = tid >> 3, xrow = (xt & 16) | ((xt & 3) << 2) | ((xt >> 2) & 3), xc = tid & 7;
   const float* xp[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) { int gm = m0 + xrow + 32 * i; gm = gm < p_M ? gm : p_M - 1; xp[i] = p_X + (long long)gm * p_ldx + xc * 4; }
   // W staging: the packed planes are contiguous per (tile, 32-block): 16 bytes per lane, 1 KiB per wave instruction
-  const int srow = tid >> 1, sh = tid & 1;
-  const f16* wp = p_Wp + (size_t)nt * nblk32 * (2 * 128 * 32) + tid * 16;
+  // (row order: the eight rows a 16-lane pass of a 16-byte store covers are all even or all odd: their 32-byte pieces then fall on disjoint bank ranges)
+  const int stt = tid >> 1, srow = (stt & ~15) | ((stt & 7) << 1) | ((stt >> 3) & 1), sh = tid & 1;
+  const f16* wp = p_Wp + (size_t)nt * nblk32 * (2 * 128 * 32) + srow * 32 + sh * 16;
   f32x4 xr[NB][4]; u32x4 whr[NB][2], wlr[NB][2];
   auto gload = [&](int kc) {
 #pragma unroll
