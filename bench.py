@@ -58,12 +58,12 @@ sys.path.insert(0, str(ROOT))
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md: the F16 forms take the same cycles)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 T_START = time.perf_counter()
-# cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r05_parity_mode.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
+# cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r05_parity_full.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
 # extract, the fp32 decode of its 27 jobs x all bars, and the 16-bit decode of the same jobs
 PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "8"))
 PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.2"))
 PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "1.5"))
-PARITY_BF16_S_PER_CLIP = float(os.environ.get("ETD_PARITY_BF16_S", "0.45"))
+PARITY_F16_S_PER_CLIP = float(os.environ.get("ETD_PARITY_F16_S", "0.45"))
 
 
 def since_process_start() -> float:
@@ -239,7 +239,7 @@ def n8_share_extras(args, dev, exs, wavs, grid, vocab, headline_value):
     per_eng = (n_jobs + n_eng - 1) // n_eng
     decs = []; pipe = None
     try:
-        decs = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng,
+        decs = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=per_eng,
                              max_prefill_rows=min(262144, per_eng * 520))]
         decs += [decs[0].clone() for _ in range(n_eng - 1)]
         pipe = ClipBatchPipeline(exs[:2], decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
@@ -286,7 +286,7 @@ def bar_divergence(ra, rb):
     return same, comparable, jobs_same
 
 
-def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_engines, time_left):
+def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engines, time_left):
     """extras.parity_mode: what exact parity costs.  north_star's "identical token-id sequences under greedy decode" holds in the fp32 mode (the reference
     runs fp32: etude_decoder.py:333); the headline is timed in the 16-bit serving mode (IEEE-half operands).  The SAME chain (extract .. notes) on the first `n_clips` clips of this rank with the fp32
     extractor and fp32 decoder engines (every dense contraction at fp32 grade on the f16 matrix cores: csrc/gemm3.h), ONE timed pass after a 2-bar warm-up pass;
@@ -363,8 +363,8 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, bf16_eng
         d32 = []
         pipe32.close(); pipe32 = None
         # the 16-bit decoder on the same condition bars: the headline's engines when they hold enough streams, else nothing (no new allocations this late)
-        if time_left() > 25.0 and bf16_engines and sum(d.max_streams for d in bf16_engines) >= n_jobs:
-            pipe16 = ClipBatchPipeline([ex32], bf16_engines, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
+        if time_left() > 25.0 and f16_engines and sum(d.max_streams for d in f16_engines) >= n_jobs:
+            pipe16 = ClipBatchPipeline([ex32], f16_engines, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
             t4 = time.perf_counter()
             res16, st16 = pipe16.decode_stage(conds, max_bars=max_bars)
             torch.cuda.synchronize(dev)
@@ -490,7 +490,7 @@ def main():
         per_eng = min(args.max_streams, (n_jobs + n_eng - 1) // n_eng)
         # one batched-prefill pass carries up to 256 k prompt rows (~500 prompts at the 512-token truncation): a bar boundary of 1728 streams is then
         # four passes, and the host assembles / stages pass k + 1 while the GPU runs pass k (one 886 k-row pass left the queue empty for ~6 ms per bar)
-        decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=per_eng, max_prefill_rows=min(262144, per_eng * 520))]
+        decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=per_eng, max_prefill_rows=min(262144, per_eng * 520))]
         decs += [decs[0].clone() for _ in range(n_eng - 1)]            # engines share one weight set (own KV caches and state)
         return decs, n_jobs, per_eng
 
@@ -558,7 +558,7 @@ def main():
         short = lambda t: 0.12 * t + 0.5                      # noqa: E731  (a 4-bar step: the whole extract stage + 4 of 92 bars)
         # full warm-up steps only if they leave room for EVERYTHING that follows the timed steps (24 stamped bars, serial pass, extras incl. the exact-parity pass,
         # CPU baseline: ~90 s); otherwise the warm-up steps shrink first -- they are untimed and everything is allocated, captured and cached after the first one
-        FULL_POST_S = 0.27 * t_first + 4.0 + 14.0 + (PARITY_FIXED_S + args.parity_clips * (PARITY_EXTRACT_S_PER_CLIP + PARITY_DECODE_S_PER_CLIP + PARITY_BF16_S_PER_CLIP)) + 30.0
+        FULL_POST_S = 0.27 * t_first + 4.0 + 14.0 + (PARITY_FIXED_S + args.parity_clips * (PARITY_EXTRACT_S_PER_CLIP + PARITY_DECODE_S_PER_CLIP + PARITY_F16_S_PER_CLIP)) + 30.0
         if since + (rest + args.steps) * t_first + max(OVERHEAD_S, FULL_POST_S if rest > 0 else 0.0) > args.budget_s:
             if since + args.steps * t_first + rest * short(t_first) + OVERHEAD_S <= args.budget_s:
                 warm_mode = "first warm-up step full, the others 4 bars per job (W + K full steps exceed the harness budget)"
@@ -811,7 +811,7 @@ def main():
     if not args.no_extras and rank == 0 and args.parity_clips > 0:
         extras = result.setdefault("extras", {})
         nb_mean = float(np.mean(nbars))
-        cost = lambda c, b: PARITY_FIXED_S + c * (PARITY_EXTRACT_S_PER_CLIP + (PARITY_DECODE_S_PER_CLIP + PARITY_BF16_S_PER_CLIP) * (b or nb_mean) / nb_mean)   # noqa: E731
+        cost = lambda c, b: PARITY_FIXED_S + c * (PARITY_EXTRACT_S_PER_CLIP + (PARITY_DECODE_S_PER_CLIP + PARITY_F16_S_PER_CLIP) * (b or nb_mean) / nb_mean)   # noqa: E731
         cands = [(args.parity_clips, args.parity_bars)] if args.parity_bars else \
                 [(c, b) for c in sorted({args.parity_clips, max(1, args.parity_clips // 2), max(1, args.parity_clips // 4)}, reverse=True) for b in (0, 24, 8)]
         pick = next(((c, b) for c, b in cands if c <= len(wavs) and cost(c, b) < time_left() - CPU_RESERVE_S - 5.0), None)
@@ -867,7 +867,7 @@ def decoder_stream_bench(dcfg, dev, n_streams: int = 128, ctx0: int = 512, steps
     from etude_amd.decoder import EtudeDecoder
     engines = max(1, min(engines, n_streams))
     per = [n_streams // engines + (1 if e < n_streams % engines else 0) for e in range(engines)]
-    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=max(per), max_ctx=4096)]
+    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=max(per), max_ctx=4096)]
     while len(decs) < engines:
         decs.append(decs[0].clone())
     if streams:

@@ -24,7 +24,7 @@ c_f32_p = C.POINTER(C.c_float)
 
 
 class _SizedCfg(C.Structure):
-    """Config structs of ABI version 2 lead with `struct_bytes` = sizeof of the caller's layout; the library refuses any other."""
+    """Config structs (since ABI version 2) lead with `struct_bytes` = sizeof of the caller's layout; the library refuses any other."""
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -68,7 +68,7 @@ class Note(C.Structure):
     _fields_ = [("onset", C.c_double), ("offset", C.c_double), ("pitch", C.c_int32), ("velocity", C.c_int32)]
 
 
-ABI_VERSION = 2          # == ETD_ABI_VERSION of include/etude_hip.h; lib() refuses any other
+ABI_VERSION = 3          # == ETD_ABI_VERSION of include/etude_hip.h; lib() refuses any other
 
 # name -> (restype, argtypes); mirrors include/etude_hip.h (the boundary) and include/etude_hip_debug.h (test / measurement hooks) one to one
 SIGNATURES = {

@@ -25,39 +25,49 @@ if os.environ.get("ETD_KERNARG_PRELOAD", "1") != "0":
 # VGPRs and back around each VALU use (online-softmax rescale, epilogues): 2 209 v_accvgpr moves across the library, 256 of them per key tile in the prefill
 # attention.  With the VGPR form there are none, the kernels need 15-40 % fewer registers (k_attn 200 -> 134, k_embed 424 -> 250) and the arithmetic is unchanged.
 # (k_dmlp_fused places its operands by asm constraints and is not affected.)  ETD_MFMA_VGPR_FORM=0 turns it off.
-def _llvm_flag_ok(flag: str) -> bool:
-    """Does this hipcc's LLVM know the (hidden) -mllvm option?  One trivial gfx950 compile, the answer cached next to the objects (keyed by the compiler binary's
-    mtime): a toolchain without it would otherwise abort the whole build with 'Unknown command line argument'."""
-    import json
+SIDECAR = LIB.with_suffix(".flags.json")      # the optional flags the .so next to it was built with (written by build(), read by src_hash(): loading never probes)
+_LOADED = Path(os.environ["ETD_LIB_PATH"]).resolve().with_suffix(".flags.json") if os.environ.get("ETD_LIB_PATH") else SIDECAR      # ... of the .so a process LOADS
+_VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+
+
+def _probe_llvm_flag(flag: str) -> bool:
+    """Does this hipcc's LLVM know the (hidden) -mllvm option?  One trivial gfx950 compile.  Called from build() ONLY (never at import, never when the library is
+    loaded: a serving / test / profiled process that has initialised the GPU must not fork a compiler): a toolchain without the option would otherwise abort the
+    whole build with 'Unknown command line argument'."""
     import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = Path(td) / "p.hip"
+        src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(float* p) { p[0] = 1.f; }\n")
+        r = subprocess.run([_hipcc(), "-O1", "--offload-arch=gfx950", "-mllvm", flag, "-c", str(src), "-o", str(Path(td) / "p.o")],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    return r.returncode == 0
+
+
+def _optional_flags(probe: bool = False) -> list:
+    """The flags that depend on the toolchain.  probe=True (build()): ask the compiler and record the answer in SIDECAR.  probe=False (importing this module,
+    `src_hash()` for the loader's build-id check): the answer recorded beside the .so, or -- no sidecar, e.g. a tree that was never built -- the default set."""
+    import json
+    if os.environ.get("ETD_MFMA_VGPR_FORM", "1") == "0":
+        return []
+    if probe:
+        ok = _probe_llvm_flag("-amdgpu-mfma-vgpr-form")
+        if not ok:
+            print("etude_amd.build: this hipcc does not know -mllvm -amdgpu-mfma-vgpr-form; building without it (MFMA accumulators in AGPRs: correct, 15-40 % more registers)",
+                  file=sys.stderr)
+        try:
+            SIDECAR.write_text(json.dumps({"mfma_vgpr_form": ok}))
+        except OSError:
+            pass
+        return list(_VGPR_FORM) if ok else []
     try:
-        hipcc = next(c for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc") if c and (Path(c).exists() or c == "hipcc"))
-        key = f"{hipcc}:{Path(hipcc).stat().st_mtime_ns if Path(hipcc).exists() else 0}:{flag}"
-        cache = OBJ / "flag_probe.json"
-        known = json.loads(cache.read_text()) if cache.exists() else {}
-        if key in known:
-            return bool(known[key])
-        with tempfile.TemporaryDirectory() as td:
-            src = Path(td) / "p.hip"
-            src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(float* p) { p[0] = 1.f; }\n")
-            r = subprocess.run([hipcc, "-O1", "--offload-arch=gfx950", "-mllvm", flag, "-c", str(src), "-o", str(Path(td) / "p.o")],
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        ok = r.returncode == 0
-        OBJ.mkdir(exist_ok=True)
-        known[key] = ok
-        cache.write_text(json.dumps(known))
-        return ok
-    except Exception:      # noqa: BLE001  (no compiler here at all: let the build itself report that)
-        return True
+        return list(_VGPR_FORM) if json.loads(_LOADED.read_text()).get("mfma_vgpr_form", True) else []
+    except Exception:      # noqa: BLE001
+        return list(_VGPR_FORM)
 
 
-if os.environ.get("ETD_MFMA_VGPR_FORM", "1") != "0":
-    if _llvm_flag_ok("-amdgpu-mfma-vgpr-form"):
-        FLAGS += ["-mllvm", "-amdgpu-mfma-vgpr-form"]      # (part of every file's flag set, hence of the build id: builds with and without it never mix)
-    else:
-        print("etude_amd.build: this hipcc does not know -mllvm -amdgpu-mfma-vgpr-form; building without it (MFMA accumulators in AGPRs: correct, 15-40 % more registers)",
-              file=sys.stderr)
-FLAGS += os.environ.get("ETD_EXTRA_FLAGS", "").split()      # diagnostic builds (e.g. -DETD_HEAD_STAMP, -DETD_LIN_STAMP)
+BASE_FLAGS = list(FLAGS)
+EXTRA_FLAGS = os.environ.get("ETD_EXTRA_FLAGS", "").split()      # diagnostic builds (e.g. -DETD_HEAD_STAMP, -DETD_LIN_STAMP)
+FLAGS = BASE_FLAGS + _optional_flags() + EXTRA_FLAGS      # (part of every file's flag set, hence of the build id: builds with and without an option never mix)
 # -ffp-contract=off applies to HOST code only in effect: device kernels use explicit fmaf where wanted.
 
 
@@ -96,8 +106,10 @@ def _hipcc() -> str:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
+    global FLAGS
     OBJ.mkdir(exist_ok=True)
     hipcc = _hipcc()
+    FLAGS = BASE_FLAGS + _optional_flags(probe=True) + EXTRA_FLAGS    # the ONE place that asks the compiler; the answer is recorded beside the .so
     headers = list(CSRC.glob("*.h")) + [HERE.parent / "include" / "etude_hip.h", HERE.parent / "include" / "etude_hip_debug.h"]
     newest_h = max(h.stat().st_mtime for h in headers)
     objs = []
@@ -135,6 +147,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}")
+    if force and not os.environ.get("ETD_LIB_OUT"):
+        # a forced build of the shipped library is the tree's clean point: objects of other flag sets / older sources (measurement builds) go
+        for o in OBJ.glob("*.o"):
+            if o not in objs:
+                o.unlink()
+        (OBJ / "flag_probe.json").unlink(missing_ok=True)
     return LIB
 
 

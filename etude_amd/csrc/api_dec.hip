@@ -299,7 +299,7 @@ int forward_body_x3(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipS
 int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStream_t st, const PrefillInfo* pf = nullptr, bool ln0_done = false,
                  const LastOnly* lo = nullptr, bool* compact = nullptr, bool is_step = false) {
   if (compact) *compact = false;
-  if (!d->bf16w && M >= G3_MIN_ROWS && d->X1f && d->layers[0].qkv.Wp && d->layers[0].down.Wp && !getenv("ETD_NO_GEMM3")) return forward_body_x3(d, M, rows, hfinal, st, pf, lo, compact);
+  if (!d->bf16w && M >= G3_MIN_ROWS && d->X1f && d->layers[0].qkv.Wp && d->layers[0].down.Wp && g3_enabled()) return forward_body_x3(d, M, rows, hfinal, st, pf, lo, compact);
   float* hin = d->h; float* hout = d->h2;
   const size_t esz = d->bf16w ? 2 : 4;
   const bool bpipe = d->bf16w && (M > 1 || is_step);     // (is_step with M == 1: the fused step kernels for a single stream, ETD_FUSED_M1)
@@ -517,7 +517,7 @@ int forward_body(etd_dec* d, int M, const DecRows& rows, float** hfinal, hipStre
 
 // final LayerNorm + lm_head for `n` rows of X (fp32 [n][H]) -> logits [n][V]
 int head_logits(etd_dec* d, const float* X, int n, float* logits, hipStream_t st) {
-  if (!d->bf16w && n >= G3_MIN_ROWS && d->X1f && d->head.Wp && !getenv("ETD_NO_GEMM3")) {
+  if (!d->bf16w && n >= G3_MIN_ROWS && d->X1f && d->head.Wp && g3_enabled()) {
     ETD_TRY(launch_ln_rows_f32(X, n, d->H, d->lnfg, d->lnfb, nullptr, nullptr, d->cfg.layer_norm_eps, d->X1f, nullptr, st));
     DGemmArgs lm = g3_args(d->X1f, d->H, d->head, d->xf_log2, n);
     lm.bias = nullptr; lm.Y = logits; lm.ldy = d->V;

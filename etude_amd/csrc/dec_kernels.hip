@@ -1132,10 +1132,11 @@ static void dgemm_dispatch(const DGemmArgs& a, int epi, int path, hipStream_t st
 #undef ETD_DG
 }
 
+bool g3_enabled();                                                   // csrc/gemm3.hip: ETD_NO_GEMM3, read once for every call site
 bool gemm3_s_takes(const DGemmArgs& a, int epi);                     // csrc/gemm3.hip: the fp32 mode's small-M GEMM on the f16 matrix cores
 int launch_gemm3_s(const DGemmArgs& a, int epi, hipStream_t st);
 int launch_dgemm(const DGemmArgs& a, int epi, bool w_bf16, hipStream_t st) {
-  static const bool g3s_on = !getenv("ETD_NO_GEMM3");
+  const bool g3s_on = g3_enabled();
   if (!w_bf16 && g3s_on && gemm3_s_takes(a, epi)) return launch_gemm3_s(a, epi, st);
   if (a.M <= 0 || a.Npad % 128 || a.K % 256 || a.N > a.Npad) ETD_FAIL(ETD_EINVAL, "dgemm: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
   if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "dgemm: QKV epilogue needs head_dim 64 and rotary_ndims 16");

@@ -12,7 +12,7 @@
 // are unchanged.  N % 32 == 0, K % 16 == 0.
 // The extractor's 16-bit operand type.  IEEE half by default: on gfx950 v_mfma_f32_32x32x16_f16 has the layout and the rate of the bf16 form, and its 11
 // significant bits (against 8) cut the extractor's distance to the fp32 reference by ~6x at no cost (measured: profiles/r05_ext_f16.txt; why the range suffices:
-// DESIGN section 2).  -DETD_EXT_BF16 builds the bf16 extractor of rounds 1-4 from the same sources.  The EtudeDecoder's serving mode stays bf16.
+// DESIGN section 2).  -DETD_EXT_BF16 builds the bf16 extractor of rounds 1-4 from the same sources.  The EtudeDecoder's 16-bit serving mode is IEEE half as well (d16, dec_kernels.h).
 #ifdef ETD_EXT_BF16
 typedef bf16 e16; typedef bf16x8 e16x8; typedef bf16x4 e16x4; typedef bf16x2 e16x2;
 #ifdef __HIPCC__

@@ -17,6 +17,9 @@
 #pragma once
 #include "dec_kernels.h"
 
+// ETD_NO_GEMM3 (measurement: the round-4 fp32-MFMA / VALU kernel sequence instead) is read ONCE per process, here, for every call site
+bool g3_enabled();
+
 #define G3_MIN_ROWS 513            // below: the weight-streaming fp32 kernels (k_dgemm_s / k_dgemv), where a 128-token tile would idle most of the chip
 
 // weights [N][K] fp32 -> planes in the order k_gemm3 streams them: [Npad/128 tile][K/32 chunk][plane hi|lo][128 rows][32 k] f16.

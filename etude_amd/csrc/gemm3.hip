@@ -286,6 +286,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const float* __restrict__ p_X,
   }
 }
 
+bool g3_enabled() { static const bool on = !getenv("ETD_NO_GEMM3"); return on; }
+
 int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st) {
   if (a.M <= 0 || a.Npad % 128 || a.K % 32 || a.N > a.Npad || !a.Wp || !a.X || (a.ldx % 4) || ((uintptr_t)a.X & 15)) ETD_FAIL(ETD_EINVAL, "gemm3: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
   if (epi == DEPI_QKV && (a.rot_half != 8 || a.N % 192)) ETD_FAIL(ETD_EINVAL, "gemm3: QKV epilogue needs head_dim 64 and rotary_ndims 16");
@@ -300,9 +302,13 @@ int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st) {
 #ifndef G3_KC_MAX
 #define G3_KC_MAX 32
 #endif
-  const bool k64 = G3_KC_MAX >= 64 && a.K % 64 == 0;
+#if G3_KC_MAX >= 64      // (the KC = 64 instances -- 72 KiB of static LDS, six epilogues -- exist only in such a measurement build)
+  const bool k64 = a.K % 64 == 0;
 #define G3_LAUNCH(E) do { if (k64) hipLaunchKernelGGL((k_gemm3<E, 64>), g, dim3(256), 0, st, a.X, a.ldx, (const f16*)a.Wp, a.M, a.K, xs, inv, a); \
                           else hipLaunchKernelGGL((k_gemm3<E, 32>), g, dim3(256), 0, st, a.X, a.ldx, (const f16*)a.Wp, a.M, a.K, xs, inv, a); } while (0)
+#else
+#define G3_LAUNCH(E) hipLaunchKernelGGL((k_gemm3<E, 32>), g, dim3(256), 0, st, a.X, a.ldx, (const f16*)a.Wp, a.M, a.K, xs, inv, a)
+#endif
   switch (epi) {
     case DEPI_BIAS: G3_LAUNCH(DEPI_BIAS); break;
     case DEPI_GELU: G3_LAUNCH(DEPI_GELU); break;

@@ -102,8 +102,10 @@ class EtudeDecoder:
         precision = precision or os.environ.get("ETD_DECODER_PRECISION", "fp32")
         if precision not in ("fp32", "f16", "bf16"):
             raise ValueError("precision must be 'fp32' (token-parity mode) or 'f16' (alias 'bf16': the 16-bit serving mode)")
-        precision = "fp32" if precision == "fp32" else "bf16"        # (internal name of the serving mode: kept for the C ABI's precision = 1)
+        precision = "fp32" if precision == "fp32" else "f16"
         self.precision = precision
+        # the arithmetic type of the 16-bit mode's operands in THIS library build (etd_decoder_operand_type: 1 = IEEE half, 0 = bf16 of a -DETD_DEC_BF16 build)
+        self.operand_dtype = torch.float32 if precision == "fp32" else (torch.float16 if _lib.lib().etd_decoder_operand_type() == 1 else torch.bfloat16)
         self.max_streams = int(max_streams)
         # KV positions per stream.  A bar touches prompt + limit - 1 positions, and the prompt (after the truncation rule of
         # etude_decoder.py:285-289, + Bar_BOS) is at most max(max_pos - limit, int(max_pos * ratio)) + 1 tokens: with the reference's
@@ -120,7 +122,7 @@ class EtudeDecoder:
                           max_position_embeddings=config.max_position_embeddings, num_classes=config.num_classes,
                           num_attribute_bins=config.num_attribute_bins, attribute_emb_dim=config.attribute_emb_dim,
                           rotary_pct=config.rotary_pct, rope_theta=config.rope_theta, layer_norm_eps=config.layer_norm_eps,
-                          max_streams=self.max_streams, max_ctx=self.max_ctx, precision=1 if precision == "bf16" else 0,
+                          max_streams=self.max_streams, max_ctx=self.max_ctx, precision=1 if precision == "f16" else 0,
                           max_prefill_rows=self.max_prefill_rows)
         names, ptrs, numels, n, keep = _lib.weights_arrays(state)
         h = C.c_void_p()
@@ -134,7 +136,7 @@ class EtudeDecoder:
         """A second engine over the same device weights (own KV cache / workspaces / stream state): what `generate_many`
         callers use to run several engines side by side without one weight copy per engine."""
         other = object.__new__(EtudeDecoder)
-        for k in ("device", "config", "precision", "max_streams", "max_ctx", "max_prefill_rows"):
+        for k in ("device", "config", "precision", "operand_dtype", "max_streams", "max_ctx", "max_prefill_rows"):
             setattr(other, k, getattr(self, k))
         h = C.c_void_p()
         with torch.cuda.device(self.device):

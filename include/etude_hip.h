@@ -36,8 +36,11 @@ extern "C" {
 
 /* ABI history: 1 = rounds 1-2 (etd_ext_cfg without `precision` / etd_sched_cfg without the job keys in its first builds);
  * 2 = round 3: struct_bytes leads every config struct, so a caller compiled against another layout is refused instead of misread;
- * etd_decoder_stats / _stats_reset / _stamp added; the diagnostic hooks moved to etude_hip_debug.h. */
-#define ETD_ABI_VERSION 2
+ * etd_decoder_stats / _stats_reset / _stamp added; the diagnostic hooks moved to etude_hip_debug.h;
+ * 3 = round 6 (the change itself is round 5's): the element type of every 16-bit buffer reachable through this API -- KV cache rows, activation taps and peeks of the
+ * debug header -- is IEEE half (was bf16; `etd_decoder_operand_type` / `etd_extractor_operand_type` name the type of a given build); `etd_frontend_run(feat = NULL)`
+ * sizes its output; no struct layout changed. */
+#define ETD_ABI_VERSION 3
 #define ETD_OK 0
 #define ETD_EINVAL (-22)
 #define ETD_ENOMEM (-12)

@@ -138,6 +138,7 @@ def test_config1_single_clip_full_chain(dev, golden_dir, tmp_path):
     write_wav_f32(tmp_path / "origin.wav", wav, 44100)
     ex4.extract(str(tmp_path / "origin.wav"), str(tmp_path / "extract.json"), str(tmp_path / "extract.mid"))
     js = json.loads((tmp_path / "extract.json").read_text())
+    print(f"configs[1] extract(): {len(js)} notes written from the wav file (device front end) vs {int(g['n_kept'])} the reference writes from its features")
     assert abs(len(js) - int(g["n_kept"])) <= max(3, int(g["n_kept"]) // 50)
     assert (tmp_path / "extract.mid").read_bytes()[:4] == b"MThd"
     ex4.close(); ex1.close()
@@ -163,7 +164,7 @@ def test_config1_single_clip_full_chain(dev, golden_dir, tmp_path):
     assert gen == g["gen_ids"].tolist()                                              # bit-exact integer parity over the whole song
     ids32 = d32.generate_ids(v, bars, attrs, temperature=0.0)
     d32.close()
-    d16 = EtudeDecoder(dcfg, dsd, "cuda", precision="bf16")
+    d16 = EtudeDecoder(dcfg, dsd, "cuda", precision="f16")
     ids16 = d16.generate_ids(v, bars, attrs, temperature=0.0)
     d16.close()
     same_bars = sum(1 for a, b in zip(ids32, ids16) if a == b)
@@ -229,7 +230,7 @@ def test_config3_128_streams_at_4k_context(dev):
     assert got32.tolist() == want
     # ---- bf16, 128 streams (64 copies of each prompt, interleaved), 64 steps through the captured decode step: streams
     # with equal prompts must produce equal tokens whatever slot they sit in, and the start agrees with the fp32 ids
-    d16 = EtudeDecoder(dcfg, sd_np, "cuda", precision="bf16", max_streams=128, max_ctx=4096)
+    d16 = EtudeDecoder(dcfg, sd_np, "cuda", precision="f16", max_streams=128, max_ctx=4096)
     # the 16-bit contract is stated on logits: the batched prefill (MFMA attention from the cache rows, 55 key tiles per query) at T = 3 500 against the oracle, every 50th position
     for k, (ids, cls, a4) in enumerate(base):
         lg16 = d16.prefill_logits(ids, cls, a4)
@@ -241,15 +242,15 @@ def test_config3_128_streams_at_4k_context(dev):
     for s in range(2, 128):
         assert np.array_equal(got16[s], got16[s % 2]), s
     agree = [int(np.argmax(np.r_[got16[k][: n_chk + 1] != np.asarray(want[k]), True])) for k in range(2)]
-    print(f"configs[3]: fp32 ids == oracle over {n_chk + 1} tokens at ctx {ctx0}; bf16 first divergence from fp32 after {agree} tokens")
-    # greedy paths may part -- but only at a near tie: where the bf16 stream first leaves the fp32 ids, the token it chose sits within the bf16 logit tolerance
-    # (2 x 5e-2: both candidates move) of the reference's maximum at that step.  (Until round 4 prompts longer than 1 088 tokens took the fp32-query
+    print(f"configs[3]: fp32 ids == oracle over {n_chk + 1} tokens at ctx {ctx0}; f16 first divergence from fp32 after {agree} tokens")
+    # greedy paths may part -- but only at a near tie: where the f16 stream first leaves the fp32 ids, the token it chose sits within the 16-bit logit tolerance
+    # (2 x TOL16 = 2e-2: both candidates move) of the reference's maximum at that step.  (Until round 4 prompts longer than 1 088 tokens took the fp32-query
     # attention and this test asked for >= 1 equal token; they now run on the MFMA prefill attention like every other prompt.)
     for k in range(2):
         if agree[k] <= n_chk:
             lgk = want_lg[k * (n_chk + 1) + agree[k]]
             gap = float(lgk[want[k][agree[k]]] - lgk[int(got16[k][agree[k]])])
-            print(f"  prompt {k}: bf16 token {int(got16[k][agree[k]])} vs {want[k][agree[k]]} at step {agree[k]}: reference logit gap {gap:.4f}")
+            print(f"  prompt {k}: f16 token {int(got16[k][agree[k]])} vs {want[k][agree[k]]} at step {agree[k]}: reference logit gap {gap:.4f}")
             assert 0.0 <= gap < 2 * TOL16, (k, agree[k], gap)
 
 
@@ -282,7 +283,7 @@ def test_generate_kv_window_bound_with_large_overlap_ratio(dev):
     small.close()
 
 
-def test_bf16_greedy_divergence_rate_full_song_all_tuples(dev):
+def test_f16_greedy_divergence_rate_full_song_all_tuples(dev):
     """SURVEY.md section 7 hard part 2: the reference decodes in fp32; bf16 weights / KV flip near-tie argmaxes.  Whole configs[0]
     song (92 bars) x all 27 attribute tuples, fp32 engine vs bf16 engine, same scheduler: per-bar comparison.  A bar can only be
     compared while the two histories are still equal, so the rate is 'bars identical among bars whose context was identical'."""
@@ -295,7 +296,7 @@ def test_bf16_greedy_divergence_rate_full_song_all_tuples(dev):
     d32 = EtudeDecoder(dcfg, sd_np, "cuda", precision="fp32", max_streams=27)
     r32 = d32.generate_many(jobs, v)
     d32.close()
-    d16 = EtudeDecoder(dcfg, sd_np, "cuda", precision="bf16", max_streams=27)
+    d16 = EtudeDecoder(dcfg, sd_np, "cuda", precision="f16", max_streams=27)
     r16 = d16.generate_many(jobs, v)
     d16.close()
     comparable = same = tok = tok_same = 0

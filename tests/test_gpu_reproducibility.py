@@ -52,9 +52,9 @@ def _run(precision, n_engines, n_jobs, n_bars, reps, bar_tokens=24, stagger_s=0.
     return outs
 
 
-@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("precision", ["f16", "fp32"])
 def test_one_engine_is_reproducible(precision):
-    outs = _run(precision, 1, 54 if precision == "bf16" else 16, 4, 3)
+    outs = _run(precision, 1, 54 if precision == "f16" else 16, 4, 3)
     assert sum(len(b) for job in outs[0] for b in job) > 1000
     assert outs[1] == outs[0] and outs[2] == outs[0]
 
@@ -64,11 +64,11 @@ def test_concurrent_fp32_engines_are_reproducible():
     assert outs[1] == outs[0]
 
 
-def test_concurrent_bf16_engines_are_reproducible():
+def test_concurrent_f16_engines_are_reproducible():
     """4 engines x 54 jobs x 10 bars of 32 tokens, three times, the engines started 4 ms apart so that every engine's batched prefills
     (54 prompts, the big-tile path) fall into the other engines' decode steps -- the configuration in which 15-40 of the headline's 216
     jobs used to differ between identical runs (a build with -DETD_AD_CROSSED_PK=1 fails this test)."""
-    outs = _run("bf16", 4, 216, 10, 3, bar_tokens=32, stagger_s=0.004)
+    outs = _run("f16", 4, 216, 10, 3, bar_tokens=32, stagger_s=0.004)
     for k in (1, 2):
         differ = sum(1 for a, b in zip(outs[0], outs[k]) if a != b)
         assert differ == 0, f"concurrent bf16 engines: {differ} of {len(outs[0])} jobs differ between identical runs"
@@ -81,7 +81,7 @@ def test_decode_steps_beside_the_extract_stage_are_reproducible():
     from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig, run_engines
     from etude_amd.extractor import AMTAPC_Extractor
     cfg = EtudeDecoderConfig(**synth.decoder_dims())
-    dec = EtudeDecoder(cfg, synth.decoder_state_dict(1, {}), "cuda", precision="bf16", max_streams=54)
+    dec = EtudeDecoder(cfg, synth.decoder_state_dict(1, {}), "cuda", precision="f16", max_streams=54)
     jobs, v = _jobs(54, 4), _vocab()
     alone, _ = run_engines([dec], jobs, v, force_bar_tokens=24)()
     torch.cuda.synchronize()
@@ -113,8 +113,8 @@ def test_tokens_do_not_depend_on_the_number_of_engines():
     """the same 54 jobs on 1, 2 and 4 engines (different batch compositions, different overlap of prefills and steps): every job's
     greedy tokens are the same -- on the big-tile / fused-step paths (batches of 16 jobs and more) a row's arithmetic does not depend on
     which rows share its launch; smaller batches take other kernel paths with other bf16 roundings (tools/probe_batch_dependence.py)"""
-    ref = _run("bf16", 1, 54, 4, 1)[0]
+    ref = _run("f16", 1, 54, 4, 1)[0]
     for n in (2, 4):
-        out = _run("bf16", n, 54, 4, 1)[0]
+        out = _run("f16", n, 54, 4, 1)[0]
         differ = sum(1 for a, b in zip(ref, out) if a != b)
         assert differ == 0, f"{differ} of {len(ref)} jobs differ between 1 and {n} engines"

@@ -58,7 +58,7 @@ def _first_tokens(dec, ids, cls, a4, n_streams, temperature, top_p, seed, key0=0
     return out[:, 0].copy()
 
 
-@pytest.mark.parametrize("precision,temperature,top_p", [("fp32", 0.8, 0.9), ("fp32", 1.5, 0.6), ("bf16", 1.0, 1.0)])
+@pytest.mark.parametrize("precision,temperature,top_p", [("fp32", 0.8, 0.9), ("fp32", 1.5, 0.6), ("f16", 1.0, 1.0)])
 def test_first_token_distribution_matches_the_reference_filter(dev, precision, temperature, top_p):
     from oracle import neox
     dec = _decoder(precision, max_streams=256)
@@ -81,7 +81,7 @@ def test_first_token_distribution_matches_the_reference_filter(dev, precision, t
     assert (freq > 0).sum() > 1 or sorted_p[0] > 0.99                               # it does sample, not argmax
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "f16"])
 def test_degenerate_sampling_equals_greedy_and_seeds_reproduce(dev, precision):
     dec = _decoder(precision, max_streams=6)
     v = _vocab()

@@ -201,7 +201,7 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
 
 
 def test_config_structs_carry_their_size():
-    """ABI version 2: every config struct leads with struct_bytes and the library refuses another layout (host-only entry point)"""
+    """since ABI version 2 every config struct leads with struct_bytes and the library refuses another layout (host-only entry point)"""
     import ctypes as C
     import numpy as np
     from etude_amd import _lib

@@ -25,7 +25,7 @@ if __name__ == "__main__":
     tg = np.asarray([2, 1, 1, 1], np.int32)
     decs = []
     for e in range(E):
-        decs.append(decs[0].clone() if decs else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=1024))
+        decs.append(decs[0].clone() if decs else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=S, max_ctx=1024))
     slots = np.arange(S, dtype=np.int32)
     for rep in range(3):
         outs = []

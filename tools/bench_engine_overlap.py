@@ -29,7 +29,7 @@ if __name__ == "__main__":
     import ctypes as C
     hip = C.CDLL("libamdhip64.so")
     for e in range(4):
-        dec = decs[0].clone() if decs else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=MAXCTX)
+        dec = decs[0].clone() if decs else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=S, max_ctx=MAXCTX)
         if mask_mode != "none":
             bits = [0] * 256
             if mask_mode == "thirds":

@@ -49,7 +49,7 @@ def main():
     rng = np.random.default_rng(0)
     M = a.prompts * a.ctx
     S = max(a.rows, a.prompts)
-    eS = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=a.ctx + 600, max_prefill_rows=M)
+    eS = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=S, max_ctx=a.ctx + 600, max_prefill_rows=M)
     eP = eS.clone()
     if a.mask_steps:
         eS._ts = masked_stream(0, a.mask_steps, dev)

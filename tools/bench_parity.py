@@ -57,9 +57,9 @@ def main():
     n_jobs = a.clips * len(grid)
     n_eng = a.engines or (1 if n_jobs >= 512 else 4)
     per_eng = (n_jobs + n_eng - 1) // n_eng
-    extp = a.ext_precision or ("bf16" if a.skip_extract else a.precision)
+    extp = a.ext_precision or ("f16" if a.skip_extract else a.precision)
     exs = [AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(0), dev, max_windows=4, precision=extp) for _ in range(a.ext_engines)]
-    rows = a.prefill_rows or min(262144 if a.precision == "bf16" else 131072, per_eng * 520)
+    rows = a.prefill_rows or min(262144 if a.precision == "f16" else 131072, per_eng * 520)
     decs = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision=a.precision, max_streams=per_eng, max_prefill_rows=rows)]
     decs += [decs[0].clone() for _ in range(n_eng - 1)]
     pipe = ClipBatchPipeline(exs, decs, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=a.bar_tokens)

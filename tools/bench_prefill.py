@@ -39,7 +39,7 @@ def main():
     rng = np.random.default_rng(0)
     T = (np.full(a.prompts, a.tokens, np.int32) if not a.ragged else rng.integers(a.tokens - a.ragged, a.tokens + 1, a.prompts).astype(np.int32))
     M = int(T.sum())
-    dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=a.prompts, max_ctx=a.tokens + 64, max_prefill_rows=M)
+    dec = EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=a.prompts, max_ctx=a.tokens + 64, max_prefill_rows=M)
     st = dec._stream()
     ids = rng.integers(6, 154, M).astype(np.int32); cls = rng.integers(1, 3, M).astype(np.int32)
     a4 = np.ascontiguousarray(rng.integers(0, 3, (4, M)).astype(np.int32))

@@ -36,7 +36,7 @@ def main():
     lib = _lib.lib()
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
     max_ctx = a.max_ctx or max(2112, a.ctx + a.steps * 3 + 64)
-    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=a.rows, max_ctx=max_ctx, max_prefill_rows=max(a.rows * 64, 8192))]
+    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=a.rows, max_ctx=max_ctx, max_prefill_rows=max(a.rows * 64, 8192))]
     while len(decs) < a.engines:
         decs.append(decs[0].clone())
     rng = np.random.default_rng(0)

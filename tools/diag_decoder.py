@@ -32,7 +32,7 @@ def run(name, dims, seed, kw, limit):
     cfg = EtudeDecoderConfig(**synth.decoder_dims(**dims))
     sd = synth.decoder_state_dict(seed, dims, **kw)
     v = vocab()
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "f16"):
         dec = EtudeDecoder(cfg, sd, "cuda", precision=prec, max_streams=4)
         a4 = np.stack([g["prompt_overlap"][0], g["prompt_polyphony"][0], g["prompt_sustain"][0], g["prompt_rhythm"][0]])
         lg = dec.prefill_logits(g["prompt_ids"][0], g["prompt_cls"][0], a4)
@@ -61,7 +61,7 @@ def throughput():
     cfg = EtudeDecoderConfig(**synth.decoder_dims())
     sd = synth.decoder_state_dict(1, {})
     v = vocab()
-    for prec, S in (("fp32", 1), ("bf16", 1), ("bf16", 128), ("fp32", 128)):
+    for prec, S in (("fp32", 1), ("f16", 1), ("f16", 128), ("fp32", 128)):
         dec = EtudeDecoder(cfg, sd, "cuda", precision=prec, max_streams=S)
         jobs = []
         for s in range(S):

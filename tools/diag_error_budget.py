@@ -33,10 +33,10 @@ if __name__ == "__main__":
         ex.close()
     print(f"{'stage':8s} {'max|err|/max|ref|':>18s} {'rms err / rms ref':>18s}")
     for i, n in enumerate(names):
-        a, b = res["fp32"][0][i], res["bf16"][0][i]
+        a, b = res["fp32"][0][i], res["f16"][0][i]
         print(f"{n:8s} {np.abs(a - b).max() / np.abs(a).max():18.4e} {np.sqrt(((a - b) ** 2).mean()) / np.sqrt((a ** 2).mean()):18.4e}")
     for j, n in enumerate(("onset", "offset", "mpe")):
-        a, b = res["fp32"][1][j], res["bf16"][1][j]
+        a, b = res["fp32"][1][j], res["f16"][1][j]
         print(f"p_{n:6s} max {np.abs(a - b).max():.3e}  mean {np.abs(a - b).mean():.3e}   fraction of frames on opposite sides of 0.5: {float(((a >= 0.5) != (b >= 0.5)).mean()):.4f}")
-    lg32, lg16 = res["fp32"][2], res["bf16"][2]
-    print(f"velocity logits: max {np.abs(lg32 - lg16).max():.3e}, argmax agreement {float((res['fp32'][1][3] == res['bf16'][1][3]).mean()):.4f}")
+    lg32, lg16 = res["fp32"][2], res["f16"][2]
+    print(f"velocity logits: max {np.abs(lg32 - lg16).max():.3e}, argmax agreement {float((res['fp32'][1][3] == res['f16'][1][3]).mean()):.4f}")

@@ -9,7 +9,7 @@ from test_gpu_reproducibility import _jobs, _vocab
 from etude_amd import synth
 from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig, run_engines
 cfg = EtudeDecoderConfig(**synth.decoder_dims())
-dec = EtudeDecoder(cfg, synth.decoder_state_dict(1, {}), "cuda", precision="bf16", max_streams=54)
+dec = EtudeDecoder(cfg, synth.decoder_state_dict(1, {}), "cuda", precision="f16", max_streams=54)
 jobs, v = _jobs(54, 6), _vocab()
 full = run_engines([dec], jobs, v, force_bar_tokens=24)()[0]
 for n in (1, 2, 4, 8, 16):

@@ -8,7 +8,7 @@ from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
 dev = torch.device("cuda:0"); torch.cuda.set_device(0)
 lib = _lib.lib()
 S, ctx0, steps = 54, 320, 96
-dec = EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=1024)
+dec = EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=S, max_ctx=1024)
 rng = np.random.default_rng(0); tg = np.asarray([2, 1, 1, 1], np.int32); slots = np.arange(S, dtype=np.int32)
 prompts = [(rng.integers(6, 154, ctx0).astype(np.int32), rng.integers(1, 3, ctx0).astype(np.int32), rng.integers(0, 3, (4, ctx0)).astype(np.int32)) for _ in range(S)]
 def reset():

@@ -18,7 +18,7 @@ if __name__ == "__main__":
     n_jobs = int(sys.argv[2]) if len(sys.argv) > 2 else 216
     n_bars = int(sys.argv[3]) if len(sys.argv) > 3 else 92
     reps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-    prec = sys.argv[5] if len(sys.argv) > 5 else "bf16"
+    prec = sys.argv[5] if len(sys.argv) > 5 else "f16"
     bar_tokens = int(sys.argv[6]) if len(sys.argv) > 6 else 48          # 1: every bar is a prefill and nothing else
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)

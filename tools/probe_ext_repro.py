@@ -23,7 +23,7 @@ if __name__ == "__main__":
     lib = _lib.lib()
     S, T0 = 54, 340
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
-    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=1088)]
+    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=S, max_ctx=1088)]
     decs.append(decs[0].clone())
     ex = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(7), "cuda", max_windows=4)
     xs = torch.from_numpy(synth.window_features(5, 4)).to(dev)

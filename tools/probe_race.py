@@ -29,7 +29,7 @@ if __name__ == "__main__":
     decs = []
     own0 = len(sys.argv) > 3 and sys.argv[3] == "own0"            # the prefilling engine is NOT a clone: it has its own weights
     for e in range(4):
-        decs.append(decs[1].clone() if (own0 and e > 1) else decs[0].clone() if (decs and not (own0 and e == 1)) else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision=(os.environ.get("PROBE_PREC0") or os.environ.get("PROBE_PREC", "bf16")) if e == 0 else os.environ.get("PROBE_PREC", "bf16"), max_streams=S, max_ctx=1088))
+        decs.append(decs[1].clone() if (own0 and e > 1) else decs[0].clone() if (decs and not (own0 and e == 1)) else EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision=(os.environ.get("PROBE_PREC0") or os.environ.get("PROBE_PREC", "f16")) if e == 0 else os.environ.get("PROBE_PREC", "f16"), max_streams=S, max_ctx=1088))
     slots = np.arange(S, dtype=np.int32)
     tg = np.tile(np.asarray([2, 1, 1, 1], np.int32), S)
     eos = np.full(S, -1, np.int32); lim = np.full(S, 60, np.int32)

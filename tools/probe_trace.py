@@ -25,7 +25,7 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     lib = _lib.lib()
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
-    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="bf16", max_streams=S, max_ctx=1088)]
+    decs = [EtudeDecoder(dcfg, synth.decoder_state_dict(1, {}), dev, precision="f16", max_streams=S, max_ctx=1088)]
     decs.append(decs[0].clone())
     slots = np.arange(S, dtype=np.int32)
     tg = np.tile(np.asarray([2, 1, 1, 1], np.int32), S)
