@@ -25,13 +25,16 @@ generate()'s.  value = audio seconds taken through the WHOLE chain per wall seco
                 decode stage with all engines running (etd_decoder_stamp), algorithmic bytes from the library's exact counters;
                 decode_stage = all decode-step bytes of the timed steps / the decode stage's wall time
   cpu_baseline  the CPU oracle on this node's host cores, bounded sample (rank 0, N = 1 only)
-  extras        configs[2] (extractor only), configs[1] (one clip), configs[3] (128 streams at ctx 512 and 3.5 k), parity_mode (the chain with fp32 extractor + fp32
-                decoder on 8 of the clips: what exact parity costs), outside the timed region
+  extras        outside the timed region: configs[2] (extractor only), configs[1] (one clip), configs[3] (128 streams at ctx 512 and 3.5 k); parity_mode (the chain with the fp32
+                extractor + fp32 decoder on the largest of 64 / 32 / 16 / 8 clips the budget allows -- what exact parity costs -- with its own roofline and, as
+                parity_mode.oracle_check, the CPU oracle's bars of cpu_baseline() compared id by id with that pass's job for the same clip / tuple / bars); ragged_bars (the
+                reference's stopping rule -- Bar_EOS, 512 / 25 600 limits -- under continuous batching, and the reference's own 13 217 ids of tests/golden/clip_ctx.npz in the
+                exact-parity mode); n8_share (one rank's share of the N = 8 run); bar_tokens_144 (the decode stage at 144 forced tokens per bar)
 Harness budget: the driver runs `--steps 20 --warmup 5` under a 600 s wall-clock limit; bench.py plans against ETD_BENCH_BUDGET_S (default 560 s, counted from process
 start).  The first warm-up step is always a full step (and the estimate).  The other warm-up steps are full steps only if that leaves room for everything that follows the
-timed steps (~90 s: 24 stamped bars, serial event pass, extras incl. the exact-parity pass, CPU baseline); otherwise they run 4 bars per job (same launches, same widths:
-everything is allocated, captured and cached by then).  Behind the timed steps the optional parts are shed in this order when the run is late: extras.parity_mode (bars, then
-clips), the extras, the serial pass, the stamped stage 24 -> 8 bars; the CPU baseline goes last.  Only if K full steps + that minimum cannot fit does the batch per step shrink
+timed steps (~130 s: 24 stamped bars, serial event pass, extras incl. the exact-parity pass, CPU baseline); otherwise they run 4 bars per job (same launches, same widths:
+everything is allocated, captured and cached by then).  Behind the timed steps the optional parts are sized / shed by the time left: extras.parity_mode (clips 64 -> 32 -> 16 -> 8, then bars), bar_tokens_144 (clips), ragged_bars,
+n8_share, the configs[1..3] extras, the serial pass, the stamped stage 24 -> 8 bars; the CPU baseline goes last.  Only if K full steps + that minimum cannot fit does the batch per step shrink
 (32 / 16 / 8 clips per rank) -- all of it written into config.workload / config.warmup_step.  The K timed steps are always full steps of the stated batch.
 """
 from __future__ import annotations
@@ -58,12 +61,22 @@ sys.path.insert(0, str(ROOT))
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 / f16 MFMA (MI355X_MICROARCH.md: the F16 forms take the same cycles)
 PEAK_HBM_GBS = 8000.0         # HBM3E spec
 T_START = time.perf_counter()
-# cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r05_parity_full.json): fp32 engines' set-up + warm-up pass, then per clip the fp32
-# extract, the fp32 decode of its 27 jobs x all bars, and the 16-bit decode of the same jobs
-PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "8"))
-PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.2"))
-PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "1.5"))
+# cost model of extras.parity_mode (seconds, measured on one MI355X: profiles/r05_parity_full.json, one engine x 27 * clips streams from 512 jobs up): fp32 engines' set-up +
+# warm-up pass, then per clip the fp32 extract, the fp32 decode of its 27 jobs x all bars (+ its share of the 8 stamped bars); the 16-bit decode of the same jobs
+# (the per-bar divergence) runs on the first 8 clips only
+PARITY_FIXED_S = float(os.environ.get("ETD_PARITY_FIXED_S", "9"))
+PARITY_EXTRACT_S_PER_CLIP = float(os.environ.get("ETD_PARITY_EXTRACT_S", "0.14"))
+PARITY_DECODE_S_PER_CLIP = float(os.environ.get("ETD_PARITY_DECODE_S", "0.75"))
+PARITY_DECODE_S_PER_CLIP_SMALL = float(os.environ.get("ETD_PARITY_DECODE_SMALL_S", "1.5"))      # 8 clips: 4 x 54 streams, the latency-bound regime
 PARITY_F16_S_PER_CLIP = float(os.environ.get("ETD_PARITY_F16_S", "0.45"))
+PARITY_F16_CLIPS = 8
+
+
+def parity_cost(clips: int, bars: int, nb_mean: float) -> float:
+    """estimated wall seconds of parity_mode_extras(clips, bars)"""
+    dec = PARITY_DECODE_S_PER_CLIP if clips * 27 >= 512 else PARITY_DECODE_S_PER_CLIP_SMALL
+    frac = (bars or nb_mean) / nb_mean
+    return PARITY_FIXED_S + clips * (PARITY_EXTRACT_S_PER_CLIP + dec * (frac + 8.0 / nb_mean)) + min(clips, PARITY_F16_CLIPS) * PARITY_F16_S_PER_CLIP * frac
 
 
 def since_process_start() -> float:
@@ -178,10 +191,12 @@ def cpu_baseline(bars, seconds_budget: float = 25.0, clip_seconds: float = 180.0
     at_t = {neox.ATTR_KEY_MAP[k]: torch.tensor([al[k]]) for k in user_keys}
     kv = None
     ntok = 0
+    steady = [4]                 # (Bar_BOS: bar_bos_id 4 of the generate_ids call above)
     with torch.no_grad():
         for _ in range(bar_tokens):
             logits, kv = neox.forward_logits(tsd, neox.NeoxDims(), ids_t, cls_t, at_t, kv)
             nxt = int(torch.argmax(logits[:, -1, :], dim=-1).item())
+            steady.append(nxt)
             ntok += 1
             ids_t, cls_t = torch.tensor([[nxt]]), torch.tensor([[2]])
             at_t = {neox.ATTR_KEY_MAP[k]: torch.tensor([[synth.attrs()[k]]]) for k in user_keys}
@@ -197,7 +212,8 @@ def cpu_baseline(bars, seconds_budget: float = 25.0, clip_seconds: float = 180.0
                       f"oracle generate on one clip's own condition bars: {nb - 1} ramp-up bars in {t_ramp:.1f}s, then ONE steady-state bar "
                       f"(prompt of {len(toks)} tokens + {bar_tokens} forced tokens) in {t_bar:.1f}s on {dthreads} threads",
             "extract_audio_s_per_s": round(nwin * 8.192 / t_ext, 4),
-            "decoder_tokens_per_s": round(bar_tokens / t_bar, 2), "decoder_cores": dthreads}
+            "decoder_tokens_per_s": round(bar_tokens / t_bar, 2), "decoder_cores": dthreads,
+            "_oracle_ids": [list(b) for b in out] + [steady]}      # (popped by the caller: the checker leg compares them with the device engines' ids)
 
 def default_engines(n_jobs: int, world: int = 1) -> int:
     """decoder engines for `n_jobs` jobs on one rank when --engines is not given: whatever measured fastest (round 5, profiles/r05_engines.txt: 64 clips on one GPU 567 /
@@ -286,12 +302,23 @@ def bar_divergence(ra, rb):
     return same, comparable, jobs_same
 
 
+DEFAULT_TUPLE_INDEX = 13      # (polyphony, rhythm, sustain) = (1, 1, 1) in pipeline.attr_grid(27): infer.py's CLI defaults, the tuple cpu_baseline() decodes
+
+
+def first_bars(flat, lens, n):
+    """the first n bars of one job's (flat ids, bar lengths) as id lists"""
+    ends = np.cumsum(np.asarray(lens, np.int64))
+    return [np.asarray(flat[e - l: e]).tolist() for l, e in zip(np.asarray(lens).tolist()[:n], ends.tolist()[:n])]
+
+
 def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engines, time_left):
     """extras.parity_mode: what exact parity costs.  north_star's "identical token-id sequences under greedy decode" holds in the fp32 mode (the reference
     runs fp32: etude_decoder.py:333); the headline is timed in the 16-bit serving mode (IEEE-half operands).  The SAME chain (extract .. notes) on the first `n_clips` clips of this rank with the fp32
-    extractor and fp32 decoder engines (every dense contraction at fp32 grade on the f16 matrix cores: csrc/gemm3.h), ONE timed pass after a 2-bar warm-up pass;
-    then a few stamped steady-state bars for the roofline of the fp32 attention launches; then the 16-bit decoder on the SAME condition bars (the fp32 extractor's)
-    for the per-bar divergence of the two decoders.  Whatever happens, every engine and the extractor are closed on the way out."""
+    extractor and fp32 decoder engines (every dense contraction at fp32 grade on the f16 matrix cores: csrc/gemm3.h) -- from 512 jobs up ONE engine x 27 * n_clips streams, the layout
+    tests/test_gpu_decoder_parity.py holds to the oracle at 1 728 rows -- ONE timed pass after a 2-bar warm-up pass; then 8 stamped bars (4 of them steady-state) for the roofline of the
+    fp32 attention launches; then the 16-bit decoder on the SAME condition bars (the fp32 extractor's; the first 8 clips) for the per-bar divergence of the two decoders.
+    Returns (dict for the JSON line, oracle-check material or None): the first five condition bars of clip 0 and the ids the fp32 (and 16-bit) engines generated for them with the
+    default attribute tuple, INSIDE this batch -- what cpu_baseline()'s oracle bars are compared with.  Whatever happens, every engine and the extractor are closed on the way out."""
     import torch
     from etude_amd import synth
     from etude_amd.config import ExtractorConfig
@@ -303,6 +330,7 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engi
     n_eng = 1 if n_jobs >= 512 else (4 if n_jobs >= 64 else 1)
     per_eng = (n_jobs + n_eng - 1) // n_eng
     ex32 = None; d32 = []; pipe32 = None; pipe16 = None
+    check = None
     try:
         ex32 = AMTAPC_Extractor(ExtractorConfig(), synth.extractor_state_dict(0), dev, max_windows=4, precision="fp32")
         d32 = [EtudeDecoder(EtudeDecoderConfig(**synth.decoder_dims()), synth.decoder_state_dict(1, {}), dev, precision="fp32", max_streams=per_eng,
@@ -337,13 +365,17 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engi
                            f"+ fp32 decoder (fp32 weights, KV cache and activations; every dense contraction as a two-plane f16 split, three MFMAs per product, fp32 accumulate: "
                            f"csrc/gemm3.h; {n_eng} engine(s) x {per_eng} streams), {args.bar_tokens} tokens per bar"
                            + (f"; ONLY THE FIRST {max_bars} BARS of every job were decoded to stay inside the harness budget (audio_s_per_s scales the decode stage to all bars)" if max_bars else ""),
+               "clips": n_clips, "jobs": n_jobs, "engines": n_eng, "streams_per_engine": per_eng,
                "extract_s": round(t1 - t0, 3), "decode_s": round(t2 - t1, 3), "notes_s": round(t3 - t2, 3),
                "audio_s_per_s": round(args.seconds * n_clips / ((t1 - t0) + (t2 - t1) / frac + (t3 - t2) / frac), 2),
                "extract_audio_s_per_s": round(args.seconds * n_clips / (t1 - t0), 1), "decoder_tokens_per_s": round(ntok / (t2 - t1), 1),
                "tokens_sha256": hashlib.sha256(np.concatenate([r[0] for r in res32]).astype(np.int32).tobytes()).hexdigest()[:16],
-               "full_batch": "profiles/r05_parity_full.json: the same mode on the whole 64-clip batch (one engine x 1728 streams), a gpurun of tools/bench_parity.py --clips 64 --stamp"}
+               "full_batch": "profiles/r06_parity_full.json: the same mode on the whole 64-clip batch (one engine x 1728 streams), a gpurun of tools/bench_parity.py --clips 64 --stamp"}
+        if len(grid) > DEFAULT_TUPLE_INDEX and len(conds[0].bars) >= 5 and (not max_bars or max_bars >= 5):
+            check = {"bars": [conds[0].bars.bar(i) for i in range(5)], "fp32": first_bars(*res32[DEFAULT_TUPLE_INDEX], 5),
+                     "where": f"job (clip 0, tuple (1, 1, 1)) of the exact-parity batch above: row {DEFAULT_TUPLE_INDEX} of {per_eng} rows per launch on engine 0 of {n_eng}"}
         # roofline of the fp32 attention launches (k_dattn<float>: 4-byte K / V, no weights in the launch), steady-state bars, device stamps as for the headline
-        if time_left() > 20.0 and nb_mean >= 8:
+        if time_left() > 12.0 + 8.0 * per_bar * 1.5 and nb_mean >= 8:
             for d in d32:
                 d.stamp(True, skip_steps=4 * (args.bar_tokens - 1))
                 d.stats_reset()
@@ -356,27 +388,30 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engi
             if launches > 0 and secs > 0:
                 out["roofline"] = {"kernel": "k_dattn<float>", "bound": "hbm", "achieved": round(byts / secs / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                    "frac": round(byts / secs / 1e9 / PEAK_HBM_GBS, 4), "launches": int(launches), "avg_launch_ms": round(1e3 * secs / launches, 5),
-                                   "alg_bytes_per_launch": byts / launches, "traffic": None,
+                                   "alg_bytes_per_launch": byts / launches, "rows_per_launch": per_eng, "traffic": None,
                                    "note": "device stamps of every attention launch of bars 4-7 (steady-state contexts), all engines running; algorithmic bytes = fp32 K + V rows of every (row, head) context"}
         for d in reversed(d32):
             d.close()
         d32 = []
         pipe32.close(); pipe32 = None
-        # the 16-bit decoder on the same condition bars: the headline's engines when they hold enough streams, else nothing (no new allocations this late)
-        if time_left() > 25.0 and f16_engines and sum(d.max_streams for d in f16_engines) >= n_jobs:
+        # the 16-bit decoder on the same condition bars (the first 8 clips of the pass): the headline's engines when they hold enough streams, else nothing (no new allocations this late)
+        n16 = min(n_clips, PARITY_F16_CLIPS)
+        j16 = n16 * len(grid)
+        if time_left() > 6.0 + n16 * PARITY_F16_S_PER_CLIP * frac * 1.5 and f16_engines and sum(d.max_streams for d in f16_engines) >= j16:
             pipe16 = ClipBatchPipeline([ex32], f16_engines, vocab, synthetic_tempo(), grid, 44100, force_bar_tokens=args.bar_tokens)
             t4 = time.perf_counter()
-            res16, st16 = pipe16.decode_stage(conds, max_bars=max_bars)
+            res16, st16 = pipe16.decode_stage(conds[:n16], max_bars=max_bars)
             torch.cuda.synchronize(dev)
             t5 = time.perf_counter()
-            same, comparable, jobs_same = bar_divergence(res32, res16)
-            out["f16_same_conditions"] = {"decode_s": round(t5 - t4, 3), "decoder_tokens_per_s": round(sum(s["tokens"] for s in st16) / (t5 - t4), 1),
+            same, comparable, jobs_same = bar_divergence(res32[:j16], res16)
+            out["f16_same_conditions"] = {"clips": n16, "decode_s": round(t5 - t4, 3), "decoder_tokens_per_s": round(sum(s["tokens"] for s in st16) / (t5 - t4), 1),
                                            "bars_identical": same, "bars_comparable": comparable, "bar_divergence_rate": round(1.0 - same / max(1, comparable), 5),
-                                           "jobs_identical_end_to_end": jobs_same, "jobs": len(res32),
-                                           "note": "the headline's 16-bit decoder engines (IEEE-half weights and KV cache; rounds 1-4: bf16, 8.5 % of the bars diverged) on the fp32 extractor's condition bars; a bar is comparable while both histories are still equal"}
-            out["fp32_over_f16_decode_time"] = round((t2 - t1) / (t5 - t4), 2)
+                                           "jobs_identical_end_to_end": jobs_same, "jobs": j16,
+                                           "note": f"the headline's 16-bit decoder engines (IEEE-half weights and KV cache; rounds 1-4: bf16, 8.5 % of the bars diverged) on the fp32 extractor's condition bars of the first {n16} clips; a bar is comparable while both histories are still equal"}
+            if check is not None:
+                check["f16"] = first_bars(*res16[DEFAULT_TUPLE_INDEX], 5)
         out["wall_s"] = round(time.perf_counter() - t_in, 2)
-        return out
+        return out, check
     finally:
         for d in reversed(d32):
             try:
@@ -394,6 +429,108 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engi
                 ex32.close()
             except Exception:      # noqa: BLE001
                 pass
+
+
+def ragged_bars_extras(args, dev, conds, grid, vocab, time_left):
+    """extras.ragged_bars: the reference's OWN stopping rule under load (etude_decoder.py:300-352): a bar ends at Bar_EOS or after max_bar_token_limit = 512 tokens, the song at
+    max_output_tokens = 25 600.  The benchmark weights never emit Bar_EOS at a musically meaningful rate, so this uses the context weights of the goldens
+    (synth.decoder_state_dict_ctx: on the reference's configs[1] song 81 of 92 bars end in Bar_EOS, mean ~144 tokens): 8 of the batch's clips x 27 tuples on 4 engines x 54 streams of
+    the 16-bit serving mode, ragged bars under continuous batching (a stream that ends its bar waits for the engine's next begin_bars pass; the scheduler admits the next bar of every
+    finished stream together).  Reported: tokens/s, bars ended by EOS, tokens per bar, mean active rows per decode step (scheduler occupancy = that / streams).
+    Then, in the EXACT-PARITY mode, the reference's own song: tests/golden/clip_ctx.npz -- the (1,1,1) job of the configs[1] clip (seed 1234, the reference's condition bars from
+    clip_full.npz), 13 217 ids generated by the reference's generate(): `clip_ctx_ids_identical`."""
+    import torch
+    from etude_amd import synth
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig, run_engines
+    n_clips = min(8, len(conds))
+    n_jobs = n_clips * len(grid)
+    n_eng = default_engines(n_jobs, 8)
+    per_eng = (n_jobs + n_eng - 1) // n_eng
+    decs = []
+    out = {}
+    try:
+        sd = synth.decoder_state_dict_ctx(1)
+        dcfg = EtudeDecoderConfig(**synth.decoder_dims())
+        decs = [EtudeDecoder(dcfg, sd, dev, precision="f16", max_streams=per_eng, max_prefill_rows=min(262144, per_eng * 520))]
+        decs += [decs[0].clone() for _ in range(n_eng - 1)]
+        a4s = [np.asarray([a[k] for k in ("pitch_overlap_bin", "polyphony_bin", "sustain_bin", "rhythm_intensity_bin")], np.int32) for a in grid]
+        jobs = [(cd.bars, np.tile(a4, (len(cd.bars), 1))) for cd in conds[:n_clips] for a4 in a4s]
+        kw = dict(max_output_tokens=25600, max_bar_token_limit=512, temperature=0.0, as_arrays=True)
+        short = [(type(j[0])(j[0].ids[: j[0].offsets[2]], j[0].offsets[:3]), j[1][:2]) for j in jobs]
+        run_engines(decs, short, vocab, **kw)()                  # allocations, graph captures
+        torch.cuda.synchronize(dev)
+        for d in decs:
+            d.stats_reset()
+        t0 = time.perf_counter()
+        res, st = run_engines(decs, jobs, vocab, **kw)()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        dst = [d.stats() for d in decs]
+        eos = vocab.get_bar_eos_id()
+        lens = np.concatenate([r[1] for r in res]) - 1                         # generated tokens per bar (Bar_BOS is the prompt's)
+        n_bars = int(lens.size)
+        ends = [np.cumsum(r[1]) for r in res]
+        n_eos = int(sum(int((r[0][e - 1] == eos).sum()) for r, e in zip(res, ends)))
+        ntok = int(sum(s["tokens"] for s in st))
+        steps = sum(s["steps"] for s in dst); row_steps = sum(s["row_steps"] for s in dst)
+        out = {"workload": f"{n_clips} of the batch's clips x {len(grid)} tuples = {n_jobs} jobs, context weights (synth.decoder_state_dict_ctx), the reference's stopping rule: Bar_EOS ends a bar, "
+                           f"max_bar_token_limit 512, max_output_tokens 25600; 16-bit serving mode, {n_eng} engines x {per_eng} streams, each clip's own condition bars, one pass after a 2-bar warm-up pass",
+               "decode_s": round(dt, 3), "tokens": ntok, "decoder_tokens_per_s": round(ntok / dt, 1), "bars": n_bars, "bars_ended_by_eos": n_eos,
+               "tokens_per_bar_mean": round(float(lens.mean()), 1), "tokens_per_bar_max": int(lens.max()), "jobs_at_max_output_tokens": int(sum(int(r[1].sum() - len(r[1]) >= 25600) for r in res)),
+               "decode_steps": int(steps), "mean_active_rows_per_step": round(row_steps / max(1.0, steps), 2), "scheduler_occupancy": round(row_steps / max(1.0, steps) / per_eng, 4),
+               "audio_s_per_s_decode_only": round(args.seconds * n_clips / dt, 1)}
+        for d in reversed(decs):
+            d.close()
+        decs = []
+        # ---- the reference's own ids for the configs[1] song under this rule, exact-parity mode
+        gdir = ROOT / "tests" / "golden"
+        if time_left() > 14.0 and (gdir / "clip_ctx.npz").exists() and (gdir / "clip_full.npz").exists():
+            gc, gf = np.load(gdir / "clip_ctx.npz"), np.load(gdir / "clip_full.npz")
+            flat, bl = gf["bar_ids"].tolist(), gf["bar_lens"].tolist()
+            bars, p_ = [], 0
+            for l in bl:
+                bars.append(flat[p_: p_ + l]); p_ += l
+            d32 = EtudeDecoder(dcfg, sd, dev, precision="fp32", max_streams=1)
+            decs = [d32]
+            t0 = time.perf_counter()
+            got = d32.generate_ids(vocab, bars, [synth.attrs(1, 1, 1, 2)] * len(bars), temperature=0.0)
+            dt32 = time.perf_counter() - t0
+            ids = [t for b_ in got for t in b_]
+            ref = gc["gen_ids"].tolist()
+            out["clip_ctx_fp32"] = {"what": "tests/golden/clip_ctx.npz: the reference's generate() (default limits, Bar_EOS ends bars) on the configs[1] clip's 92 condition bars, tuple (1,1,1,2), "
+                                            "context weights; here the exact-parity engine, one stream",
+                                    "ids": len(ids), "reference_ids": len(ref), "clip_ctx_ids_identical": bool(ids == ref), "decode_s": round(dt32, 2),
+                                    "decoder_tokens_per_s": round((len(ids) - len(got)) / dt32, 1)}
+        return out
+    finally:
+        for d in reversed(decs):
+            try:
+                d.close()
+            except Exception:      # noqa: BLE001
+                pass
+
+
+def bar_tokens_sensitivity(args, dev, pipe, conds, n_clips, bar_tokens, headline_tokens_per_s):
+    """extras.bar_tokens_144: the headline depends on the 48 generated tokens per bar SURVEY 8(d) sanctioned; the reference's goldens average 144-279 tokens per bar.  One decode
+    stage of the first `n_clips` clips' jobs on the headline's engines at `bar_tokens` forced tokens per bar (contexts grow to 513 + bar_tokens)."""
+    import torch
+    old = pipe.force_bar_tokens
+    try:
+        pipe.force_bar_tokens = bar_tokens
+        sub = conds[:n_clips]
+        pipe.decode_stage(sub, max_bars=2)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        res, st = pipe.decode_stage(sub)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        ntok = sum(s["tokens"] for s in st)
+        return {"workload": f"the decode stage of {n_clips} clips x {len(pipe.attrs)} tuples on the headline's {len(pipe.decs)} engines at {bar_tokens} forced tokens per bar instead of {old} "
+                            "(extract and notes stages unchanged)", "clips": n_clips, "bar_tokens": bar_tokens, "decode_s": round(dt, 3), "tokens": int(ntok),
+                "decoder_tokens_per_s": round(ntok / dt, 1), "vs_headline_decoder_tokens_per_s": round(ntok / dt / headline_tokens_per_s, 3),
+                "decode_s_per_clip": round(dt / n_clips, 4)}
+    finally:
+        pipe.force_bar_tokens = old
 
 
 def main():
@@ -419,9 +556,9 @@ def main():
     ap.add_argument("--max-bars", type=int, default=0, help="diagnostics / profiling passes only: decode just the first N bars of every job (stated in config.workload)")
     ap.add_argument("--budget-s", type=float, default=float(os.environ.get("ETD_BENCH_BUDGET_S", "560")))
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--parity-clips", type=int, default=int(os.environ.get("ETD_PARITY_CLIPS", "8")),
-                    help="extras.parity_mode: clips taken through the chain in the exact-parity mode (fp32 extractor + fp32 decoder); 0 = skip.  Runs only when the harness "
-                         "budget has room for it (fewer bars per job, then fewer clips, are the first things shed)")
+    ap.add_argument("--parity-clips", type=int, default=int(os.environ.get("ETD_PARITY_CLIPS", "64")),
+                    help="extras.parity_mode: at most this many clips are taken through the chain in the exact-parity mode (fp32 extractor + fp32 decoder): the largest of "
+                         "64 / 32 / 16 / 8 that the harness budget has room for (then fewer bars per job); 0 = skip")
     ap.add_argument("--parity-bars", type=int, default=0, help="extras.parity_mode: decode only the first N bars of every job (0 = by the time left)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the short HIP-event pass (PMC profiling runs: its eager launches would be counted with the step's)")
@@ -558,7 +695,7 @@ def main():
         short = lambda t: 0.12 * t + 0.5                      # noqa: E731  (a 4-bar step: the whole extract stage + 4 of 92 bars)
         # full warm-up steps only if they leave room for EVERYTHING that follows the timed steps (24 stamped bars, serial pass, extras incl. the exact-parity pass,
         # CPU baseline: ~90 s); otherwise the warm-up steps shrink first -- they are untimed and everything is allocated, captured and cached after the first one
-        FULL_POST_S = 0.27 * t_first + 4.0 + 14.0 + (PARITY_FIXED_S + args.parity_clips * (PARITY_EXTRACT_S_PER_CLIP + PARITY_DECODE_S_PER_CLIP + PARITY_F16_S_PER_CLIP)) + 30.0
+        FULL_POST_S = 0.27 * t_first + 4.0 + 14.0 + parity_cost(max(1, min(args.parity_clips, 32, clips)), 0, 92.0) + 16.0 + 11.0 + 30.0
         if since + (rest + args.steps) * t_first + max(OVERHEAD_S, FULL_POST_S if rest > 0 else 0.0) > args.budget_s:
             if since + args.steps * t_first + rest * short(t_first) + OVERHEAD_S <= args.budget_s:
                 warm_mode = "first warm-up step full, the others 4 bars per job (W + K full steps exceed the harness budget)"
@@ -807,40 +944,95 @@ def main():
             except Exception as e:
                 extras[key] = {"error": repr(e)}
 
-    # ---- extras.parity_mode: the cost of exact parity (fp32 extractor + fp32 decoder), sized to the time that is left
+    # ---- extras.parity_mode: the cost of exact parity (fp32 extractor + fp32 decoder) on the LARGEST of 64 / 32 / 16 / 8 clips the time left allows (one engine x 27 * clips streams)
+    oracle_check = None
+    nb_mean = float(np.mean(nbars))
+    RAGGED_S, N8_S, BT144_S = 16.0, 11.0, 6.0          # what the extras behind this one need (reserved while sizing it)
     if not args.no_extras and rank == 0 and args.parity_clips > 0:
         extras = result.setdefault("extras", {})
-        nb_mean = float(np.mean(nbars))
-        cost = lambda c, b: PARITY_FIXED_S + c * (PARITY_EXTRACT_S_PER_CLIP + (PARITY_DECODE_S_PER_CLIP + PARITY_F16_S_PER_CLIP) * (b or nb_mean) / nb_mean)   # noqa: E731
-        cands = [(args.parity_clips, args.parity_bars)] if args.parity_bars else \
-                [(c, b) for c in sorted({args.parity_clips, max(1, args.parity_clips // 2), max(1, args.parity_clips // 4)}, reverse=True) for b in (0, 24, 8)]
-        pick = next(((c, b) for c, b in cands if c <= len(wavs) and cost(c, b) < time_left() - CPU_RESERVE_S - 5.0), None)
+        want = [c for c in (64, 32, 16, 8, 4, 2, 1) if c <= min(args.parity_clips, len(wavs))] or [min(args.parity_clips, len(wavs))]
+        cands = [(want[0], args.parity_bars)] if args.parity_bars else [(c, 0) for c in want] + [(want[-1], 24), (want[-1], 8)]
+        room = lambda: time_left() - CPU_RESERVE_S - (RAGGED_S + N8_S if world == 1 else 0.0) - 5.0      # noqa: E731
+        pick = next(((c, b) for c, b in cands if parity_cost(c, b, nb_mean) < room()), None)
         if pick is None:
-            extras["parity_mode"] = {"skipped": f"{time_left():.0f} s of the harness budget left: not enough for the smallest exact-parity pass ({cost(*cands[-1]):.0f} s estimated); "
+            extras["parity_mode"] = {"skipped": f"{time_left():.0f} s of the harness budget left: not enough for the smallest exact-parity pass ({parity_cost(*cands[-1], nb_mean):.0f} s estimated); "
                                                 "python bench.py --steps 1 --warmup 1 runs it whole (profiles/)"}
         else:
             try:
-                extras["parity_mode"] = parity_mode_extras(args, dev, wavs, grid, vocab, pick[0], pick[1], decs, lambda: time_left() - CPU_RESERVE_S)
+                log(f"extras.parity_mode: {pick[0]} clips" + (f", {pick[1]} bars" if pick[1] else "") + f" (estimated {parity_cost(*pick, nb_mean):.0f} s, {time_left():.0f} s left)")
+                extras["parity_mode"], oracle_check = parity_mode_extras(args, dev, wavs, grid, vocab, pick[0], pick[1], decs, lambda: time_left() - CPU_RESERVE_S)
             except Exception as e:      # extras must never take the headline down
                 extras["parity_mode"] = {"error": repr(e)}
 
-    # ---- extras.n8_share: the per-rank batch of the N = 8 run, measured on this GPU (the scaling expectation the N = 1 line carries)
-    if not args.no_extras and rank == 0 and world == 1 and clips >= 8 and time_left() > CPU_RESERVE_S + 25.0:
+    # ---- extras.ragged_bars: the reference's own stopping rule (Bar_EOS ends a bar; 512 / 25 600 limits) under continuous batching, + the reference's ids for clip_ctx.npz
+    if not args.no_extras and rank == 0 and world == 1 and clips >= 8 and time_left() > CPU_RESERVE_S + N8_S + RAGGED_S:
         try:
+            log(f"extras.ragged_bars ({time_left():.0f} s left)")
+            result.setdefault("extras", {})["ragged_bars"] = ragged_bars_extras(args, dev, conds, grid, vocab, lambda: time_left() - CPU_RESERVE_S - N8_S)
+        except Exception as e:      # extras must never take the headline down
+            result.setdefault("extras", {})["ragged_bars"] = {"error": repr(e)}
+
+    # ---- extras.n8_share: the per-rank batch of the N = 8 run, measured on this GPU (the scaling expectation the N = 1 line carries)
+    if not args.no_extras and rank == 0 and world == 1 and clips >= 8 and time_left() > CPU_RESERVE_S + N8_S:
+        try:
+            log(f"extras.n8_share ({time_left():.0f} s left)")
             result.setdefault("extras", {})["n8_share"] = n8_share_extras(args, dev, exs, wavs, grid, vocab, result["value"])
         except Exception as e:      # extras must never take the headline down
             result.setdefault("extras", {})["n8_share"] = {"error": repr(e)}
+
+    # ---- extras.bar_tokens_144: the headline's sensitivity to the 48 forced tokens per bar (as many clips as the time left allows; a 64-clip decode stage at 144 tokens is ~45 s)
+    if not args.no_extras and rank == 0 and world == 1 and args.bar_tokens != 144:
+        per_clip = 3.2 * (t_dec / max(1, args.steps)) / max(1, clips)          # ~3 x the tokens at longer contexts
+        nc = next((c for c in (64, 32, 16, 8) if c <= clips and 1.15 * c * per_clip + 3.0 < time_left() - CPU_RESERVE_S), 0)
+        if nc:
+            try:
+                log(f"extras.bar_tokens_144: {nc} clips ({time_left():.0f} s left)")
+                result.setdefault("extras", {})["bar_tokens_144"] = bar_tokens_sensitivity(args, dev, pipe, conds, nc, 144, result["decoder_tokens_per_s"])
+            except Exception as e:      # extras must never take the headline down
+                result.setdefault("extras", {})["bar_tokens_144"] = {"error": repr(e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline and late(6.0):
         result["cpu_baseline"] = {"skipped": "the run is within 6 s of its harness budget"}
     elif rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cd0 = conds[0]
-            bars0 = [cd0.bars.bar(i) for i in range(min(5, len(cd0.bars)))]
-            if args.synthetic_bars:
-                bars0 = synth.song_bars(seed=1234, n_bars=5)
-            result["cpu_baseline"] = cpu_baseline(bars0, clip_seconds=args.seconds, windows_per_clip=result["config"]["windows_per_clip"], attr_tuples=args.attr_grid,
-                                                  bars_per_job=int(np.mean(nbars)), bar_tokens=args.bar_tokens)
+            # the oracle decodes the first five condition bars of clip 0 with the default tuple: the exact-parity pass's bars (the fp32 extractor's) when it ran -- its ids for the
+            # same job are then compared with the oracle's -- else the headline's
+            if oracle_check is not None:
+                bars0 = oracle_check["bars"]
+            else:
+                cd0 = conds[0]
+                bars0 = [cd0.bars.bar(i) for i in range(min(5, len(cd0.bars)))]
+                if args.synthetic_bars:
+                    bars0 = synth.song_bars(seed=1234, n_bars=5)
+            cb = cpu_baseline(bars0, clip_seconds=args.seconds, windows_per_clip=result["config"]["windows_per_clip"], attr_tuples=args.attr_grid,
+                              bars_per_job=int(np.mean(nbars)), bar_tokens=args.bar_tokens)
+            oracle_ids = cb.pop("_oracle_ids", None)
+            result["cpu_baseline"] = cb
+            # ---- the CHECKER leg: the oracle's greedy ids of those bars against the engines' ids for the same clip / tuple / bars
+            if oracle_ids is not None and not args.no_extras:
+                cmp_ = lambda got: sum(int(list(a_) == list(b_)) for a_, b_ in zip(got, oracle_ids))      # noqa: E731
+                chk = {"bars": len(oracle_ids), "tokens_per_bar": args.bar_tokens,
+                       "what": "cpu_baseline()'s oracle bars (oracle.neox: bars 0-3 through generate_ids, bar 4 -- the first with a full 4-pair history, prompt at the 512-token truncation -- "
+                               "through forward_logits) against the ids the device engines generated for the SAME clip 0 / tuple (1,1,1,2) / condition bars"}
+                if oracle_check is not None:
+                    chk["oracle_bars_identical"] = f"{cmp_(oracle_check['fp32'])}/{len(oracle_ids)}"
+                    chk["fp32_engine"] = oracle_check["where"]
+                    if "f16" in oracle_check:
+                        chk["oracle_bars_identical_f16"] = f"{cmp_(oracle_check['f16'])}/{len(oracle_ids)}"
+                    result.setdefault("extras", {}).setdefault("parity_mode", {})["oracle_check"] = chk
+                else:
+                    # no exact-parity pass in this run: a one-stream fp32 engine on the headline's bars (not the wide launch shape; stated)
+                    from etude_amd.decoder import EtudeDecoder as _ED
+                    d1 = _ED(dcfg, synth.decoder_state_dict(1, {}), dev, precision="fp32", max_streams=1)
+                    try:
+                        got = d1.generate_many([(bars0, [synth.attrs()] * len(bars0))], vocab, force_bar_tokens=args.bar_tokens)[0]
+                    finally:
+                        d1.close()
+                    chk["oracle_bars_identical"] = f"{cmp_(got)}/{len(oracle_ids)}"
+                    chk["fp32_engine"] = "a ONE-stream fp32 engine on the headline's (16-bit extractor's) bars: the exact-parity batch pass did not fit this run"
+                    if not args.synthetic_bars and len(results) > DEFAULT_TUPLE_INDEX:
+                        chk["oracle_bars_identical_f16"] = f"{cmp_(first_bars(*results[DEFAULT_TUPLE_INDEX], len(oracle_ids)))}/{len(oracle_ids)}"
+                    result.setdefault("extras", {})["oracle_check"] = chk
         except Exception as e:
             result["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:
