@@ -311,7 +311,7 @@ def first_bars(flat, lens, n):
     return [np.asarray(flat[e - l: e]).tolist() for l, e in zip(np.asarray(lens).tolist()[:n], ends.tolist()[:n])]
 
 
-def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engines, time_left):
+def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engines, time_left, headline_decode_s_per_clip=None):
     """extras.parity_mode: what exact parity costs.  north_star's "identical token-id sequences under greedy decode" holds in the fp32 mode (the reference
     runs fp32: etude_decoder.py:333); the headline is timed in the 16-bit serving mode (IEEE-half operands).  The SAME chain (extract .. notes) on the first `n_clips` clips of this rank with the fp32
     extractor and fp32 decoder engines (every dense contraction at fp32 grade on the f16 matrix cores: csrc/gemm3.h) -- from 512 jobs up ONE engine x 27 * n_clips streams, the layout
@@ -371,6 +371,9 @@ def parity_mode_extras(args, dev, wavs, grid, vocab, n_clips, max_bars, f16_engi
                "extract_audio_s_per_s": round(args.seconds * n_clips / (t1 - t0), 1), "decoder_tokens_per_s": round(ntok / (t2 - t1), 1),
                "tokens_sha256": hashlib.sha256(np.concatenate([r[0] for r in res32]).astype(np.int32).tobytes()).hexdigest()[:16],
                "full_batch": "profiles/r06_parity_full.json: the same mode on the whole 64-clip batch (one engine x 1728 streams), a gpurun of tools/bench_parity.py --clips 64 --stamp"}
+        if headline_decode_s_per_clip and n_jobs >= 512:
+            # both stages at >= 512 rows per launch (throughput regime): the 16-bit decode stage of the timed steps against this pass, per clip
+            out["fp32_over_f16_decode_time"] = round((t2 - t1) / frac / n_clips / headline_decode_s_per_clip, 2)
         if len(grid) > DEFAULT_TUPLE_INDEX and len(conds[0].bars) >= 5 and (not max_bars or max_bars >= 5):
             check = {"bars": [conds[0].bars.bar(i) for i in range(5)], "fp32": first_bars(*res32[DEFAULT_TUPLE_INDEX], 5),
                      "where": f"job (clip 0, tuple (1, 1, 1)) of the exact-parity batch above: row {DEFAULT_TUPLE_INDEX} of {per_eng} rows per launch on engine 0 of {n_eng}"}
@@ -960,7 +963,8 @@ def main():
         else:
             try:
                 log(f"extras.parity_mode: {pick[0]} clips" + (f", {pick[1]} bars" if pick[1] else "") + f" (estimated {parity_cost(*pick, nb_mean):.0f} s, {time_left():.0f} s left)")
-                extras["parity_mode"], oracle_check = parity_mode_extras(args, dev, wavs, grid, vocab, pick[0], pick[1], decs, lambda: time_left() - CPU_RESERVE_S)
+                extras["parity_mode"], oracle_check = parity_mode_extras(args, dev, wavs, grid, vocab, pick[0], pick[1], decs, lambda: time_left() - CPU_RESERVE_S,
+                                                                               headline_decode_s_per_clip=(t_dec / max(1, args.steps) / clips) if not args.max_bars else None)
             except Exception as e:      # extras must never take the headline down
                 extras["parity_mode"] = {"error": repr(e)}
 

@@ -778,6 +778,28 @@ extern "C" int etd_decoder_create(const etd_dec_cfg* cfg, const char* const* nam
       w.q_log2 = g3_scale_log2(2.f * bnd[0]); w.k_log2 = g3_scale_log2(2.f * bnd[1]); w.v_log2 = g3_scale_log2(bnd[2]);
       w.m_log2 = g3_scale_log2(g3_bound_linear_of_ln(Wu, bu, d->I, H, g2, b2));
     }
+#if ETD_DEC_IS_F16
+    if (d->bf16w) {
+      // The 16-bit mode's operands are IEEE half (dec_kernels.h): unlike bf16 they END at 65 504, and an Inf in a LayerNorm row, a cache row or the hidden layer becomes NaN in
+      // the softmax / the next LayerNorm.  Every 16-bit tensor of this path is a weight, a LayerNorm output, a projection of one (Q / K / V after the rotary mix, GELU(up): |gelu(u)| <= |u|)
+      // or a convex combination of V rows: the same provable bounds the fp32-grade path takes its plane scales from (csrc/gemm3.h) say at load time whether THIS checkpoint
+      // can leave the range, whatever the input.  A checkpoint that could is refused (a -DETD_DEC_BF16 build, or precision "fp32", takes it).
+      const float* g1 = Ld.get(p + "input_layernorm.weight", H); const float* b1 = Ld.get(p + "input_layernorm.bias", H);
+      const float* g2 = Ld.get(p + "post_attention_layernorm.weight", H); const float* b2l = Ld.get(p + "post_attention_layernorm.bias", H);
+      const float* Wq = Ld.get(p + "attention.query_key_value.weight", (int64_t)3 * H * H); const float* bq = Ld.get(p + "attention.query_key_value.bias", 3 * H);
+      const float* Wu = Ld.get(p + "mlp.dense_h_to_4h.weight", (int64_t)d->I * H); const float* bu = Ld.get(p + "mlp.dense_h_to_4h.bias", d->I);
+      if (!g1 || !b1 || !g2 || !b2l || !Wq || !bq || !Wu || !bu) return fail(ETD_EINVAL);
+      std::vector<float> rb((size_t)3 * H);
+      g3_row_bounds_of_ln(Wq, bq, 3 * H, H, g1, b1, rb.data());
+      float qkv_b = 0.f;
+      for (int j = 0; j < 3 * H; ++j) qkv_b = fmaxf(qkv_b, (((j % 192) >> 6) < 2 ? 2.f : 1.f) * rb[j]);      // (the rotary embedding mixes two dims of a Q / K row)
+      const float bounds[4] = {g3_bound_ln(g1, b1, H), g3_bound_ln(g2, b2l, H), qkv_b, g3_bound_linear_of_ln(Wu, bu, d->I, H, g2, b2l)};
+      static const char* const what[4] = {"input_layernorm rows", "post_attention_layernorm rows", "Q / K / V rows", "gelu(dense_h_to_4h) rows"};
+      for (int i = 0; i < 4; ++i)
+        if (!(bounds[i] < 65504.f)) { g_etd_err = "decoder_create: layer " + std::to_string(l) + ": " + what[i] + " can reach " + std::to_string(bounds[i]) +
+                                                  " (provable bound), beyond the IEEE-half range of the 16-bit serving mode; use precision \"fp32\" or a -DETD_DEC_BF16 build"; return fail(ETD_EINVAL); }
+    }
+#endif
     if (d->bf16w) {
       // h_new - h = W2 gelu(..) + b2 + Wd attn + bd  ==  [W2 | Wd] [gelu(..) ; attn] + (b2 + bd)
       const float* W2 = Ld.get(p + "mlp.dense_4h_to_h.weight", (int64_t)H * d->I);

@@ -264,6 +264,26 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
       }
       bf[o] = (float)(bacc + (double)center * wsum);  // x = (x - center) + center
     }
+#if ETD_EXT_IS_F16
+    {
+      // IEEE-half operands end at 65 504 (bf16 did not): the only 16-bit tensor of this path that no LayerNorm bounds is the first encoder layer's input,
+      // x = 16 (Wf . window + b) + pos, for log-mel features in [-F, F] (F = max(|min_value|, 32): log(mel + 1e-8) >= -18.4 and full-scale audio stays below 15;
+      // the HFT_Transformer wrapper pads with -80).  Its worst case over such inputs, from the folded weights; a checkpoint that could leave the range is refused.
+      const float F = fmaxf(fabsf(c.min_value), 32.f);
+      float pmax = 0.f, xb = 0.f;
+      for (int i = 0; i < 256 * 256; ++i) pmax = fmaxf(pmax, fabsf(pe[i]));
+      for (int o = 0; o < 256; ++o) {
+        double l1 = 0;
+        for (int t = 0; t < 65; ++t) l1 += fabs((double)Wf[o * 80 + t]);
+        xb = fmaxf(xb, (float)(16.0 * (l1 * (F + 8.0) + fabs((double)bf[o]))));      // (the kernel feeds x - center, center = -8)
+      }
+      if (!(xb + pmax < 65504.f)) {
+        g_etd_err = "extractor_create: the first encoder layer's input can reach " + std::to_string(xb + pmax) + " for log-mel features in [-" + std::to_string((int)F) + ", " + std::to_string((int)F) +
+                    "], beyond the IEEE-half range of the 16-bit mode; use precision \"fp32\" (etd_ext_cfg.precision 1) or a -DETD_EXT_BF16 build";
+        return fail(ETD_EINVAL);
+      }
+    }
+#endif
     int rc = up_bf16(P, &e->Wf, Wf.data(), Wf.size()); if (rc) return fail(rc);
     rc = up_f32(P, &e->bfold, bf.data(), 256); if (rc) return fail(rc);
     rc = up_bf16(P, &e->pos_freq_enc, pe, 256 * 256); if (rc) return fail(rc);

@@ -16,6 +16,8 @@
 #include "dec_kernels.h"
 #include "prof.h"
 
+#include <cstdlib>
+
 #define PA_LDK 72     // K tile row stride (elements): 144 B, conflict-free ds_read_b128
 #define PA_LDV 96     // V tile row stride (elements): 192 B -> key rows 4 h + q of a transposing read fall on bank groups 0, 192, 128, 64 (mod 256 B)
 
@@ -193,29 +195,40 @@ int launch_pattn(const PAttnArgs& a, hipStream_t st) {
 typedef const __attribute__((address_space(1))) void* pq_gptr_t;
 typedef __attribute__((address_space(3))) void* pq_lptr_t;
 
-__global__ __launch_bounds__(512, 2) void k_pqkv(PQkvArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PQ_TILE_ELEMS * 2 + 8 * 32 * PQ_EPP * 2 + 1536 * 4];
+// NW = waves per workgroup: 8 (256 tokens per weight byte pulled from L2; 141 KiB of LDS and 8 x 238 registers: the workgroup needs a whole, EMPTY CU) or 4 (128 tokens;
+// 104 KiB and one wave per SIMD: half a CU's registers, so that a decode step's attention workgroups of another engine -- 8 waves x 88 registers, 19 KiB -- fit beside it and
+// a CU that still holds such workgroups can take it: ETD_PQKV_WAVES=4, round 6's co-residency experiment)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_pqkv(PQkvArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PQ_TILE_ELEMS * 2 + NW * 32 * PQ_EPP * 2 + 1536 * 4];
   d16* ring = reinterpret_cast<d16*>(smem);
   d16* stg_all = reinterpret_cast<d16*>(smem + 2 * PQ_TILE_ELEMS * 2);
-  float* sb = reinterpret_cast<float*>(smem + 2 * PQ_TILE_ELEMS * 2 + 8 * 32 * PQ_EPP * 2);
+  float* sb = reinterpret_cast<float*>(smem + 2 * PQ_TILE_ELEMS * 2 + NW * 32 * PQ_EPP * 2);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   d16* stg = stg_all + wave * (32 * PQ_EPP);
   const int NT = a.N >> 5;                                   // 48 tiles
-  const int mw = blockIdx.x * 256 + wave * 32;               // the wave's first token
+  const int mw = blockIdx.x * (32 * NW) + wave * 32;         // the wave's first token
   const int m = mw + r, mc = m < a.M ? m : a.M - 1;
 
-  // tile t -> slot t & 1: 32 one-KiB pieces, 4 per wave
+  // tile t -> slot t & 1: 32 one-KiB pieces, 32 / NW per wave
   auto issue = [&](int t) {
-    const d16* src = a.Wf + (long long)t * PQ_TILE_ELEMS + wave * (4 * 512) + lane * 8;
-    d16* dst = ring + (t & 1) * PQ_TILE_ELEMS + wave * (4 * 512);
+    constexpr int PW = 32 / NW;
+    const d16* src = a.Wf + (long long)t * PQ_TILE_ELEMS + wave * (PW * 512) + lane * 8;
+    d16* dst = ring + (t & 1) * PQ_TILE_ELEMS + wave * (PW * 512);
     // (one address, four immediate offsets: the offset field serves the global and the LDS address alike)
     __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 1024, 0);
     __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 2048, 0);
     __builtin_amdgcn_global_load_lds((pq_gptr_t)src, (pq_lptr_t)dst, 16, 3072, 0);
+    if constexpr (PW == 8) {
+      __builtin_amdgcn_global_load_lds((pq_gptr_t)(src + 2048), (pq_lptr_t)(dst + 2048), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((pq_gptr_t)(src + 2048), (pq_lptr_t)(dst + 2048), 16, 1024, 0);
+      __builtin_amdgcn_global_load_lds((pq_gptr_t)(src + 2048), (pq_lptr_t)(dst + 2048), 16, 2048, 0);
+      __builtin_amdgcn_global_load_lds((pq_gptr_t)(src + 2048), (pq_lptr_t)(dst + 2048), 16, 3072, 0);
+    }
   };
   issue(0);
-  for (int i = tid; i < a.N; i += 512) sb[i] = a.bias[i];
+  for (int i = tid; i < a.N; i += 64 * NW) sb[i] = a.bias[i];
   // the wave's 32 tokens as B fragments: lane (token r, half h) holds x[token][16 s + 8 h .. + 8]
   d16x8 xf[32];
   {
@@ -324,7 +337,9 @@ int launch_pqkv(const PQkvArgs& a, hipStream_t st) {
     ETD_FAIL(ETD_EINVAL, "pqkv: bad arguments");
   ETD_LAUNCH_FILTER("k_pqkv");
   ProfScope ps("k_pqkv", st, 2.0 * a.M * a.N * 512.0, ((double)a.M * 512 + (double)a.N * 512 + 3.0 * a.M * 512) * 2);
-  hipLaunchKernelGGL(k_pqkv, dim3((a.M + 255) / 256), dim3(512), 0, st, a);
+  static const int nw = getenv("ETD_PQKV_WAVES") ? atoi(getenv("ETD_PQKV_WAVES")) : 8;
+  if (nw == 4) hipLaunchKernelGGL(k_pqkv<4>, dim3((a.M + 127) / 128), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(k_pqkv<8>, dim3((a.M + 255) / 256), dim3(512), 0, st, a);
   HIP_TRY(hipGetLastError());
   return ETD_OK;
 }

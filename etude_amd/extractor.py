@@ -170,6 +170,7 @@ class AMTAPC_Extractor:
         feat = torch.as_tensor(np.asarray(a_feature, dtype=np.float32)).to(self.device)
         out = self.transcript(feat, want_A=True)
         res = tuple(o.cpu().numpy() for o in out)
+        self.check_feature_range()
         return res if mode == "combination" else res[:4]
 
     _M2N_VEL = {"ignore_zero": 0, "org": 1}
@@ -283,6 +284,7 @@ class AMTAPC_Extractor:
         in the reference's return order onset/offset/mpe/velocity A then B)."""
         assert feat.is_cuda and feat.dtype == torch.float32 and feat.is_contiguous()
         T = feat.shape[0]
+        self._feat_absmax = feat.abs().amax() if feat.numel() else None      # (device scalar, no sync: `check_feature_range` reads it once the outputs are on the host)
         tp = ((T + self.n_frame - 1) // self.n_frame) * self.n_frame
         B = self._alloc(tp)
         A = self._alloc(tp) if want_A else [None] * 4
@@ -297,6 +299,7 @@ class AMTAPC_Extractor:
         """device [B, n_bin, n_frame + 2*margin] fp32 (the model's own input) -> outputs over B*n_frame rows."""
         assert spec.is_cuda and spec.dtype == torch.float32 and spec.is_contiguous()
         nb = spec.shape[0]
+        self._feat_absmax = spec.abs().amax() if spec.numel() else None
         B = self._alloc(nb * self.n_frame)
         A = self._alloc(nb * self.n_frame) if want_A else [None] * 4
         st = torch.cuda.current_stream(self.device).cuda_stream
@@ -305,6 +308,20 @@ class AMTAPC_Extractor:
                                                          *[(t.data_ptr() if t is not None else None) for t in A], C.c_void_p(st)),
                        "etd_transcript_windows")
         return tuple(A) + tuple(B) if want_A else tuple(B)
+
+    def check_feature_range(self) -> None:
+        """The library sizes its 16-bit planes for log-mel features in [-F, F], F = max(|min_value|, 32) (include/etude_hip.h: etd_transcript): log(mel + 1e-8) >= -18.4,
+        full-scale audio stays below 15, the HFT_Transformer wrapper pads with -80.  Features outside that range (e.g. a spectrogram of int16-scale samples) could overflow an
+        IEEE-half plane into Inf / NaN probabilities, so the last `transcript*` call's input maximum is checked here -- by the entry points that bring results to the host
+        (one scalar read behind a synchronisation they need anyway); callers of the device-level `transcript*` call it themselves."""
+        mx = getattr(self, "_feat_absmax", None)
+        if mx is None:
+            return
+        self._feat_absmax = None
+        F = max(abs(float(self.config.input.min_value)), 32.0)
+        v = float(mx)
+        if not v <= F:
+            raise ValueError(f"log-mel features reach |x| = {v:.1f}, outside the [-{F:g}, {F:g}] this extractor's planes are sized for (unnormalised audio?)")
 
     def _alloc(self, rows: int):
         nn = self.n_note
@@ -324,6 +341,7 @@ class AMTAPC_Extractor:
         on, off, mpe, vel = self.transcript(feat)
         inf = self.config.infer
         arr = self.mpe2note_device(on, off, mpe, vel, inf.onset_threshold, inf.offset_threshold, inf.frame_threshold)
+        self.check_feature_range()
         if min_duration is not None:
             arr = arr[~((arr["offset"] - arr["onset"]) < min_duration)]
         return arr

@@ -114,7 +114,12 @@ int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* names, const
 void etd_extractor_destroy(etd_ext*);
 /* feat_dev [T][n_bin] fp32 -> outputs over T_pad = ceil(T/n_frame)*n_frame rows of n_note:
  * onset/offset/mpe fp32 probabilities and int8 velocity argmax of the time ("B") heads; the "A"
- * (frequency) head outputs are produced only when all four *_A pointers are non-NULL. */
+ * (frequency) head outputs are produced only when all four *_A pointers are non-NULL.
+ * PRECONDITION on the input (both entry points, both precisions): log-mel features lie in [-F, F], F = max(|min_value|, 32) -- what
+ * log(mel + 1e-8) of audio in [-1, 1] gives (>= -18.4, < 15) and what the wrappers pad with (-18 / -80).  The library's 16-bit operand
+ * planes (IEEE half; in the exact-parity mode the two-plane splits of csrc/gemm3.h) are scaled from bounds that assume it; finite features
+ * beyond it (a spectrogram of int16-scale samples) can overflow a plane into Inf / NaN probabilities.  Not checked here (the call is
+ * asynchronous); the Python mirror checks it (AMTAPC_Extractor.check_feature_range). */
 int etd_transcript(etd_ext*, const float* feat_dev, long long T,
                    float* onset_B, float* offset_B, float* mpe_B, int8_t* vel_B,
                    float* onset_A, float* offset_A, float* mpe_A, int8_t* vel_A, void* stream);

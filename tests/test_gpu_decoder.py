@@ -336,3 +336,24 @@ def test_token_stationary_qkv_is_bit_identical_to_the_big_tile_gemm(dev):
         assert d["rows"] == 51300
         outs.append((d["first_token_sha256"], d["kv_rowsums_sha256"]))
     assert outs[0] == outs[1], outs
+
+
+def test_f16_mode_refuses_a_checkpoint_that_can_leave_the_half_range(dev):
+    """The 16-bit serving mode's operands are IEEE half (max 65 504; the bf16 of rounds 1-4 had fp32's range): at load time the library bounds every 16-bit tensor of the
+    path by the checkpoint's own parameters (LayerNorm rows by gamma / beta, Q / K / V and GELU(up) by Cauchy-Schwarz on the weight rows: csrc/gemm3.h's g3_bound_*) and refuses
+    a checkpoint that could overflow -- instead of turning an Inf into NaN logits at run time.  The exact-parity mode scales its planes by the same bounds and takes it."""
+    from etude_amd import _lib
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig
+    sd = {k: v.copy() for k, v in synth.decoder_state_dict(1, {}).items()}
+    sd["transformer.layers.3.post_attention_layernorm.weight"] *= 4000.0          # LN2 rows up to ~4000 * sqrt(511): beyond 65 504
+    cfg = EtudeDecoderConfig(**synth.decoder_dims())
+    with pytest.raises(_lib.EtudeHipError, match="IEEE-half range"):
+        EtudeDecoder(cfg, sd, "cuda", precision="f16")
+    d32 = EtudeDecoder(cfg, sd, "cuda", precision="fp32")
+    rng = np.random.default_rng(0)
+    lg = d32.prefill_logits(rng.integers(4, 154, 12), rng.integers(1, 3, 12), rng.integers(0, 3, (4, 12)))
+    assert np.isfinite(lg).all()
+    d32.close()
+    d16 = _decoder("f16")                                                           # the benchmark checkpoint: bounds ~33, far inside
+    assert d16.operand_dtype in (torch.float16, torch.bfloat16) and d16.precision == "f16"
+    d16.close()

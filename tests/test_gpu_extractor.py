@@ -152,6 +152,31 @@ def test_window_batch_invariance_and_determinism(dev):
             assert np.array_equal(a[w * nf:(w + 1) * nf], b)
 
 
+def test_out_of_range_features_and_checkpoints_are_refused(dev):
+    """The 16-bit planes (IEEE half; the exact-parity mode's two-plane splits) are sized for log-mel features in [-F, F], F = max(|min_value|, 32) (include/etude_hip.h,
+    etd_transcript): the host mirror refuses features outside it instead of returning Inf / NaN probabilities, and the 16-bit mode refuses a checkpoint whose first encoder layer
+    input could leave the half range for such features."""
+    from etude_amd import _lib
+    from etude_amd.extractor import AMTAPC_Extractor
+    nf = 64
+
+    def _cfg(n):
+        c = ExtractorConfig()
+        c.input.num_frame = n
+        return c
+    for prec in ("f16", "fp32"):
+        ex = AMTAPC_Extractor(_cfg(nf), synth.extractor_state_dict(7, dict(n_frame=nf)), "cuda", precision=prec)
+        feat = np.clip(np.random.default_rng(1).normal(-8, 2, (70, 256)), -18, 5).astype(np.float32)
+        assert np.isfinite(ex._transcript(feat)[4]).all()
+        with pytest.raises(ValueError, match="outside the"):
+            ex._transcript(feat * 1000.0)
+        ex.close()
+    sd = {k: v.copy() for k, v in synth.extractor_state_dict(7, dict(n_frame=nf)).items()}
+    sd["encoder.tok_embedding_freq.weight"] *= 100.0
+    with pytest.raises(_lib.EtudeHipError, match="IEEE-half range"):
+        AMTAPC_Extractor(_cfg(nf), sd, "cuda", precision="f16")
+
+
 def test_unsupported_architecture_fails_loudly(dev):
     from etude_amd import _lib
     from etude_amd.extractor import AMTAPC_Extractor

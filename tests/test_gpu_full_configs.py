@@ -139,7 +139,7 @@ def test_config1_single_clip_full_chain(dev, golden_dir, tmp_path):
     ex4.extract(str(tmp_path / "origin.wav"), str(tmp_path / "extract.json"), str(tmp_path / "extract.mid"))
     js = json.loads((tmp_path / "extract.json").read_text())
     print(f"configs[1] extract(): {len(js)} notes written from the wav file (device front end) vs {int(g['n_kept'])} the reference writes from its features")
-    assert abs(len(js) - int(g["n_kept"])) <= max(3, int(g["n_kept"]) // 50)
+    assert abs(len(js) - int(g["n_kept"])) <= max(3, int(g["n_kept"]) // 100)          # measured: 3 262 vs 3 248 (0.43 %: the device front end + the 16-bit model)
     assert (tmp_path / "extract.mid").read_bytes()[:4] == b"MThd"
     ex4.close(); ex1.close()
     # ---- tokenizer (native) on the REFERENCE notes -> exactly the reference's condition bars
