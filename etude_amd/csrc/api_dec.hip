@@ -631,7 +631,7 @@ int stage_and_forward(etd_dec* d, int n, const int32_t* slots, const int32_t* T,
   e.rows = DecRows{sg->row_slot, sg->row_pos, sg->row_active, sg->row_seq};
   ETD_TRY(launch_dembed(e, st));
   PrefillInfo pf{n, sg->seq_row0, sg->seq_len, max_len, aflops};
-  const bool can_mfma_attn = (d->bf16w ? d->Qb != nullptr : d->X1f != nullptr) && !getenv("ETD_NO_MFMA_PREFILL_ATTN");
+  const bool can_mfma_attn = (d->bf16w ? d->Qb != nullptr : d->X1f != nullptr) && !ETD_XENV("ETD_NO_MFMA_PREFILL_ATTN");
   LastOnly lo{n, sg->last_idx, DecRows{sg->last_slot, sg->last_pos, sg->last_active}};
   ETD_TRY(forward_body(d, M, e.rows, hfinal, st, can_mfma_attn ? &pf : nullptr, false, last_only ? &lo : nullptr, last_only));
   return ETD_OK;
@@ -675,7 +675,7 @@ int alloc_workspaces(etd_dec* d) {
   rc = rc ? rc : d->alloc(&d->n_out, S, true); rc = rc ? rc : d->alloc(&d->eos, S, true); rc = rc ? rc : d->alloc(&d->limit, S, true);
   rc = rc ? rc : d->alloc(&d->tgt_proj, S * (size_t)d->H, true);
   rc = rc ? rc : d->alloc(&d->tgt_attrs, 4 * S, true); rc = rc ? rc : d->alloc(&d->out_tok, S * d->out_cap, true);
-  if (!rc && !getenv("ETD_NO_PINNED")) {
+  if (!rc && !ETD_XENV("ETD_NO_PINNED")) {
     d->pin_stage_ints = 10 * M + 13 * S;
     if (hipHostMalloc((void**)&d->pin_stage, d->pin_stage_ints * 4, hipHostMallocDefault) != hipSuccess) { d->pin_stage = nullptr; (void)hipGetLastError(); }
     if (hipHostMalloc((void**)&d->pin_rb, (2 * S + S * (size_t)d->out_cap) * 4, hipHostMallocDefault) != hipSuccess) { d->pin_rb = nullptr; (void)hipGetLastError(); }
@@ -1070,9 +1070,9 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   const int vpad = (d->V + 31) / 32 * 32;
   // A single stream steps on the fused kernels too (round 3; ETD_FUSED_M1=0: the GEMV sequence of rounds 1-2): 25 launches per step instead of ~36 and the same
   // arithmetic as inside a batch -- one job of 92 bars x 48 tokens 1.09 -> 0.66 s (tools/runs3/r3_run20.sh), every decoder golden unchanged.
-  static const bool fused_m1 = !(getenv("ETD_FUSED_M1") && atoi(getenv("ETD_FUSED_M1")) == 0);
+  static const bool fused_m1 = !(ETD_XENV("ETD_FUSED_M1") && atoi(ETD_XENV("ETD_FUSED_M1")) == 0);
   const bool fused = d->bf16w && (n_active > 1 || fused_m1) && n_active <= DS_STEP_MAX_ROWS && (d->I + d->H) % (5 * 64 * 8) == 0 && d->H == 512 && vpad <= 256 &&
-                     vpad <= d->head.Npad && d->head_frag && !getenv("ETD_NO_FUSED_STEP");
+                     vpad <= d->head.Npad && d->head_frag && !ETD_XENV("ETD_NO_FUSED_STEP");
   d->last_step_fused = fused;
   d->stamp_on = d->stamp_armed && d->stamp_skip <= 0;          // (a whole call is stamped or not: the scheduler issues one bar's steps per call)
   if (d->stamp_armed && d->stamp_skip > 0) d->stamp_skip -= n_steps;
@@ -1140,7 +1140,7 @@ extern "C" int etd_decoder_step(etd_dec* d, const int32_t* slots, int n_active, 
   // The step is ~50 short dependent kernels: replay it as a hipGraph (captured once per n_active; every
   // kernel argument is a fixed workspace/state pointer, the slot list lives in device memory).  Capture needs
   // a non-default stream and must not contain the profiler's event records.
-  const bool use_graph = st != nullptr && !prof_enabled() && !getenv("ETD_NO_GRAPH");
+  const bool use_graph = st != nullptr && !prof_enabled() && !ETD_XENV("ETD_NO_GRAPH");
   if (use_graph) {
     const int gkey = 16 * n_active + (d->logits_dbg_on ? 8 : 0) + (d->stamp_on ? 4 : 0) + (d->step_pair ? 2 : 0) + (d->rows_identity ? 1 : 0);
     auto it = d->graphs.find(gkey);

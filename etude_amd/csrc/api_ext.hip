@@ -222,7 +222,7 @@ extern "C" int etd_extractor_create(const etd_ext_cfg* cfg, const char* const* n
   etd_ext* e = new etd_ext();
   e->cfg = c; e->nf = c.n_frame; e->nn = c.n_note; e->margin = c.n_margin; e->wb = c.max_windows;
   e->fc = c.chunk_frames > 0 ? c.chunk_frames : c.n_frame;   // measured: whole-window launches beat MALL-sized chunks (2.9 vs 4.4 ms/window)
-  if (const char* s = getenv("ETD_CHUNK_FRAMES")) e->fc = atoi(s);
+  if (const char* s = ETD_XENV("ETD_CHUNK_FRAMES")) e->fc = atoi(s);
   if (e->fc > e->nf) e->fc = e->nf;
   if (e->fc < 1) e->fc = e->nf;
   Loader L;
@@ -412,19 +412,19 @@ namespace {
 
 const float kScaleLog2e = 0.125f * 1.4426950408889634f;
 // ETD_NO_FUSED_FFN=1: the round-1 sequence (FFN1 launch, 512-wide hidden through HBM, FFN2 + LayerNorm launch) for A/B runs
-bool fused_ffn() { static const bool on = !getenv("ETD_NO_FUSED_FFN"); return on; }
+bool fused_ffn() { static const bool on = !ETD_XENV("ETD_NO_FUSED_FFN"); return on; }
 // ETD_NO_FUSED_PROJ=1: the K = 256 projections on round 1's k_linear tiles instead of k_proj256
-bool fused_proj() { static const bool on = !getenv("ETD_NO_FUSED_PROJ"); return on; }
+bool fused_proj() { static const bool on = !ETD_XENV("ETD_NO_FUSED_PROJ"); return on; }
 // ETD_NO_FUSED_LAYER=1: encoder layers as four launches (QKV, attention, fc_o + LN, FFN) instead of k_enc_layer
-bool fused_layer() { static const bool on = !getenv("ETD_NO_FUSED_LAYER"); return on; }
+bool fused_layer() { static const bool on = !ETD_XENV("ETD_NO_FUSED_LAYER"); return on; }
 // ETD_NO_FRAG_ATTN=1: attention on k_attn (K row-major, V^T) instead of k_attn_frag (K / V as MFMA-fragment images)
-bool frag_attn() { static const bool on = !getenv("ETD_NO_FRAG_ATTN") && !getenv("ETD_NO_FUSED_PROJ"); return on; }
+bool frag_attn() { static const bool on = !ETD_XENV("ETD_NO_FRAG_ATTN") && !ETD_XENV("ETD_NO_FUSED_PROJ"); return on; }
 // ETD_POST_ATTN=1: fc_o + LayerNorm + feed-forward block of the decoder layers as ONE launch (k_post_attn).  Measured equal in time to the
 // two launches it replaces (0.319 vs 0.309 ms per window: its mid-kernel LayerNorm costs what the saved HBM round trip gains), so the
 // two-launch sequence stays the default
 // (a measured dead end: compiled with -DETD_EXPERIMENTS only)
 #ifdef ETD_EXPERIMENTS
-bool fused_post() { static const bool on = getenv("ETD_POST_ATTN") && atoi(getenv("ETD_POST_ATTN")) != 0 && !getenv("ETD_NO_FUSED_PROJ") && !getenv("ETD_NO_FUSED_FFN"); return on; }
+bool fused_post() { static const bool on = getenv("ETD_POST_ATTN") && atoi(getenv("ETD_POST_ATTN")) != 0 && !ETD_XENV("ETD_NO_FUSED_PROJ") && !ETD_XENV("ETD_NO_FUSED_FFN"); return on; }
 #else
 constexpr bool fused_post() { return false; }
 #endif
@@ -520,7 +520,7 @@ int run_window_batch(etd_ext* e, const EmbedArgs& src_tmpl, int w0, int nw, long
     ea.nf = nf; ea.margin = e->margin; ea.center = -8.0f; ea.pad_value = e->cfg.min_value;
     ETD_TRY(launch_embed(ea, st));
     // diagnostic (tools/probe_race.py): stop the launch sequence early -- 1: after the embedding, 2: after the encoder layers (outputs are garbage)
-    static const int stop_stage = getenv("ETD_EXT_STOP_STAGE") ? atoi(getenv("ETD_EXT_STOP_STAGE")) : 0;
+    static const int stop_stage = ETD_XENV("ETD_EXT_STOP_STAGE") ? atoi(ETD_XENV("ETD_EXT_STOP_STAGE")) : 0;
     if (stop_stage == 1) return ETD_OK;
     const bool first = (w0 == 0 && f0 == 0);
     ETD_TRY(tap(e, 0, e->X, (size_t)Mtok * 512, first, st));

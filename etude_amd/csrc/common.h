@@ -19,6 +19,15 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
+// ---- measurement switches.  The shipped library reads the environment only for the switches a test or a tool of this tree sets (getenv at their call sites); the A/B and
+// diagnostic switches of earlier rounds' experiments (LABNOTES.md names them) are read only in a -DETD_EXPERIMENTS build (`etd_has_experiments()`), and are absent otherwise.
+#include <stdlib.h>
+#ifdef ETD_EXPERIMENTS
+#define ETD_XENV(name) getenv(name)
+#else
+#define ETD_XENV(name) ((const char*)nullptr)
+#endif
+
 // ---- error plumbing (no exceptions cross the C ABI) -------------------------------------------
 extern thread_local std::string g_etd_err;
 #define ETD_OK 0

@@ -633,17 +633,17 @@ int launch_dstep_qkv_up(const DGemmArgs& q, const DGemmArgs& up, hipStream_t st)
   ProfScope ps("k_dstep_qkv_up", st, 2.0 * q.M * (q.N + up.N) * q.K, (double)(q.Npad + up.Npad) * q.K * 2);
   const int split = q.Npad / 32;
   const int ftiles = split + up.Npad / 32;
-  static const bool mt_on = !(getenv("ETD_QKV_MT") && atoi(getenv("ETD_QKV_MT")) == 0);
+  static const bool mt_on = !(ETD_XENV("ETD_QKV_MT") && atoi(ETD_XENV("ETD_QKV_MT")) == 0);
   // rows from which the 128 x 128 form runs.  Measured (tools/runs3/r3_run21.sh, us per launch, 32 x 32 form / 128 x 128 form): 54 rows 7.2 / 12.3, 128: 9.2 / 12.6,
   // 216: 12.9 / 12.8, 320: 15.8 / 13.3, 432: 18.9 / 13.1, 512: 19.5 / 13.3, 1 728: 40 / 18 -- the two cross at ~220 rows; bit-identical either way
-  static const int mt_min = getenv("ETD_QKV_MT_MIN") ? atoi(getenv("ETD_QKV_MT_MIN")) : 256;
+  static const int mt_min = ETD_XENV("ETD_QKV_MT_MIN") ? atoi(ETD_XENV("ETD_QKV_MT_MIN")) : 256;
   if (mt_on && q.M >= mt_min && q.Npad % 128 == 0 && up.Npad % 128 == 0 && q.Wf && up.Wf) {
     const int split128 = q.Npad / 128, ft128 = split128 + up.Npad / 128, RT128 = (q.M + 127) / 128;
     hipLaunchKernelGGL(k_dstep_qkv_up_mt, dim3((unsigned)(((ft128 + 7) / 8) * 8 * RT128)), dim3(256), 0, st, q.M, split128, ft128, (const d16*)q.Wf, (const d16*)up.Wf, q.Xb, up.Xb, q.ldx, up.ldx, q, up);
     HIP_TRY(hipGetLastError());
     return ETD_OK;
   }
-  static const int rpt_env = getenv("ETD_QKV_RPT") ? atoi(getenv("ETD_QKV_RPT")) : 0;
+  static const int rpt_env = ETD_XENV("ETD_QKV_RPT") ? atoi(ETD_XENV("ETD_QKV_RPT")) : 0;
   const int rpt = rpt_env > 0 ? rpt_env : (q.M > DS_MAX_ROWS ? 4 : 1);
   const int RT = (q.M + 31) / 32, RG = (RT + rpt - 1) / rpt;
   hipLaunchKernelGGL(k_dstep_qkv_up, dim3((unsigned)(((ftiles + 7) / 8) * 8 * RG)), dim3(64 * DS_WAVES), 0, st, q.M, q.K, split, ftiles, q.W, up.W, q.Xb, up.Xb, q.ldx, up.ldx, rpt, q, up);
@@ -1762,7 +1762,7 @@ int launch_dstep_attn_down(const DAttnArgs& a, const DGemmArgs& g, const DRowFin
   // 0.1985 -> 0.1894 ms, four engines 9.78 -> 10.03 engine-steps / ms, the job +0.3 % (within its spread)
   // -- at the headline's shape (54 rows x ~340 keys).  Whether it pays depends on rows, context and on how many engines share the chip: the host decides
   // per call (DAttnArgs::pair, api_dec.hip etd_decoder_step); ETD_AD_PAIR=0 / 1 force either form
-  static const int pair_env = getenv("ETD_AD_PAIR") ? atoi(getenv("ETD_AD_PAIR")) : -1;
+  static const int pair_env = ETD_XENV("ETD_AD_PAIR") ? atoi(ETD_XENV("ETD_AD_PAIR")) : -1;
   const bool pair = (pair_env < 0 ? a.pair != 0 : pair_env > 0) && !fin && ad_waves(a.M) == 4;
   const int nw = pair ? 8 : ad_waves(a.M), units = nw / 2;
   const int RT = (a.M + 31) / 32, FT = g.Npad / 32;

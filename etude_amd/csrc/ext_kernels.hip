@@ -537,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void k_linear(LinArgs a) {
 
 // token tiles padded to a multiple of 8 (one per XCD), times the feature blocks of the launch
 static unsigned lin_grid_x(int M, int nby) { return (unsigned)(((M + 127) / 128 + 7) / 8 * 8 * nby); }
-static int lin_dbg() { static const int v = getenv("ETD_LIN_DBG") ? atoi(getenv("ETD_LIN_DBG")) : 0; return v; }
+static int lin_dbg() { static const int v = ETD_XENV("ETD_LIN_DBG") ? atoi(ETD_XENV("ETD_LIN_DBG")) : 0; return v; }
 int launch_linear(const LinArgs& a, int nz, hipStream_t st) {
   if (a.K % 128 || a.N % 256 || a.M <= 0) ETD_FAIL(ETD_EINVAL, "linear: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
   if (a.vt_block >= 0 && (a.S % 4 || a.Spad % 4 || !a.VT)) ETD_FAIL(ETD_EINVAL, "linear: bad V^T args");

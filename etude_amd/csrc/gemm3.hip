@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm3(const float* __restrict__ p_X,
   }
 }
 
-bool g3_enabled() { static const bool on = !getenv("ETD_NO_GEMM3"); return on; }
+bool g3_enabled() { static const bool on = !ETD_XENV("ETD_NO_GEMM3"); return on; }
 
 int launch_gemm3(const DGemmArgs& a, int epi, hipStream_t st) {
   if (a.M <= 0 || a.Npad % 128 || a.K % 32 || a.N > a.Npad || !a.Wp || !a.X || (a.ldx % 4) || ((uintptr_t)a.X & 15)) ETD_FAIL(ETD_EINVAL, "gemm3: bad shape M=%d N=%d Npad=%d K=%d", a.M, a.N, a.Npad, a.K);
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64 * G3S_WAVES) void k_gemm3_s(int p_M, int p_Npad,
 // workgroups walking the whole K one after the other (measured, tools/bench_gemm3.py step: attention.dense 21.8 -> 12.1 us at 576 rows, 22.3 -> 20.3 at 1 728; the
 // K = 2 048 down projection 70.9 -> 29.5 and 71.7 -> 54.7; QKV and up, 1 536 / 2 048 wide, are faster on the tiles from 576 rows up).  ETD_G3S_MAX_ROWS overrides the row limit.
 static int g3s_max_rows(int npad) {
-  static const int v = getenv("ETD_G3S_MAX_ROWS") ? atoi(getenv("ETD_G3S_MAX_ROWS")) : 0;
+  static const int v = ETD_XENV("ETD_G3S_MAX_ROWS") ? atoi(ETD_XENV("ETD_G3S_MAX_ROWS")) : 0;
   return v > 0 ? v : (npad <= 512 ? 2048 : 512);
 }
 bool gemm3_s_takes(const DGemmArgs& a, int epi) {

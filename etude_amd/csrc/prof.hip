@@ -39,7 +39,7 @@ bool launch_skipped(const char* name) {
   return true;
 }
 
-bool launch_log_on() { static const bool on = getenv("ETD_LAUNCH_LOG") && atoi(getenv("ETD_LAUNCH_LOG")) > 0; return on; }
+bool launch_log_on() { static const bool on = ETD_XENV("ETD_LAUNCH_LOG") && atoi(ETD_XENV("ETD_LAUNCH_LOG")) > 0; return on; }
 void launch_log(const char* name, hipStream_t st, bool after) {
   if (!after) { fprintf(stderr, "[launch] %s\n", name); fflush(stderr); return; }
   const hipError_t e = hipStreamSynchronize(st);

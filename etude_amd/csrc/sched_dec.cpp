@@ -110,7 +110,7 @@ extern "C" int etd_decoder_run_jobs(etd_dec* d, const etd_sched_cfg* cfg, const 
 
   // ETD_SCHED_STATS=1: host time this engine spends with its queue EMPTY at bar boundaries (from the moment the poll reports
   // finished bars to the moment the next bars' launches have been issued), printed once per call
-  const bool want_stats = getenv("ETD_SCHED_STATS") != nullptr;
+  const bool want_stats = ETD_XENV("ETD_SCHED_STATS") != nullptr;
   double host_gap_us = 0, poll_us = 0, read_us = 0, begin_us = 0; long long n_gaps = 0;
   auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   // start the next bar of the given jobs (prefill in as few passes as the row budget allows); jobs that are finished are retired

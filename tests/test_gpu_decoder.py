@@ -321,7 +321,8 @@ def test_token_stationary_qkv_is_bit_identical_to_the_big_tile_gemm(dev):
     """k_pqkv (csrc/dec_prefill.hip: the prefill's QKV projection with the wave's tokens stationary in registers and the weights streamed through LDS, from 48 k rows up)
     multiplies the operands of k_linear<QKV> in the same order and applies the same epilogue formulas: the queries, the K / V cache rows and with them every first
     token of a 100-prompt pass (51 300 rows, a ragged last workgroup) must be the SAME BYTES with ETD_NO_PQKV=1.  The digests are tools/bench_prefill.py --digest's:
-    sha256 of the prompts' first generated tokens and of 32-bit sums over every K and V cache row of all eight layers.  (The switch is read once per process.)"""
+    sha256 of the prompts' first generated tokens and of 32-bit sums over every K and V cache row of all eight layers.  (The switch is read once per process.)
+    ETD_PQKV_WAVES=4: the same kernel as 4-wave workgroups of 128 tokens (half a CU's registers: round 6's co-residency experiment, LABNOTES) -- the same bytes again."""
     import json
     import os
     import subprocess
@@ -329,13 +330,13 @@ def test_token_stationary_qkv_is_bit_identical_to_the_big_tile_gemm(dev):
     from pathlib import Path
     tool = Path(__file__).resolve().parent.parent / "tools" / "bench_prefill.py"
     outs = []
-    for env in ({}, {"ETD_NO_PQKV": "1"}):
+    for env in ({}, {"ETD_NO_PQKV": "1"}, {"ETD_PQKV_WAVES": "4"}):
         r = subprocess.run([sys.executable, str(tool), "--prompts", "100", "--tokens", "513", "--reps", "1", "--digest"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert d["rows"] == 51300
         outs.append((d["first_token_sha256"], d["kv_rowsums_sha256"]))
-    assert outs[0] == outs[1], outs
+    assert outs[0] == outs[1] == outs[2], outs
 
 
 def test_f16_mode_refuses_a_checkpoint_that_can_leave_the_half_range(dev):

@@ -120,6 +120,10 @@ def test_bench_line_small_configuration():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["launches"] > 0 and r["decode_stage"]["frac"] > 0
     assert set(d["extras"]) >= {"extractor_only", "single_clip", "decoder_streams", "decoder_streams_4k"}
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    # the checker leg: the CPU oracle's greedy bars of cpu_baseline() against the exact-parity engine's ids for the same clip / tuple / condition bars
+    chk = d["extras"].get("oracle_check") or d["extras"]["parity_mode"]["oracle_check"]
+    assert chk["bars"] == 5 and chk["oracle_bars_identical"] == "5/5", chk
+    assert "_oracle_ids" not in d["cpu_baseline"]
     assert abs(d["value"] - 24.0 * 2 / (d["ms_per_step"] / 1e3)) / d["value"] < 1e-3
 
 
