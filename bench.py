@@ -546,8 +546,9 @@ def main():
     ap.add_argument("--clips", type=int, default=0, help="clips per rank (overrides --batch-clips / N)")
     ap.add_argument("--attr-grid", type=int, default=27, help="attribute tuples per clip: 1 -> (1,1,1); 27 -> {0,1,2}^3")
     ap.add_argument("--ext-engines", type=int, default=int(os.environ.get("ETD_EXT_ENGINES", "0")),
-                    help="extractor instances that transcribe different clips at the same time (own stream + host thread each); 0 = three beside one decoder engine, "
-                         "two beside four (hardware queues).  Measured on the 64-clip extract stage: 2 -> 4 850, 3 -> 5 040, 4 -> 5 080 audio-s/s")
+                    help="extractor instances that transcribe different clips at the same time (own stream + host thread each); 0 = three beside up to three decoder engines, "
+                         "two beside four (hardware queues).  Measured on the 64-clip extract stage: 2 -> 4 850-5 050, 3 -> 5 040-5 240, 4 -> 5 080-5 220 audio-s/s (round 6, gpurun r6_env: "
+                         "three instead of two beside the three decoder engines is +3.9 % of the extract stage = +0.4 % of the step)")
     ap.add_argument("--engines", type=int, default=int(os.environ.get("ETD_ENGINES", "0")),
                     help="decoder engines (own HIP stream + KV cache each, driven from host threads); 0 = by the jobs per rank, whatever measured fastest: THREE engines "
                          "(576 streams each) from 1024 jobs up (and from 512 on a single GPU), four below (216 jobs per rank at N = 8: the latency-bound regime, where four "
@@ -616,8 +617,9 @@ def main():
     cfg = ExtractorConfig()
     wb = int(os.environ.get("ETD_WB", "4"))
     n_jobs0 = (args.clips if args.clips > 0 else args.batch_clips // world) * args.attr_grid
-    one_engine = args.engines == 1
-    n_ext = args.ext_engines if args.ext_engines > 0 else (3 if one_engine else 2)
+    # streams of the process: decoder engines + extractor instances + torch's default stream must stay within the 8 hardware queues (top of this file)
+    want_eng = args.engines if args.engines > 0 else default_engines(n_jobs0, world)
+    n_ext = args.ext_engines if args.ext_engines > 0 else (3 if want_eng <= 3 else 2)
     exs = [AMTAPC_Extractor(cfg, synth.extractor_state_dict(0), dev, max_windows=wb) for _ in range(n_ext)]
     dcfg = EtudeDecoderConfig(**synth.decoder_dims())
     grid = attr_grid(args.attr_grid)
