@@ -30,7 +30,7 @@
 // alone is 1 216 clocks of VALU per chunk), the token fragments' loads 18 k + 10 k (x2, attention rows: fragment-shaped), chunk 64 + the dense chunks 42 k, epilogue 88 k
 // (768 KB per workgroup: 12 B / clk per CU with every CU streaming).  A dead end on the way: the DMA issue BETWEEN the independent MFMAs of a down group gave wrong
 // results in round 2 (a register the compiler took for free was still the A operand of a queued MFMA) -- the asm form is only safe where the compiler's reuse
-// distance is known; starting a launch's first round of workgroups staggered only added the idle time (round 4: whole XCDs apart, s_sleep by blockIdx & 7; round 6: four phase groups INSIDE every XCD, (blockIdx >> 3) & 3 -- 1.448 / 1.471 / 1.521 / 1.533 ms at 8 / 16 / 31 / 47 us steps against 1.46).
+// distance is known; starting a launch's first round of workgroups staggered (s_sleep by blockIdx & 7) only added the idle time (round 4).
 //   * a wave owns 32 tokens; x2 enters once as the 32 B-operand fragments of v_mfma_f32_32x32x16_bf16 (128 registers);
 //   * the 2048-wide hidden layer exists 32 features at a time: acc1 = W1[32 rows] . x2 (32 chained MFMAs), bias + erf-GELU +
 //     d16 rounding in registers; two v_permlane32_swap per k-step turn the accumulator's row order into the natural k order of a
