@@ -105,6 +105,35 @@ def main():
             print(f"== k_dstep_attn_down<8, false, true> in the kernel trace (whole run, every queue): {n_u} launches, sum of durations {sum_u:.3f} s, UNION of the dispatch intervals {uni_u:.3f} s "
                   f"(x {sum_u / uni_u:.2f} overlap); at the stamped launches' {apl / 1e6:.1f} MB per launch: per launch {apl * n_u / sum_u / 8e12:.3f} of 8 TB/s, on the union {apl * n_u / uni_u / 8e12:.3f} "
                   "(the ramp-up bars of every stage read less than that per launch: the bench's own figures count bytes exactly)")
+        # every kernel of the run: the time during which ANY kernel was running against the span from the first dispatch to the last (idle = host gaps + dependency bubbles)
+        n_a, sum_a, uni_a = union_of(os.path.join(root, "prof_trace"), "")
+        lo, hi = None, None
+        for f in glob.glob(os.path.join(root, "prof_trace", "**", "*kernel_trace.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    a_, b_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                    lo = a_ if lo is None or a_ < lo else lo; hi = b_ if hi is None or b_ > hi else hi
+        # the decoder's kernels alone (steps + batched prefill of every engine): their union against the decode stages' wall time of the same run (the JSON line)
+        dec_pref = ("k_dstep", "k_dmlp", "k_pqkv", "k_pattn", "k_resid_ln", "k_dembed", "k_dgemm", "k_dattn", "k_dargmax", "k_gather_rows", "k_ln_rows", "k_linear<1")
+        ivd = []
+        for f in glob.glob(os.path.join(root, "prof_trace", "**", "*kernel_trace.csv"), recursive=True):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    if short(r.get("Kernel_Name", "")).startswith(dec_pref):
+                        ivd.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        if ivd:
+            ivd.sort(); tot_d = 0; cs, ce = ivd[0]
+            for a_, b_ in ivd[1:]:
+                if a_ > ce:
+                    tot_d += ce - cs; cs, ce = a_, b_
+                elif b_ > ce:
+                    ce = b_
+            tot_d += ce - cs
+            print(f"== decoder kernels (decode steps + batched prefill, every engine): {len(ivd)} launches, UNION {tot_d * 1e-9:.3f} s (some decoder kernel running); the run holds one warm-up, "
+                  "one timed and one stamped decode stage + the 4-bar serial pass: compare with ~3.05 x roofline.decode_stage.stage_s_per_step of the line")
+        if n_a and hi:
+            print(f"== every kernel of the trace: {n_a} launches, sum of durations {sum_a:.3f} s, UNION {uni_a:.3f} s of the {(hi - lo) * 1e-9:.3f} s between the first dispatch and the last "
+                  f"(some kernel running {100 * uni_a / ((hi - lo) * 1e-9):.1f} % of that span; the span includes the host-side set-up between the stages)")
     except Exception as e:      # noqa: BLE001
         print("(no union of the attention launches:", e, ")")
     fe = pmc(os.path.join(root, "prof_fetch"), "FETCH_SIZE")
