@@ -118,3 +118,32 @@ def test_tokens_do_not_depend_on_the_number_of_engines():
         out = _run("f16", n, 54, 4, 1)[0]
         differ = sum(1 for a, b in zip(ref, out) if a != b)
         assert differ == 0, f"{differ} of {len(ref)} jobs differ between 1 and {n} engines"
+
+
+def test_ragged_eos_bars_are_reproducible_and_invariant_in_fp32():
+    """The reference's stopping rule (Bar_EOS ends a bar) makes streams finish at different steps: the scheduler restarts them one by one (continuous batching), so WHICH rows share a
+    prefill pass and a step launch depends on the tokens themselves.  With the context weights (ragged bars of 2 .. 128 tokens) and concurrent engines: (i) the 16-bit mode gives the same
+    ids run after run (what extras.ragged_bars of bench.py times is a deterministic job); (ii) in the exact-parity mode the ids do not depend on the engine layout either (1 x 54 = 2 x 27)."""
+    from etude_amd.decoder import EtudeDecoder, EtudeDecoderConfig, run_engines
+    cfg = EtudeDecoderConfig(**synth.decoder_dims())
+    sd = synth.decoder_state_dict_ctx(1)
+    v = _vocab()
+    jobs = _jobs(54, 6)
+    kw = dict(max_bar_token_limit=128, temperature=0.0)
+    res = {}
+    for prec, n_eng in (("f16", 2), ("fp32", 1), ("fp32", 2)):
+        per = (len(jobs) + n_eng - 1) // n_eng
+        decs = [EtudeDecoder(cfg, sd, "cuda", precision=prec, max_streams=per)]
+        decs += [decs[0].clone() for _ in range(n_eng - 1)]
+        outs = []
+        for _ in range(2):
+            out, _stats = run_engines(decs, jobs, v, **kw)()
+            torch.cuda.synchronize()
+            outs.append(out)
+        for d in reversed(decs):
+            d.close()
+        assert outs[0] == outs[1], f"{prec} x {n_eng} engines: ragged ids differ between identical runs"
+        res[(prec, n_eng)] = outs[0]
+    lens = {len(b) for job in res[("fp32", 1)] for b in job}
+    assert len(lens) > 10, "the bars of this job list should be ragged"
+    assert res[("fp32", 1)] == res[("fp32", 2)], "exact-parity ids depend on the engine layout"
